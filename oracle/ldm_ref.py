@@ -1,0 +1,230 @@
+"""Oracle (test infrastructure): fp32 CPU restatement of the ldm UNet hot path, functional over a
+reference-layout state dict (keys as in SURVEY.md Appendix A).
+
+Rows: A1/A2 CrossAttention (ldm/modules/attention.py:145-194), A3 BasicTransformerBlock/GEGLU
+(:49-76, :271-275), A4 SpatialTransformer (:321-340), A5 ResBlock
+(ldm/modules/diffusionmodules/openaimodel.py:254-274), Down/Upsample (:108-118,:157-159),
+A6 GroupNorm32 (util.py:217-219) / Normalize (attention.py:88-89), A7 UNetModel.forward
+(openaimodel.py:754-786; constructor walk :542-730).
+"""
+import torch
+import torch.nn.functional as F
+
+from .schedule_ref import timestep_embedding
+
+
+# ------------------------------------------------------------------ A6 norms
+def group_norm32(x, w, b, eps=1e-5, groups=32):
+    """util.py:217-219: GroupNorm computed in fp32, cast back to the input dtype."""
+    return F.group_norm(x.float(), groups, w.float(), b.float(), eps).type(x.dtype)
+
+
+def group_norm_nhwc_manual(x, w, b, eps, groups=32):
+    """Independent (non-ATen) statement of the same arithmetic on [B,HW,C]; used to cross-check."""
+    B, N, C = x.shape
+    xg = x.float().reshape(B, N, groups, C // groups)
+    mean = xg.mean(dim=(1, 3), keepdim=True)
+    var = ((xg - mean) ** 2).mean(dim=(1, 3), keepdim=True)
+    y = ((xg - mean) / torch.sqrt(var + eps)).reshape(B, N, C)
+    return y * w + b
+
+
+def silu(x):
+    return x * torch.sigmoid(x)
+
+
+# ------------------------------------------------------------------ A1/A2 attention
+def cross_attention(sd, p, x, context=None, mask=None, heads=8):
+    """attention.py:163-194.  sd[p+'to_q.weight'] etc.  fp32 logits, softmax(-1), PV, to_out."""
+    q = F.linear(x, sd[p + "to_q.weight"])
+    ctx = x if context is None else context
+    k = F.linear(ctx, sd[p + "to_k.weight"])
+    v = F.linear(ctx, sd[p + "to_v.weight"])
+    B, N, inner = q.shape
+    d = inner // heads
+    scale = d ** -0.5
+
+    def split(t):  # 'b n (h d) -> (b h) n d'
+        return t.reshape(B, t.shape[1], heads, d).permute(0, 2, 1, 3).reshape(B * heads, t.shape[1], d)
+
+    q, k, v = split(q), split(k), split(v)
+    sim = torch.einsum("bid,bjd->bij", q.float(), k.float()) * scale
+    if mask is not None:
+        m = mask.reshape(B, -1)
+        m = m[:, None, None, :].expand(B, heads, 1, m.shape[-1]).reshape(B * heads, 1, -1)
+        sim = sim.masked_fill(~m, -torch.finfo(sim.dtype).max)
+    sim = sim.softmax(dim=-1)
+    out = torch.einsum("bij,bjd->bid", sim, v)
+    out = out.reshape(B, heads, N, d).permute(0, 2, 1, 3).reshape(B, N, inner)
+    return F.linear(out, sd[p + "to_out.0.weight"], sd[p + "to_out.0.bias"])
+
+
+def sdpa_core(q, k, v, scale, bias=None):
+    """softmax(q k^T * scale + bias) v on [BH,N,D] fp32 — the fused-op contract (attention.py:222-233)."""
+    sim = torch.einsum("bid,bjd->bij", q.float(), k.float()) * scale
+    if bias is not None:
+        sim = sim + bias
+    return torch.einsum("bij,bjd->bid", sim.softmax(dim=-1), v.float())
+
+
+# ------------------------------------------------------------------ A3 transformer block
+def geglu_ff(sd, p, x):
+    """attention.py:49-76: proj -> chunk -> x*gelu(gate) (exact-erf GELU) -> Linear."""
+    h = F.linear(x, sd[p + "net.0.proj.weight"], sd[p + "net.0.proj.bias"])
+    a, gate = h.chunk(2, dim=-1)
+    h = a * F.gelu(gate)
+    return F.linear(h, sd[p + "net.2.weight"], sd[p + "net.2.bias"])
+
+
+def basic_transformer_block(sd, p, x, context, heads, disable_self_attn=False):
+    """attention.py:271-275 (LayerNorm eps 1e-5, :263-265)."""
+    C = x.shape[-1]
+    ln = lambda t, i: F.layer_norm(t, (C,), sd[p + f"norm{i}.weight"], sd[p + f"norm{i}.bias"], 1e-5)
+    x = cross_attention(sd, p + "attn1.", ln(x, 1), context if disable_self_attn else None, heads=heads) + x
+    x = cross_attention(sd, p + "attn2.", ln(x, 2), context, heads=heads) + x
+    x = geglu_ff(sd, p + "ff.", ln(x, 3)) + x
+    return x
+
+
+# ------------------------------------------------------------------ A4 spatial transformer
+def spatial_transformer(sd, p, x, context, heads, depth=1, use_linear=False):
+    """attention.py:321-340 (GroupNorm eps 1e-6, :88-89)."""
+    B, C, H, W = x.shape
+    x_in = x
+    x = F.group_norm(x, 32, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-6)
+    if not use_linear:
+        x = F.conv2d(x, sd[p + "proj_in.weight"], sd[p + "proj_in.bias"])
+    x = x.permute(0, 2, 3, 1).reshape(B, H * W, -1)
+    if use_linear:
+        x = F.linear(x, sd[p + "proj_in.weight"], sd[p + "proj_in.bias"])
+    for d in range(depth):
+        x = basic_transformer_block(sd, p + f"transformer_blocks.{d}.", x, context, heads)
+    if use_linear:
+        x = F.linear(x, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"])
+    x = x.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+    if not use_linear:
+        x = F.conv2d(x, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"])
+    return x + x_in
+
+
+# ------------------------------------------------------------------ A5 resblock & resampling
+def resblock(sd, p, x, emb):
+    """openaimodel.py:254-274 (no up/down, no scale-shift — the SD-1.5 configuration)."""
+    h = silu(group_norm32(x, sd[p + "in_layers.0.weight"], sd[p + "in_layers.0.bias"]))
+    h = F.conv2d(h, sd[p + "in_layers.2.weight"], sd[p + "in_layers.2.bias"], padding=1)
+    emb_out = F.linear(silu(emb), sd[p + "emb_layers.1.weight"], sd[p + "emb_layers.1.bias"])
+    h = h + emb_out[:, :, None, None]
+    h = silu(group_norm32(h, sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"]))
+    h = F.conv2d(h, sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=1)
+    if (p + "skip_connection.weight") in sd:
+        wsk = sd[p + "skip_connection.weight"]
+        x = F.conv2d(x, wsk, sd[p + "skip_connection.bias"], padding=wsk.shape[-1] // 2)
+    return x + h
+
+
+def downsample(sd, p, x):
+    """openaimodel.py:157-159: conv3x3 stride 2 pad 1."""
+    return F.conv2d(x, sd[p + "op.weight"], sd[p + "op.bias"], stride=2, padding=1)
+
+
+def upsample(sd, p, x):
+    """openaimodel.py:108-118: nearest x2 then conv3x3."""
+    x = F.interpolate(x, scale_factor=2, mode="nearest")
+    return F.conv2d(x, sd[p + "conv.weight"], sd[p + "conv.bias"], padding=1)
+
+
+# ------------------------------------------------------------------ A7 UNet
+def unet_plan(cfg):
+    """Walk of UNetModel.__init__ (openaimodel.py:542-730) for use_spatial_transformer=True, legacy=False,
+    num_head_channels=-1.  Returns (input_blocks, middle, output_blocks): lists of layer tuples."""
+    mc = cfg["model_channels"]
+    mult = list(cfg["channel_mult"])
+    nrb = cfg["num_res_blocks"]
+    nrb = [nrb] * len(mult) if isinstance(nrb, int) else list(nrb)
+    attn_res = set(cfg["attention_resolutions"])
+    heads = cfg["num_heads"]
+    depth = cfg.get("transformer_depth", 1)
+    inp = [[("conv", cfg["in_channels"], mc)]]
+    chans = [mc]
+    ch, ds = mc, 1
+    for level, m in enumerate(mult):
+        for _ in range(nrb[level]):
+            layers = [("res", ch, m * mc)]
+            ch = m * mc
+            if ds in attn_res:
+                layers.append(("st", ch, heads, ch // heads, depth))
+            inp.append(layers)
+            chans.append(ch)
+        if level != len(mult) - 1:
+            inp.append([("down", ch, ch)])
+            chans.append(ch)
+            ds *= 2
+    mid = [("res", ch, ch), ("st", ch, heads, ch // heads, depth), ("res", ch, ch)]
+    out = []
+    for level, m in list(enumerate(mult))[::-1]:
+        for i in range(nrb[level] + 1):
+            ich = chans.pop()
+            layers = [("res", ch + ich, mc * m)]
+            ch = mc * m
+            if ds in attn_res:
+                layers.append(("st", ch, heads, ch // heads, depth))
+            if level and i == nrb[level]:
+                layers.append(("up", ch, ch))
+                ds //= 2
+            out.append(layers)
+    return inp, mid, out
+
+
+def _run_layers(sd, prefix, layers, h, emb, context, use_linear):
+    for j, L in enumerate(layers):
+        p = f"{prefix}{j}."
+        kind = L[0]
+        if kind == "conv":
+            h = F.conv2d(h, sd[p + "weight"], sd[p + "bias"], padding=1)
+        elif kind == "res":
+            h = resblock(sd, p, h, emb)
+        elif kind == "st":
+            h = spatial_transformer(sd, p, h, context, heads=L[2], depth=L[4], use_linear=use_linear)
+        elif kind == "down":
+            h = downsample(sd, p, h)
+        elif kind == "up":
+            h = upsample(sd, p, h)
+    return h
+
+
+def unet_forward(sd, cfg, x, timesteps, context):
+    """openaimodel.py:754-786."""
+    inp, mid, out = unet_plan(cfg)
+    use_linear = cfg.get("use_linear_in_transformer", False)
+    t_emb = timestep_embedding(timesteps, cfg["model_channels"])
+    emb = F.linear(t_emb, sd["time_embed.0.weight"], sd["time_embed.0.bias"])
+    emb = F.linear(silu(emb), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
+    hs = []
+    h = x.float()
+    for i, layers in enumerate(inp):
+        h = _run_layers(sd, f"input_blocks.{i}.", layers, h, emb, context, use_linear)
+        hs.append(h)
+    h = _run_layers(sd, "middle_block.", mid, h, emb, context, use_linear)
+    for i, layers in enumerate(out):
+        h = torch.cat([h, hs.pop()], dim=1)
+        h = _run_layers(sd, f"output_blocks.{i}.", layers, h, emb, context, use_linear)
+    h = silu(group_norm32(h, sd["out.0.weight"], sd["out.0.bias"]))
+    return F.conv2d(h, sd["out.2.weight"], sd["out.2.bias"], padding=1)
+
+
+def diffusion_wrapper(sd, cfg, x, t, c_concat=None, c_crossattn=None, conditioning_key="hybrid"):
+    """ldm/models/diffusion/ddpm.py:1332-1363 (the keys in-tree callers use)."""
+    if conditioning_key is None:
+        return unet_forward(sd, cfg, x, t, None)
+    if conditioning_key == "concat":
+        return unet_forward(sd, cfg, torch.cat([x] + c_concat, dim=1), t, None)
+    if conditioning_key == "crossattn":
+        return unet_forward(sd, cfg, x, t, torch.cat(c_crossattn, 1))
+    if conditioning_key == "hybrid":
+        return unet_forward(sd, cfg, torch.cat([x] + c_concat, dim=1), t, torch.cat(c_crossattn, 1))
+    raise NotImplementedError(conditioning_key)
+
+
+SD15_CFG = dict(image_size=64, in_channels=8, model_channels=320, out_channels=4, num_res_blocks=2,
+                attention_resolutions=[4, 2, 1], channel_mult=[1, 2, 4, 4], num_heads=8,
+                use_spatial_transformer=True, transformer_depth=1, context_dim=768, legacy=False)

@@ -1,0 +1,201 @@
+"""Pins the oracle (our CPU restatement) against golden vectors produced by the reference's own code
+(tools/gen_golden.py).  CPU only.  Integer bookkeeping: bit-exact.  Floats: fp32 round-off."""
+import numpy as np
+import torch
+
+from conftest import load_golden, sub_sd, T
+from oracle import schedule_ref as S
+from oracle import ldm_ref as L
+from oracle import ddim_ref as D
+from oracle import sam_ref as M
+
+TINY = dict(image_size=8, in_channels=8, model_channels=32, out_channels=4, num_res_blocks=1,
+            attention_resolutions=[1, 2], channel_mult=[1, 2], num_heads=4, use_spatial_transformer=True,
+            transformer_depth=1, context_dim=16, legacy=False)
+
+
+def close(a, b, tol=2e-5):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = float((a - b).abs().max())
+    ref = float(b.abs().max()) + 1e-12
+    assert err <= tol * max(ref, 1.0), f"max abs err {err} (ref max {ref})"
+
+
+def test_schedule_bit_exact():
+    g = load_golden("schedule")
+    betas = S.make_beta_schedule("linear", 1000, 0.00085, 0.0120)
+    assert betas.dtype == np.float64 and np.array_equal(betas, g["betas"])
+    for s in (7, 20, 30, 50, 100):
+        ts = S.make_ddim_timesteps("uniform", s, 1000)
+        assert ts.dtype == g[f"ts_uniform_{s}"].dtype and np.array_equal(ts, g[f"ts_uniform_{s}"])
+    assert len(S.make_ddim_timesteps("uniform", 30, 1000)) == 31  # G4
+    assert S.make_ddim_timesteps("uniform", 50, 1000)[-1] == 981 and S.make_ddim_timesteps("uniform", 20, 1000)[1] == 51
+    for s in (10, 50):
+        assert np.array_equal(S.make_ddim_timesteps("quad", s, 1000), g[f"ts_quad_{s}"])
+    ac = np.cumprod(1.0 - betas, axis=0)
+    assert np.array_equal(ac, g["alphas_cumprod"])
+    for s in (20, 50):
+        for eta in (0.0, 1.0):
+            sig, a, ap = S.make_ddim_sampling_parameters(ac, g[f"ts_uniform_{s}"], eta)
+            tag = f"S{s}_eta{int(eta)}"
+            assert np.array_equal(sig, g[f"sig_{tag}"]) and np.array_equal(a, g[f"a_{tag}"]) and np.array_equal(ap, g[f"ap_{tag}"])
+    for name in ("cosine", "sqrt_linear", "sqrt"):
+        assert np.allclose(S.make_beta_schedule(name, 50, 1e-4, 2e-2), g[f"betas_{name}"], rtol=0, atol=1e-15)
+    t = T(g["temb_t"])
+    assert torch.equal(S.timestep_embedding(t, 320), T(g["temb_320"]))
+    assert torch.equal(S.timestep_embedding(t, 33), T(g["temb_33"]))
+
+
+def test_norms():
+    g = load_golden("norms")
+    x = T(g["x"])
+    y = L.group_norm32(x, T(g["gn_w"]), T(g["gn_b"]))
+    close(y, g["gn_y"])
+    close(L.silu(y), g["gn_silu_y"])
+    close(torch.nn.functional.group_norm(x, 32, T(g["gn6_w"]), T(g["gn6_b"]), 1e-6), g["gn6_y"])
+    # the independent NHWC statement agrees with ATen's
+    xn = x.permute(0, 2, 3, 1).reshape(2, 64, 64)
+    yn = L.group_norm_nhwc_manual(xn, T(g["gn_w"]), T(g["gn_b"]), 1e-5)
+    close(yn.reshape(2, 8, 8, 64).permute(0, 3, 1, 2), g["gn_y"])
+
+
+def test_attention():
+    g = load_golden("attention")
+    for name in ("self_n64_d40", "cross_n256_d80_k77", "self_n196_d80", "self_n144_d160", "masked"):
+        cfg = g[f"{name}.cfg"]
+        sd = sub_sd(g, f"{name}.w.")
+        ctx = T(g[f"{name}.ctx"]) if f"{name}.ctx" in g else None
+        mask = T(g[f"{name}.mask"]) if f"{name}.mask" in g else None
+        y = L.cross_attention(sd, "", T(g[f"{name}.x"]), ctx, mask=mask, heads=int(cfg[3]))
+        close(y, g[f"{name}.y"])
+
+
+def test_transformer_blocks():
+    g = load_golden("transformer")
+    sd = sub_sd(g, "btb.w.")
+    close(L.basic_transformer_block(sd, "", T(g["btb.x"]), T(g["btb.ctx"]), heads=2), g["btb.y"])
+    close(L.geglu_ff(sub_sd(g, "ff.w."), "", T(g["ff.x"])), g["ff.y"])
+    for tag, lin in (("st", False), ("st_lin", True)):
+        sd = sub_sd(g, f"{tag}.w.")
+        y = L.spatial_transformer(sd, "", T(g[f"{tag}.x"]), T(g[f"{tag}.ctx"]), heads=2, use_linear=lin)
+        close(y, g[f"{tag}.y"])
+
+
+def test_resblock_and_resampling():
+    g = load_golden("resblock")
+    for tag in ("same", "diff"):
+        sd = sub_sd(g, f"{tag}.w.")
+        close(L.resblock(sd, "", T(g[f"{tag}.x"]), T(g[f"{tag}.emb"])), g[f"{tag}.y"])
+    close(L.downsample(sub_sd(g, "down.w."), "", T(g["down.x"])), g["down.y"])
+    close(L.downsample(sub_sd(g, "down.w."), "", T(g["down.x7"])), g["down.y7"])
+    close(L.upsample(sub_sd(g, "up.w."), "", T(g["up.x"])), g["up.y"])
+
+
+def test_unet_tiny():
+    g = load_golden("unet_tiny")
+    sd = sub_sd(g, "w.")
+    y = L.unet_forward(sd, TINY, T(g["x"]), T(g["t"]), T(g["ctx"]))
+    close(y, g["y"], tol=5e-5)
+    y16 = L.unet_forward(sd, TINY, T(g["x16"]), T(g["t"])[:1], T(g["ctx"])[:1])
+    close(y16, g["y16"], tol=5e-5)
+    assert float(torch.as_tensor(g["y"]).abs().max()) > 1e-3  # G1: the fixture is not identically zero
+
+
+def _tiny_ldm():
+    gu = load_golden("unet_tiny")
+    sd = sub_sd(gu, "w.")
+    buffers = S.register_schedule("linear", 1000, 0.00085, 0.0120)
+
+    def apply_model(x, t, cond):
+        return L.diffusion_wrapper(sd, TINY, x, t, cond["c_concat"], cond["c_crossattn"], "hybrid")
+    return buffers, apply_model
+
+
+def test_model_buffers_and_apply_model():
+    g = load_golden("ddim_tiny")
+    buffers, apply_model = _tiny_ldm()
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod"):
+        assert torch.equal(buffers[k], T(g[f"model.{k}"])), k
+    cond = {"c_concat": [T(g["img_lat"])], "c_crossattn": [T(g["ctx"])]}
+    close(apply_model(T(g["x_T"]), T(g["apply.t"]), cond), g["apply.y"], tol=5e-5)
+    assert torch.equal(D.q_sample(buffers, T(g["x_T"]), T(g["apply.t"]), T(g["qs.noise"])), T(g["qs.y"]))
+
+
+def test_ddim_sampler():
+    g = load_golden("ddim_tiny")
+    buffers, apply_model = _tiny_ldm()
+    cond = {"c_concat": [T(g["img_lat"])], "c_crossattn": [T(g["ctx"])]}
+    uncond = {"c_concat": [T(g["img_lat"])], "c_crossattn": [T(g["null_ctx"])]}
+    x_T = T(g["x_T"])
+    for tag, s, scale, use_mask in (("s5_nocfg", 5, 1.0, False), ("s5_cfg", 5, 7.5, False),
+                                    ("s20_cfg", 20, 7.5, False), ("s7_cfg_mask", 7, 3.0, True)):
+        kw = dict(mask=T(g[f"{tag}.mask"]), x0=T(g[f"{tag}.x0"])) if use_mask else {}
+        torch.manual_seed(1234)
+        img, inter, sched = D.ddim_sample(apply_model, buffers, s, tuple(x_T.shape), cond, eta=0.0, x_T=x_T,
+                                          scale=scale, uc=uncond if scale != 1.0 else None, log_every_t=1, **kw)
+        # integer bookkeeping bit-exact
+        assert np.array_equal(sched["ddim_timesteps"], g[f"{tag}.ddim_timesteps"])
+        assert sched["ddim_timesteps"].dtype == g[f"{tag}.ddim_timesteps"].dtype
+        for k in ("ddim_alphas", "ddim_alphas_prev", "ddim_sigmas", "ddim_sqrt_one_minus_alphas"):
+            a = np.asarray(sched[k])
+            assert a.dtype == g[f"{tag}.{k}"].dtype, (k, a.dtype)  # G5 dtype mix
+            assert np.array_equal(a, g[f"{tag}.{k}"]), k
+        close(img, g[f"{tag}.samples"], tol=2e-4)
+        close(inter["pred_x0"][-1], g[f"{tag}.pred_x0_last"], tol=2e-4)
+        assert len(inter["x_inter"]) == g[f"{tag}.x_inter"].shape[0]
+    torch.manual_seed(77)
+    img, _, _ = D.ddim_sample(apply_model, buffers, 5, tuple(x_T.shape), cond, eta=1.0, x_T=x_T, scale=7.5, uc=uncond)
+    close(img, g["s5_eta1.samples"], tol=2e-4)
+    # SDEdit: stochastic_encode + decode
+    sched = S.make_ddim_schedule(buffers, 10, "uniform", 0.0)
+    enc = D.stochastic_encode(sched, x_T, torch.tensor([6, 6]), T(g["qs.noise"]))
+    close(enc, g["sdedit.enc"], tol=1e-6)
+    torch.manual_seed(5)
+    dec = D.ddim_decode(apply_model, sched, enc, cond, 6, scale=7.5, uc=uncond)
+    close(dec, g["sdedit.dec"], tol=2e-4)
+
+
+def test_eps_mse_matches_p_losses():
+    g = load_golden("ddim_tiny")
+    buffers, apply_model = _tiny_ldm()
+    cond = {"c_concat": [T(g["img_lat"])], "c_crossattn": [T(g["ctx"])]}
+    x0, t, noise = T(g["x_T"]), T(g["apply.t"]), T(g["qs.noise"])
+    pred = apply_model(D.q_sample(buffers, x0, t, noise), t, cond)
+    close(D.eps_mse(pred, noise), g["ploss.loss_simple"], tol=1e-5)
+
+
+def test_conditioning_dropout_masks():
+    p = 0.05
+    rp = torch.tensor([0.01, 0.049, 0.05, 0.0999, 0.1, 0.1499, 0.15, 0.9])
+    pm, im = D.conditioning_dropout_masks(rp, p)
+    assert pm.tolist() == [True, True, True, True, False, False, False, False]
+    assert im.tolist() == [1, 1, 0, 0, 0, 0, 1, 1]
+
+
+def test_sam():
+    g = load_golden("sam_tiny")
+    rp = T(g["relpos.table27"])
+    assert torch.equal(M.get_rel_pos(14, 14, rp), T(g["relpos.q14k14"]))
+    close(M.get_rel_pos(8, 8, rp), g["relpos.q8k8_interp"], tol=1e-6)
+    close(M.get_rel_pos(4, 8, rp[:15]), g["relpos.q4k8"], tol=1e-6)
+    w, pad = M.window_partition(T(g["win.x"]), 4)
+    assert torch.equal(w, T(g["win.w"])) and list(pad) == g["win.pad"].tolist()
+    assert torch.equal(M.window_unpartition(w, 4, pad, (10, 10)), T(g["win.back"]))
+    w64, pad64 = M.window_partition(T(g["win64.x"]), 14)
+    assert torch.equal(w64, T(g["win64.w"])) and list(pad64) == [70, 70]
+    for tag in ("attn_g8", "attn_w14"):
+        cfg = g[f"{tag}.cfg"]
+        close(M.attention(sub_sd(g, f"{tag}.w."), "", T(g[f"{tag}.x"]), int(cfg[4])), g[f"{tag}.y"])
+    close(M.block(sub_sd(g, "blk_win.w."), "", T(g["blk_win.x"]), 2, 4), g["blk_win.y"])
+    close(M.block(sub_sd(g, "blk_glob.w."), "", T(g["blk_glob.x"]), 2, 0), g["blk_glob.y"])
+    y = M.image_encoder(sub_sd(g, "enc.w."), "", T(g["enc.x"]), 8, 2, 2, 4, (1,))
+    close(y, g["enc.y"], tol=5e-5)
+
+
+def test_gelu_silu_points():
+    g = load_golden("misc")
+    x = T(g["gelu.x"])
+    close(torch.nn.functional.gelu(x), g["gelu.y"], tol=1e-7)
+    close(L.silu(x), g["silu.y"], tol=1e-6)

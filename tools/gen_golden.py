@@ -1,0 +1,473 @@
+#!/usr/bin/env python3
+"""Dev-time golden-fixture generator (runs ONLY in the build container).
+
+Imports the reference's own `ldm/` and `segment_anything/` code from /root/reference with inert import
+stubs, runs it on CPU in fp32 on small seeded inputs and writes
+inputs + weights + expected outputs as .npz files under tests/golden/.
+
+Nothing from the reference is copied: the fixtures are data (tensors).  The reference never
+travels to the GPU box; tests read only the .npz files.
+
+Usage:  PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+"""
+import os
+import sys
+import types
+import importlib.util
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+
+
+# ----------------------------------------------------------------------------------------------
+# inert stubs for packages the image lacks
+# ----------------------------------------------------------------------------------------------
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class ListConfig(list):
+    pass
+
+
+_mod("omegaconf", ListConfig=ListConfig)
+_mod("omegaconf.listconfig", ListConfig=ListConfig)
+
+
+class LightningModule(nn.Module):
+    @property
+    def device(self):
+        p = next(self.parameters(), None)
+        return p.device if p is not None else torch.device("cpu")
+
+
+_mod("pytorch_lightning", LightningModule=LightningModule)
+_mod("pytorch_lightning.utilities")
+_mod("pytorch_lightning.utilities.rank_zero", rank_zero_only=lambda f: f)
+_mod("torchvision")
+_mod("torchvision.utils", make_grid=lambda *a, **k: None)
+
+from ldm.modules.diffusionmodules import util as rutil  # noqa: E402
+from ldm.modules import attention as rattn  # noqa: E402
+from ldm.modules.diffusionmodules import openaimodel as rom  # noqa: E402
+from ldm.models.diffusion.ddim import DDIMSampler  # noqa: E402
+import ldm.models.diffusion.ddpm as rddpm  # noqa: E402
+
+
+def _load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+# SAM modeling files are loaded by file path (package import would need torchvision)
+_sam_pkg = types.ModuleType("samref")
+_sam_pkg.__path__ = [os.path.join(REF, "segment_anything/segment_anything/modeling")]
+sys.modules["samref"] = _sam_pkg
+_load_by_path("samref.common", os.path.join(REF, "segment_anything/segment_anything/modeling/common.py"))
+rsam = _load_by_path("samref.image_encoder",
+                     os.path.join(REF, "segment_anything/segment_anything/modeling/image_encoder.py"))
+
+
+class CPUDDIMSampler(DDIMSampler):
+    # G2: reference hard-codes .to("cuda") in register_buffer (ddim.py:17-21)
+    def register_buffer(self, name, attr):
+        setattr(self, name, attr)
+
+
+class OracleLDM(rddpm.LatentDiffusion):
+    def instantiate_first_stage(self, config):
+        self.first_stage_model = None
+
+    def instantiate_cond_stage(self, config):
+        self.cond_stage_model = None
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {name}.npz  ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+def sd_np(module, prefix="w."):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+
+
+def unzero(module, gen, std=0.02):
+    """G1: re-initialise zero-initialised layers, else outputs test nothing."""
+    for m in module.modules():
+        targets = []
+        if isinstance(m, rom.ResBlock):
+            targets.append(m.out_layers[-1])
+        if isinstance(m, rattn.SpatialTransformer):
+            targets.append(m.proj_out)
+        if isinstance(m, rom.UNetModel):
+            targets.append(m.out[-1])
+        for t in targets:
+            for p in t.parameters():
+                p.data = torch.randn(p.shape, generator=gen) * std
+
+
+def randomize_norm_affine(module, gen):
+    """Norm layers default to weight=1,bias=0; perturb so affine handling is actually tested."""
+    for m in module.modules():
+        if isinstance(m, (nn.GroupNorm, nn.LayerNorm)):
+            m.weight.data = 1.0 + 0.1 * torch.randn(m.weight.shape, generator=gen)
+            m.bias.data = 0.1 * torch.randn(m.bias.shape, generator=gen)
+
+
+def G(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@torch.no_grad()
+def gen_schedule():
+    print("[schedule]")
+    betas = rutil.make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.0120)
+    arrs = {"betas": betas}
+    for S in (7, 20, 30, 50, 100):
+        arrs[f"ts_uniform_{S}"] = rutil.make_ddim_timesteps("uniform", S, 1000, verbose=False)
+    arrs["ts_quad_10"] = rutil.make_ddim_timesteps("quad", 10, 1000, verbose=False)
+    arrs["ts_quad_50"] = rutil.make_ddim_timesteps("quad", 50, 1000, verbose=False)
+    alphas_cumprod = np.cumprod(1.0 - betas, axis=0)
+    arrs["alphas_cumprod"] = alphas_cumprod
+    for S in (20, 50):
+        ts = arrs[f"ts_uniform_{S}"]
+        for eta in (0.0, 1.0):
+            s, a, ap = rutil.make_ddim_sampling_parameters(alphas_cumprod, ts, eta, verbose=False)
+            tag = f"S{S}_eta{int(eta)}"
+            arrs[f"sig_{tag}"], arrs[f"a_{tag}"], arrs[f"ap_{tag}"] = s, a, ap
+    # the float32 buffers the sampler actually consumes (G5 dtype mix), via a model stub
+    for cos in ("cosine", "sqrt_linear", "sqrt"):
+        arrs[f"betas_{cos}"] = np.asarray(rutil.make_beta_schedule(cos, 50, 1e-4, 2e-2))
+    for t in ([1, 981, 500, 0], ):
+        tt = torch.tensor(t, dtype=torch.long)
+        arrs["temb_t"] = tt
+        arrs["temb_320"] = rutil.timestep_embedding(tt, 320)
+        arrs["temb_33"] = rutil.timestep_embedding(tt, 33)
+    npz("schedule", **arrs)
+
+
+@torch.no_grad()
+def gen_norms():
+    print("[norms]")
+    g = G(10)
+    x = torch.randn(2, 64, 8, 8, generator=g) * 1.5 + 0.3
+    gn = rutil.normalization(64)
+    randomize_norm_affine(gn, g)
+    y = gn(x)
+    ys = nn.SiLU()(y)
+    gn6 = rattn.Normalize(64)
+    randomize_norm_affine(gn6, g)
+    y6 = gn6(x)
+    ln = nn.LayerNorm(64)
+    randomize_norm_affine(ln, g)
+    xl = torch.randn(2, 10, 64, generator=g)
+    npz("norms", x=x, gn_w=gn.weight, gn_b=gn.bias, gn_y=y, gn_silu_y=ys,
+        gn6_w=gn6.weight, gn6_b=gn6.bias, gn6_y=y6,
+        ln_x=xl, ln_w=ln.weight, ln_b=ln.bias, ln_y=ln(xl))
+
+
+@torch.no_grad()
+def gen_attention():
+    print("[attention]")
+    arrs = {}
+    cases = {  # name: (B, N, query_dim, heads, dim_head, context_dim, Nk)
+        "self_n64_d40": (2, 64, 80, 2, 40, None, None),
+        "cross_n256_d80_k77": (1, 256, 160, 2, 80, 48, 77),
+        "self_n196_d80": (1, 196, 160, 2, 80, None, None),
+        "self_n144_d160": (1, 144, 320, 2, 160, None, None),
+    }
+    for i, (name, (B, N, qd, h, dh, cd, Nk)) in enumerate(cases.items()):
+        g = G(20 + i)
+        torch.manual_seed(20 + i)
+        m = rattn.CrossAttention(qd, context_dim=cd, heads=h, dim_head=dh)
+        x = torch.randn(B, N, qd, generator=g)
+        ctx = torch.randn(B, Nk, cd, generator=g) if cd is not None else None
+        y = m(x, context=ctx)
+        arrs.update({f"{name}.x": x, f"{name}.y": y, f"{name}.cfg": np.array([B, N, qd, h, dh, cd or 0, Nk or 0])})
+        if ctx is not None:
+            arrs[f"{name}.ctx"] = ctx
+        arrs.update(sd_np(m, f"{name}.w."))
+    # boolean mask path (attention.py:183-187)
+    g = G(29)
+    torch.manual_seed(29)
+    m = rattn.CrossAttention(64, context_dim=32, heads=2, dim_head=32)
+    x = torch.randn(2, 16, 64, generator=g)
+    ctx = torch.randn(2, 9, 32, generator=g)
+    mask = torch.rand(2, 9, generator=g) > 0.3
+    mask[:, 0] = True
+    arrs.update({"masked.x": x, "masked.ctx": ctx, "masked.mask": mask, "masked.y": m(x, context=ctx, mask=mask),
+                 "masked.cfg": np.array([2, 16, 64, 2, 32, 32, 9])})
+    arrs.update(sd_np(m, "masked.w."))
+    npz("attention", **arrs)
+
+
+@torch.no_grad()
+def gen_transformer():
+    print("[transformer]")
+    arrs = {}
+    g = G(30)
+    torch.manual_seed(30)
+    blk = rattn.BasicTransformerBlock(64, 2, 32, context_dim=24, checkpoint=False)
+    randomize_norm_affine(blk, g)
+    x = torch.randn(2, 16, 64, generator=g)
+    ctx = torch.randn(2, 7, 24, generator=g)
+    arrs.update({"btb.x": x, "btb.ctx": ctx, "btb.y": blk(x, context=ctx)})
+    arrs.update(sd_np(blk, "btb.w."))
+    ff = rattn.FeedForward(64, glu=True)
+    arrs.update({"ff.x": x, "ff.y": ff(x)})
+    arrs.update(sd_np(ff, "ff.w."))
+    for use_linear in (False, True):
+        tag = "st_lin" if use_linear else "st"
+        torch.manual_seed(31)
+        st = rattn.SpatialTransformer(64, 2, 32, depth=1, context_dim=24, use_linear=use_linear, use_checkpoint=False)
+        unzero(st, g)
+        randomize_norm_affine(st, g)
+        xs = torch.randn(2, 64, 4, 4, generator=g)
+        arrs.update({f"{tag}.x": xs, f"{tag}.ctx": ctx, f"{tag}.y": st(xs, context=ctx)})
+        arrs.update(sd_np(st, f"{tag}.w."))
+    npz("transformer", **arrs)
+
+
+@torch.no_grad()
+def gen_resblock():
+    print("[resblock]")
+    arrs = {}
+    g = G(40)
+    for tag, (cin, cout) in {"same": (64, 64), "diff": (96, 64)}.items():
+        torch.manual_seed(40)
+        rb = rom.ResBlock(cin, 128, 0.0, out_channels=cout, dims=2, use_checkpoint=False)
+        unzero(rb, g)
+        randomize_norm_affine(rb, g)
+        x = torch.randn(2, cin, 8, 8, generator=g)
+        emb = torch.randn(2, 128, generator=g)
+        arrs.update({f"{tag}.x": x, f"{tag}.emb": emb, f"{tag}.y": rb(x, emb)})
+        arrs.update(sd_np(rb, f"{tag}.w."))
+    torch.manual_seed(41)
+    down = rom.Downsample(64, True, dims=2, out_channels=64)
+    up = rom.Upsample(64, True, dims=2, out_channels=64)
+    x = torch.randn(2, 64, 8, 8, generator=g)
+    arrs.update({"down.x": x, "down.y": down(x), "up.x": x, "up.y": up(x)})
+    arrs.update(sd_np(down, "down.w."))
+    arrs.update(sd_np(up, "up.w."))
+    # odd spatial size for the stride-2 conv (edge case)
+    x7 = torch.randn(1, 64, 7, 9, generator=g)
+    arrs.update({"down.x7": x7, "down.y7": down(x7)})
+    npz("resblock", **arrs)
+
+
+TINY_UNET = dict(image_size=8, in_channels=8, model_channels=32, out_channels=4, num_res_blocks=1,
+                 attention_resolutions=[1, 2], channel_mult=[1, 2], num_heads=4, use_spatial_transformer=True,
+                 transformer_depth=1, context_dim=16, legacy=False, use_checkpoint=False)
+
+
+def build_tiny_unet(seed=50):
+    torch.manual_seed(seed)
+    g = G(seed)
+    unet = rom.UNetModel(**TINY_UNET)
+    unzero(unet, g, std=0.05)
+    randomize_norm_affine(unet, g)
+    return unet.eval()
+
+
+@torch.no_grad()
+def gen_unet():
+    print("[unet]")
+    unet = build_tiny_unet()
+    g = G(51)
+    x = torch.randn(3, 8, 8, 8, generator=g)
+    t = torch.tensor([1, 501, 981], dtype=torch.long)
+    ctx = torch.randn(3, 5, 16, generator=g)
+    y = unet(x, t, context=ctx)
+    arrs = {"x": x, "t": t, "ctx": ctx, "y": y}
+    arrs.update(sd_np(unet, "w."))
+    # non-square / 16x16 input through the same weights
+    x2 = torch.randn(1, 8, 16, 16, generator=g)
+    arrs.update({"x16": x2, "y16": unet(x2, t[:1], context=ctx[:1])})
+    npz("unet_tiny", **arrs)
+    print("   params:", sum(p.numel() for p in unet.parameters()))
+
+
+def build_ldm(unet_params):
+    ldm = OracleLDM(first_stage_config=None, cond_stage_config="__is_unconditional__",
+                    force_null_conditioning=True, conditioning_key="hybrid",
+                    unet_config={"target": "ldm.modules.diffusionmodules.openaimodel.UNetModel",
+                                 "params": dict(unet_params)},
+                    timesteps=1000, linear_start=0.00085, linear_end=0.0120, use_ema=False,
+                    image_size=8, channels=4)
+    return ldm.eval()
+
+
+@torch.no_grad()
+def gen_ddim():
+    print("[ddim]")
+    tiny = build_tiny_unet()
+    ldm = build_ldm(TINY_UNET)
+    ldm.model.diffusion_model.load_state_dict(tiny.state_dict())
+    g = G(60)
+    B = 2
+    x_T = torch.randn(B, 4, 8, 8, generator=g)
+    img_lat = torch.randn(B, 4, 8, 8, generator=g) * 0.18215
+    ctx = torch.randn(B, 5, 16, generator=g)
+    null_ctx = torch.randn(1, 5, 16, generator=g).repeat(B, 1, 1)
+    cond = {"c_concat": [img_lat], "c_crossattn": [ctx]}
+    uncond = {"c_concat": [img_lat], "c_crossattn": [null_ctx]}
+    arrs = {"x_T": x_T, "img_lat": img_lat, "ctx": ctx, "null_ctx": null_ctx}
+
+    # buffers of the model (float32) and apply_model / q_sample
+    arrs["model.betas"] = ldm.betas
+    arrs["model.alphas_cumprod"] = ldm.alphas_cumprod
+    arrs["model.alphas_cumprod_prev"] = ldm.alphas_cumprod_prev
+    arrs["model.sqrt_alphas_cumprod"] = ldm.sqrt_alphas_cumprod
+    arrs["model.sqrt_one_minus_alphas_cumprod"] = ldm.sqrt_one_minus_alphas_cumprod
+    t = torch.tensor([981, 21], dtype=torch.long)
+    arrs["apply.t"] = t
+    arrs["apply.y"] = ldm.apply_model(x_T, t, cond)
+    noise = torch.randn(B, 4, 8, 8, generator=g)
+    arrs["qs.noise"] = noise
+    arrs["qs.y"] = ldm.q_sample(x_T, t, noise=noise)
+
+    sampler = CPUDDIMSampler(ldm)
+    import io
+    import contextlib
+    for tag, S, scale, use_mask in (("s5_nocfg", 5, 1.0, False), ("s5_cfg", 5, 7.5, False),
+                                    ("s20_cfg", 20, 7.5, False), ("s7_cfg_mask", 7, 3.0, True)):
+        kw = {}
+        if use_mask:
+            mask = (torch.rand(B, 1, 8, 8, generator=g) > 0.5).float()
+            x0 = torch.randn(B, 4, 8, 8, generator=g)
+            kw = dict(mask=mask, x0=x0)
+            arrs[f"{tag}.mask"], arrs[f"{tag}.x0"] = mask, x0
+        torch.manual_seed(1234)  # G11: RNG consumption order is part of the contract
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            samples, inter = sampler.sample(S, B, (4, 8, 8), cond, eta=0.0, x_T=x_T, verbose=False,
+                                            unconditional_guidance_scale=scale,
+                                            unconditional_conditioning=uncond if scale != 1.0 else None,
+                                            log_every_t=1, **kw)
+        arrs[f"{tag}.samples"] = samples
+        arrs[f"{tag}.pred_x0_last"] = inter["pred_x0"][-1]
+        arrs[f"{tag}.x_inter"] = torch.stack(inter["x_inter"])
+        arrs[f"{tag}.ddim_timesteps"] = sampler.ddim_timesteps
+        arrs[f"{tag}.ddim_alphas"] = np.asarray(sampler.ddim_alphas)
+        arrs[f"{tag}.ddim_alphas_prev"] = np.asarray(sampler.ddim_alphas_prev)
+        arrs[f"{tag}.ddim_sigmas"] = np.asarray(sampler.ddim_sigmas)
+        arrs[f"{tag}.ddim_sqrt_one_minus_alphas"] = np.asarray(sampler.ddim_sqrt_one_minus_alphas)
+    # eta=1 stochastic run (seeded torch RNG on CPU)
+    torch.manual_seed(77)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        samples, _ = sampler.sample(5, B, (4, 8, 8), cond, eta=1.0, x_T=x_T, verbose=False,
+                                    unconditional_guidance_scale=7.5, unconditional_conditioning=uncond)
+    arrs["s5_eta1.samples"] = samples
+    # stochastic_encode + decode (ddim.py:300-336)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        sampler.make_schedule(10, ddim_eta=0.0, verbose=False)
+        tt = torch.tensor([6, 6], dtype=torch.long)
+        enc = sampler.stochastic_encode(x_T, tt, noise=noise)
+        torch.manual_seed(5)
+        dec = sampler.decode(enc, cond, 6, unconditional_guidance_scale=7.5, unconditional_conditioning=uncond)
+    arrs["sdedit.enc"], arrs["sdedit.dec"] = enc, dec
+    # p_losses / eps-MSE (ddpm.py:889-932, 367-380)
+    torch.manual_seed(9)
+    loss, ld = ldm.p_losses(x_T, cond, t, noise=noise)
+    arrs["ploss.loss"] = loss
+    arrs["ploss.loss_simple"] = ld["val/loss_simple"]
+    npz("ddim_tiny", **arrs)
+
+
+@torch.no_grad()
+def gen_sam():
+    print("[sam]")
+    arrs = {}
+    g = G(70)
+    # get_rel_pos: equal size and interpolated
+    rp = torch.randn(2 * 14 - 1, 16, generator=g)
+    arrs["relpos.table27"] = rp
+    arrs["relpos.q14k14"] = rsam.get_rel_pos(14, 14, rp)
+    arrs["relpos.q8k8_interp"] = rsam.get_rel_pos(8, 8, rp)
+    arrs["relpos.q4k8"] = rsam.get_rel_pos(4, 8, rp[:15])
+    # window partition round trip 10x10 -> pad 12x12 (window 4) ; and 64->70 (window 14)
+    x = torch.randn(2, 10, 10, 8, generator=g)
+    w, pad = rsam.window_partition(x, 4)
+    arrs["win.x"], arrs["win.w"], arrs["win.pad"] = x, w, np.array(pad)
+    arrs["win.back"] = rsam.window_unpartition(w, 4, pad, (10, 10))
+    x64 = torch.randn(1, 64, 64, 2, generator=g)
+    w64, pad64 = rsam.window_partition(x64, 14)
+    arrs["win64.x"], arrs["win64.w"], arrs["win64.pad"] = x64, w64, np.array(pad64)
+    # Attention: global 8x8 with rel-pos, windowed 14x14 (d=80 like ViT-H: dim 160, 2 heads)
+    for tag, (B, H, W, dim, heads) in {"attn_g8": (2, 8, 8, 64, 2), "attn_w14": (3, 14, 14, 160, 2)}.items():
+        torch.manual_seed(71)
+        a = rsam.Attention(dim, num_heads=heads, qkv_bias=True, use_rel_pos=True, rel_pos_zero_init=False,
+                           input_size=(H, W))
+        a.rel_pos_h.data = torch.randn(a.rel_pos_h.shape, generator=g) * 0.2
+        a.rel_pos_w.data = torch.randn(a.rel_pos_w.shape, generator=g) * 0.2
+        xx = torch.randn(B, H, W, dim, generator=g)
+        arrs[f"{tag}.x"], arrs[f"{tag}.y"] = xx, a(xx)
+        arrs[f"{tag}.cfg"] = np.array([B, H, W, dim, heads])
+        arrs.update(sd_np(a, f"{tag}.w."))
+    # Block: windowed with padding (10x10 tokens, window 4) and global
+    for tag, ws in {"blk_win": 4, "blk_glob": 0}.items():
+        torch.manual_seed(72)
+        b = rsam.Block(64, 2, use_rel_pos=True, rel_pos_zero_init=False, window_size=ws, input_size=(10, 10),
+                       norm_layer=lambda d: nn.LayerNorm(d, eps=1e-6))
+        b.attn.rel_pos_h.data = torch.randn(b.attn.rel_pos_h.shape, generator=g) * 0.2
+        b.attn.rel_pos_w.data = torch.randn(b.attn.rel_pos_w.shape, generator=g) * 0.2
+        randomize_norm_affine(b, g)
+        xx = torch.randn(2, 10, 10, 64, generator=g)
+        arrs[f"{tag}.x"], arrs[f"{tag}.y"] = xx, b(xx)
+        arrs.update(sd_np(b, f"{tag}.w."))
+    # tiny encoder: 80x80 image, patch 8 -> 10x10 tokens, depth 2 (block 0 windowed w=4, block 1 global)
+    torch.manual_seed(73)
+    enc = rsam.ImageEncoderViT(img_size=80, patch_size=8, in_chans=3, embed_dim=64, depth=2, num_heads=2,
+                               mlp_ratio=4.0, out_chans=32, qkv_bias=True,
+                               norm_layer=lambda d: nn.LayerNorm(d, eps=1e-6), use_abs_pos=True, use_rel_pos=True,
+                               rel_pos_zero_init=False, window_size=4, global_attn_indexes=(1,))
+    for p in enc.parameters():
+        if p.abs().sum() == 0:
+            p.data = torch.randn(p.shape, generator=g) * 0.1
+    randomize_norm_affine(enc, g)
+    img = torch.randn(2, 3, 80, 80, generator=g)
+    arrs["enc.x"], arrs["enc.y"] = img, enc(img)
+    arrs.update(sd_np(enc, "enc.w."))
+    npz("sam_tiny", **arrs)
+
+
+@torch.no_grad()
+def gen_ldm_misc():
+    """GEGLU/gelu exactness + DiffusionWrapper conditioning-key switch (ddpm.py:1332-1363)."""
+    print("[misc]")
+    g = G(80)
+    x = torch.linspace(-6, 6, 97)
+    arrs = {"gelu.x": x, "gelu.y": torch.nn.functional.gelu(x), "silu.y": torch.nn.functional.silu(x)}
+    npz("misc", **arrs)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    gen_schedule()
+    gen_norms()
+    gen_attention()
+    gen_transformer()
+    gen_resblock()
+    gen_unet()
+    gen_ddim()
+    gen_sam()
+    gen_ldm_misc()
+    print("done")
