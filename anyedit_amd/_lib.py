@@ -1,0 +1,83 @@
+"""ctypes binding of libanyedit_hip.so (include/anyedit_hip.h).
+
+There is NO fallback: if the HIP extension is missing or fails to load, importing this module raises.
+`import torch` happens first on purpose: the extension must bind to the same libamdhip64 the torch
+allocator/streams live in (one HIP runtime per process).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libanyedit_hip.so")
+
+c_void_p, c_int, c_long, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/anyedit_hip.h 1:1
+SIGNATURES = {
+    "ae_version": [],
+    "ae_last_error": [],
+    "ae_device_arch": [ctypes.c_char_p, c_int],
+    "ae_device_info": [ctypes.POINTER(c_int), ctypes.POINTER(c_long), ctypes.POINTER(c_int)],
+    "ae_gemm_bf16": [c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int,
+                     c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_void_p],
+    "ae_conv3x3_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                        c_int, c_int, c_void_p],
+    "ae_groupnorm_rows_per_chunk": [c_int],
+    "ae_groupnorm_workspace_floats": [c_int, c_int, c_int],
+    "ae_groupnorm_nhwc_bf16": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                               c_int, c_void_p, c_void_p],
+    "ae_layernorm_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "ae_attn_fwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                         c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long,
+                         c_float, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "ae_transpose_last2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "ae_concat_channels_bf16": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_void_p],
+    "ae_timestep_embedding": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "ae_ddim_step_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_float, c_float,
+                         c_float, c_float, c_float, c_float, c_float, c_void_p],
+    "ae_mask_blend_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_void_p],
+    "ae_q_sample_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p],
+    "ae_silu_to_bf16": [c_void_p, c_int, c_void_p, c_long, c_void_p],
+    "ae_add_bcast_bf16": [c_void_p, c_void_p, c_void_p, c_long, c_long, c_void_p],
+    "ae_window_partition_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "ae_sam_relpos_terms": [c_void_p, c_long, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                            c_int, c_int, c_int, c_void_p],
+    "ae_patchify_f32_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "ae_mse_f32": [c_void_p, c_void_p, c_void_p, c_long, c_void_p],
+    "ae_task_gate": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+}
+_RESTYPES = {"ae_last_error": ctypes.c_char_p, "ae_groupnorm_workspace_floats": c_long}
+
+
+class AnyEditHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is REQUIRED (no CPU/eager fallback exists). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or `python anyedit_amd/build.py`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.ae_last_error()
+        raise AnyEditHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def device_arch():
+    buf = ctypes.create_string_buffer(128)
+    check(lib.ae_device_arch(buf, 128), "ae_device_arch")
+    return buf.value.decode()

@@ -1,0 +1,67 @@
+"""Builds anyedit_amd/libanyedit_hip.so (gfx950 code object) IN-TREE with hipcc.
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the gpurun snapshot.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libanyedit_hip.so")
+SOURCES = ["c_api.hip", "gemm_conv.hip", "attention.hip", "norm.hip", "elementwise.hip", "gate.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+
+
+def _digest():
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build_library(force=False, verbose=True):
+    stamp = LIB + ".sha256"
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = _hipcc()
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    objs = []
+    for src, obj, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    with open(stamp, "w") as f:
+        f.write(dig)
+    if verbose:
+        print(f"built {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)

@@ -1,0 +1,328 @@
+// Fused multi-head attention forward for gfx950 (MI355X): out = softmax(q k^T * scale + bias) v
+//
+// Replaces:
+//   A1/A2  ldm/modules/attention.py:163-194  CrossAttention.forward (self + cross; fp32 logits, optional bool mask)
+//          and the xformers call it swaps in at attention.py:222-233;
+//   A10    segment_anything/.../image_encoder.py:224-240 Attention.forward with the decomposed relative-position
+//          bias of :325-361 added as rel_h[q, key/kW] + rel_w[q, key%kW] (computed from the UNSCALED q, G13).
+//
+// Design (wave64, flash-style online softmax, never materialises the [N,N] logits):
+//   * 256 threads = 4 waves; each wave owns 16*QF query rows and keeps Q in registers as MFMA operands;
+//   * K/V are streamed in 64-key tiles through LDS, global loads issued one tile ahead (register staged);
+//   * logits are computed TRANSPOSED, S^T = K Q^T with v_mfma_f32_16x16x32_bf16, so a lane holds 16 logits of
+//     ONE query row per tile: row max / row sum need 2 cross-lane steps, and the exponentiated P registers are
+//     already laid out as the B operand of the O^T = V^T P^T MFMA (contraction slots permuted consistently on
+//     both operands -> no cross-lane traffic for P);
+//   * V is transposed while it is written to LDS (key index permuted so each lane's 8 contraction slots are one
+//     16-byte ds_read_b128);
+//   * head_dim is padded inside the kernel (40 -> 64 for QK^T, 48 for PV); q/k/v/out are addressed through
+//     (batch, head, row) strides, so the 'b n (h d) -> (b h) n d' rearranges of the reference never happen;
+//   * softmax in fp32, exp2 domain; bf16 P; fp32 accumulation of O.
+#include "common.hpp"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int KT = 64;  // keys per tile
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG_BIG = -1.0e30f;  // finite "masked" logit: behaves like masked_fill(-finfo.max) (attention.py:186-187)
+
+struct AttnArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
+    int B, H, Nq, Nk;
+    long q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, v_sb, v_sh, v_sn, o_sb, o_sh, o_sn;
+    float scale;
+    const float* rel_h; const float* rel_w; int kH, kW;  // optional decomposed bias, fp32 [B*H, Nq, kH|kW]
+    const uint8_t* key_mask;                               // optional [B, Nk], 0 = masked
+};
+
+__device__ __forceinline__ int vt_pos(int key) {  // key = 16 f + 4 g + r  ->  16 g + 4 f + r
+    return ((key >> 2) & 3) * 16 + (key >> 4) * 4 + (key & 3);
+}
+
+template <int D, int QF, bool HAS_BIAS>
+__global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
+    constexpr int DQK = (D + 31) / 32 * 32;
+    constexpr int DV = (D + 15) / 16 * 16;
+    constexpr int NC = DQK / 32;   // QK^T MFMAs per (key frag, q frag)
+    constexpr int NDF = DV / 16;   // 16-row fragments of O^T
+    constexpr int DCH = D / 8;     // 16-byte chunks per K/V row
+    constexpr int KROW = DQK + 8;  // LDS row strides (elements), +16 B pad
+    constexpr int VROW = KT + 8;
+    constexpr int KCH = (KT * DCH + NT - 1) / NT;
+    constexpr int VCH = ((KT / 2) * DCH + NT - 1) / NT;
+    static_assert(D % 8 == 0, "head_dim must be a multiple of 8");
+
+    __shared__ __attribute__((aligned(16))) bf16_t sK[KT * KROW];
+    __shared__ __attribute__((aligned(16))) bf16_t sVt[DV * VROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    constexpr int QB = 4 * 16 * QF;  // query rows per block
+    const int nqb = (p.Nq + QB - 1) / QB;
+    const int vb = xcd_remap(blockIdx.x, nqb * p.B * p.H);
+    const int bh = vb / nqb, qb = vb % nqb;
+    const int b = bh / p.H, h = bh % p.H;
+    const int q0 = qb * QB + wave * 16 * QF;
+
+    const bf16_t* qp = p.q + (long)b * p.q_sb + (long)h * p.q_sh;
+    const bf16_t* kp = p.k + (long)b * p.k_sb + (long)h * p.k_sh;
+    const bf16_t* vp = p.v + (long)b * p.v_sb + (long)h * p.v_sh;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    // zero the pad columns of K (d in [D, DQK)) and pad rows of V^T (d in [D, DV)) once
+    if (DQK > D) {
+        for (int i = tid; i < KT * (DQK - D); i += NT) sK[(i / (DQK - D)) * KROW + D + i % (DQK - D)] = 0;
+    }
+    if (DV > D) {
+        for (int i = tid; i < (DV - D) * VROW; i += NT) sVt[D * VROW + i] = 0;
+    }
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane (q = l15, g) holds Q[q][32c + 8g .. +8]
+    bf16x8_t qf[QF][NC];
+#pragma unroll
+    for (int a = 0; a < QF; ++a) {
+        const int qrow = q0 + a * 16 + l15;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int d = c * 32 + lg * 8;
+            u32x4 t = zero4;
+            if (qrow < p.Nq && d < D) t = *reinterpret_cast<const u32x4*>(qp + (long)qrow * p.q_sn + d);
+            qf[a][c] = as_bf16x8(t);
+        }
+    }
+
+    f32x4 o[QF][NDF];
+    float m_run[QF], l_run[QF];
+#pragma unroll
+    for (int a = 0; a < QF; ++a) {
+        m_run[a] = NEG_BIG;
+        l_run[a] = 0.f;
+#pragma unroll
+        for (int df = 0; df < NDF; ++df) o[a][df] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    u32x4 rk[KCH], rv[VCH][2];
+    auto load_kv = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int id = tid + i * NT;
+            const int key = id / DCH, c = id - key * DCH;
+            rk[i] = (id < KT * DCH && k0 + key < p.Nk)
+                        ? *reinterpret_cast<const u32x4*>(kp + (long)(k0 + key) * p.k_sn + c * 8) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            const int id = tid + i * NT;
+            const int pr = id / DCH, c = id - pr * DCH;
+            const int key = 2 * pr;
+            const bool in = id < (KT / 2) * DCH;
+            rv[i][0] = (in && k0 + key < p.Nk) ? *reinterpret_cast<const u32x4*>(vp + (long)(k0 + key) * p.v_sn + c * 8) : zero4;
+            rv[i][1] = (in && k0 + key + 1 < p.Nk) ? *reinterpret_cast<const u32x4*>(vp + (long)(k0 + key + 1) * p.v_sn + c * 8) : zero4;
+        }
+    };
+    auto store_kv = [&]() {
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int id = tid + i * NT;
+            const int key = id / DCH, c = id - key * DCH;
+            if (id < KT * DCH) *reinterpret_cast<u32x4*>(sK + key * KROW + c * 8) = rk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            const int id = tid + i * NT;
+            const int pr = id / DCH, c = id - pr * DCH;
+            if (id < (KT / 2) * DCH) {
+                const int pos = vt_pos(2 * pr);  // even; key 2pr+1 lands at pos+1
+                const uint32_t a0[4] = {rv[i][0].x, rv[i][0].y, rv[i][0].z, rv[i][0].w};
+                const uint32_t a1[4] = {rv[i][1].x, rv[i][1].y, rv[i][1].z, rv[i][1].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // d = c*8 + 2e (low halves) and c*8 + 2e + 1 (high halves)
+                    const uint32_t lo = (a0[e] & 0xffffu) | (a1[e] << 16);
+                    const uint32_t hi = (a0[e] >> 16) | (a1[e] & 0xffff0000u);
+                    *reinterpret_cast<uint32_t*>(sVt + (c * 8 + 2 * e) * VROW + pos) = lo;
+                    *reinterpret_cast<uint32_t*>(sVt + (c * 8 + 2 * e + 1) * VROW + pos) = hi;
+                }
+            }
+        }
+    };
+
+    const float c2 = p.scale * LOG2E;
+    const int ntiles = (p.Nk + KT - 1) / KT;
+    load_kv(0);
+    __syncthreads();  // pad zero-fill visible / ordered before the first tile write (disjoint addresses, cheap)
+    store_kv();
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * KT;
+        if (t + 1 < ntiles) load_kv(k0 + KT);
+
+        // ---- S^T = K Q^T : lane holds S^T[key = 16f + 4g + r][q = l15] --------------------------
+        f32x4 s[QF][4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+#pragma unroll
+            for (int a = 0; a < QF; ++a) s[a][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const bf16x8_t kf = as_bf16x8(*reinterpret_cast<const u32x4*>(sK + (f * 16 + l15) * KROW + c * 32 + lg * 8));
+#pragma unroll
+                for (int a = 0; a < QF; ++a) s[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[a][c], s[a][f], 0, 0, 0);
+            }
+        }
+
+        // ---- online softmax (fp32, exp2 domain) ---------------------------------------------------
+        const bool tail = (k0 + KT > p.Nk);
+        bf16x8_t pb[QF][2];
+#pragma unroll
+        for (int a = 0; a < QF; ++a) {
+            const int qrow = q0 + a * 16 + l15;
+            const int qc = qrow < p.Nq ? qrow : p.Nq - 1;
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int kb = k0 + f * 16 + lg * 4;
+                float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (HAS_BIAS) {
+                    const float* rh = p.rel_h + ((long)bh * p.Nq + qc) * p.kH;
+                    const float* rw = p.rel_w + ((long)bh * p.Nq + qc) * p.kW;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kb + r;
+                        if (key < p.Nk) {
+                            const int khh = key / p.kW;
+                            bias4[r] = (rh[khh] + rw[key - khh * p.kW]) * LOG2E;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = s[a][f][r] * c2 + bias4[r];
+                    const int key = kb + r;
+                    if (p.key_mask && key < p.Nk && p.key_mask[(long)b * p.Nk + key] == 0) v = NEG_BIG;
+                    if (tail && key >= p.Nk) v = NEG_BIG;
+                    s[a][f][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[a], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[a] - m_new);
+            m_run[a] = m_new;
+            float rs = 0.f;
+            float pv[4][4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float e = __builtin_amdgcn_exp2f(s[a][f][r] - m_new);
+                    if (tail && (k0 + f * 16 + lg * 4 + r) >= p.Nk) e = 0.f;
+                    pv[f][r] = e;
+                    rs += e;
+                }
+            l_run[a] = l_run[a] * alpha + rs;
+#pragma unroll
+            for (int df = 0; df < NDF; ++df) {
+                o[a][df][0] *= alpha; o[a][df][1] *= alpha; o[a][df][2] *= alpha; o[a][df][3] *= alpha;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                u32x4 w;
+                w.x = pack_bf16x2(pv[2 * j][0], pv[2 * j][1]);
+                w.y = pack_bf16x2(pv[2 * j][2], pv[2 * j][3]);
+                w.z = pack_bf16x2(pv[2 * j + 1][0], pv[2 * j + 1][1]);
+                w.w = pack_bf16x2(pv[2 * j + 1][2], pv[2 * j + 1][3]);
+                pb[a][j] = as_bf16x8(w);
+            }
+        }
+
+        // ---- O^T += V^T P^T : lane holds O^T[d = 16 df + 4g + r][q = l15] -------------------------
+#pragma unroll
+        for (int df = 0; df < NDF; ++df) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8_t vf = as_bf16x8(*reinterpret_cast<const u32x4*>(sVt + (df * 16 + l15) * VROW + lg * 16 + j * 8));
+#pragma unroll
+                for (int a = 0; a < QF; ++a) o[a][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[a][j], o[a][df], 0, 0, 0);
+            }
+        }
+
+        __syncthreads();  // every wave is done reading this tile
+        if (t + 1 < ntiles) {
+            store_kv();
+            __syncthreads();
+        }
+    }
+
+    // ---- normalise and store: 4 consecutive d per lane -> 8-byte stores ------------------------------
+    bf16_t* op = p.o + (long)b * p.o_sb + (long)h * p.o_sh;
+#pragma unroll
+    for (int a = 0; a < QF; ++a) {
+        float l = l_run[a];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int qrow = q0 + a * 16 + l15;
+        if (qrow >= p.Nq) continue;
+#pragma unroll
+        for (int df = 0; df < NDF; ++df) {
+            const int d = df * 16 + lg * 4;
+            if (d < D) {
+                u32x2 pk = {pack_bf16x2(o[a][df][0] * inv, o[a][df][1] * inv), pack_bf16x2(o[a][df][2] * inv, o[a][df][3] * inv)};
+                *reinterpret_cast<u32x2*>(op + (long)qrow * p.o_sn + d) = pk;
+            }
+        }
+    }
+}
+
+template <int D, int QF>
+int launch_attn(const AttnArgs& a, hipStream_t stream) {
+    constexpr int QB = 4 * 16 * QF;
+    const long blocks = (long)((a.Nq + QB - 1) / QB) * a.B * a.H;
+    dim3 grid((unsigned)blocks), block(NT);
+    if (a.rel_h) hipLaunchKernelGGL((attn_kernel<D, QF, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((attn_kernel<D, QF, false>), grid, block, 0, stream, a);
+    return ae_check_launch("ae_attn_fwd_bf16");
+}
+
+}  // namespace
+
+extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int D,
+                                long q_sb, long q_sh, long q_sn, long k_sb, long k_sh, long k_sn,
+                                long v_sb, long v_sh, long v_sn, long o_sb, long o_sh, long o_sn, float scale,
+                                const float* rel_h, const float* rel_w, int kH, int kW, const unsigned char* key_mask,
+                                void* stream) {
+    AE_REQUIRE(q && k && v && out, "ae_attn_fwd_bf16: null pointer");
+    AE_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0, "ae_attn_fwd_bf16: bad sizes B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
+    AE_REQUIRE((q_sb | q_sh | q_sn | k_sb | k_sh | k_sn | v_sb | v_sh | v_sn) % 8 == 0 && (o_sb | o_sh | o_sn) % 4 == 0,
+               "ae_attn_fwd_bf16: strides must keep rows 16-byte aligned");
+    AE_REQUIRE(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0 && ((uintptr_t)out & 7) == 0,
+               "ae_attn_fwd_bf16: pointers must be 16-byte aligned");
+    AE_REQUIRE((rel_h == nullptr) == (rel_w == nullptr), "ae_attn_fwd_bf16: rel_h and rel_w go together");
+    if (rel_h) AE_REQUIRE(kH > 0 && kW > 0 && (long)kH * kW == Nk, "ae_attn_fwd_bf16: kH*kW must equal Nk");
+    AttnArgs a{};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)out;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk;
+    a.q_sb = q_sb; a.q_sh = q_sh; a.q_sn = q_sn; a.k_sb = k_sb; a.k_sh = k_sh; a.k_sn = k_sn;
+    a.v_sb = v_sb; a.v_sh = v_sh; a.v_sn = v_sn; a.o_sb = o_sb; a.o_sh = o_sh; a.o_sn = o_sn;
+    a.scale = scale; a.rel_h = rel_h; a.rel_w = rel_w; a.kH = kH; a.kW = kW; a.key_mask = key_mask;
+    hipStream_t s = (hipStream_t)stream;
+    switch (D) {
+        case 8: return launch_attn<8, 2>(a, s);
+        case 16: return launch_attn<16, 2>(a, s);
+        case 32: return launch_attn<32, 2>(a, s);
+        case 40: return launch_attn<40, 2>(a, s);
+        case 48: return launch_attn<48, 2>(a, s);
+        case 64: return launch_attn<64, 2>(a, s);
+        case 80: return launch_attn<80, 2>(a, s);
+        case 96: return launch_attn<96, 2>(a, s);
+        case 128: return launch_attn<128, 2>(a, s);
+        case 160: return launch_attn<160, 2>(a, s);
+        default:
+            ae_set_error("ae_attn_fwd_bf16: unsupported head_dim %d (supported: 8,16,32,40,48,64,80,96,128,160)", D);
+            return AE_ERR_UNSUPPORTED;
+    }
+}

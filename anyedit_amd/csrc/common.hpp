@@ -1,0 +1,75 @@
+// anyedit_amd — shared device/host helpers for the gfx950 (CDNA4, wave64) kernels.
+// No CUDA compatibility layer, no dual paths: this code targets MI355X only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits (storage type at the C ABI)
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // MFMA 16x16x32 A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4;       // MFMA 16x16 accumulator fragment
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;    // 16-byte global/LDS transaction
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define AE_OK 0
+#define AE_ERR_ARG -1
+#define AE_ERR_LAUNCH -2
+#define AE_ERR_UNSUPPORTED -3
+
+// error plumbing (c_api.hip)
+void ae_set_error(const char* fmt, ...);
+int ae_check_launch(const char* what);
+
+#define AE_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            ae_set_error(__VA_ARGS__);        \
+            return AE_ERR_ARG;                \
+        }                                     \
+    } while (0)
+
+// ---------------------------------------------------------------- bf16 <-> f32
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round-to-nearest-even, NaN preserved
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ bf16x8_t as_bf16x8(u32x4 v) {
+    union { u32x4 u; bf16x8_t b; } c;
+    c.u = v;
+    return c.b;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// XCD-aware, bijective block remap: hardware places block b on XCD b % 8.  Give every XCD a contiguous
+// run of logical tile ids so neighbouring tiles (which share operand panels) hit the same private L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int NX = 8;
+    int xcd = bid % NX, j = bid / NX;
+    int q = nblocks / NX, r = nblocks % NX;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + j;
+}
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

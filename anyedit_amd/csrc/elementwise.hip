@@ -1,0 +1,327 @@
+// Elementwise / data-movement kernels of the denoising loop for gfx950 — all HBM- or latency-bound.
+//
+// Replaces:
+//   A7  timestep_embedding (ldm/modules/diffusionmodules/util.py:154-174, [cos, sin] order), layout changes at the
+//       UNet boundary (NCHW fp32 <-> channels-last bf16), th.cat skip-concat (openaimodel.py:780);
+//   A8  p_sample_ddim arithmetic (ldm/models/diffusion/ddim.py:211-212, 228-250) fused with the CFG combine
+//       (2-branch ddim.py:211-212 or 3-branch InstructPix2Pix global_tool.py:172-177), q_sample (ddpm.py:356-359)
+//       and the masked-latent blend (ddim.py:154-157 / global_tool.py:183-184);
+//   A10 SAM window_partition / window_unpartition (image_encoder.py:243-289), decomposed rel-pos terms (:325-355),
+//       PatchEmbed im2col (:364-395);
+//   A11 eps-MSE reduction (train.py:696).
+// The DDIM update is compiled with fp contraction OFF so that, given the same eps, it is bit-identical to the
+// reference's unfused fp32 torch expression sequence.
+#include "common.hpp"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float ld_any(const void* p, long i, int is_bf16) {
+    return is_bf16 ? bf16_to_f32(reinterpret_cast<const bf16_t*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void st_any(void* p, long i, float v, int is_bf16) {
+    if (is_bf16) reinterpret_cast<bf16_t*>(p)[i] = f32_to_bf16(v);
+    else reinterpret_cast<float*>(p)[i] = v;
+}
+
+// out[b, y, x] = in[b, x, y] for x < X, zero for X <= x < Xpad.  32x32 LDS tile, coalesced both ways.
+__global__ void transpose_kernel(const void* in, void* out, int X, int Y, int Xpad, int in_bf16, int out_bf16) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int x = x0 + j, y = y0 + tx;
+        tile[j][tx] = (x < X && y < Y) ? ld_any(in, ((long)b * X + x) * Y + y, in_bf16) : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int y = y0 + j, x = x0 + tx;
+        if (y < Y && x < Xpad) st_any(out, ((long)b * Y + y) * Xpad + x, tile[tx][j], out_bf16);
+    }
+}
+
+__global__ void concat_kernel(const bf16_t* a, int Ca, const bf16_t* b, int Cb, bf16_t* y, long rows) {
+    const int C = Ca + Cb, ncc = C / 8;
+    const long total = rows * ncc;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long r = i / ncc;
+        const int ch = (int)(i % ncc) * 8;
+        const u32x4 v = ch < Ca ? *reinterpret_cast<const u32x4*>(a + r * Ca + ch) : *reinterpret_cast<const u32x4*>(b + r * Cb + (ch - Ca));
+        *reinterpret_cast<u32x4*>(y + r * C + ch) = v;
+    }
+}
+
+__global__ void timestep_embedding_kernel(const long* t_i64, const float* t_f32, bf16_t* out_bf16, float* out_f32, int B,
+                                          int dim, float max_period) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= B * dim) return;
+    const int b = i / dim, j = i % dim;
+    const float t = t_i64 ? (float)t_i64[b] : t_f32[b];
+    float v = 0.f;
+    if (j < 2 * half) {
+        const int k = j < half ? j : j - half;
+        const float freq = expf(-logf(max_period) * (float)k / (float)half);
+        const float arg = t * freq;
+        v = j < half ? cosf(arg) : sinf(arg);
+    }
+    if (out_bf16) out_bf16[i] = f32_to_bf16(v);
+    if (out_f32) out_f32[i] = v;
+}
+
+struct DdimArgs {
+    const float* x; const float* eps; const float* noise; float* x_prev; float* pred_x0; float* e_out;
+    long n;         // elements per branch = B*C*H*W
+    int branches;   // 1, 2 (uncond, cond) or 3 (text, image, uncond)
+    float s0, s1;   // 2-branch: s0 = scale ; 3-branch: s0 = s_txt, s1 = s_img
+    float sqrt_one_minus_at, sqrt_at, sqrt_a_prev, dir_coef, sigma_t, temperature;
+};
+
+#pragma clang fp contract(off)
+__global__ void ddim_step_kernel(const DdimArgs p) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < p.n; i += (long)gridDim.x * NT) {
+        float e;
+        if (p.branches == 1) {
+            e = p.eps[i];
+        } else if (p.branches == 2) {  // ddim.py:211-212: e_uncond + s * (e_cond - e_uncond); batch order [uncond, cond]
+            const float eu = p.eps[i], ec = p.eps[p.n + i];
+            e = eu + p.s0 * (ec - eu);
+        } else {  // global_tool.py:172-177; batch order [text, image, uncond]
+            const float et = p.eps[i], ei = p.eps[p.n + i], eu = p.eps[2 * p.n + i];
+            e = eu + p.s0 * (et - ei) + p.s1 * (ei - eu);
+        }
+        const float x = p.x[i];
+        const float px0 = (x - p.sqrt_one_minus_at * e) / p.sqrt_at;          // ddim.py:235
+        const float dir = p.dir_coef * e;                                     // ddim.py:246
+        const float nz = p.sigma_t * (p.noise ? p.noise[i] : 0.f) * p.temperature;  // ddim.py:247
+        p.x_prev[i] = p.sqrt_a_prev * px0 + dir + nz;                         // ddim.py:250
+        if (p.pred_x0) p.pred_x0[i] = px0;
+        if (p.e_out) p.e_out[i] = e;
+    }
+}
+
+// out = (sa*x0 + s1*noise) * mask + (1 - mask) * img   (ddim.py:154-157 with q_sample ddpm.py:356-359);
+// mask is [B,1,H,W] broadcast over C.  order!=0 -> IP2P order: img*mask + q*(1-mask) (global_tool.py:183-184)
+__global__ void mask_blend_kernel(const float* img, const float* x0, const float* noise, const float* mask, float* out,
+                                  long n, int C, int HW, float sa, float s1, int ip2p_order) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const long b = i / ((long)C * HW);
+        const int hw = (int)(i % HW);
+        const float m = mask[b * HW + hw];
+        const float q = sa * x0[i] + s1 * noise[i];
+        out[i] = ip2p_order ? (img[i] * m + q * (1.f - m)) : (q * m + (1.f - m) * img[i]);
+    }
+}
+
+__global__ void q_sample_kernel(const float* x0, const float* noise, const float* sa, const float* s1, float* out, long per_sample,
+                                long n) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const long b = i / per_sample;
+        out[i] = sa[b] * x0[i] + s1[b] * noise[i];
+    }
+}
+#pragma clang fp contract(fast)
+
+__global__ void add_bcast_kernel(const bf16_t* x, const bf16_t* p, bf16_t* y, long n, long period) {
+    for (long i = ((long)blockIdx.x * NT + threadIdx.x) * 8; i < n; i += (long)gridDim.x * NT * 8) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(x + i);
+        const u32x4 b = *reinterpret_cast<const u32x4*>(p + (i % period));
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(bf16lo(aw[e]) + bf16lo(bw[e]), bf16hi(aw[e]) + bf16hi(bw[e]));
+        *reinterpret_cast<u32x4*>(y + i) = (u32x4){o[0], o[1], o[2], o[3]};
+    }
+}
+
+__global__ void silu_kernel(const void* x, int in_bf16, bf16_t* y, long n) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) y[i] = f32_to_bf16(silu_f(ld_any(x, i, in_bf16)));
+}
+
+// x [B,H,W,C] -> windows [B*nH*nW, ws, ws, C], zero padded bottom/right (image_encoder.py:243-264); reverse drops padding.
+__global__ void window_kernel(const bf16_t* src, bf16_t* dst, int B, int H, int W, int C, int ws, int nH, int nW, int reverse) {
+    const int ncc = C / 8;
+    const long total = (long)B * nH * nW * ws * ws * ncc;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int cc = (int)(i % ncc);
+        long r = i / ncc;
+        const int wx = (int)(r % ws); r /= ws;
+        const int wy = (int)(r % ws); r /= ws;
+        const int jw = (int)(r % nW); r /= nW;
+        const int jh = (int)(r % nH); r /= nH;
+        const int b = (int)r;
+        const int y = jh * ws + wy, x = jw * ws + wx;
+        const bool in = y < H && x < W;
+        const long img_off = (((long)b * H + y) * W + x) * C + cc * 8;
+        const long win_off = (i / ncc) * C + cc * 8;
+        if (!reverse) {
+            *reinterpret_cast<u32x4*>(dst + win_off) = in ? *reinterpret_cast<const u32x4*>(src + img_off) : zero4;
+        } else if (in) {
+            *reinterpret_cast<u32x4*>(dst + img_off) = *reinterpret_cast<const u32x4*>(src + win_off);
+        }
+    }
+}
+
+// rel_h[bh, y*W+x, kh] = sum_c q[b, y*W+x, h, c] * Rh[y, kh, c] ; rel_w[bh, y*W+x, kw] = sum_c q[...] * Rw[x, kw, c]
+// (image_encoder.py:349-355).  q addressed by (batch, head, row) strides; Rh/Rw fp32 [qH, kH, D] / [qW, kW, D].
+__global__ void relpos_kernel(const bf16_t* q, long q_sb, long q_sh, long q_sn, const float* Rh, const float* Rw, float* rel_h,
+                              float* rel_w, int B, int Hh, int qH, int qW, int kH, int kW, int D) {
+    extern __shared__ float qs[];  // [D]
+    const int bh = blockIdx.y, n = blockIdx.x;
+    const int b = bh / Hh, h = bh % Hh;
+    const int y = n / qW, x = n % qW;
+    const bf16_t* qr = q + (long)b * q_sb + (long)h * q_sh + (long)n * q_sn;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) qs[c] = bf16_to_f32(qr[c]);
+    __syncthreads();
+    const long N = (long)qH * qW;
+    for (int k = threadIdx.x; k < kH + kW; k += blockDim.x) {
+        const float* R = k < kH ? Rh + ((long)y * kH + k) * D : Rw + ((long)x * kW + (k - kH)) * D;
+        float acc = 0.f;
+        for (int c = 0; c < D; ++c) acc += qs[c] * R[c];
+        if (k < kH) rel_h[((long)bh * N + n) * kH + k] = acc;
+        else rel_w[((long)bh * N + n) * kW + (k - kH)] = acc;
+    }
+}
+
+// PatchEmbed im2col: x [B,Cin,H,W] fp32 -> patches [B*(H/P)*(W/P), Cin*P*P] bf16, K order (c, ky, kx) = conv weight order
+__global__ void patchify_kernel(const float* x, bf16_t* y, int B, int Cin, int H, int W, int P) {
+    const int gh = H / P, gw = W / P, K = Cin * P * P;
+    const long total = (long)B * gh * gw * K;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int k = (int)(i % K);
+        long r = i / K;
+        const int px = (int)(r % gw); r /= gw;
+        const int py = (int)(r % gh); r /= gh;
+        const int b = (int)r;
+        const int c = k / (P * P), kk = k % (P * P), ky = kk / P, kx = kk % P;
+        y[i] = f32_to_bf16(x[(((long)b * Cin + c) * H + py * P + ky) * W + px * P + kx]);
+    }
+}
+
+// sum((a-b)^2) -> out[0] via one atomicAdd per block (caller zeroes out first; scaled by inv_n)
+__global__ void mse_kernel(const float* a, const float* b, float* out, long n, float inv_n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const float d = a[i] - b[i];
+        s += d * d;
+    }
+    s = wave_reduce_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+}
+
+inline unsigned grid_for(long n, int per_thread = 1) {
+    long b = (n + (long)NT * per_thread - 1) / ((long)NT * per_thread);
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int ae_transpose_last2(const void* in, void* out, int B, int X, int Y, int Xpad, int in_bf16, int out_bf16, void* stream) {
+    AE_REQUIRE(in && out && B > 0 && X > 0 && Y > 0 && Xpad >= X, "ae_transpose_last2: bad arguments");
+    AE_REQUIRE(B <= 65535, "ae_transpose_last2: batch %d too large", B);
+    dim3 grid((Xpad + 31) / 32, (Y + 31) / 32, B);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, X, Y, Xpad, in_bf16, out_bf16);
+    return ae_check_launch("ae_transpose_last2");
+}
+
+extern "C" int ae_concat_channels_bf16(const void* a, int Ca, const void* b, int Cb, void* y, long rows, void* stream) {
+    AE_REQUIRE(a && b && y && rows > 0 && Ca > 0 && Cb > 0 && Ca % 8 == 0 && Cb % 8 == 0, "ae_concat_channels_bf16: bad arguments");
+    hipLaunchKernelGGL(concat_kernel, dim3(grid_for(rows * ((Ca + Cb) / 8))), dim3(NT), 0, (hipStream_t)stream,
+                       (const bf16_t*)a, Ca, (const bf16_t*)b, Cb, (bf16_t*)y, rows);
+    return ae_check_launch("ae_concat_channels_bf16");
+}
+
+extern "C" int ae_timestep_embedding(const long* t_i64, const float* t_f32, void* out_bf16, float* out_f32, int B, int dim,
+                                     float max_period, void* stream) {
+    AE_REQUIRE((t_i64 != nullptr) != (t_f32 != nullptr), "ae_timestep_embedding: pass exactly one of t_i64 / t_f32");
+    AE_REQUIRE((out_bf16 || out_f32) && B > 0 && dim > 1, "ae_timestep_embedding: bad arguments");
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((B * dim + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, t_i64, t_f32,
+                       (bf16_t*)out_bf16, out_f32, B, dim, max_period);
+    return ae_check_launch("ae_timestep_embedding");
+}
+
+extern "C" int ae_ddim_step_f32(const float* x, const float* eps, const float* noise, float* x_prev, float* pred_x0, float* e_out,
+                                long n, int branches, float s0, float s1, float sqrt_one_minus_at, float sqrt_at,
+                                float sqrt_a_prev, float dir_coef, float sigma_t, float temperature, void* stream) {
+    AE_REQUIRE(x && eps && x_prev && n > 0, "ae_ddim_step_f32: null pointer / bad n");
+    AE_REQUIRE(branches >= 1 && branches <= 3, "ae_ddim_step_f32: branches must be 1, 2 or 3 (got %d)", branches);
+    DdimArgs a{x, eps, noise, x_prev, pred_x0, e_out, n, branches, s0, s1, sqrt_one_minus_at, sqrt_at, sqrt_a_prev, dir_coef, sigma_t, temperature};
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, a);
+    return ae_check_launch("ae_ddim_step_f32");
+}
+
+extern "C" int ae_mask_blend_f32(const float* img, const float* x0, const float* noise, const float* mask, float* out, int B,
+                                 int C, int HW, float sqrt_ac, float sqrt_one_minus_ac, int ip2p_order, void* stream) {
+    AE_REQUIRE(img && x0 && noise && mask && out && B > 0 && C > 0 && HW > 0, "ae_mask_blend_f32: bad arguments");
+    const long n = (long)B * C * HW;
+    hipLaunchKernelGGL(mask_blend_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, img, x0, noise, mask, out, n, C, HW,
+                       sqrt_ac, sqrt_one_minus_ac, ip2p_order);
+    return ae_check_launch("ae_mask_blend_f32");
+}
+
+extern "C" int ae_q_sample_f32(const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_one_minus_ac, float* out,
+                               int B, long per_sample, void* stream) {
+    AE_REQUIRE(x0 && noise && sqrt_ac && sqrt_one_minus_ac && out && B > 0 && per_sample > 0, "ae_q_sample_f32: bad arguments");
+    const long n = (long)B * per_sample;
+    hipLaunchKernelGGL(q_sample_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, x0, noise, sqrt_ac, sqrt_one_minus_ac, out,
+                       per_sample, n);
+    return ae_check_launch("ae_q_sample_f32");
+}
+
+extern "C" int ae_silu_to_bf16(const void* x, int in_bf16, void* y, long n, void* stream) {
+    AE_REQUIRE(x && y && n > 0, "ae_silu_to_bf16: bad arguments");
+    hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, x, in_bf16, (bf16_t*)y, n);
+    return ae_check_launch("ae_silu_to_bf16");
+}
+
+extern "C" int ae_add_bcast_bf16(const void* x, const void* p, void* y, long n, long period, void* stream) {
+    AE_REQUIRE(x && p && y && n > 0 && period > 0 && n % 8 == 0 && period % 8 == 0 && n % period == 0, "ae_add_bcast_bf16: bad arguments");
+    hipLaunchKernelGGL(add_bcast_kernel, dim3(grid_for(n, 8)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)p,
+                       (bf16_t*)y, n, period);
+    return ae_check_launch("ae_add_bcast_bf16");
+}
+
+extern "C" int ae_window_partition_bf16(const void* x, void* windows, int B, int H, int W, int C, int ws, int reverse, void* stream) {
+    AE_REQUIRE(x && windows && B > 0 && H > 0 && W > 0 && ws > 0 && C % 8 == 0, "ae_window_partition_bf16: bad arguments");
+    const int nH = (H + ws - 1) / ws, nW = (W + ws - 1) / ws;
+    const long total = (long)B * nH * nW * ws * ws * (C / 8);
+    // forward: x=image -> windows ; reverse: x=windows -> image (argument order stays (image, windows))
+    if (!reverse)
+        hipLaunchKernelGGL(window_kernel, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)windows, B, H, W, C, ws, nH, nW, 0);
+    else
+        hipLaunchKernelGGL(window_kernel, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)windows, (bf16_t*)x, B, H, W, C, ws, nH, nW, 1);
+    return ae_check_launch("ae_window_partition_bf16");
+}
+
+extern "C" int ae_sam_relpos_terms(const void* q, long q_sb, long q_sh, long q_sn, const float* Rh, const float* Rw, float* rel_h,
+                                   float* rel_w, int B, int heads, int qH, int qW, int kH, int kW, int D, void* stream) {
+    AE_REQUIRE(q && Rh && Rw && rel_h && rel_w && B > 0 && heads > 0 && D > 0, "ae_sam_relpos_terms: bad arguments");
+    AE_REQUIRE((long)B * heads <= 65535, "ae_sam_relpos_terms: B*heads too large for grid.y");
+    dim3 grid(qH * qW, B * heads);
+    hipLaunchKernelGGL(relpos_kernel, grid, dim3(128), D * sizeof(float), (hipStream_t)stream, (const bf16_t*)q, q_sb, q_sh, q_sn, Rh, Rw,
+                       rel_h, rel_w, B, heads, qH, qW, kH, kW, D);
+    return ae_check_launch("ae_sam_relpos_terms");
+}
+
+extern "C" int ae_patchify_f32_bf16(const float* x, void* y, int B, int Cin, int H, int W, int P, void* stream) {
+    AE_REQUIRE(x && y && B > 0 && Cin > 0 && P > 0 && H % P == 0 && W % P == 0, "ae_patchify_f32_bf16: bad arguments");
+    const long total = (long)B * Cin * H * W;
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, x, (bf16_t*)y, B, Cin, H, W, P);
+    return ae_check_launch("ae_patchify_f32_bf16");
+}
+
+extern "C" int ae_mse_f32(const float* a, const float* b, float* out, long n, void* stream) {
+    AE_REQUIRE(a && b && out && n > 0, "ae_mse_f32: bad arguments");
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) { ae_set_error("ae_mse_f32: memset failed: %s", hipGetErrorString(e)); return AE_ERR_LAUNCH; }
+    hipLaunchKernelGGL(mse_kernel, dim3(grid_for(n) > 1024 ? 1024 : grid_for(n)), dim3(NT), 0, (hipStream_t)stream, a, b, out, n, 1.0f / (float)n);
+    return ae_check_launch("ae_mse_f32");
+}

@@ -1,0 +1,302 @@
+// bf16 MFMA GEMM and implicit-GEMM 3x3 convolution for gfx950 (MI355X).
+//
+//   C[M,N] = epi( A[M,K] * W[N,K]^T )            A, W bf16 K-contiguous; fp32 accumulate
+//
+// Replaces: nn.Linear / 1x1 nn.Conv2d created through ldm/modules/diffusionmodules/util.py:202-238
+// (rows A1-A4), and the ResBlock / Downsample / Upsample 3x3 convolutions of openaimodel.py:108-118,157-159,254-274
+// (row A5) on channels-last activations, where conv3x3 is the same GEMM with an on-the-fly im2col gather
+// (M = B*Ho*Wo, K = 9*Cin ordered (ky,kx,cin)); stride-2 and nearest-x2 upsampling are folded into the gather.
+//
+// Structure (wave64, 256 threads = 2x2 waves):
+//   * block tile BM x BN x 64, double-buffered in LDS with a 16-byte-chunk XOR swizzle (conflict-free
+//     ds_read_b128 of MFMA fragments), register-staged global loads issued one K-tile ahead (issue-early /
+//     write-late), one barrier per K-tile;
+//   * v_mfma_f32_16x16x32_bf16 with the operands swapped (W fragment as the row operand) so each lane ends up
+//     with 4 consecutive output columns -> 8-byte bf16 stores;
+//   * fused epilogues: +bias, +per-(batch,channel) vector (time embedding), SiLU / exact-erf GELU / GEGLU gate,
+//     +residual, bf16 or fp32 output;
+//   * XCD-aware bijective tile remap so tiles sharing an A panel run on the same XCD's L2.
+#include "common.hpp"
+
+namespace {
+
+constexpr int BK = 64;  // 64 bf16 = 128 B per tile row = 8 chunks of 16 B
+constexpr int NT = 256;
+
+enum { A_DENSE = 0, A_CONV3 = 1 };
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GEGLU = 2, EPI_SILU = 3 };
+
+struct GemmArgs {
+    const bf16_t* A;
+    const bf16_t* A2;  // dense only: columns [Ksplit, K) come from A2 (channel-concat without a copy)
+    const bf16_t* W;
+    void* C;
+    const float* bias;
+    const bf16_t* res;
+    const float* addvec;
+    int M, N, K, Ksplit;
+    long lda, lda2, ldw, ldc, ldr;
+    int epi, out_f32, rows_per_batch;
+    int H, Wd, Cin, CinPad, Ho, Wo, stride, ups;  // conv3x3: Cin = channels in memory, CinPad = per-tap K extent
+};
+
+template <int BM, int BN, int AMODE>
+__global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
+    constexpr int FM = BM / 32, FN = BN / 32;  // 16x16 fragments per wave (waves tiled 2x2)
+    constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];
+    bf16_t* sA = smem;
+    bf16_t* sB = smem + 2 * BM * BK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+    const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+
+    // ---- per-thread staging descriptors -------------------------------------------------
+    bool a_ok[A_CH];
+    long a_base[A_CH];            // dense: element offset of (row, chunk) at k=0 ; conv: pixel base of the batch
+    int a_iy[A_CH], a_ix[A_CH];   // conv: top-left tap coordinate in the (virtual) input
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int id = tid + i * NT, row = id >> 3, c = id & 7;
+        const int m = m0 + row;
+        a_ok[i] = m < p.M;
+        if (AMODE == A_DENSE) {
+            a_base[i] = (long)m * p.lda + c * 8;
+            a_iy[i] = a_ix[i] = 0;
+        } else {
+            const int hw = p.Ho * p.Wo;
+            const int mm = a_ok[i] ? m : 0;
+            const int b = mm / hw, rem = mm - b * hw;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_base[i] = (long)b * p.H * p.Wd;
+            a_iy[i] = oy * p.stride - 1;
+            a_ix[i] = ox * p.stride - 1;
+        }
+    }
+    bool b_ok[B_CH];
+    long b_base[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        const int id = tid + i * NT, row = id >> 3, c = id & 7;
+        b_ok[i] = (n0 + row) < p.N;
+        b_base[i] = (long)(n0 + row) * p.ldw + c * 8;
+    }
+
+    u32x4 ra[A_CH], rb[B_CH];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const int KT = (p.K + BK - 1) / BK;
+    int ld_tap = 0, ld_ci = 0;  // conv: tap / channel offset of the NEXT tile to load
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        if (AMODE == A_DENSE) {
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                const int id = tid + i * NT, row = id >> 3, c = id & 7;
+                const int k = k0 + c * 8;
+                const bf16_t* src = (k >= p.Ksplit) ? p.A2 + (long)(m0 + row) * p.lda2 + (k - p.Ksplit) : p.A + a_base[i] + k0;
+                ra[i] = (a_ok[i] && k < p.K) ? *reinterpret_cast<const u32x4*>(src) : zero4;
+            }
+        } else {
+            const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
+            const int Hv = p.ups ? 2 * p.H : p.H, Wv = p.ups ? 2 * p.Wd : p.Wd;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                const int c = (tid + i * NT) & 7;
+                const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+                const int ci = ld_ci + c * 8;
+                const bool ok = a_ok[i] && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv && ci < p.Cin;
+                const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+                const bf16_t* src = p.A + (a_base[i] + (long)sy * p.Wd + sx) * p.Cin + ci;
+                ra[i] = ok ? *reinterpret_cast<const u32x4*>(src) : zero4;
+            }
+            ld_ci += BK;
+            if (ld_ci >= p.CinPad) { ld_ci = 0; ++ld_tap; }
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i)
+            rb[i] = (b_ok[i] && (k0 + (int)((tid + i * NT) & 7) * 8) < p.K) ? *reinterpret_cast<const u32x4*>(p.W + b_base[i] + k0) : zero4;
+    };
+
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int id = tid + i * NT, row = id >> 3, c = id & 7;
+            *reinterpret_cast<u32x4*>(sA + buf * BM * BK + row * BK + ((c ^ (row & 7)) << 3)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            const int id = tid + i * NT, row = id >> 3, c = id & 7;
+            *reinterpret_cast<u32x4*>(sB + buf * BN * BK + row * BK + ((c ^ (row & 7)) << 3)) = rb[i];
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) load_tile(kt + 1);  // global loads in flight under the MFMAs below
+        const bf16_t* cA = sA + cur * BM * BK + (wm * (BM / 2)) * BK;
+        const bf16_t* cB = sB + cur * BN * BK + (wn * (BN / 2)) * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t af[FM], bfr[FN];
+            const int ch = kk * 4 + lg;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int row = i * 16 + l15;  // (wm*(BM/2)) is a multiple of 8 -> same swizzle phase
+                af[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(cA + row * BK + ((ch ^ (row & 7)) << 3)));
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int row = j * 16 + l15;
+                bfr[j] = as_bf16x8(*reinterpret_cast<const u32x4*>(cB + row * BK + ((ch ^ (row & 7)) << 3)));
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    // D[n][m]: lane holds m = l15, n = 4*lg + r  (operands swapped on purpose)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + l15;
+        if (m >= p.M) continue;
+        const float* av = p.addvec ? p.addvec + (long)(m / p.rows_per_batch) * p.N : nullptr;
+        if (p.epi == EPI_GEGLU) {
+#pragma unroll
+            for (int j = 0; j < FN; j += 2) {
+                const int na = n0 + wn * (BN / 2) + j * 16 + lg * 4;  // packed 'a' rows; gate rows at +16
+                if (na >= p.N) continue;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = acc[i][j][r] + (p.bias ? p.bias[na + r] : 0.f);
+                    const float g = acc[i][j + 1][r] + (p.bias ? p.bias[na + 16 + r] : 0.f);
+                    o[r] = a * gelu_erf_f(g);
+                }
+                const int nc = (n0 + wn * (BN / 2) + j * 16) / 2 + lg * 4;
+                u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + nc) = pk;
+            }
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
+            if (n >= p.N) continue;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[i][j][r];
+                if (p.bias) v += p.bias[n + r];
+                if (av) v += av[n + r];
+                if (p.epi == EPI_SILU) v = silu_f(v);
+                else if (p.epi == EPI_GELU) v = gelu_erf_f(v);
+                o[r] = v;
+            }
+            if (p.res) {
+                const u32x2 rr = *reinterpret_cast<const u32x2*>(p.res + (long)m * p.ldr + n);
+                o[0] += bf16lo(rr.x); o[1] += bf16hi(rr.x); o[2] += bf16lo(rr.y); o[3] += bf16hi(rr.y);
+            }
+            if (p.out_f32) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = (f32x4){o[0], o[1], o[2], o[3]};
+            } else {
+                u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) = pk;
+            }
+        }
+    }
+}
+
+template <int AMODE>
+int launch(const GemmArgs& a, hipStream_t stream) {
+    // tile choice: the largest tile that still fills the 256 CUs and does not waste >10% of N
+    const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    int pick = 2;
+    for (int c = 0; c < 3; ++c) {
+        const long tm = (a.M + cand[c][0] - 1) / cand[c][0], tn = (a.N + cand[c][1] - 1) / cand[c][1];
+        const double waste = (double)(tn * cand[c][1]) / (double)a.N;
+        if (tm * tn >= 256 && waste <= 1.10) { pick = c; break; }
+    }
+    const int BM = cand[pick][0], BN = cand[pick][1];
+    const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    dim3 grid((unsigned)tiles), block(NT);
+    if (pick == 0) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE>), grid, block, 0, stream, a);
+    else if (pick == 1) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((gemm_kernel<64, 64, AMODE>), grid, block, 0, stream, a);
+    return ae_check_launch(AMODE == A_DENSE ? "ae_gemm_bf16" : "ae_conv3x3_bf16");
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, int Ksplit, const void* W, long ldw,
+                            void* C, long ldc, int M, int N, int K, const float* bias, const void* residual, long ldr,
+                            const float* addvec, int rows_per_batch, int epilogue, int out_f32, void* stream) {
+    AE_REQUIRE(A && W && C, "ae_gemm_bf16: null pointer");
+    AE_REQUIRE(M > 0 && N > 0 && K > 0, "ae_gemm_bf16: M,N,K must be positive (got %d,%d,%d)", M, N, K);
+    AE_REQUIRE(K % 8 == 0, "ae_gemm_bf16: K=%d must be a multiple of 8", K);
+    AE_REQUIRE(N % 4 == 0, "ae_gemm_bf16: N=%d must be a multiple of 4", N);
+    AE_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && aligned16(A) && aligned16(W), "ae_gemm_bf16: A/W rows must be 16-byte aligned");
+    AE_REQUIRE(ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0, "ae_gemm_bf16: C must be 16-byte aligned, ldc %% 4 == 0");
+    AE_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_SILU, "ae_gemm_bf16: bad epilogue %d", epilogue);
+    if (A2) {
+        AE_REQUIRE(Ksplit > 0 && Ksplit < K && Ksplit % 8 == 0 && lda2 % 8 == 0 && aligned16(A2),
+                   "ae_gemm_bf16: bad two-source split (Ksplit=%d, K=%d)", Ksplit, K);
+    }
+    if (epilogue == EPI_GEGLU) {
+        AE_REQUIRE(N % 32 == 0 && !residual && !addvec && !out_f32, "ae_gemm_bf16: GEGLU needs N %% 32 == 0, bf16 out, no residual");
+    }
+    if (residual) AE_REQUIRE(ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(residual) & 7) == 0, "ae_gemm_bf16: residual alignment");
+    if (addvec) AE_REQUIRE(rows_per_batch > 0, "ae_gemm_bf16: rows_per_batch must be > 0 with addvec");
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.A2 = (const bf16_t*)A2; a.W = (const bf16_t*)W; a.C = C;
+    a.bias = bias; a.res = (const bf16_t*)residual; a.addvec = addvec;
+    a.M = M; a.N = N; a.K = K; a.Ksplit = A2 ? Ksplit : K;
+    a.lda = lda; a.lda2 = lda2; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
+    a.epi = epilogue; a.out_f32 = out_f32; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+    return launch<A_DENSE>(a, (hipStream_t)stream);
+}
+
+extern "C" int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float* addvec, const void* residual,
+                               void* y, int B, int H, int W, int Cin, int Cout, int stride, int upsample2x, int out_f32,
+                               void* stream) {
+    AE_REQUIRE(x && w && y, "ae_conv3x3_bf16: null pointer");
+    AE_REQUIRE(B > 0 && H > 0 && W > 0, "ae_conv3x3_bf16: bad shape B=%d H=%d W=%d", B, H, W);
+    AE_REQUIRE(Cin % 8 == 0, "ae_conv3x3_bf16: Cin=%d must be a multiple of 8", Cin);
+    AE_REQUIRE(Cout % 4 == 0, "ae_conv3x3_bf16: Cout=%d must be a multiple of 4", Cout);
+    AE_REQUIRE(stride == 1 || stride == 2, "ae_conv3x3_bf16: stride must be 1 or 2");
+    AE_REQUIRE(!(upsample2x && stride != 1), "ae_conv3x3_bf16: upsample2x requires stride 1");
+    AE_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), "ae_conv3x3_bf16: pointers must be 16-byte aligned");
+    const int Hv = upsample2x ? 2 * H : H, Wv = upsample2x ? 2 * W : W;
+    const int Ho = (Hv + 2 - 3) / stride + 1, Wo = (Wv + 2 - 3) / stride + 1;
+    GemmArgs a{};
+    a.A = (const bf16_t*)x; a.A2 = nullptr; a.W = (const bf16_t*)w; a.C = y;
+    a.bias = bias; a.res = (const bf16_t*)residual; a.addvec = addvec;
+    const int CinPad = (Cin + BK - 1) / BK * BK;  // weights are packed [Cout, 9*CinPad], zero padded per tap
+    a.M = B * Ho * Wo; a.N = Cout; a.K = 9 * CinPad; a.Ksplit = a.K;
+    a.lda = 0; a.lda2 = 0; a.ldw = 9L * CinPad; a.ldc = Cout; a.ldr = Cout;
+    a.epi = EPI_NONE; a.out_f32 = out_f32; a.rows_per_batch = Ho * Wo;
+    a.H = H; a.Wd = W; a.Cin = Cin; a.CinPad = CinPad; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.ups = upsample2x;
+    return launch<A_CONV3>(a, (hipStream_t)stream);
+}

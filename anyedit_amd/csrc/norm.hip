@@ -1,0 +1,236 @@
+// GroupNorm(+SiLU) and LayerNorm on channels-last bf16 activations for gfx950 — HBM-bandwidth kernels.
+//
+// Replaces: GroupNorm32.forward (ldm/modules/diffusionmodules/util.py:217-219, eps 1e-5),
+// Normalize (ldm/modules/attention.py:88-89, eps 1e-6) with the nn.SiLU that follows them in ResBlock / UNet.out
+// (openaimodel.py:200-204, 224-231, 726-730); nn.LayerNorm in BasicTransformerBlock (attention.py:263-265) and in the
+// SAM Block (image_encoder.py:166-182, eps 1e-6).  Statistics are fp32 exactly as the reference forces them.
+//
+// GroupNorm is two launches: (1) per-(batch, row-chunk) partial sums for all 32 groups, deterministic (no float
+// atomics to global memory); (2) apply: each block folds the partials into mean/rstd, builds per-channel
+// scale/shift in LDS and streams rows with 16-byte loads/stores, SiLU fused.  The input may be the channel-concat
+// of two tensors (decoder skip connections, openaimodel.py:780) — read in place, never materialised.
+#include "common.hpp"
+
+namespace {
+
+struct GNArgs {
+    const bf16_t* x; const bf16_t* x2;  // x: channels [0, C1), x2: channels [C1, C)
+    int C1;
+    const float* gamma; const float* beta;
+    bf16_t* y;
+    float* part;  // [B][nchunk][groups][2]
+    int B, HW, C, groups, rows_per_chunk, nchunk, act;
+    float eps;
+};
+
+__device__ __forceinline__ u32x4 gn_load(const GNArgs& p, long row, int cc) {
+    const int ch = cc * 8;
+    if (ch < p.C1) return *reinterpret_cast<const u32x4*>(p.x + row * p.C1 + ch);
+    return *reinterpret_cast<const u32x4*>(p.x2 + row * (p.C - p.C1) + (ch - p.C1));
+}
+
+// blockDim.x = ncc * rpp  (ncc = C/8 column chunks, rpp rows in flight); grid = (nchunk, B)
+__global__ void gn_stats_kernel(const GNArgs p) {
+    extern __shared__ float lds[];  // [2*C]
+    const int ncc = p.C / 8;
+    const int cc = threadIdx.x % ncc, rr = threadIdx.x / ncc, rpp = blockDim.x / ncc;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    for (int i = threadIdx.x; i < 2 * p.C; i += blockDim.x) lds[i] = 0.f;
+    __syncthreads();
+    float s[8], ss[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
+    const int r0 = chunk * p.rows_per_chunk;
+    const int r1 = min(r0 + p.rows_per_chunk, p.HW);
+    if (rr < rpp) {
+        for (int r = r0 + rr; r < r1; r += rpp) {
+            const u32x4 v = gn_load(p, (long)b * p.HW + r, cc);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = bf16lo(w[e]), c = bf16hi(w[e]);
+                s[2 * e] += a; ss[2 * e] += a * a;
+                s[2 * e + 1] += c; ss[2 * e + 1] += c * c;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            atomicAdd(&lds[cc * 8 + e], s[e]);
+            atomicAdd(&lds[p.C + cc * 8 + e], ss[e]);
+        }
+    }
+    __syncthreads();
+    const int cpg = p.C / p.groups;
+    if (threadIdx.x < p.groups) {
+        float a = 0.f, c = 0.f;
+        for (int i = 0; i < cpg; ++i) {
+            a += lds[threadIdx.x * cpg + i];
+            c += lds[p.C + threadIdx.x * cpg + i];
+        }
+        float* dst = p.part + (((long)b * p.nchunk + chunk) * p.groups + threadIdx.x) * 2;
+        dst[0] = a;
+        dst[1] = c;
+    }
+}
+
+__global__ void gn_apply_kernel(const GNArgs p) {
+    extern __shared__ float lds[];  // scale[C], shift[C], mean[groups], rstd[groups]
+    float* scale = lds;
+    float* shift = lds + p.C;
+    float* mean = lds + 2 * p.C;
+    float* rstd = mean + p.groups;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int cpg = p.C / p.groups;
+    if (threadIdx.x < p.groups) {
+        float a = 0.f, c = 0.f;
+        const float* src = p.part + ((long)b * p.nchunk * p.groups + threadIdx.x) * 2;
+        for (int i = 0; i < p.nchunk; ++i) {  // fixed order -> deterministic
+            a += src[(long)i * p.groups * 2];
+            c += src[(long)i * p.groups * 2 + 1];
+        }
+        const float n = (float)cpg * (float)p.HW;
+        const float mu = a / n;
+        const float var = fmaxf(c / n - mu * mu, 0.f);
+        mean[threadIdx.x] = mu;
+        rstd[threadIdx.x] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+        const int g = c / cpg;
+        const float sc = p.gamma[c] * rstd[g];
+        scale[c] = sc;
+        shift[c] = p.beta[c] - mean[g] * sc;
+    }
+    __syncthreads();
+    const int ncc = p.C / 8;
+    const int r0 = chunk * p.rows_per_chunk;
+    const int r1 = min(r0 + p.rows_per_chunk, p.HW);
+    const int total = (r1 - r0) * ncc;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int r = r0 + i / ncc, cc = i % ncc;
+        const long row = (long)b * p.HW + r;
+        const u32x4 v = gn_load(p, row, cc);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c0 = cc * 8 + 2 * e;
+            float a = bf16lo(w[e]) * scale[c0] + shift[c0];
+            float c = bf16hi(w[e]) * scale[c0 + 1] + shift[c0 + 1];
+            if (p.act == 1) { a = silu_f(a); c = silu_f(c); }
+            o[e] = pack_bf16x2(a, c);
+        }
+        *reinterpret_cast<u32x4*>(p.y + row * p.C + cc * 8) = (u32x4){o[0], o[1], o[2], o[3]};
+    }
+}
+
+// LayerNorm over the last dim: one wave per row, 16-byte loads, two-pass (mean, then centred variance) in registers.
+template <int MAXCH>  // max 16-byte chunks per lane
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y,
+                                                        int M, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    const int ncc = C / 8;
+    u32x4 v[MAXCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int cc = lane + i * 64;
+        if (cc < ncc) {
+            v[i] = *reinterpret_cast<const u32x4*>(x + row * C + cc * 8);
+            const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += bf16lo(w[e]) + bf16hi(w[e]);
+        }
+    }
+    const float mu = wave_reduce_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int cc = lane + i * 64;
+        if (cc < ncc) {
+            const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = bf16lo(w[e]) - mu, c = bf16hi(w[e]) - mu;
+                q += a * a + c * c;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_reduce_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int cc = lane + i * 64;
+        if (cc < ncc) {
+            const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            uint32_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c0 = cc * 8 + 2 * e;
+                const float a = (bf16lo(w[e]) - mu) * rstd * gamma[c0] + beta[c0];
+                const float c = (bf16hi(w[e]) - mu) * rstd * gamma[c0 + 1] + beta[c0 + 1];
+                o[e] = pack_bf16x2(a, c);
+            }
+            *reinterpret_cast<u32x4*>(y + row * C + cc * 8) = (u32x4){o[0], o[1], o[2], o[3]};
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ae_groupnorm_rows_per_chunk(int HW) {
+    // at most 64 chunks per image so the apply prologue stays short; at least 8 rows per chunk
+    int r = (HW + 63) / 64;
+    return r < 8 ? (HW < 8 ? HW : 8) : r;
+}
+
+extern "C" long ae_groupnorm_workspace_floats(int B, int HW, int groups) {
+    const int rpc = ae_groupnorm_rows_per_chunk(HW);
+    const int nchunk = (HW + rpc - 1) / rpc;
+    return (long)B * nchunk * groups * 2;
+}
+
+extern "C" int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y,
+                                      int B, int HW, int C, int groups, float eps, int act, float* workspace, void* stream) {
+    AE_REQUIRE(x && gamma && beta && y && workspace, "ae_groupnorm_nhwc_bf16: null pointer");
+    AE_REQUIRE(B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, "ae_groupnorm_nhwc_bf16: bad shape C=%d groups=%d", C, groups);
+    AE_REQUIRE(C % 8 == 0 && C / 8 <= 1024, "ae_groupnorm_nhwc_bf16: C=%d must be a multiple of 8 and <= 8192", C);
+    AE_REQUIRE(groups <= 64, "ae_groupnorm_nhwc_bf16: groups=%d > 64 unsupported", groups);
+    AE_REQUIRE(act == 0 || act == 1, "ae_groupnorm_nhwc_bf16: act must be 0 (none) or 1 (SiLU)");
+    if (x2) AE_REQUIRE(C1 > 0 && C1 < C && C1 % 8 == 0, "ae_groupnorm_nhwc_bf16: bad concat split C1=%d C=%d", C1, C);
+    AE_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)x2 & 15) == 0, "ae_groupnorm_nhwc_bf16: 16-byte alignment");
+    GNArgs p{};
+    p.x = (const bf16_t*)x; p.x2 = (const bf16_t*)x2; p.C1 = x2 ? C1 : C;
+    p.gamma = gamma; p.beta = beta; p.y = (bf16_t*)y; p.part = workspace;
+    p.B = B; p.HW = HW; p.C = C; p.groups = groups; p.act = act; p.eps = eps;
+    p.rows_per_chunk = ae_groupnorm_rows_per_chunk(HW);
+    p.nchunk = (HW + p.rows_per_chunk - 1) / p.rows_per_chunk;
+    const int ncc = C / 8;
+    int rpp = 256 / ncc;
+    if (rpp < 1) rpp = 1;
+    int threads = ncc * rpp;
+    if (threads < 64) threads = 64;  // need >= groups threads for the group fold (rr >= rpp lanes idle)
+    dim3 grid(p.nchunk, B);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), 2 * C * sizeof(float), (hipStream_t)stream, p);
+    int rc = ae_check_launch("ae_groupnorm_nhwc_bf16(stats)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), (2 * C + 2 * groups) * sizeof(float), (hipStream_t)stream, p);
+    return ae_check_launch("ae_groupnorm_nhwc_bf16(apply)");
+}
+
+extern "C" int ae_layernorm_bf16(const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps,
+                                 void* stream) {
+    AE_REQUIRE(x && gamma && beta && y, "ae_layernorm_bf16: null pointer");
+    AE_REQUIRE(M > 0 && C > 0 && C % 8 == 0, "ae_layernorm_bf16: C=%d must be a positive multiple of 8", C);
+    AE_REQUIRE(C <= 4096, "ae_layernorm_bf16: C=%d > 4096 unsupported", C);
+    AE_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "ae_layernorm_bf16: 16-byte alignment");
+    dim3 grid((M + 3) / 4), block(256);
+    const int ncc = C / 8;
+    hipStream_t s = (hipStream_t)stream;
+    if (ncc <= 64) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);
+    else if (ncc <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);
+    else if (ncc <= 192) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);
+    return ae_check_launch("ae_layernorm_bf16");
+}

@@ -1,0 +1,258 @@
+"""Mirror of ldm/modules/attention.py (reference file:line cited per class) on HIP kernels.
+
+Public signatures, sub-module names and state-dict keys are the reference's, so a checkpoint / YAML written for
+`ldm.modules.attention` loads unchanged.  Public `forward`s accept the reference layouts ([B,N,C] tokens or [B,C,H,W]
+feature maps, any float dtype) and return the same; internally everything moves as channels-last bf16 rows through
+`*_rows` methods, which is what UNetModel calls (no layout changes between layers).
+"""
+import torch
+import torch.nn as nn
+
+from anyedit_amd import ops
+from anyedit_amd.ldm.util import default, exists
+from anyedit_amd.ldm.modules.diffusionmodules.util import Linear, Conv2d, LayerNorm, checkpoint  # noqa: F401
+
+BF16 = torch.bfloat16
+
+
+def zero_module(module):
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+class _GN6(nn.GroupNorm):
+    """Normalize(): GroupNorm(32, C, eps=1e-6, affine) (attention.py:88-89)."""
+
+    def _affine(self):
+        pk = getattr(self, "_pk", None)
+        if pk is None or pk[0].device != self.weight.device:
+            pk = (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous())
+            self._pk = pk
+        return pk
+
+    def repack(self):
+        self._pk = None
+
+    def rows(self, x, B, HW):
+        g, b = self._affine()
+        return ops.groupnorm(x, g, b, B, HW, self.eps, silu=False, groups=self.num_groups)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        return ops.rows_to_nchw(self.rows(ops.nchw_to_rows(x), B, H * W), B, H, W, out_dtype=x.dtype)
+
+
+def Normalize(in_channels):
+    return _GN6(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+class GEGLU(nn.Module):
+    """attention.py:49-58; the gate (exact-erf GELU) is fused into the projection GEMM's epilogue."""
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = Linear(dim_in, dim_out * 2)
+        self._pk = None
+
+    def repack(self):
+        self._pk = None
+
+    def rows(self, x):
+        if self._pk is None or self._pk[0].device != self.proj.weight.device:
+            self._pk = ops.pack_geglu(self.proj.weight, self.proj.bias)
+        w, b = self._pk
+        return ops.gemm(x, w, b, epilogue=ops.EPI_GEGLU)
+
+    def forward(self, x):
+        shp = x.shape
+        return self.rows(x.reshape(-1, shp[-1]).to(BF16).contiguous()).reshape(*shp[:-1], -1).to(x.dtype)
+
+
+class FeedForward(nn.Module):
+    """attention.py:61-76."""
+
+    def __init__(self, dim, dim_out=None, mult=4, glu=False, dropout=0.):
+        super().__init__()
+        inner_dim = int(dim * mult)
+        dim_out = default(dim_out, dim)
+        if not glu:
+            raise NotImplementedError("FeedForward(glu=False) is not used on the SD-1.5 path (gated_ff=True)")
+        project_in = GEGLU(dim, inner_dim)
+        self.net = nn.Sequential(project_in, nn.Dropout(dropout), Linear(inner_dim, dim_out))
+
+    def rows(self, x, residual=None):
+        return self.net[2].rows(self.net[0].rows(x), residual=residual)
+
+    def forward(self, x):
+        shp = x.shape
+        return self.rows(x.reshape(-1, shp[-1]).to(BF16).contiguous()).reshape(shp).to(x.dtype)
+
+
+class CrossAttention(nn.Module):
+    """attention.py:145-194.  q/k/v projections are fused into one (self) or two (cross) GEMMs, the softmax(QK^T)V core
+    is the flash-style HIP kernel reading heads in place (no 'b n (h d) -> (b h) n d' copies), to_out fuses +bias."""
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        inner_dim = dim_head * heads
+        self.is_self = context_dim is None
+        context_dim = default(context_dim, query_dim)
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        self.dim_head = dim_head
+        self.to_q = Linear(query_dim, inner_dim, bias=False)
+        self.to_k = Linear(context_dim, inner_dim, bias=False)
+        self.to_v = Linear(context_dim, inner_dim, bias=False)
+        self.to_out = nn.Sequential(Linear(inner_dim, query_dim), nn.Dropout(dropout))
+        self._pk = None
+
+    def repack(self):
+        self._pk = None
+
+    def _packed(self):
+        if self._pk is None or self._pk["dev"] != self.to_q.weight.device:
+            wq, wk, wv = (ops.pack_linear(m.weight) for m in (self.to_q, self.to_k, self.to_v))
+            pk = {"dev": self.to_q.weight.device, "q": wq, "kv": torch.cat([wk, wv], 0).contiguous()}
+            if wq.shape[1] == wk.shape[1]:
+                pk["qkv"] = torch.cat([wq, wk, wv], 0).contiguous()
+            self._pk = pk
+        return self._pk
+
+    def project_kv(self, ctx_rows):
+        """K|V of a context [B*Nk, Dc] -> [B*Nk, 2*inner] (step-invariant for text conditioning: cache it)."""
+        return ops.gemm(ctx_rows, self._packed()["kv"])
+
+    def rows(self, x, B, N, context_rows=None, Nk=None, kv=None, key_mask=None, residual=None):
+        """x: [B*N, C] bf16 rows.  context_rows: [B*Nk, Dc] or None (self-attention).  Returns to_out(attn) (+residual)."""
+        pk = self._packed()
+        h, d = self.heads, self.dim_head
+        inner = h * d
+        if context_rows is None and kv is None:
+            qkv = ops.gemm(x, pk["qkv"])  # [B*N, 3*inner]
+            s = (N * 3 * inner, d, 3 * inner)
+            o = ops.attention(qkv, qkv[:, inner:], qkv[:, 2 * inner:], B, h, N, N, d, self.scale, s, s, s, key_mask=key_mask)
+        else:
+            q = ops.gemm(x, pk["q"])
+            if kv is None:
+                kv = self.project_kv(context_rows)
+            Nk = kv.shape[0] // B
+            qs = (N * inner, d, inner)
+            ks = (Nk * 2 * inner, d, 2 * inner)
+            o = ops.attention(q, kv, kv[:, inner:], B, h, N, Nk, d, self.scale, qs, ks, ks, key_mask=key_mask)
+        return self.to_out[0].rows(o.reshape(B * N, inner), residual=residual)
+
+    def forward(self, x, context=None, mask=None):
+        B, N, C = x.shape
+        xr = x.reshape(B * N, C).to(BF16).contiguous()
+        ctx = None
+        if context is not None:
+            ctx = context.reshape(-1, context.shape[-1]).to(BF16).contiguous()
+        km = None
+        if exists(mask):
+            km = mask.reshape(B, -1).to(torch.uint8).contiguous()
+        if ctx is None and not self.is_self:
+            raise ValueError("CrossAttention built with context_dim needs a context of that width")
+        if ctx is not None and self.is_self:
+            # reference semantics: context_dim defaults to query_dim, any context of that width is accepted
+            y = self.rows(xr, B, N, context_rows=ctx, key_mask=km)
+        else:
+            y = self.rows(xr, B, N, context_rows=ctx, key_mask=km)
+        return y.reshape(B, N, -1).to(x.dtype)
+
+
+class MemoryEfficientCrossAttention(CrossAttention):
+    """attention.py:197-243 — same operator; the xformers call site (:233) is `ops.attention_bhnd`."""
+
+
+class BasicTransformerBlock(nn.Module):
+    """attention.py:246-275."""
+    ATTENTION_MODES = {"softmax": CrossAttention, "softmax-xformers": MemoryEfficientCrossAttention,
+                       "softmax-hip": CrossAttention}
+
+    def __init__(self, dim, n_heads, d_head, dropout=0., context_dim=None, gated_ff=True, checkpoint=True,
+                 disable_self_attn=False):
+        super().__init__()
+        attn_cls = self.ATTENTION_MODES["softmax-hip"]
+        self.disable_self_attn = disable_self_attn
+        self.attn1 = attn_cls(query_dim=dim, heads=n_heads, dim_head=d_head, dropout=dropout,
+                              context_dim=context_dim if self.disable_self_attn else None)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+        self.attn2 = attn_cls(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.norm1 = LayerNorm(dim)
+        self.norm2 = LayerNorm(dim)
+        self.norm3 = LayerNorm(dim)
+        self.checkpoint = checkpoint
+
+    def rows(self, x, B, N, context_rows=None, kv_cache=None):
+        """x: [B*N, C] bf16.  kv_cache: optional dict id(attn)->projected K|V of the (step-invariant) context."""
+        c1 = context_rows if self.disable_self_attn else None
+        x = self.attn1.rows(self.norm1.rows(x), B, N, context_rows=c1, residual=x)
+        kv2 = None
+        if kv_cache is not None and context_rows is not None:
+            key = id(self.attn2)
+            kv2 = kv_cache.get(key)
+            if kv2 is None:
+                kv2 = kv_cache[key] = self.attn2.project_kv(context_rows)
+        x = self.attn2.rows(self.norm2.rows(x), B, N, context_rows=context_rows, kv=kv2, residual=x)
+        x = self.ff.rows(self.norm3.rows(x), residual=x)
+        return x
+
+    def forward(self, x, context=None):
+        B, N, C = x.shape
+        ctx = None if context is None else context.reshape(-1, context.shape[-1]).to(BF16).contiguous()
+        y = self.rows(x.reshape(B * N, C).to(BF16).contiguous(), B, N, context_rows=ctx)
+        return y.reshape(B, N, C).to(x.dtype)
+
+    _forward = forward
+
+
+class SpatialTransformer(nn.Module):
+    """attention.py:278-340.  On channels-last rows the two 'b c h w <-> b (h w) c' rearranges vanish and the 1x1 convs
+    are plain GEMMs; proj_out fuses the residual add."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0., context_dim=None, disable_self_attn=False,
+                 use_linear=False, use_checkpoint=True):
+        super().__init__()
+        if exists(context_dim) and not isinstance(context_dim, list):
+            context_dim = [context_dim] * depth
+        if context_dim is None:
+            context_dim = [None] * depth
+        self.in_channels = in_channels
+        inner_dim = n_heads * d_head
+        self.norm = Normalize(in_channels)
+        if not use_linear:
+            self.proj_in = Conv2d(in_channels, inner_dim, kernel_size=1, stride=1, padding=0)
+        else:
+            self.proj_in = Linear(in_channels, inner_dim)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(inner_dim, n_heads, d_head, dropout=dropout, context_dim=context_dim[d],
+                                   disable_self_attn=disable_self_attn, checkpoint=use_checkpoint) for d in range(depth)])
+        if not use_linear:
+            self.proj_out = zero_module(Conv2d(inner_dim, in_channels, kernel_size=1, stride=1, padding=0))
+        else:
+            self.proj_out = zero_module(Linear(in_channels, inner_dim))
+        self.use_linear = use_linear
+
+    def rows(self, x, B, H, W, context_rows=None, kv_cache=None):
+        if isinstance(context_rows, (list, tuple)):
+            ctxs = list(context_rows)
+        else:
+            ctxs = [context_rows] * len(self.transformer_blocks)
+        N = H * W
+        h = self.norm.rows(x, B, N)
+        pin = self.proj_in._packed()
+        h = ops.gemm(h, pin["w"], pin["b"])
+        for i, blk in enumerate(self.transformer_blocks):
+            h = blk.rows(h, B, N, context_rows=ctxs[i], kv_cache=kv_cache)
+        pout = self.proj_out._packed()
+        return ops.gemm(h, pout["w"], pout["b"], residual=x)
+
+    def forward(self, x, context=None):
+        B, C, H, W = x.shape
+        if isinstance(context, list):
+            ctx = [None if c is None else c.reshape(-1, c.shape[-1]).to(BF16).contiguous() for c in context]
+        else:
+            ctx = None if context is None else context.reshape(-1, context.shape[-1]).to(BF16).contiguous()
+        y = self.rows(ops.nchw_to_rows(x), B, H, W, context_rows=ctx)
+        return ops.rows_to_nchw(y, B, H, W, out_dtype=x.dtype)

@@ -1,0 +1,328 @@
+"""Mirror of ldm/modules/diffusionmodules/openaimodel.py (UNetModel and its blocks) on HIP kernels.
+
+Constructor arguments, sub-module names and state-dict keys follow the reference (openaimodel.py:412-730; key schema in
+SURVEY.md Appendix A), including the parameter CREATION ORDER, so `torch.manual_seed(s); UNetModel(**cfg)` yields the
+same initial weights as the reference constructor.  Forward data flow (openaimodel.py:754-786) runs on channels-last bf16
+rows end to end; NCHW fp32 exists only at the model boundary.
+"""
+from abc import abstractmethod
+
+import torch
+import torch.nn as nn
+
+from anyedit_amd import ops
+from anyedit_amd.ldm.util import exists
+from anyedit_amd.ldm.modules.attention import SpatialTransformer
+from anyedit_amd.ldm.modules.diffusionmodules.util import (conv_nd, linear, normalization, zero_module,
+                                                           timestep_embedding, checkpoint)  # noqa: F401
+
+BF16 = torch.bfloat16
+
+
+class TimestepBlock(nn.Module):
+    """openaimodel.py:60-69."""
+
+    @abstractmethod
+    def forward(self, x, emb):
+        """Apply the module to `x` given `emb` timestep embeddings."""
+
+
+class Feat:
+    """Channels-last activation handle: rows [B*H*W, C] bf16 (+ optional second source = pending channel-concat)."""
+    __slots__ = ("t", "B", "H", "W", "t2")
+
+    def __init__(self, t, B, H, W, t2=None):
+        self.t, self.B, self.H, self.W, self.t2 = t, B, H, W, t2
+
+    def materialize(self):
+        if self.t2 is not None:
+            self.t = ops.concat_channels(self.t, self.t2)
+            self.t2 = None
+        return self.t
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    """openaimodel.py:73-87."""
+
+    def rows(self, f, emb_silu, context_rows=None, kv_cache=None):
+        for layer in self:
+            if isinstance(layer, TimestepBlock):
+                f = layer.rows(f, emb_silu)
+            elif isinstance(layer, SpatialTransformer):
+                f = Feat(layer.rows(f.materialize(), f.B, f.H, f.W, context_rows=context_rows, kv_cache=kv_cache), f.B, f.H, f.W)
+            else:
+                f = layer.rows(f)
+        return f
+
+    def forward(self, x, emb, context=None):
+        for layer in self:
+            if isinstance(layer, TimestepBlock):
+                x = layer(x, emb)
+            elif isinstance(layer, SpatialTransformer):
+                x = layer(x, context)
+            else:
+                x = layer(x)
+        return x
+
+
+class Upsample(nn.Module):
+    """openaimodel.py:90-118: nearest x2 folded into the conv's gather (no 4x intermediate tensor)."""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.use_conv = use_conv
+        self.dims = dims
+        if not use_conv or dims != 2:
+            raise NotImplementedError("Upsample without conv / non-2D is not on the SD-1.5 path")
+        self.conv = conv_nd(dims, self.channels, self.out_channels, 3, padding=padding)
+
+    def rows(self, f):
+        y, Ho, Wo = self.conv.rows(f.materialize(), f.B, f.H, f.W, upsample2x=True)
+        return Feat(y, f.B, Ho, Wo)
+
+    def forward(self, x):
+        assert x.shape[1] == self.channels
+        B, C, H, W = x.shape
+        f = self.rows(Feat(ops.nchw_to_rows(x), B, H, W))
+        return ops.rows_to_nchw(f.t, B, f.H, f.W, out_dtype=x.dtype)
+
+
+class Downsample(nn.Module):
+    """openaimodel.py:131-159: conv3x3 stride 2 pad 1."""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.use_conv = use_conv
+        self.dims = dims
+        if not use_conv or dims != 2:
+            raise NotImplementedError("Downsample without conv / non-2D is not on the SD-1.5 path")
+        self.op = conv_nd(dims, self.channels, self.out_channels, 3, stride=2, padding=padding)
+
+    def rows(self, f):
+        y, Ho, Wo = self.op.rows(f.materialize(), f.B, f.H, f.W)
+        return Feat(y, f.B, Ho, Wo)
+
+    def forward(self, x):
+        assert x.shape[1] == self.channels
+        B, C, H, W = x.shape
+        f = self.rows(Feat(ops.nchw_to_rows(x), B, H, W))
+        return ops.rows_to_nchw(f.t, B, f.H, f.W, out_dtype=x.dtype)
+
+
+class ResBlock(TimestepBlock):
+    """openaimodel.py:162-274 (SD configuration: no up/down, no scale-shift norm).
+
+    HIP data flow: GN+SiLU kernel -> conv3x3 (+bias +time-embedding vector in the epilogue) -> GN+SiLU -> conv3x3
+    (+bias +skip residual in the epilogue).  The skip is the input itself or a 1x1-conv GEMM; a pending channel-concat
+    input (decoder) is consumed in place by the GN and the skip GEMM (two-source kernels), never materialised."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False, use_scale_shift_norm=False,
+                 dims=2, use_checkpoint=False, up=False, down=False):
+        super().__init__()
+        self.channels = channels
+        self.emb_channels = emb_channels
+        self.dropout = dropout
+        self.out_channels = out_channels or channels
+        self.use_conv = use_conv
+        self.use_checkpoint = use_checkpoint
+        self.use_scale_shift_norm = use_scale_shift_norm
+        if up or down or use_scale_shift_norm:
+            raise NotImplementedError("resblock_updown / use_scale_shift_norm are not on the SD-1.5 path")
+        self.in_layers = nn.Sequential(normalization(channels), nn.SiLU(), conv_nd(dims, channels, self.out_channels, 3, padding=1))
+        self.updown = False
+        self.h_upd = self.x_upd = nn.Identity()
+        self.emb_layers = nn.Sequential(nn.SiLU(), linear(emb_channels, self.out_channels))
+        self.out_layers = nn.Sequential(normalization(self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+                                        zero_module(conv_nd(dims, self.out_channels, self.out_channels, 3, padding=1)))
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        elif use_conv:
+            self.skip_connection = conv_nd(dims, channels, self.out_channels, 3, padding=1)
+        else:
+            self.skip_connection = conv_nd(dims, channels, self.out_channels, 1)
+
+    def rows(self, f, emb_silu):
+        """f: Feat (possibly with a pending concat); emb_silu: bf16 [B, emb_channels] = SiLU(emb)."""
+        B, H, W = f.B, f.H, f.W
+        emb_out = self.emb_layers[1].rows(emb_silu, out_f32=True)  # [B, Cout] fp32
+        h = self.in_layers[0].rows(f.t, B, H * W, silu=True, x2=f.t2)
+        h, _, _ = self.in_layers[2].rows(h, B, H, W, addvec=emb_out)
+        h = self.out_layers[0].rows(h, B, H * W, silu=True)
+        if isinstance(self.skip_connection, nn.Identity):
+            res = f.materialize()
+        elif self.skip_connection.kernel_size[0] == 1:
+            res, _, _ = self.skip_connection.rows(f.t, B, H, W, a2=f.t2)
+        else:
+            res, _, _ = self.skip_connection.rows(f.materialize(), B, H, W)
+        y, _, _ = self.out_layers[3].rows(h, B, H, W, residual=res)
+        return Feat(y, B, H, W)
+
+    def forward(self, x, emb):
+        B, C, H, W = x.shape
+        f = self.rows(Feat(ops.nchw_to_rows(x), B, H, W), ops.silu_to_bf16(emb))
+        return ops.rows_to_nchw(f.t, B, H, W, out_dtype=x.dtype)
+
+    _forward = forward
+
+
+class UNetModel(nn.Module):
+    """openaimodel.py:412-786 for use_spatial_transformer=True (the AnySD / SD-1.5 / AnyDoor configurations)."""
+
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, use_checkpoint=False,
+                 use_fp16=False, num_heads=-1, num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False,
+                 resblock_updown=False, use_new_attention_order=False, use_spatial_transformer=False, transformer_depth=1,
+                 context_dim=None, n_embed=None, legacy=True, disable_self_attentions=None, num_attention_blocks=None,
+                 disable_middle_self_attn=False, use_linear_in_transformer=False):
+        super().__init__()
+        if not use_spatial_transformer:
+            raise NotImplementedError("legacy AttentionBlock path (use_spatial_transformer=False) is unused by AnyEdit (SURVEY §2 C2)")
+        assert context_dim is not None, "use_spatial_transformer needs context_dim (openaimodel.py:474-475)"
+        if not isinstance(context_dim, (int, type(None))):
+            context_dim = list(context_dim)
+        if num_classes is not None or n_embed is not None or resblock_updown or use_scale_shift_norm or dims != 2:
+            raise NotImplementedError("num_classes / n_embed / resblock_updown / scale-shift / dims!=2 are outside the AnyEdit hot path")
+        if num_heads_upsample == -1:
+            num_heads_upsample = num_heads
+        if num_heads == -1:
+            assert num_head_channels != -1, "Either num_heads or num_head_channels has to be set"
+        if num_head_channels == -1:
+            assert num_heads != -1, "Either num_heads or num_head_channels has to be set"
+        self.image_size = image_size
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        if isinstance(num_res_blocks, int):
+            self.num_res_blocks = len(channel_mult) * [num_res_blocks]
+        else:
+            if len(num_res_blocks) != len(channel_mult):
+                raise ValueError("provide num_res_blocks either as an int or as a per-level list")
+            self.num_res_blocks = list(num_res_blocks)
+        if disable_self_attentions is not None:
+            assert len(disable_self_attentions) == len(channel_mult)
+        if num_attention_blocks is not None:
+            assert len(num_attention_blocks) == len(self.num_res_blocks)
+        self.attention_resolutions = attention_resolutions
+        self.dropout = dropout
+        self.channel_mult = channel_mult
+        self.conv_resample = conv_resample
+        self.num_classes = num_classes
+        self.use_checkpoint = use_checkpoint
+        self.dtype = torch.float32
+        self.num_heads = num_heads
+        self.num_head_channels = num_head_channels
+        self.num_heads_upsample = num_heads_upsample
+        self.predict_codebook_ids = False
+
+        def heads_for(ch, nh):
+            if num_head_channels == -1:
+                return nh, ch // nh
+            return ch // num_head_channels, num_head_channels
+
+        def make_st(ch, nh, level, is_middle=False):
+            n_h, d_h = heads_for(ch, nh)
+            if legacy:
+                d_h = ch // n_h
+            dsa = disable_middle_self_attn if is_middle else (disable_self_attentions[level] if exists(disable_self_attentions) else False)
+            return SpatialTransformer(ch, n_h, d_h, depth=transformer_depth, context_dim=context_dim, disable_self_attn=dsa,
+                                      use_linear=use_linear_in_transformer, use_checkpoint=use_checkpoint)
+
+        time_embed_dim = model_channels * 4
+        self.time_embed = nn.Sequential(linear(model_channels, time_embed_dim), nn.SiLU(), linear(time_embed_dim, time_embed_dim))
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(conv_nd(dims, in_channels, model_channels, 3, padding=1))])
+        self._feature_size = model_channels
+        input_block_chans = [model_channels]
+        ch = model_channels
+        ds = 1
+        for level, mult in enumerate(channel_mult):
+            for nr in range(self.num_res_blocks[level]):
+                layers = [ResBlock(ch, time_embed_dim, dropout, out_channels=mult * model_channels, dims=dims,
+                                   use_checkpoint=use_checkpoint, use_scale_shift_norm=use_scale_shift_norm)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    if not exists(num_attention_blocks) or nr < num_attention_blocks[level]:
+                        layers.append(make_st(ch, num_heads, level))
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                self._feature_size += ch
+                input_block_chans.append(ch)
+            if level != len(channel_mult) - 1:
+                out_ch = ch
+                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, conv_resample, dims=dims, out_channels=out_ch)))
+                ch = out_ch
+                input_block_chans.append(ch)
+                ds *= 2
+                self._feature_size += ch
+        self.middle_block = TimestepEmbedSequential(
+            ResBlock(ch, time_embed_dim, dropout, dims=dims, use_checkpoint=use_checkpoint, use_scale_shift_norm=use_scale_shift_norm),
+            make_st(ch, num_heads, 0, is_middle=True),
+            ResBlock(ch, time_embed_dim, dropout, dims=dims, use_checkpoint=use_checkpoint, use_scale_shift_norm=use_scale_shift_norm))
+        self._feature_size += ch
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(self.num_res_blocks[level] + 1):
+                ich = input_block_chans.pop()
+                layers = [ResBlock(ch + ich, time_embed_dim, dropout, out_channels=model_channels * mult, dims=dims,
+                                   use_checkpoint=use_checkpoint, use_scale_shift_norm=use_scale_shift_norm)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    if not exists(num_attention_blocks) or i < num_attention_blocks[level]:
+                        layers.append(make_st(ch, num_heads_upsample, level))
+                if level and i == self.num_res_blocks[level]:
+                    out_ch = ch
+                    layers.append(Upsample(ch, conv_resample, dims=dims, out_channels=out_ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+                self._feature_size += ch
+        self.out = nn.Sequential(normalization(ch), nn.SiLU(), zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def repack(self):
+        """Drop cached packed weights (call after load_state_dict / optimizer steps on UNet parameters)."""
+        for m in self.modules():
+            if m is not self and hasattr(m, "repack"):
+                m.repack()
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.repack()
+        return r
+
+    def context_rows(self, context):
+        """[B, L, Dc] (any float dtype) -> bf16 rows [B*L, Dc] (once per prompt; the context is step-invariant)."""
+        if isinstance(context, (list, tuple)):
+            return [self.context_rows(c) for c in context]
+        return context.reshape(-1, context.shape[-1]).to(BF16).contiguous()
+
+    def forward_rows(self, x, timesteps, context_rows, kv_cache=None):
+        """x: [B, Cin, H, W] fp32/bf16 NCHW; context_rows: bf16 [B*L, Dc].  Returns eps [B, Cout, H, W] fp32."""
+        B, C, H, W = x.shape
+        t_emb = ops.timestep_embedding(timesteps, self.model_channels)                 # bf16 [B, mc]
+        emb = self.time_embed[0].rows(t_emb, epilogue=ops.EPI_SILU)                   # Linear + SiLU fused
+        emb_silu = self.time_embed[2].rows(emb, epilogue=ops.EPI_SILU)                # SiLU(emb): what every ResBlock consumes
+        f = Feat(ops.nchw_to_rows(x, (C + 7) // 8 * 8), B, H, W)
+        hs = []
+        for module in self.input_blocks:
+            if isinstance(module[0], TimestepBlock) or isinstance(module[0], (Downsample, Upsample)) or len(module) > 1:
+                f = module.rows(f, emb_silu, context_rows, kv_cache)
+            else:  # stem conv
+                y, _, _ = module[0].rows(f.t, B, H, W)
+                f = Feat(y, B, H, W)
+            hs.append(f)
+        f = self.middle_block.rows(f, emb_silu, context_rows, kv_cache)
+        for module in self.output_blocks:
+            skip = hs.pop()
+            f = Feat(f.materialize(), f.B, f.H, f.W, t2=skip.materialize())  # th.cat([h, hs.pop()], 1), deferred
+            f = module.rows(f, emb_silu, context_rows, kv_cache)
+        h = self.out[0].rows(f.materialize(), f.B, f.H * f.W, silu=True)
+        y, _, _ = self.out[2].rows(h, f.B, f.H, f.W, out_f32=True)
+        return ops.rows_to_nchw(y, f.B, f.H, f.W, out_dtype=torch.float32)
+
+    def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
+        """openaimodel.py:754-786."""
+        assert (y is not None) == (self.num_classes is not None), "must specify y if and only if the model is class-conditional"
+        out = self.forward_rows(x, timesteps, self.context_rows(context) if context is not None else None)
+        return out.to(x.dtype) if x.dtype != torch.float32 else out

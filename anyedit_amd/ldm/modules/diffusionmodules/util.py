@@ -1,0 +1,214 @@
+"""Mirror of ldm/modules/diffusionmodules/util.py — schedules (host, numpy f64, bit-exact integer bookkeeping) and
+the layer factories through which every UNet layer is created (util.py:202-238), here returning HIP-backed layers.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from anyedit_amd import ops
+
+
+# ---------------------------------------------------------------------------------------------- schedules (host)
+def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
+    """util.py:21-43 (float64 on the host, like the reference)."""
+    if schedule == "linear":
+        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2
+    elif schedule == "cosine":
+        timesteps = torch.arange(n_timestep + 1, dtype=torch.float64) / n_timestep + cosine_s
+        alphas = timesteps / (1 + cosine_s) * np.pi / 2
+        alphas = torch.cos(alphas).pow(2)
+        alphas = alphas / alphas[0]
+        betas = 1 - alphas[1:] / alphas[:-1]
+        betas = torch.clamp(betas, min=0, max=0.999)
+    elif schedule == "sqrt_linear":
+        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64)
+    elif schedule == "sqrt":
+        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64) ** 0.5
+    else:
+        raise ValueError(f"schedule '{schedule}' unknown.")
+    return betas.numpy()
+
+
+def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=True):
+    """util.py:46-60 — integer bookkeeping, bit-exact (length != S when S does not divide T, as in the reference)."""
+    if ddim_discr_method == "uniform":
+        c = num_ddpm_timesteps // num_ddim_timesteps
+        ddim_timesteps = np.asarray(list(range(0, num_ddpm_timesteps, c)))
+    elif ddim_discr_method == "quad":
+        ddim_timesteps = ((np.linspace(0, np.sqrt(num_ddpm_timesteps * .8), num_ddim_timesteps)) ** 2).astype(int)
+    else:
+        raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discr_method}"')
+    steps_out = ddim_timesteps + 1
+    if verbose:
+        print(f"Selected timesteps for ddim sampler: {steps_out}")
+    return steps_out
+
+
+def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=True):
+    """util.py:63-74."""
+    alphas = alphacums[ddim_timesteps]
+    alphas_prev = np.asarray([alphacums[0]] + alphacums[ddim_timesteps[:-1]].tolist())
+    sigmas = eta * np.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+    if verbose:
+        print(f"Selected alphas for ddim sampler: a_t: {alphas}; a_(t-1): {alphas_prev}")
+        print(f"For the chosen value of eta, which is {eta}, this results in the following sigma_t schedule for ddim sampler {sigmas}")
+    return sigmas, alphas, alphas_prev
+
+
+def extract_into_tensor(a, t, x_shape):
+    """util.py:96-99."""
+    b, *_ = t.shape
+    out = a.gather(-1, t)
+    return out.reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
+def checkpoint(func, inputs, params, flag):
+    """util.py:102-118: gradient checkpointing is a training-memory device; the forward value is func(*inputs)."""
+    return func(*inputs)
+
+
+def timestep_embedding(timesteps, dim, max_period=10000, repeat_only=False):
+    """util.py:154-174 on the GPU ([cos, sin] order); returns fp32 [N, dim]."""
+    if repeat_only:
+        return timesteps[:, None].repeat(1, dim)
+    return ops.timestep_embedding(timesteps, dim, max_period, out_f32=True)
+
+
+def zero_module(module):
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+def noise_like(shape, device, repeat=False):
+    """util.py:267-270."""
+    if repeat:
+        return torch.randn((1, *shape[1:]), device=device).repeat(shape[0], *((1,) * (len(shape) - 1)))
+    return torch.randn(shape, device=device)
+
+
+# ---------------------------------------------------------------------------------------------- HIP-backed layers
+class _Packed:
+    """Mixin: lazily packed bf16 weights for the HIP kernels; call .repack() after changing parameters."""
+
+    def repack(self):
+        self._pk = None
+
+    def _packed(self):
+        pk = getattr(self, "_pk", None)
+        if pk is None or pk["device"] != self.weight.device:
+            pk = self._pack()
+            pk["device"] = self.weight.device
+            self._pk = pk
+        return pk
+
+
+class Linear(nn.Linear, _Packed):
+    """nn.Linear whose forward is ae_gemm_bf16.  State-dict identical to nn.Linear."""
+
+    def _pack(self):
+        return {"w": ops.pack_linear(self.weight), "b": None if self.bias is None else self.bias.detach().float().contiguous()}
+
+    def rows(self, x, residual=None, epilogue=ops.EPI_NONE, out_f32=False, a2=None):
+        pk = self._packed()
+        return ops.gemm(x, pk["w"], pk["b"], residual=residual, epilogue=epilogue, out_f32=out_f32, a2=a2)
+
+    def forward(self, x):
+        shp = x.shape
+        y = self.rows(x.reshape(-1, shp[-1]).to(torch.bfloat16).contiguous())
+        return y.reshape(*shp[:-1], -1).to(x.dtype)
+
+
+class Conv2d(nn.Conv2d, _Packed):
+    """nn.Conv2d (3x3 pad 1 stride 1/2, or 1x1) whose forward is the implicit-GEMM / GEMM HIP kernel."""
+
+    def _pack(self):
+        k = self.kernel_size[0]
+        b = None if self.bias is None else self.bias.detach().float().contiguous()
+        if k == 1:
+            return {"w": ops.pack_linear(self.weight), "b": b}
+        if k == 3 and self.padding[0] == 1 and self.stride[0] in (1, 2) and self.groups == 1 and self.dilation[0] == 1:
+            return {"w": ops.pack_conv3x3(self.weight), "b": b}
+        raise NotImplementedError(f"anyedit_amd Conv2d: unsupported configuration k={k} stride={self.stride} padding={self.padding}")
+
+    def rows(self, x, B, H, W, addvec=None, residual=None, upsample2x=False, out_f32=False, a2=None):
+        """x: channels-last rows [B*H*W, Cin] -> (rows [B*Ho*Wo, Cout], Ho, Wo)."""
+        pk = self._packed()
+        if self.kernel_size[0] == 1:
+            return ops.gemm(x, pk["w"], pk["b"], residual=residual, out_f32=out_f32, a2=a2), H, W
+        return ops.conv3x3(x, pk["w"], pk["b"], B, H, W, addvec=addvec, residual=residual, stride=self.stride[0],
+                           upsample2x=upsample2x, out_f32=out_f32)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        cpad = (C + 7) // 8 * 8
+        if cpad != C and self.kernel_size[0] == 1:
+            raise NotImplementedError("1x1 conv with channels not a multiple of 8")
+        y, Ho, Wo = self.rows(ops.nchw_to_rows(x, cpad), B, H, W)
+        return ops.rows_to_nchw(y, B, Ho, Wo, out_dtype=x.dtype)
+
+
+class GroupNorm32(nn.GroupNorm):
+    """util.py:217-219: statistics in fp32.  `rows` runs the fused GroupNorm(+SiLU) HIP kernel on channels-last rows."""
+
+    def _affine(self):
+        pk = getattr(self, "_pk", None)
+        if pk is None or pk[0].device != self.weight.device:
+            pk = (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous())
+            self._pk = pk
+        return pk
+
+    def repack(self):
+        self._pk = None
+
+    def rows(self, x, B, HW, silu=False, x2=None):
+        g, b = self._affine()
+        return ops.groupnorm(x, g, b, B, HW, self.eps, silu=silu, groups=self.num_groups, x2=x2)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        y = self.rows(ops.nchw_to_rows(x), B, H * W)
+        return ops.rows_to_nchw(y, B, H, W, out_dtype=x.dtype)
+
+
+class LayerNorm(nn.LayerNorm):
+    def _affine(self):
+        pk = getattr(self, "_pk", None)
+        if pk is None or pk[0].device != self.weight.device:
+            pk = (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous())
+            self._pk = pk
+        return pk
+
+    def repack(self):
+        self._pk = None
+
+    def rows(self, x):
+        g, b = self._affine()
+        return ops.layernorm(x, g, b, self.eps)
+
+    def forward(self, x):
+        shp = x.shape
+        return self.rows(x.reshape(-1, shp[-1]).to(torch.bfloat16).contiguous()).reshape(shp).to(x.dtype)
+
+
+def conv_nd(dims, *args, **kwargs):
+    """util.py:222-232."""
+    if dims == 2:
+        return Conv2d(*args, **kwargs)
+    raise ValueError(f"unsupported dimensions: {dims} (the AnyEdit hot path is 2-D)")
+
+
+def linear(*args, **kwargs):
+    """util.py:235-238."""
+    return Linear(*args, **kwargs)
+
+
+def normalization(channels):
+    """util.py:202-208."""
+    return GroupNorm32(32, channels)
+
+
+def avg_pool_nd(dims, *args, **kwargs):
+    raise NotImplementedError("avg_pool_nd: conv_resample=False is not on the AnyEdit/SD-1.5 path")

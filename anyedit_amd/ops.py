@@ -1,0 +1,298 @@
+"""Thin Python operators over the C ABI (include/anyedit_hip.h).  Tensor plumbing only: shape/dtype/contiguity
+checks, output allocation, stream lookup.  All arithmetic happens in the HIP kernels; there is no fallback path.
+
+Activations are channels-last bf16: [rows, C] with rows = B*H*W.
+"""
+import math
+
+import torch
+
+from ._lib import lib, check
+
+BF16 = torch.bfloat16
+EPI_NONE, EPI_GELU, EPI_GEGLU, EPI_SILU = 0, 1, 2, 3
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t, dtype, name, dims=None):
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a GPU tensor (anyedit_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if dims is not None and t.dim() != dims:
+        raise ValueError(f"{name}: expected {dims} dims, got shape {tuple(t.shape)}")
+
+
+# --------------------------------------------------------------------------- weight packing (host side, once)
+def pack_linear(w):
+    """nn.Linear / 1x1 conv weight -> bf16 [N, K] contiguous."""
+    return w.detach().reshape(w.shape[0], -1).to(BF16).contiguous()
+
+
+def pack_conv3x3(w, cin_pad=None):
+    """[Cout, Cin, 3, 3] -> bf16 [Cout, 9*Cin_pad], K ordered (ky, kx, cin) to match the implicit-GEMM gather."""
+    cout, cin = w.shape[0], w.shape[1]
+    cin_pad = cin_pad or ((cin + 63) // 64 * 64)
+    wp = torch.zeros(cout, 3, 3, cin_pad, dtype=BF16, device=w.device)
+    wp[..., :cin] = w.detach().permute(0, 2, 3, 1).to(BF16)
+    return wp.reshape(cout, 9 * cin_pad).contiguous()
+
+
+def pack_geglu(w, b):
+    """GEGLU proj [2*inner, dim]: interleave 16 'a' rows with the matching 16 'gate' rows (AE_EPI_GEGLU layout)."""
+    inner = w.shape[0] // 2
+    assert inner % 16 == 0
+    a, g = w[:inner], w[inner:]
+    wp = torch.stack([a.reshape(inner // 16, 16, -1), g.reshape(inner // 16, 16, -1)], dim=1).reshape(2 * inner, -1)
+    bp = torch.stack([b[:inner].reshape(-1, 16), b[inner:].reshape(-1, 16)], dim=1).reshape(-1)
+    return wp.detach().to(BF16).contiguous(), bp.detach().float().contiguous()
+
+
+# --------------------------------------------------------------------------- GEMM / conv
+def gemm(a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue=EPI_NONE, out_f32=False, a2=None, out=None):
+    """out[M,N] = epi(cat([a, a2], 1) @ w^T).  a: [M,K1] bf16 (row stride free), w: [N,K] bf16."""
+    _chk(a, BF16, "gemm.a", 2)
+    _chk(w, BF16, "gemm.w", 2)
+    M, K1 = a.shape
+    N, K = w.shape
+    if a.stride(1) != 1 or w.stride(1) != 1:
+        raise ValueError("gemm: a and w must have unit inner stride")
+    K2 = 0
+    if a2 is not None:
+        _chk(a2, BF16, "gemm.a2", 2)
+        K2 = a2.shape[1]
+        if a2.shape[0] != M or a2.stride(1) != 1:
+            raise ValueError("gemm: a2 shape mismatch")
+    if K1 + K2 != K:
+        raise ValueError(f"gemm: K mismatch: a has {K1}+{K2} columns, w has {K}")
+    n_out = N // 2 if epilogue == EPI_GEGLU else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.float32 if out_f32 else BF16, device=a.device)
+    if bias is not None:
+        _chk(bias, torch.float32, "gemm.bias", 1)
+    if residual is not None:
+        _chk(residual, BF16, "gemm.residual", 2)
+    if addvec is not None:
+        _chk(addvec, torch.float32, "gemm.addvec", 2)
+    check(lib.ae_gemm_bf16(_p(a), a.stride(0), _p(a2), a2.stride(0) if a2 is not None else 0, K1, _p(w), w.stride(0),
+                           _p(out), out.stride(0), M, N, K, _p(bias), _p(residual),
+                           residual.stride(0) if residual is not None else 0, _p(addvec), rows_per_batch, epilogue,
+                           1 if out_f32 else 0, _s()), "ae_gemm_bf16")
+    return out
+
+
+def conv3x3(x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2x=False, out_f32=False, out=None):
+    """x: [B*H*W, Cin] bf16 channels-last, w: packed [Cout, 9*Cin].  Returns ([B*Ho*Wo, Cout], Ho, Wo)."""
+    _chk(x, BF16, "conv3x3.x", 2)
+    _chk(w, BF16, "conv3x3.w", 2)
+    Cin = x.shape[1]
+    Cout = w.shape[0]
+    if x.shape[0] != B * H * W or not x.is_contiguous():
+        raise ValueError(f"conv3x3: x must be contiguous [B*H*W, Cin] = [{B * H * W}, Cin], got {tuple(x.shape)}")
+    if w.shape[1] != 9 * ((Cin + 63) // 64 * 64):
+        raise ValueError(f"conv3x3: packed weight has K={w.shape[1]}, expected {9 * ((Cin + 63) // 64 * 64)}")
+    Hv, Wv = (2 * H, 2 * W) if upsample2x else (H, W)
+    Ho, Wo = (Hv - 1) // stride + 1, (Wv - 1) // stride + 1
+    if out is None:
+        out = torch.empty(B * Ho * Wo, Cout, dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    if residual is not None:
+        _chk(residual, BF16, "conv3x3.residual", 2)
+        if residual.shape != (B * Ho * Wo, Cout) or not residual.is_contiguous():
+            raise ValueError("conv3x3: residual shape mismatch")
+    check(lib.ae_conv3x3_bf16(_p(x), _p(w), _p(bias), _p(addvec), _p(residual), _p(out), B, H, W, Cin, Cout, stride,
+                              1 if upsample2x else 0, 1 if out_f32 else 0, _s()), "ae_conv3x3_bf16")
+    return out, Ho, Wo
+
+
+# --------------------------------------------------------------------------- norms
+def groupnorm(x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, out=None):
+    """GroupNorm(+SiLU) over channels-last [B*HW, C]; x2: optional second tensor concatenated along channels."""
+    _chk(x, BF16, "groupnorm.x", 2)
+    C1 = x.shape[1]
+    C = C1 + (x2.shape[1] if x2 is not None else 0)
+    if not x.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
+        raise ValueError("groupnorm: inputs must be contiguous")
+    if out is None:
+        out = torch.empty(B * HW, C, dtype=BF16, device=x.device)
+    ws = torch.empty(lib.ae_groupnorm_workspace_floats(B, HW, groups), dtype=torch.float32, device=x.device)
+    check(lib.ae_groupnorm_nhwc_bf16(_p(x), _p(x2), C1, _p(gamma), _p(beta), _p(out), B, HW, C, groups, eps,
+                                     1 if silu else 0, _p(ws), _s()), "ae_groupnorm_nhwc_bf16")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    _chk(x, BF16, "layernorm.x", 2)
+    if not x.is_contiguous():
+        raise ValueError("layernorm: x must be contiguous")
+    M, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.ae_layernorm_bf16(_p(x), _p(gamma), _p(beta), _p(out), M, C, eps, _s()), "ae_layernorm_bf16")
+    return out
+
+
+# --------------------------------------------------------------------------- attention
+def attention(q, k, v, B, H, Nq, Nk, D, scale, q_strides, k_strides, v_strides, out=None, rel_h=None, rel_w=None,
+              kH=0, kW=0, key_mask=None):
+    """q/k/v: bf16 tensors (any shape) addressed via (batch, head, row) element strides; out: [B, Nq, H*D] bf16."""
+    if out is None:
+        out = torch.empty(B, Nq, H * D, dtype=BF16, device=q.device)
+    o_strides = (Nq * H * D, D, H * D)
+    check(lib.ae_attn_fwd_bf16(_p(q), _p(k), _p(v), _p(out), B, H, Nq, Nk, D, *q_strides, *k_strides, *v_strides, *o_strides,
+                               scale, _p(rel_h), _p(rel_w), kH, kW, _p(key_mask), _s()), "ae_attn_fwd_bf16")
+    return out
+
+
+def attention_bhnd(q, k, v, scale=None, key_mask=None):
+    """xformers-style entry: q [BH, Nq, D], k/v [BH, Nk, D] contiguous bf16 -> [BH, Nq, D] (attention.py:222-233)."""
+    _chk(q, BF16, "attention.q", 3)
+    BH, Nq, D = q.shape
+    Nk = k.shape[1]
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    out = torch.empty(BH, Nq, D, dtype=BF16, device=q.device)
+    scale = scale if scale is not None else D ** -0.5
+    check(lib.ae_attn_fwd_bf16(_p(q), _p(k), _p(v), _p(out), BH, 1, Nq, Nk, D, Nq * D, 0, D, Nk * D, 0, D, Nk * D, 0, D,
+                               Nq * D, 0, D, scale, None, None, 0, 0, _p(key_mask), _s()), "ae_attn_fwd_bf16")
+    return out
+
+
+# --------------------------------------------------------------------------- layout / elementwise
+def nchw_to_rows(x, c_pad=None):
+    """[B,C,H,W] (fp32 or bf16) -> channels-last bf16 [B*H*W, Cpad] (zero padded channels)."""
+    B, C, H, W = x.shape
+    x = x.contiguous()
+    c_pad = c_pad or C
+    out = torch.empty(B * H * W, c_pad, dtype=BF16, device=x.device)
+    check(lib.ae_transpose_last2(_p(x), _p(out), B, C, H * W, c_pad, 1 if x.dtype == BF16 else 0, 1, _s()), "ae_transpose_last2")
+    return out
+
+
+def rows_to_nchw(x, B, H, W, out_dtype=torch.float32):
+    """channels-last [B*H*W, C] (bf16 or fp32) -> [B,C,H,W]."""
+    C = x.shape[1]
+    x = x.contiguous()
+    out = torch.empty(B, C, H, W, dtype=out_dtype, device=x.device)
+    check(lib.ae_transpose_last2(_p(x), _p(out), B, H * W, C, H * W, 1 if x.dtype == BF16 else 0,
+                                 1 if out_dtype == BF16 else 0, _s()), "ae_transpose_last2")
+    return out
+
+
+def concat_channels(a, b):
+    out = torch.empty(a.shape[0], a.shape[1] + b.shape[1], dtype=BF16, device=a.device)
+    check(lib.ae_concat_channels_bf16(_p(a), a.shape[1], _p(b), b.shape[1], _p(out), a.shape[0], _s()), "ae_concat_channels_bf16")
+    return out
+
+
+def timestep_embedding(t, dim, max_period=10000.0, out_f32=False):
+    B = t.shape[0]
+    out = torch.empty(B, dim, dtype=torch.float32 if out_f32 else BF16, device=t.device)
+    t_i64 = t if t.dtype == torch.int64 else None
+    t_f32 = None if t_i64 is not None else t.float().contiguous()
+    check(lib.ae_timestep_embedding(_p(t_i64), _p(t_f32), None if out_f32 else _p(out), _p(out) if out_f32 else None, B, dim,
+                                    float(max_period), _s()), "ae_timestep_embedding")
+    return out
+
+
+def ddim_step(x, eps, coeffs, branches, s0=1.0, s1=0.0, noise=None, temperature=1.0, want_pred_x0=True):
+    """coeffs = (sqrt_one_minus_at, sqrt_at, sqrt_a_prev, dir_coef, sigma_t) as python floats holding fp32 values."""
+    _chk(x, torch.float32, "ddim_step.x")
+    _chk(eps, torch.float32, "ddim_step.eps")
+    x = x.contiguous()
+    eps = eps.contiguous()
+    n = x.numel()
+    if eps.numel() != branches * n:
+        raise ValueError(f"ddim_step: eps has {eps.numel()} elements, expected {branches}*{n}")
+    x_prev = torch.empty_like(x)
+    pred_x0 = torch.empty_like(x) if want_pred_x0 else None
+    s1m, sat, sap, dirc, sig = coeffs
+    check(lib.ae_ddim_step_f32(_p(x), _p(eps), _p(noise), _p(x_prev), _p(pred_x0), None, n, branches, s0, s1, s1m, sat, sap,
+                               dirc, sig, temperature, _s()), "ae_ddim_step_f32")
+    return x_prev, pred_x0
+
+
+def mask_blend(img, x0, noise, mask, sqrt_ac, sqrt_one_minus_ac, ip2p_order=False):
+    B, C, H, W = img.shape
+    out = torch.empty_like(img)
+    check(lib.ae_mask_blend_f32(_p(img.contiguous()), _p(x0.contiguous()), _p(noise.contiguous()), _p(mask.contiguous().float()),
+                                _p(out), B, C, H * W, sqrt_ac, sqrt_one_minus_ac, 1 if ip2p_order else 0, _s()), "ae_mask_blend_f32")
+    return out
+
+
+def q_sample(x0, noise, sqrt_ac_t, sqrt_one_minus_ac_t):
+    """per-sample fp32 coefficient vectors [B] (already gathered at t)."""
+    out = torch.empty_like(x0)
+    B = x0.shape[0]
+    check(lib.ae_q_sample_f32(_p(x0.contiguous()), _p(noise.contiguous()), _p(sqrt_ac_t.contiguous()),
+                              _p(sqrt_one_minus_ac_t.contiguous()), _p(out), B, x0.numel() // B, _s()), "ae_q_sample_f32")
+    return out
+
+
+def silu_to_bf16(x):
+    """silu(x) -> bf16 (ResBlock.emb_layers[0], openaimodel.py:212-214)."""
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(lib.ae_silu_to_bf16(_p(x), 1 if x.dtype == BF16 else 0, _p(out), x.numel(), _s()), "ae_silu_to_bf16")
+    return out
+
+
+def add_bcast(x, p):
+    out = torch.empty_like(x)
+    check(lib.ae_add_bcast_bf16(_p(x), _p(p), _p(out), x.numel(), p.numel(), _s()), "ae_add_bcast_bf16")
+    return out
+
+
+def window_partition(x, B, H, W, ws):
+    C = x.shape[-1]
+    nH, nW = (H + ws - 1) // ws, (W + ws - 1) // ws
+    out = torch.empty(B * nH * nW * ws * ws, C, dtype=BF16, device=x.device)
+    check(lib.ae_window_partition_bf16(_p(x), _p(out), B, H, W, C, ws, 0, _s()), "ae_window_partition_bf16")
+    return out, (nH * ws, nW * ws)
+
+
+def window_unpartition(windows, B, H, W, ws):
+    C = windows.shape[-1]
+    out = torch.empty(B * H * W, C, dtype=BF16, device=windows.device)
+    check(lib.ae_window_partition_bf16(_p(out), _p(windows), B, H, W, C, ws, 1, _s()), "ae_window_partition_bf16")
+    return out
+
+
+def sam_relpos_terms(q, q_strides, Rh, Rw, B, heads, qH, qW, D):
+    kH, kW = Rh.shape[1], Rw.shape[1]
+    rel_h = torch.empty(B * heads, qH * qW, kH, dtype=torch.float32, device=q.device)
+    rel_w = torch.empty(B * heads, qH * qW, kW, dtype=torch.float32, device=q.device)
+    check(lib.ae_sam_relpos_terms(_p(q), *q_strides, _p(Rh), _p(Rw), _p(rel_h), _p(rel_w), B, heads, qH, qW, kH, kW, D, _s()),
+          "ae_sam_relpos_terms")
+    return rel_h, rel_w
+
+
+def patchify(x, P):
+    B, Cin, H, W = x.shape
+    out = torch.empty(B * (H // P) * (W // P), Cin * P * P, dtype=BF16, device=x.device)
+    check(lib.ae_patchify_f32_bf16(_p(x.float().contiguous()), _p(out), B, Cin, H, W, P, _s()), "ae_patchify_f32_bf16")
+    return out
+
+
+def mse(a, b):
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    check(lib.ae_mse_f32(_p(a.float().contiguous()), _p(b.float().contiguous()), _p(out), a.numel(), _s()), "ae_mse_f32")
+    return out[0]
+
+
+def task_gate(task_emb, edit_code, Wg, bg):
+    B = edit_code.shape[0]
+    n_tasks, Dt = task_emb.shape
+    E = Wg.shape[0]
+    probs = torch.empty(B, E, dtype=torch.float32, device=task_emb.device)
+    top1 = torch.empty(B, dtype=torch.int32, device=task_emb.device)
+    top1p = torch.empty(B, dtype=torch.float32, device=task_emb.device)
+    check(lib.ae_task_gate(_p(task_emb.float().contiguous()), _p(edit_code.long().contiguous()), _p(Wg.float().contiguous()),
+                           _p(bg.float().contiguous()) if bg is not None else None, B, n_tasks, Dt, E, _p(probs), _p(top1),
+                           _p(top1p), _s()), "ae_task_gate")
+    return probs, top1, top1p

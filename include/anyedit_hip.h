@@ -1,0 +1,115 @@
+/* libanyedit_hip.so — C ABI of the MI355X (gfx950) AnyEdit denoising hot path.
+ *
+ * The reference (DCDmllm/AnyEdit) has NO C ABI on this path: its boundaries are Python callables that it already
+ * swaps at exactly these points (SURVEY.md §8b): the attention-class registry ldm/modules/attention.py:247-256,
+ * the fused-op call xformers.ops.memory_efficient_attention at attention.py:222-233, the layer factories
+ * conv_nd/linear/normalization at ldm/modules/diffusionmodules/util.py:202-238, and — the one real FFI in the tree —
+ * pybind11 `_C.ms_deform_attn_forward` (GroundingDINO/.../csrc/vision.cpp:53-56).  Each entry point below names the
+ * reference interface it replaces.  INTEGRATION.md shows the reference-side ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = error (AE_ERR_*); ae_last_error() returns the message (thread local);
+ *   - never throws, never allocates caller-visible memory, never synchronises the device;
+ *   - all data pointers are DEVICE pointers borrowed for the duration of the call; inputs are not mutated;
+ *   - the last argument is the hipStream_t (as void*) the work is enqueued on (graph-capture safe);
+ *   - "bf16" buffers are raw bfloat16 bits (uint16); activations are channels-last: [B, H*W, C] / [rows, C].
+ */
+#ifndef ANYEDIT_HIP_H
+#define ANYEDIT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AE_OK 0
+#define AE_ERR_ARG (-1)
+#define AE_ERR_LAUNCH (-2)
+#define AE_ERR_UNSUPPORTED (-3)
+
+/* epilogue selector of ae_gemm_bf16 */
+#define AE_EPI_NONE 0  /* out = acc + bias + addvec (+ residual)                         */
+#define AE_EPI_GELU 1  /* out = gelu_erf(acc + bias) (+ residual)   (SAM MLPBlock, common.py:13-27) */
+#define AE_EPI_GEGLU 2 /* out[:, j] = a_j * gelu_erf(g_j), W rows interleaved 16 a / 16 g (attention.py:49-58) */
+#define AE_EPI_SILU 3  /* out = silu(acc + bias)                    (time_embed, openaimodel.py:526-531) */
+
+int ae_version(void);
+const char* ae_last_error(void);
+int ae_device_arch(char* buf, int n);                          /* e.g. "gfx950:sramecc+:xnack-" */
+int ae_device_info(int* cus, long* hbm_bytes, int* clock_khz);
+
+/* nn.Linear / 1x1 nn.Conv2d on channels-last rows (util.py:202-238 factories; attention.py:154-161 to_q/to_k/to_v/to_out,
+ * :49-76 FeedForward/GEGLU, :296-318 proj_in/proj_out; openaimodel.py:233-240 skip 1x1, :526-531 time_embed, :214-219 emb_layers).
+ *   C[M,N] = epi(A[M,K] @ W[N,K]^T); A2 != NULL: columns [Ksplit,K) of A come from A2 (skip-concat, openaimodel.py:780).
+ *   K % 8 == 0, N % 4 == 0, rows 16-byte aligned.  addvec: fp32 [M/rows_per_batch, N].  out_f32: C is fp32.          */
+int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, int Ksplit, const void* W, long ldw, void* C, long ldc,
+                 int M, int N, int K, const float* bias, const void* residual, long ldr, const float* addvec,
+                 int rows_per_batch, int epilogue, int out_f32, void* stream);
+
+/* 3x3 convolution, padding 1, as implicit GEMM (ResBlock in/out convs openaimodel.py:200-231, stem :536-542, head :726-730,
+ * Downsample stride 2 :157-159, Upsample nearest-x2 + conv :108-118 via upsample2x=1).
+ *   x [B,H,W,Cin] bf16 channels-last (Cin % 8 == 0), w [Cout, 9*CinPad] bf16 packed (ky,kx,cin) with CinPad = Cin
+ *   rounded up to 64 (zero filled), y [B,Ho,Wo,Cout];
+ *   addvec fp32 [B,Cout] (time-embedding add, openaimodel.py:262-272), residual bf16 [B,Ho,Wo,Cout] (skip, :274).         */
+int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float* addvec, const void* residual, void* y,
+                    int B, int H, int W, int Cin, int Cout, int stride, int upsample2x, int out_f32, void* stream);
+
+/* GroupNorm32 (+SiLU) (util.py:217-219 eps 1e-5; attention.py:88-89 eps 1e-6); input may be the channel-concat [x | x2].
+ * workspace: fp32, ae_groupnorm_workspace_floats(B,HW,groups) elements.  act: 0 none, 1 SiLU.                              */
+int ae_groupnorm_rows_per_chunk(int HW);
+long ae_groupnorm_workspace_floats(int B, int HW, int groups);
+int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y, int B, int HW,
+                           int C, int groups, float eps, int act, float* workspace, void* stream);
+
+/* nn.LayerNorm over the last dim (attention.py:263-265 eps 1e-5; SAM image_encoder.py:166-182 / common.py:30-43 eps 1e-6). */
+int ae_layernorm_bf16(const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps, void* stream);
+
+/* Fused attention forward = CrossAttention.forward core (attention.py:171-193) / xformers.ops.memory_efficient_attention
+ * (attention.py:233) / SAM Attention.forward core (image_encoder.py:231-238).  q/k/v/out addressed by element strides
+ * (batch, head, row); head_dim D in {8,16,32,40,48,64,80,96,128,160}.  rel_h/rel_w: optional fp32 [B*H,Nq,kH] / [B*H,Nq,kW]
+ * decomposed relative-position bias (image_encoder.py:325-361), Nk == kH*kW.  key_mask: optional uint8 [B,Nk], 0 = masked
+ * (attention.py:183-187).                                                                                                  */
+int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int D,
+                     long q_sb, long q_sh, long q_sn, long k_sb, long k_sh, long k_sn, long v_sb, long v_sh, long v_sn,
+                     long o_sb, long o_sh, long o_sn, float scale, const float* rel_h, const float* rel_w, int kH, int kW,
+                     const unsigned char* key_mask, void* stream);
+
+/* out[b,y,x] = in[b,x,y], inner dim zero-padded to Xpad: NCHW <-> channels-last at the UNet boundary
+ * ('b c h w -> b (h w) c', attention.py:329,337).                                                                           */
+int ae_transpose_last2(const void* in, void* out, int B, int X, int Y, int Xpad, int in_bf16, int out_bf16, void* stream);
+/* th.cat([h, hs.pop()], dim=1) (openaimodel.py:780) on channels-last rows.                                                   */
+int ae_concat_channels_bf16(const void* a, int Ca, const void* b, int Cb, void* y, long rows, void* stream);
+/* timestep_embedding (util.py:154-174): [cos | sin], t given as int64 or fp32.                                               */
+int ae_timestep_embedding(const long* t_i64, const float* t_f32, void* out_bf16, float* out_f32, int B, int dim, float max_period,
+                          void* stream);
+/* CFG combine + DDIM update, fp32, unfused arithmetic (ddim.py:211-212, 228-250; 3-branch global_tool.py:172-177).
+ * eps holds `branches` stacked copies of n elements: 2 -> [uncond, cond]; 3 -> [text, image, uncond].                        */
+int ae_ddim_step_f32(const float* x, const float* eps, const float* noise, float* x_prev, float* pred_x0, float* e_out, long n,
+                     int branches, float s0, float s1, float sqrt_one_minus_at, float sqrt_at, float sqrt_a_prev, float dir_coef,
+                     float sigma_t, float temperature, void* stream);
+/* q_sample (ddpm.py:356-359) fused with the mask blend (ddim.py:154-157; ip2p_order=1: global_tool.py:183-184).               */
+int ae_mask_blend_f32(const float* img, const float* x0, const float* noise, const float* mask, float* out, int B, int C, int HW,
+                      float sqrt_ac, float sqrt_one_minus_ac, int ip2p_order, void* stream);
+int ae_q_sample_f32(const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_one_minus_ac, float* out, int B,
+                    long per_sample, void* stream);
+/* y = bf16(silu(x)): the nn.SiLU in front of ResBlock.emb_layers (openaimodel.py:212-219).                                    */
+int ae_silu_to_bf16(const void* x, int in_bf16, void* y, long n, void* stream);
+/* y = x + p broadcast with period (pos_embed add, image_encoder.py:108-109).                                                 */
+int ae_add_bcast_bf16(const void* x, const void* p, void* y, long n, long period, void* stream);
+/* window_partition / window_unpartition (image_encoder.py:243-289); arguments are always (image, windows).                    */
+int ae_window_partition_bf16(const void* image, void* windows, int B, int H, int W, int C, int ws, int reverse, void* stream);
+/* rel_h / rel_w einsums of add_decomposed_rel_pos (image_encoder.py:349-355); Rh [qH,kH,D], Rw [qW,kW,D] fp32.                */
+int ae_sam_relpos_terms(const void* q, long q_sb, long q_sh, long q_sn, const float* Rh, const float* Rw, float* rel_h,
+                        float* rel_w, int B, int heads, int qH, int qW, int kH, int kW, int D, void* stream);
+/* PatchEmbed im2col (image_encoder.py:364-395): [B,Cin,H,W] fp32 -> [B*(H/P)*(W/P), Cin*P*P] bf16.                            */
+int ae_patchify_f32_bf16(const float* x, void* y, int B, int Cin, int H, int W, int P, void* stream);
+/* mean((a-b)^2) -> out[0] (train.py:696, ddpm.py:367-380).                                                                    */
+int ae_mse_f32(const float* a, const float* b, float* out, long n, void* stream);
+/* AnySD task router (OUR spec, reference source absent — SURVEY.md §8a row A9): logits = task_emb[edit_code] @ Wg^T + bg,
+ * softmax over E experts, top-1 index + probability per sample.                                                              */
+int ae_task_gate(const float* task_emb, const long* edit_code, const float* Wg, const float* bg, int B, int n_tasks, int Dt,
+                 int E, float* probs, int* top1, float* top1_prob, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANYEDIT_HIP_H */

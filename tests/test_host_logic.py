@@ -1,0 +1,127 @@
+"""CPU tests of the host side: C-ABI exports, constructor/state-dict parity with the reference, schedule mirrors,
+weight packing.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, ROOT
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from anyedit_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "anyedit_hip.h")).read()
+    declared = set(re.findall(r"\b(ae_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in include/anyedit_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.lib.ae_version() >= 100
+
+
+def test_error_reporting_without_gpu():
+    from anyedit_amd import _lib
+    rc = _lib.lib.ae_gemm_bf16(None, 0, None, 0, 0, None, 0, None, 0, 1, 4, 64, None, None, 0, None, 0, 0, 0, None)
+    assert rc == -1 and b"null pointer" in _lib.lib.ae_last_error()
+    rc = _lib.lib.ae_ddim_step_f32(1, 1, None, 1, None, None, 10, 7, 0, 0, 0, 0, 0, 0, 0, 0, None)
+    assert rc == -1 and b"branches" in _lib.lib.ae_last_error()
+    with pytest.raises(_lib.AnyEditHipError):
+        _lib.check(rc, "ae_ddim_step_f32")
+
+
+def test_ops_refuse_cpu_tensors():
+    from anyedit_amd import ops
+    with pytest.raises(ValueError, match="no CPU path"):
+        ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(4, 64, dtype=torch.bfloat16))
+
+
+def test_constructor_matches_reference_init_and_state_dict_keys():
+    """Same seed -> same parameters as the reference constructor (creation order preserved), same key schema."""
+    from util_models import build_tiny_unet
+    g = load_golden("unet_tiny")
+    unet = build_tiny_unet()
+    sd = unet.state_dict()
+    ref_keys = {k[2:] for k in g if k.startswith("w.")}
+    assert set(sd.keys()) == ref_keys
+    for k in ref_keys:
+        assert torch.equal(sd[k], torch.from_numpy(g["w." + k])), k
+
+
+def test_sd15_key_schema_and_param_count():
+    """Appendix A of SURVEY.md: 686 tensors, 859 532 484 parameters (meta device, no memory)."""
+    from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    with torch.device("meta"):
+        unet = UNetModel(image_size=64, in_channels=8, model_channels=320, out_channels=4, num_res_blocks=2,
+                         attention_resolutions=[4, 2, 1], channel_mult=[1, 2, 4, 4], num_heads=8,
+                         use_spatial_transformer=True, transformer_depth=1, context_dim=768, legacy=False)
+    sd = unet.state_dict()
+    assert len(sd) == 686
+    assert sum(v.numel() for v in sd.values()) == 859532484
+    assert sd["input_blocks.1.1.transformer_blocks.0.attn2.to_k.weight"].shape == (320, 768)
+    assert sd["output_blocks.5.2.conv.weight"].shape == (1280, 1280, 3, 3)
+    assert sd["input_blocks.3.0.op.weight"].shape == (320, 320, 3, 3)
+    assert "output_blocks.11.0.skip_connection.weight" in sd and "input_blocks.1.0.skip_connection.weight" not in sd
+
+
+def test_schedule_mirror_bit_exact():
+    from anyedit_amd.ldm.modules.diffusionmodules import util as U
+    g = load_golden("schedule")
+    assert np.array_equal(U.make_beta_schedule("linear", 1000, 0.00085, 0.0120), g["betas"])
+    for s in (7, 20, 30, 50, 100):
+        ts = U.make_ddim_timesteps("uniform", s, 1000, verbose=False)
+        assert ts.dtype == g[f"ts_uniform_{s}"].dtype and np.array_equal(ts, g[f"ts_uniform_{s}"])
+    assert np.array_equal(U.make_ddim_timesteps("quad", 10, 1000, verbose=False), g["ts_quad_10"])
+    ac = np.cumprod(1.0 - g["betas"], axis=0)
+    sig, a, ap = U.make_ddim_sampling_parameters(ac, g["ts_uniform_50"], 1.0, verbose=False)
+    assert np.array_equal(sig, g["sig_S50_eta1"]) and np.array_equal(a, g["a_S50_eta1"]) and np.array_equal(ap, g["ap_S50_eta1"])
+
+
+def test_ddpm_buffers_and_sampler_schedule_on_cpu():
+    """DDPM.register_schedule + DDIMSampler.make_schedule (host part) against the reference's tables, bit-exact."""
+    from anyedit_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from anyedit_amd.ldm.models.diffusion.ddim import DDIMSampler
+    from util_models import build_tiny_unet
+    g = load_golden("ddim_tiny")
+    ldm = LatentDiffusion(build_tiny_unet(), conditioning_key="hybrid", timesteps=1000, linear_start=0.00085, linear_end=0.0120)
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod"):
+        assert torch.equal(getattr(ldm, k), torch.from_numpy(g[f"model.{k}"])), k
+    s = DDIMSampler(ldm)
+    for tag, S in (("s5_cfg", 5), ("s20_cfg", 20), ("s7_cfg_mask", 7)):
+        s.make_schedule(S, ddim_eta=0.0, verbose=False)
+        assert np.array_equal(s.ddim_timesteps, g[f"{tag}.ddim_timesteps"]) and s.ddim_timesteps.dtype == np.int64
+        for k in ("ddim_alphas", "ddim_alphas_prev", "ddim_sigmas", "ddim_sqrt_one_minus_alphas"):
+            assert np.array_equal(np.asarray(getattr(s, k)), g[f"{tag}.{k}"]), k
+        # the fp32 scalars handed to the kernel are exactly what torch.full would have stored
+        for idx in range(len(s.ddim_timesteps)):
+            s1m, sat, sap, dirc, sig = s._coeffs(idx, False)
+            a_t = torch.full((1,), g[f"{tag}.ddim_alphas"][idx])
+            a_prev = torch.full((1,), g[f"{tag}.ddim_alphas_prev"][idx])
+            sg = torch.full((1,), g[f"{tag}.ddim_sigmas"][idx])
+            # torch's CPU fp32 sqrt is not always correctly rounded (1 ulp off for some inputs); numpy's is,
+            # like the GPU's sqrt the reference would run -> compare within 1 ulp
+            ulp = lambda a, b: abs(np.float32(a).view(np.int32).astype(np.int64) - np.float32(b).view(np.int32).astype(np.int64)) <= 1
+            assert ulp(sat, float(a_t.sqrt())) and ulp(sap, float(a_prev.sqrt()))
+            assert ulp(dirc, float((1. - a_prev - sg ** 2).sqrt()))
+            assert s1m == float(torch.full((1,), g[f"{tag}.ddim_sqrt_one_minus_alphas"][idx]))
+
+
+def test_weight_packing_layouts():
+    from anyedit_amd import ops
+    w = torch.arange(2 * 3 * 9, dtype=torch.float32).reshape(2, 3, 3, 3)
+    p = ops.pack_conv3x3(w).float().reshape(2, 9, 64)
+    for ky in range(3):
+        for kx in range(3):
+            assert torch.equal(p[:, ky * 3 + kx, :3], w[:, :, ky, kx]) and p[:, ky * 3 + kx, 3:].abs().sum() == 0
+    inner = 32
+    wg = torch.arange(2 * inner * 8, dtype=torch.float32).reshape(2 * inner, 8)
+    bg = torch.arange(2 * inner, dtype=torch.float32)
+    wp, bp = ops.pack_geglu(wg, bg)
+    wp = wp.float()
+    for j in range(inner // 16):
+        assert torch.equal(wp[32 * j:32 * j + 16], wg[16 * j:16 * j + 16])
+        assert torch.equal(wp[32 * j + 16:32 * j + 32], wg[inner + 16 * j:inner + 16 * j + 16])
+        assert torch.equal(bp[32 * j + 16:32 * j + 32], bg[inner + 16 * j:inner + 16 * j + 16])
