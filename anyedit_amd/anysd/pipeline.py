@@ -1,0 +1,100 @@
+"""InstructPix2Pix / AnySD-style edit loop on the HIP path: 3-branch classifier-free guidance
+(text+image, image-only, unconditional — AnyEdit_Collection/adaptive_editing_pipelines/tools/global_tool.py:166-177,
+290-304; train.py:61-68 validation settings) driven by the ldm DDIM schedule/update (ldm/models/diffusion/ddim.py:23-52,
+223-250), with the masked-latent blend of global_tool.py:183-184.
+
+One UNet evaluation per step on the 3B batch, captured once as a HIP graph (torch.cuda.CUDAGraph = hipGraph) and replayed;
+the CFG combine + DDIM update is a single fused kernel per step; text/task/expert K|V are projected once per edit.
+"""
+import numpy as np
+import torch
+
+from anyedit_amd import ops
+from anyedit_amd.ldm.models.diffusion.ddim import DDIMSampler, _f32
+
+
+class EditPipeline:
+    def __init__(self, moe, schedule_model, use_graph=True):
+        """moe: anysd.MoE (or any object with prepare_conditioning/denoise); schedule_model: the DDPM-duck-typed owner of
+        betas/alphas_cumprod (anyedit_amd.ldm.models.diffusion.ddpm.DDPM or a reference LatentDiffusion)."""
+        self.moe = moe
+        self.sampler = DDIMSampler(schedule_model)
+        self.schedule_model = schedule_model
+        self.use_graph = use_graph
+        self._graph = None
+        self._graph_key = None
+        self.randn = torch.randn
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _denoise_static(self):
+        return self.moe.denoise(self._x_in, self._t, self._ctx_rows, self._kv_cache)
+
+    def _ensure_graph(self, key):
+        if self._graph is not None and self._graph_key == key:
+            return
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(2):  # warm-up outside capture (module loading, allocator pools)
+                self._denoise_static()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._eps = self._denoise_static()
+        self._graph, self._graph_key = g, key
+
+    @torch.no_grad()
+    def prepare(self, img_lat, ehs, null_ehs, ref_embeds, edit_code):
+        """Step-invariant conditioning for the 3B batch; returns nothing, state is kept for `edit`."""
+        B = img_lat.shape[0]
+        if null_ehs.shape[0] == 1:
+            null_ehs = null_ehs.expand(B, -1, -1)
+        ehs3 = torch.cat([ehs, null_ehs, null_ehs], 0)
+        ref3 = torch.cat([ref_embeds, ref_embeds, torch.zeros_like(ref_embeds)], 0)
+        code3 = torch.cat([edit_code] * 3, 0)
+        self._ctx_rows, self._kv_cache = self.moe.prepare_conditioning(ehs3, ref3, code3)
+        img_cond3 = torch.cat([img_lat, img_lat, torch.zeros_like(img_lat)], 0).float()      # global_tool.py:290-304
+        C = img_lat.shape[1]
+        self._x_in = torch.empty(3 * B, 2 * C, *img_lat.shape[2:], dtype=torch.float32, device=img_lat.device)
+        self._x_in[:, C:] = img_cond3
+        self._t = torch.zeros(3 * B, dtype=torch.long, device=img_lat.device)
+        self._graph = None  # conditioning buffers changed identity -> recapture
+
+    @torch.no_grad()
+    def edit(self, x_T, img_lat, ehs, null_ehs, ref_embeds, edit_code, steps=50, s_txt=7.5, s_img=1.5, eta=0.0, mask=None,
+             x0=None, prepared=False, step_callback=None):
+        """Returns the edited latents [B,4,h,w] fp32.  mask/x0: optional masked-latent blend (global_tool.py:183-184)."""
+        B, C = x_T.shape[0], x_T.shape[1]
+        dev = x_T.device
+        if not prepared:
+            self.prepare(img_lat, ehs, null_ehs, ref_embeds, edit_code)
+        s = self.sampler
+        s.make_schedule(ddim_num_steps=steps, ddim_eta=eta, verbose=False)
+        timesteps = s.ddim_timesteps
+        total = timesteps.shape[0]
+        img = x_T.float().contiguous()
+        blend_noise = self.randn(x0.shape, device=dev) if mask is not None else None         # one noise, as global_tool.py:161
+        if self.use_graph:
+            self._ensure_graph((tuple(x_T.shape), steps))
+        x_view = self._x_in[:, :C].view(3, B, C, *x_T.shape[2:])
+        for i, step in enumerate(np.flip(timesteps)):
+            index = total - i - 1                                                            # ddim.py:151 bookkeeping
+            x_view.copy_(img.unsqueeze(0))
+            self._t.fill_(int(step))
+            if self.use_graph:
+                self._graph.replay()
+                eps = self._eps
+            else:
+                eps = self._denoise_static()
+            noise = self.randn(img.shape, device=dev) if eta != 0.0 else None
+            img, _ = ops.ddim_step(img, eps, s._coeffs(index, False), 3, s0=float(s_txt), s1=float(s_img), noise=noise,
+                                   want_pred_x0=False)
+            if mask is not None:
+                sa = float(_f32(self.schedule_model.sqrt_alphas_cumprod[int(step)]))
+                s1 = float(_f32(self.schedule_model.sqrt_one_minus_alphas_cumprod[int(step)]))
+                img = ops.mask_blend(img, x0, blend_noise, mask, sa, s1, ip2p_order=True)
+            if step_callback is not None:
+                step_callback(i, img)
+        return img

@@ -34,6 +34,8 @@ struct AttnArgs {
     float scale;
     const float* rel_h; const float* rel_w; int kH, kW;  // optional decomposed bias, fp32 [B*H, Nq, kH|kW]
     const uint8_t* key_mask;                               // optional [B, Nk], 0 = masked
+    const float* out_scale;                                // optional [B]: out = (accum ? out : 0) + out_scale[b] * result
+    int accum;
 };
 
 __device__ __forceinline__ int vt_pos(int key) {  // key = 16 f + 4 g + r  ->  16 g + 4 f + r
@@ -264,15 +266,20 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
         float l = l_run[a];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
-        const float inv = 1.0f / l;
+        const float inv = (p.out_scale ? p.out_scale[b] : 1.0f) / l;
         const int qrow = q0 + a * 16 + l15;
         if (qrow >= p.Nq) continue;
 #pragma unroll
         for (int df = 0; df < NDF; ++df) {
             const int d = df * 16 + lg * 4;
             if (d < D) {
-                u32x2 pk = {pack_bf16x2(o[a][df][0] * inv, o[a][df][1] * inv), pack_bf16x2(o[a][df][2] * inv, o[a][df][3] * inv)};
-                *reinterpret_cast<u32x2*>(op + (long)qrow * p.o_sn + d) = pk;
+                float r0 = o[a][df][0] * inv, r1 = o[a][df][1] * inv, r2 = o[a][df][2] * inv, r3 = o[a][df][3] * inv;
+                u32x2* dst = reinterpret_cast<u32x2*>(op + (long)qrow * p.o_sn + d);
+                if (p.accum) {  // decoupled adapter attention: out += gate * Attn(q, K_ip, V_ip)
+                    const u32x2 prev = *dst;
+                    r0 += bf16lo(prev.x); r1 += bf16hi(prev.x); r2 += bf16lo(prev.y); r3 += bf16hi(prev.y);
+                }
+                *dst = (u32x2){pack_bf16x2(r0, r1), pack_bf16x2(r2, r3)};
             }
         }
     }
@@ -294,7 +301,7 @@ extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
                                 long q_sb, long q_sh, long q_sn, long k_sb, long k_sh, long k_sn,
                                 long v_sb, long v_sh, long v_sn, long o_sb, long o_sh, long o_sn, float scale,
                                 const float* rel_h, const float* rel_w, int kH, int kW, const unsigned char* key_mask,
-                                void* stream) {
+                                const float* out_scale, int accumulate, void* stream) {
     AE_REQUIRE(q && k && v && out, "ae_attn_fwd_bf16: null pointer");
     AE_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0, "ae_attn_fwd_bf16: bad sizes B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
     AE_REQUIRE((q_sb | q_sh | q_sn | k_sb | k_sh | k_sn | v_sb | v_sh | v_sn) % 8 == 0 && (o_sb | o_sh | o_sn) % 4 == 0,
@@ -309,6 +316,7 @@ extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
     a.q_sb = q_sb; a.q_sh = q_sh; a.q_sn = q_sn; a.k_sb = k_sb; a.k_sh = k_sh; a.k_sn = k_sn;
     a.v_sb = v_sb; a.v_sh = v_sh; a.v_sn = v_sn; a.o_sb = o_sb; a.o_sh = o_sh; a.o_sn = o_sn;
     a.scale = scale; a.rel_h = rel_h; a.rel_w = rel_w; a.kH = kH; a.kW = kW; a.key_mask = key_mask;
+    a.out_scale = out_scale; a.accum = accumulate;
     hipStream_t s = (hipStream_t)stream;
     switch (D) {
         case 8: return launch_attn<8, 2>(a, s);

@@ -123,8 +123,10 @@ class CrossAttention(nn.Module):
         """K|V of a context [B*Nk, Dc] -> [B*Nk, 2*inner] (step-invariant for text conditioning: cache it)."""
         return ops.gemm(ctx_rows, self._packed()["kv"])
 
-    def rows(self, x, B, N, context_rows=None, Nk=None, kv=None, key_mask=None, residual=None):
-        """x: [B*N, C] bf16 rows.  context_rows: [B*Nk, Dc] or None (self-attention).  Returns to_out(attn) (+residual)."""
+    def rows(self, x, B, N, context_rows=None, Nk=None, kv=None, key_mask=None, residual=None, adapter=None):
+        """x: [B*N, C] bf16 rows.  context_rows: [B*Nk, Dc] or None (self-attention).  Returns to_out(attn) (+residual).
+        adapter: optional (kv_ip [B*T, 2*inner] bf16, gate [B] fp32): decoupled expert attention added to the output,
+        out = Attn(q,K,V) + gate_b * Attn(q,K_ip,V_ip)  (AnySD row A9, shape template ip_adapter/attention_processor.py:141-173)."""
         pk = self._packed()
         h, d = self.heads, self.dim_head
         inner = h * d
@@ -140,6 +142,12 @@ class CrossAttention(nn.Module):
             qs = (N * inner, d, inner)
             ks = (Nk * 2 * inner, d, 2 * inner)
             o = ops.attention(q, kv, kv[:, inner:], B, h, N, Nk, d, self.scale, qs, ks, ks, key_mask=key_mask)
+            if adapter is not None:
+                kv_ip, gate = adapter
+                T_ip = kv_ip.shape[0] // B
+                ks_ip = (T_ip * 2 * inner, d, 2 * inner)
+                ops.attention(q, kv_ip, kv_ip[:, inner:], B, h, N, T_ip, d, self.scale, qs, ks_ip, ks_ip, out=o,
+                              out_scale=gate, accumulate=True)
         return self.to_out[0].rows(o.reshape(B * N, inner), residual=residual)
 
     def forward(self, x, context=None, mask=None):
@@ -188,13 +196,14 @@ class BasicTransformerBlock(nn.Module):
         """x: [B*N, C] bf16.  kv_cache: optional dict id(attn)->projected K|V of the (step-invariant) context."""
         c1 = context_rows if self.disable_self_attn else None
         x = self.attn1.rows(self.norm1.rows(x), B, N, context_rows=c1, residual=x)
-        kv2 = None
+        kv2, adapter = None, None
         if kv_cache is not None and context_rows is not None:
             key = id(self.attn2)
             kv2 = kv_cache.get(key)
             if kv2 is None:
                 kv2 = kv_cache[key] = self.attn2.project_kv(context_rows)
-        x = self.attn2.rows(self.norm2.rows(x), B, N, context_rows=context_rows, kv=kv2, residual=x)
+            adapter = kv_cache.get(("adapter", key))  # installed by anysd.MoE.prepare_conditioning
+        x = self.attn2.rows(self.norm2.rows(x), B, N, context_rows=context_rows, kv=kv2, residual=x, adapter=adapter)
         x = self.ff.rows(self.norm3.rows(x), residual=x)
         return x
 

@@ -140,13 +140,14 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
 
 # --------------------------------------------------------------------------- attention
 def attention(q, k, v, B, H, Nq, Nk, D, scale, q_strides, k_strides, v_strides, out=None, rel_h=None, rel_w=None,
-              kH=0, kW=0, key_mask=None):
+              kH=0, kW=0, key_mask=None, out_scale=None, accumulate=False):
     """q/k/v: bf16 tensors (any shape) addressed via (batch, head, row) element strides; out: [B, Nq, H*D] bf16."""
     if out is None:
         out = torch.empty(B, Nq, H * D, dtype=BF16, device=q.device)
     o_strides = (Nq * H * D, D, H * D)
     check(lib.ae_attn_fwd_bf16(_p(q), _p(k), _p(v), _p(out), B, H, Nq, Nk, D, *q_strides, *k_strides, *v_strides, *o_strides,
-                               scale, _p(rel_h), _p(rel_w), kH, kW, _p(key_mask), _s()), "ae_attn_fwd_bf16")
+                               scale, _p(rel_h), _p(rel_w), kH, kW, _p(key_mask), _p(out_scale), 1 if accumulate else 0, _s()),
+          "ae_attn_fwd_bf16")
     return out
 
 
@@ -159,7 +160,7 @@ def attention_bhnd(q, k, v, scale=None, key_mask=None):
     out = torch.empty(BH, Nq, D, dtype=BF16, device=q.device)
     scale = scale if scale is not None else D ** -0.5
     check(lib.ae_attn_fwd_bf16(_p(q), _p(k), _p(v), _p(out), BH, 1, Nq, Nk, D, Nq * D, 0, D, Nk * D, 0, D, Nk * D, 0, D,
-                               Nq * D, 0, D, scale, None, None, 0, 0, _p(key_mask), _s()), "ae_attn_fwd_bf16")
+                               Nq * D, 0, D, scale, None, None, 0, 0, _p(key_mask), None, 0, _s()), "ae_attn_fwd_bf16")
     return out
 
 
@@ -296,3 +297,97 @@ def task_gate(task_emb, edit_code, Wg, bg):
                            _p(bg.float().contiguous()) if bg is not None else None, B, n_tasks, Dt, E, _p(probs), _p(top1),
                            _p(top1p), _s()), "ae_task_gate")
     return probs, top1, top1p
+
+
+# --------------------------------------------------------------------------- per-op profiler (bench.py roofline leg)
+class OpProfiler:
+    """Records (kernel label, algorithmic flops, algorithmic bytes, HIP-event duration) for every GEMM / conv / attention /
+    norm launch issued through this module while active.  Events are recorded on torch's current stream, which is the
+    stream the kernels are launched on."""
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        global _PROF
+        _PROF = self
+        return self
+
+    def __exit__(self, *a):
+        global _PROF
+        _PROF = None
+        torch.cuda.synchronize()
+
+    def summary(self):
+        agg = {}
+        for label, flops, nbytes, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            a = agg.setdefault(label, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            a["calls"] += 1
+            a["ms"] += ms
+            a["flops"] += flops
+            a["bytes"] += nbytes
+        for a in agg.values():
+            a["avg_us"] = 1e3 * a["ms"] / a["calls"]
+            a["tflops"] = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0.0
+            a["gbps"] = a["bytes"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] > 0 else 0.0
+        return agg
+
+
+_PROF = None
+
+
+def _tile_label(M, N):
+    """Mirror of the tile choice in csrc/gemm_conv.hip::launch (for labelling only)."""
+    for bm, bn in ((128, 128), (128, 64), (64, 64)):
+        tm, tn = -(-M // bm), -(-N // bn)
+        if tm * tn >= 256 and tn * bn / N <= 1.10:
+            return f"{bm}x{bn}"
+    return "64x64"
+
+
+def _wrap_profiled(fn, label_fn):
+    def wrapped(*args, **kwargs):
+        if _PROF is None:
+            return fn(*args, **kwargs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn(*args, **kwargs)
+        e1.record()
+        label, flops, nbytes = label_fn(out, *args, **kwargs)
+        _PROF.records.append((label, flops, nbytes, e0, e1))
+        return out
+    wrapped.__doc__ = fn.__doc__
+    return wrapped
+
+
+def _gemm_label(out, a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue=EPI_NONE, out_f32=False, a2=None, **_):
+    M, (N, K) = a.shape[0], w.shape
+    nb = 2 * (M * K + N * K) + out.numel() * out.element_size() + (2 * M * N if residual is not None else 0)
+    return f"gemm_kernel<{_tile_label(M, N)},dense>", 2.0 * M * N * K, float(nb)
+
+
+def _conv_label(out, x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2x=False, out_f32=False, **_):
+    y = out[0]
+    M, Cout, Cin = y.shape[0], w.shape[0], x.shape[1]
+    nb = 2 * (x.numel() + 9 * Cin * Cout) + y.numel() * y.element_size() + (2 * y.numel() if residual is not None else 0)
+    return f"gemm_kernel<{_tile_label(M, Cout)},conv3x3>", 2.0 * M * Cout * 9 * Cin, float(nb)
+
+
+def _attn_label(out, q, k, v, B, H, Nq, Nk, D, *a, **_):
+    return f"attn_kernel<D={D}>", 4.0 * B * H * Nq * Nk * D, 2.0 * B * H * D * (2 * Nq + 2 * Nk)
+
+
+def _gn_label(out, x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, **_):
+    return "groupnorm(stats+apply)", 0.0, 2.0 * out.numel() * 2  # 1 read + 1 write algorithmic (SURVEY §8d)
+
+
+def _ln_label(out, x, *a, **_):
+    return "layernorm_kernel", 0.0, 2.0 * out.numel() * 2
+
+
+gemm = _wrap_profiled(gemm, _gemm_label)
+conv3x3 = _wrap_profiled(conv3x3, _conv_label)
+attention = _wrap_profiled(attention, _attn_label)
+groupnorm = _wrap_profiled(groupnorm, _gn_label)
+layernorm = _wrap_profiled(layernorm, _ln_label)

@@ -1,0 +1,222 @@
+"""Mirror of segment_anything/segment_anything/modeling/image_encoder.py (+ common.py) on HIP kernels — row A10.
+
+Class names, constructor arguments and state-dict keys follow the reference (ImageEncoderViT :17-116, Block :119-182,
+Attention :185-240, PatchEmbed :364-395, MLPBlock / LayerNorm2d common.py:13-43) so `build_sam_vit_h` checkpoints load.
+Tokens move as channels-last bf16 rows [B*H*W, C]; the attention core is the fused HIP kernel with the decomposed
+relative-position bias added inside the kernel (no [B*h, N, N] logits tensor — 1 GB per global block in the reference).
+"""
+from typing import Optional, Tuple, Type
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from anyedit_amd import ops
+from anyedit_amd.ldm.modules.diffusionmodules.util import Linear, Conv2d, LayerNorm
+
+BF16 = torch.bfloat16
+
+
+class MLPBlock(nn.Module):
+    """common.py:13-27; GELU (exact erf) fused into lin1's epilogue, the residual into lin2's."""
+
+    def __init__(self, embedding_dim: int, mlp_dim: int, act: Type[nn.Module] = nn.GELU) -> None:
+        super().__init__()
+        if act is not nn.GELU:
+            raise NotImplementedError("MLPBlock: only nn.GELU (the SAM configuration) is implemented")
+        self.lin1 = Linear(embedding_dim, mlp_dim)
+        self.lin2 = Linear(mlp_dim, embedding_dim)
+        self.act = act()
+
+    def rows(self, x, residual=None):
+        return self.lin2.rows(self.lin1.rows(x, epilogue=ops.EPI_GELU), residual=residual)
+
+    def forward(self, x):
+        shp = x.shape
+        return self.rows(x.reshape(-1, shp[-1]).to(BF16).contiguous()).reshape(shp).to(x.dtype)
+
+
+class LayerNorm2d(nn.Module):
+    """common.py:30-43: per-pixel LayerNorm over channels == row LayerNorm on channels-last rows."""
+
+    def __init__(self, num_channels: int, eps: float = 1e-6) -> None:
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(num_channels))
+        self.bias = nn.Parameter(torch.zeros(num_channels))
+        self.eps = eps
+
+    def rows(self, x):
+        return ops.layernorm(x, self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous(), self.eps)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        return ops.rows_to_nchw(self.rows(ops.nchw_to_rows(x)), B, H, W, out_dtype=x.dtype)
+
+
+def get_rel_pos(q_size: int, k_size: int, rel_pos: torch.Tensor) -> torch.Tensor:
+    """image_encoder.py:292-322 (table gather / linear-interp resize: parameter preparation, done once at pack time)."""
+    max_rel_dist = int(2 * max(q_size, k_size) - 1)
+    if rel_pos.shape[0] != max_rel_dist:
+        r = F.interpolate(rel_pos.reshape(1, rel_pos.shape[0], -1).permute(0, 2, 1), size=max_rel_dist, mode="linear")
+        r = r.reshape(-1, max_rel_dist).permute(1, 0)
+    else:
+        r = rel_pos
+    q_coords = torch.arange(q_size, device=rel_pos.device)[:, None] * max(k_size / q_size, 1.0)
+    k_coords = torch.arange(k_size, device=rel_pos.device)[None, :] * max(q_size / k_size, 1.0)
+    relative_coords = (q_coords - k_coords) + (k_size - 1) * max(q_size / k_size, 1.0)
+    return r[relative_coords.long()]
+
+
+class Attention(nn.Module):
+    """image_encoder.py:185-240."""
+
+    def __init__(self, dim: int, num_heads: int = 8, qkv_bias: bool = True, use_rel_pos: bool = False,
+                 rel_pos_zero_init: bool = True, input_size: Optional[Tuple[int, int]] = None) -> None:
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.head_dim = head_dim
+        self.scale = head_dim ** -0.5
+        self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = Linear(dim, dim)
+        self.use_rel_pos = use_rel_pos
+        if self.use_rel_pos:
+            assert input_size is not None, "Input size must be provided if using relative positional encoding."
+            self.rel_pos_h = nn.Parameter(torch.zeros(2 * input_size[0] - 1, head_dim))
+            self.rel_pos_w = nn.Parameter(torch.zeros(2 * input_size[1] - 1, head_dim))
+        self._rp = None
+
+    def repack(self):
+        self._rp = None
+
+    def _rel_tables(self, H, W):
+        if self._rp is None or self._rp[0] != (H, W) or self._rp[1].device != self.rel_pos_h.device:
+            Rh = get_rel_pos(H, H, self.rel_pos_h.detach().float()).contiguous()  # [H, H, d]
+            Rw = get_rel_pos(W, W, self.rel_pos_w.detach().float()).contiguous()
+            self._rp = ((H, W), Rh, Rw)
+        return self._rp[1], self._rp[2]
+
+    def rows(self, x, B, H, W, residual=None):
+        """x: [B*H*W, C] rows (B = windows or images).  Returns proj(attn) (+ residual)."""
+        C = x.shape[1]
+        h, d, N = self.num_heads, self.head_dim, H * W
+        qkv = self.qkv.rows(x)  # [B*N, 3C]; column = which*C + head*d + c  (image_encoder.py:227)
+        s = (N * 3 * C, d, 3 * C)
+        rel_h = rel_w = None
+        if self.use_rel_pos:
+            Rh, Rw = self._rel_tables(H, W)
+            rel_h, rel_w = ops.sam_relpos_terms(qkv, s, Rh, Rw, B, h, H, W, d)  # from the UNSCALED q (G13)
+        o = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B, h, N, N, d, self.scale, s, s, s, rel_h=rel_h, rel_w=rel_w,
+                          kH=H if self.use_rel_pos else 0, kW=W if self.use_rel_pos else 0)
+        return self.proj.rows(o.reshape(B * N, C), residual=residual)
+
+    def forward(self, x):
+        B, H, W, C = x.shape
+        y = self.rows(x.reshape(B * H * W, C).to(BF16).contiguous(), B, H, W)
+        return y.reshape(B, H, W, C).to(x.dtype)
+
+
+class Block(nn.Module):
+    """image_encoder.py:119-182.  G12: window padding is applied AFTER norm1 and the zero tokens take part in the softmax."""
+
+    def __init__(self, dim: int, num_heads: int, mlp_ratio: float = 4.0, qkv_bias: bool = True,
+                 norm_layer: Type[nn.Module] = nn.LayerNorm, act_layer: Type[nn.Module] = nn.GELU, use_rel_pos: bool = False,
+                 rel_pos_zero_init: bool = True, window_size: int = 0, input_size: Optional[Tuple[int, int]] = None) -> None:
+        super().__init__()
+        probe = norm_layer(dim)
+        eps = getattr(probe, "eps", 1e-5)
+        self.norm1 = LayerNorm(dim, eps=eps)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, use_rel_pos=use_rel_pos,
+                              rel_pos_zero_init=rel_pos_zero_init,
+                              input_size=input_size if window_size == 0 else (window_size, window_size))
+        self.norm2 = LayerNorm(dim, eps=eps)
+        self.mlp = MLPBlock(embedding_dim=dim, mlp_dim=int(dim * mlp_ratio), act=act_layer)
+        self.window_size = window_size
+
+    def rows(self, x, B, H, W):
+        h = self.norm1.rows(x)
+        ws = self.window_size
+        if ws > 0:
+            win, (Hp, Wp) = ops.window_partition(h, B, H, W, ws)
+            nwin = B * (Hp // ws) * (Wp // ws)
+            a = self.attn.rows(win, nwin, ws, ws)
+            a = ops.window_unpartition(a, B, H, W, ws)
+            x = ops.add_bcast(a, x)  # shortcut + attn (rows were permuted by the windows, so not fusable into proj)
+        else:
+            x = self.attn.rows(h, B, H, W, residual=x)
+        return self.mlp.rows(self.norm2.rows(x), residual=x)
+
+    def forward(self, x):
+        B, H, W, C = x.shape
+        y = self.rows(x.reshape(B * H * W, C).to(BF16).contiguous(), B, H, W)
+        return y.reshape(B, H, W, C).to(x.dtype)
+
+
+class PatchEmbed(nn.Module):
+    """image_encoder.py:364-395: non-overlapping conv == im2col (ae_patchify) + GEMM."""
+
+    def __init__(self, kernel_size=(16, 16), stride=(16, 16), padding=(0, 0), in_chans: int = 3, embed_dim: int = 768) -> None:
+        super().__init__()
+        if kernel_size != stride or padding != (0, 0) or kernel_size[0] != kernel_size[1]:
+            raise NotImplementedError("PatchEmbed: only non-overlapping square patches (the SAM configuration)")
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=kernel_size, stride=stride, padding=padding)
+        self._pk = None
+
+    def rows(self, x):
+        B, Cin, H, W = x.shape
+        P = self.proj.kernel_size[0]
+        if self._pk is None or self._pk[0].device != self.proj.weight.device:
+            self._pk = (ops.pack_linear(self.proj.weight), self.proj.bias.detach().float().contiguous())
+        return ops.gemm(ops.patchify(x, P), self._pk[0], self._pk[1]), H // P, W // P
+
+    def forward(self, x):
+        B = x.shape[0]
+        y, gh, gw = self.rows(x)
+        return y.reshape(B, gh, gw, -1).to(x.dtype)
+
+
+class ImageEncoderViT(nn.Module):
+    """image_encoder.py:17-116."""
+
+    def __init__(self, img_size: int = 1024, patch_size: int = 16, in_chans: int = 3, embed_dim: int = 768, depth: int = 12,
+                 num_heads: int = 12, mlp_ratio: float = 4.0, out_chans: int = 256, qkv_bias: bool = True,
+                 norm_layer: Type[nn.Module] = nn.LayerNorm, act_layer: Type[nn.Module] = nn.GELU, use_abs_pos: bool = True,
+                 use_rel_pos: bool = False, rel_pos_zero_init: bool = True, window_size: int = 0,
+                 global_attn_indexes: Tuple[int, ...] = ()) -> None:
+        super().__init__()
+        self.img_size = img_size
+        self.patch_embed = PatchEmbed(kernel_size=(patch_size, patch_size), stride=(patch_size, patch_size), in_chans=in_chans,
+                                      embed_dim=embed_dim)
+        self.pos_embed: Optional[nn.Parameter] = None
+        if use_abs_pos:
+            self.pos_embed = nn.Parameter(torch.zeros(1, img_size // patch_size, img_size // patch_size, embed_dim))
+        self.blocks = nn.ModuleList()
+        for i in range(depth):
+            self.blocks.append(Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                                     norm_layer=norm_layer, act_layer=act_layer, use_rel_pos=use_rel_pos,
+                                     rel_pos_zero_init=rel_pos_zero_init,
+                                     window_size=window_size if i not in global_attn_indexes else 0,
+                                     input_size=(img_size // patch_size, img_size // patch_size)))
+        self.neck = nn.Sequential(Conv2d(embed_dim, out_chans, kernel_size=1, bias=False), LayerNorm2d(out_chans),
+                                  Conv2d(out_chans, out_chans, kernel_size=3, padding=1, bias=False), LayerNorm2d(out_chans))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        B = x.shape[0]
+        h, gh, gw = self.patch_embed.rows(x)
+        if self.pos_embed is not None:
+            h = ops.add_bcast(h, self.pos_embed.detach().to(BF16).reshape(-1).contiguous())
+        for blk in self.blocks:
+            h = blk.rows(h, B, gh, gw)
+        h, _, _ = self.neck[0].rows(h, B, gh, gw)
+        h = self.neck[1].rows(h)
+        h, _, _ = self.neck[2].rows(h, B, gh, gw)
+        h = self.neck[3].rows(h)
+        return ops.rows_to_nchw(h, B, gh, gw, out_dtype=x.dtype if x.dtype != torch.uint8 else torch.float32)
+
+
+def build_sam_vit_h_encoder():
+    """build_sam.py:14-22, 65-80: the ViT-H image encoder AnyEdit's mask generator uses (tools/tool.py:166-269)."""
+    from functools import partial
+    return ImageEncoderViT(depth=32, embed_dim=1280, img_size=1024, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                           num_heads=16, patch_size=16, qkv_bias=True, use_rel_pos=True, global_attn_indexes=(7, 15, 23, 31),
+                           window_size=14, out_chans=256)

@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — AnyEdit diffusion-denoising hot path on MI355X.
+
+Metric (BASELINE.json): edited-images/sec @512x512, 50 DDIM steps.  Workload at N GPUs = BASELINE.json configs[1] per GPU:
+AnySD (SD-1.5 UNet, in_channels=8, + task embedding / routed expert adapters), bf16, batch = 4 images per GPU,
+3 CFG branches (text+image, image, uncond) -> UNet batch 12, 50 DDIM steps, synthetic latents / instruction embeddings
+(SURVEY.md §8d cfg 2), random-init weights of that architecture with the zero-init layers re-initialised (G1).
+A "step" = one full 50-DDIM-step edit of the per-GPU batch; 1 edited image = 150 UNet-sample evaluations = 120.5 TFLOP.
+VAE / CLIP encoders are outside the timed loop and outside this path's scope.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the launch stream for the dominant kernel;
+`cpu_baseline` times the oracle (oracle/, our fp32 CPU restatement — test infrastructure, here only as the measured baseline)
+on the host cores for one UNet evaluation (bounded sample) and scales it to the metric's unit.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SD15 = dict(image_size=64, in_channels=8, model_channels=320, out_channels=4, num_res_blocks=2,
+            attention_resolutions=[4, 2, 1], channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+            transformer_depth=1, context_dim=768, legacy=False)
+GFLOP_PER_UNET_SAMPLE = 803.4  # BASELINE.md §2 (64x64 latent)
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBPS = 8000.0
+
+
+def build_model(device, seed=0):
+    from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel, ResBlock
+    from anyedit_amd.ldm.modules.attention import SpatialTransformer
+    from anyedit_amd.ldm.models.diffusion.ddpm import DDPM
+    from anyedit_amd.anysd.model import MoE
+    torch.manual_seed(seed)
+    with torch.device(device):
+        unet = UNetModel(**SD15)
+    g = torch.Generator(device=device).manual_seed(seed + 1)
+    with torch.no_grad():  # G1: zero-init layers -> N(0, 0.02^2), else the UNet outputs exactly 0
+        for m in unet.modules():
+            tgt = []
+            if isinstance(m, ResBlock):
+                tgt.append(m.out_layers[-1])
+            if isinstance(m, SpatialTransformer):
+                tgt.append(m.proj_out)
+            if isinstance(m, UNetModel):
+                tgt.append(m.out[-1])
+            for t in tgt:
+                for p in t.parameters():
+                    p.copy_(torch.randn(p.shape, generator=g, device=device) * 0.02)
+    unet.eval().requires_grad_(False)
+    with torch.device(device):
+        moe = MoE(unet, expert_num=11)
+    moe.eval().requires_grad_(False)
+    sched = DDPM(unet, timesteps=1000, linear_start=0.00085, linear_end=0.0120).to(device)
+    return unet, moe, sched
+
+
+def synthetic_inputs(B, device, rank=0):
+    g = lambda s: torch.Generator(device="cpu").manual_seed(1000 * rank + s)
+    x_T = torch.randn(B, 4, 64, 64, generator=g(1)).to(device)
+    img_lat = (torch.randn(B, 4, 64, 64, generator=g(2)) * 0.18215).to(device)
+    ehs = torch.randn(B, 77, 768, generator=g(3)).to(device)
+    null = torch.randn(1, 77, 768, generator=g(6)).to(device)
+    ref = torch.randn(B, 257, 1280, generator=g(7)).to(device)
+    code = (torch.arange(B) % 3).to(device)  # add / remove / replace mix (configs[2])
+    return x_T, img_lat, ehs, null, ref, code
+
+
+def cpu_baseline_and_parity(unet, device, max_seconds=40.0):
+    """Oracle UNet evaluation (B=1, fp32, all host cores) on the SAME weights: CPU time + full-size parity of the HIP path."""
+    from oracle import ldm_ref as L
+    torch.set_num_threads(os.cpu_count())
+    t0 = time.time()
+    sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 8, 64, 64, generator=g)
+    t = torch.tensor([501], dtype=torch.long)
+    ctx = torch.randn(1, 77, 768, generator=g)
+    times = []
+    with torch.no_grad():
+        while True:
+            s = time.time()
+            ref = L.unet_forward(sd, SD15, x, t, ctx)
+            times.append(time.time() - s)
+            if len(times) >= 3 or time.time() - t0 > max_seconds:
+                break
+        got = unet(x.to(device), t.to(device), context=ctx.to(device)).float().cpu()
+    times.sort()
+    t_unet = times[len(times) // 2]
+    err = float((got - ref).norm() / ref.norm())
+    mse = float(((got - ref) ** 2).mean())
+    peak = float(ref.max() - ref.min())
+    import math
+    psnr = 10 * math.log10(peak * peak / mse) if mse > 0 else float("inf")
+    cpu = {"value": 1.0 / (150.0 * t_unet), "unit": "edited-images/sec", "cores": os.cpu_count(), "kind": "port",
+           "sample": f"oracle UNet forward B=1 [1,8,64,64], median of {len(times)} = {t_unet:.3f} s, scaled x150 evaluations/image",
+           "unet_forward_s": t_unet}
+    parity = {"unet_full_size_rel_l2_vs_oracle": err, "psnr_db": psnr}
+    return cpu, parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--images", type=int, default=4, help="images per GPU per step")
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+
+    from anyedit_amd import ops
+    from anyedit_amd.anysd.pipeline import EditPipeline
+    unet, moe, sched = build_model(device)
+    B = args.images
+    x_T, img_lat, ehs, null, ref, code = synthetic_inputs(B, device, rank)
+    pipe = EditPipeline(moe, sched, use_graph=not args.no_graph)
+
+    def one_step():
+        # inference shards by image: ranks never exchange data inside the loop
+        return pipe.edit(x_T, img_lat, ehs, null, ref, code, steps=args.ddim_steps, s_txt=7.5, s_img=1.5, eta=0.0)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out).all(), "non-finite latents"
+
+    result = None
+    if rank == 0:
+        n_unet_steps = len(pipe.sampler.ddim_timesteps)
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * B * args.steps / elapsed
+        result = {
+            "metric": "edited-images/sec @512x512, 50 DDIM steps", "value": value, "unit": "edited-images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[1]: AnySD (SD-1.5 UNet in=8 + task embedding/expert adapters) 512x512 bf16, "
+                                   f"{n_unet_steps} DDIM steps, batch={B}/GPU, 3-branch CFG (UNet batch {3 * B})",
+                       "images_per_gpu": B, "ddim_steps": n_unet_steps, "cfg_branches": 3, "hip_graph": not args.no_graph,
+                       "parallelism": f"dp{world} (image-sharded, no data-path collective)"},
+            "unet_step_ms": ms_per_step / n_unet_steps,
+            "unet_tflops": 3 * B * GFLOP_PER_UNET_SAMPLE * n_unet_steps / (ms_per_step * 1e-3) / 1e3,
+        }
+        if not args.no_roofline:
+            # eager (un-graphed) UNet evaluation with a HIP-event pair around every kernel launch on the launch stream
+            pipe.prepare(img_lat, ehs, null, ref, code)
+            pipe._x_in[:, :4].view(3, B, 4, 64, 64).copy_(x_T.unsqueeze(0))
+            pipe._t.fill_(501)
+            for _ in range(2):
+                pipe._denoise_static()
+            torch.cuda.synchronize()
+            with ops.OpProfiler() as prof:
+                for _ in range(3):
+                    pipe._denoise_static()
+            summ = prof.summary()
+            dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            name, a = dom
+            mfma = a["flops"] > 0
+            result["roofline"] = {
+                "kernel": name, "bound": "mfma" if mfma else "hbm",
+                "achieved": a["tflops"] if mfma else a["gbps"], "peak": PEAK_BF16_TFLOPS if mfma else PEAK_HBM_GBPS,
+                "unit": "TFLOP/s" if mfma else "GB/s",
+                "frac": (a["tflops"] / PEAK_BF16_TFLOPS) if mfma else (a["gbps"] / PEAK_HBM_GBPS),
+                "traffic": None, "avg_launch_us": a["avg_us"], "launches_per_unet_step": a["calls"] // 3,
+                "share_of_unet_step": a["ms"] / sum(v["ms"] for v in summ.values()),
+            }
+            result["kernels"] = {k: {"calls_per_step": v["calls"] // 3, "ms_per_step": v["ms"] / 3, "avg_us": v["avg_us"],
+                                     "tflops": v["tflops"], "gbps": v["gbps"]} for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu, parity = cpu_baseline_and_parity(unet, device)
+            result["cpu_baseline"] = cpu
+            result["parity"] = parity
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

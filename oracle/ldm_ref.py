@@ -34,8 +34,10 @@ def silu(x):
 
 
 # ------------------------------------------------------------------ A1/A2 attention
-def cross_attention(sd, p, x, context=None, mask=None, heads=8):
-    """attention.py:163-194.  sd[p+'to_q.weight'] etc.  fp32 logits, softmax(-1), PV, to_out."""
+def cross_attention(sd, p, x, context=None, mask=None, heads=8, adapter=None):
+    """attention.py:163-194.  sd[p+'to_q.weight'] etc.  fp32 logits, softmax(-1), PV, to_out.
+    adapter=(k_ip [B,T,inner], v_ip [B,T,inner], gate [B]): OUR AnySD spec (row A9, parity unpinned): a decoupled second
+    attention over expert K/V added before to_out, as ip_adapter/attention_processor.py:141-173 does."""
     q = F.linear(x, sd[p + "to_q.weight"])
     ctx = x if context is None else context
     k = F.linear(ctx, sd[p + "to_k.weight"])
@@ -55,6 +57,11 @@ def cross_attention(sd, p, x, context=None, mask=None, heads=8):
         sim = sim.masked_fill(~m, -torch.finfo(sim.dtype).max)
     sim = sim.softmax(dim=-1)
     out = torch.einsum("bij,bjd->bid", sim, v)
+    if adapter is not None:
+        k_ip, v_ip, gate = adapter
+        k_ip, v_ip = split(k_ip), split(v_ip)
+        sim_ip = (torch.einsum("bid,bjd->bij", q.float(), k_ip.float()) * scale).softmax(dim=-1)
+        out = out + gate.repeat_interleave(heads)[:, None, None] * torch.einsum("bij,bjd->bid", sim_ip, v_ip)
     out = out.reshape(B, heads, N, d).permute(0, 2, 1, 3).reshape(B, N, inner)
     return F.linear(out, sd[p + "to_out.0.weight"], sd[p + "to_out.0.bias"])
 
@@ -76,18 +83,19 @@ def geglu_ff(sd, p, x):
     return F.linear(h, sd[p + "net.2.weight"], sd[p + "net.2.bias"])
 
 
-def basic_transformer_block(sd, p, x, context, heads, disable_self_attn=False):
+def basic_transformer_block(sd, p, x, context, heads, disable_self_attn=False, adapters=None):
     """attention.py:271-275 (LayerNorm eps 1e-5, :263-265)."""
     C = x.shape[-1]
     ln = lambda t, i: F.layer_norm(t, (C,), sd[p + f"norm{i}.weight"], sd[p + f"norm{i}.bias"], 1e-5)
     x = cross_attention(sd, p + "attn1.", ln(x, 1), context if disable_self_attn else None, heads=heads) + x
-    x = cross_attention(sd, p + "attn2.", ln(x, 2), context, heads=heads) + x
+    x = cross_attention(sd, p + "attn2.", ln(x, 2), context, heads=heads,
+                        adapter=None if adapters is None else adapters.get(p + "attn2.")) + x
     x = geglu_ff(sd, p + "ff.", ln(x, 3)) + x
     return x
 
 
 # ------------------------------------------------------------------ A4 spatial transformer
-def spatial_transformer(sd, p, x, context, heads, depth=1, use_linear=False):
+def spatial_transformer(sd, p, x, context, heads, depth=1, use_linear=False, adapters=None):
     """attention.py:321-340 (GroupNorm eps 1e-6, :88-89)."""
     B, C, H, W = x.shape
     x_in = x
@@ -98,7 +106,7 @@ def spatial_transformer(sd, p, x, context, heads, depth=1, use_linear=False):
     if use_linear:
         x = F.linear(x, sd[p + "proj_in.weight"], sd[p + "proj_in.bias"])
     for d in range(depth):
-        x = basic_transformer_block(sd, p + f"transformer_blocks.{d}.", x, context, heads)
+        x = basic_transformer_block(sd, p + f"transformer_blocks.{d}.", x, context, heads, adapters=adapters)
     if use_linear:
         x = F.linear(x, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"])
     x = x.reshape(B, H, W, -1).permute(0, 3, 1, 2)
@@ -175,7 +183,7 @@ def unet_plan(cfg):
     return inp, mid, out
 
 
-def _run_layers(sd, prefix, layers, h, emb, context, use_linear):
+def _run_layers(sd, prefix, layers, h, emb, context, use_linear, adapters=None):
     for j, L in enumerate(layers):
         p = f"{prefix}{j}."
         kind = L[0]
@@ -184,7 +192,7 @@ def _run_layers(sd, prefix, layers, h, emb, context, use_linear):
         elif kind == "res":
             h = resblock(sd, p, h, emb)
         elif kind == "st":
-            h = spatial_transformer(sd, p, h, context, heads=L[2], depth=L[4], use_linear=use_linear)
+            h = spatial_transformer(sd, p, h, context, heads=L[2], depth=L[4], use_linear=use_linear, adapters=adapters)
         elif kind == "down":
             h = downsample(sd, p, h)
         elif kind == "up":
@@ -192,7 +200,7 @@ def _run_layers(sd, prefix, layers, h, emb, context, use_linear):
     return h
 
 
-def unet_forward(sd, cfg, x, timesteps, context):
+def unet_forward(sd, cfg, x, timesteps, context, adapters=None):
     """openaimodel.py:754-786."""
     inp, mid, out = unet_plan(cfg)
     use_linear = cfg.get("use_linear_in_transformer", False)
@@ -202,12 +210,12 @@ def unet_forward(sd, cfg, x, timesteps, context):
     hs = []
     h = x.float()
     for i, layers in enumerate(inp):
-        h = _run_layers(sd, f"input_blocks.{i}.", layers, h, emb, context, use_linear)
+        h = _run_layers(sd, f"input_blocks.{i}.", layers, h, emb, context, use_linear, adapters)
         hs.append(h)
-    h = _run_layers(sd, "middle_block.", mid, h, emb, context, use_linear)
+    h = _run_layers(sd, "middle_block.", mid, h, emb, context, use_linear, adapters)
     for i, layers in enumerate(out):
         h = torch.cat([h, hs.pop()], dim=1)
-        h = _run_layers(sd, f"output_blocks.{i}.", layers, h, emb, context, use_linear)
+        h = _run_layers(sd, f"output_blocks.{i}.", layers, h, emb, context, use_linear, adapters)
     h = silu(group_norm32(h, sd["out.0.weight"], sd["out.0.bias"]))
     return F.conv2d(h, sd["out.2.weight"], sd["out.2.bias"], padding=1)
 

@@ -1,0 +1,175 @@
+"""GPU parity tests of the composed path: transformer blocks, ResBlock, tiny UNet, DDIM sampler — HIP (bf16 activations,
+fp32 accumulate) against the reference-derived fp32 goldens and the oracle.
+
+Tolerance for composed bf16 graphs vs the fp32 reference: relative L2 <= 2e-2 and PSNR >= 38 dB (peak = dynamic range of
+the reference output); DDIM integer bookkeeping bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sub_sd, T, rel_l2, psnr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def close(got, ref, rl2=2e-2, db=38.0, what=""):
+    got, ref = got.detach().float().cpu(), torch.as_tensor(ref).float()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite"
+    e, p = rel_l2(got, ref), psnr(got, ref)
+    assert e <= rl2 and p >= db, f"{what}: rel_l2={e:.3e} (<= {rl2}), psnr={p:.1f} dB (>= {db})"
+
+
+def test_transformer_blocks_golden():
+    from anyedit_amd.ldm.modules.attention import BasicTransformerBlock, FeedForward, SpatialTransformer
+    g = load_golden("transformer")
+    blk = BasicTransformerBlock(64, 2, 32, context_dim=24, checkpoint=False)
+    blk.load_state_dict(sub_sd(g, "btb.w."))
+    close(blk.to(DEV)(T(g["btb.x"]).to(DEV), context=T(g["btb.ctx"]).to(DEV)), g["btb.y"], what="BasicTransformerBlock")
+    ff = FeedForward(64, glu=True)
+    ff.load_state_dict(sub_sd(g, "ff.w."))
+    close(ff.to(DEV)(T(g["ff.x"]).to(DEV)), g["ff.y"], what="FeedForward/GEGLU")
+    for tag, lin in (("st", False), ("st_lin", True)):
+        st = SpatialTransformer(64, 2, 32, depth=1, context_dim=24, use_linear=lin, use_checkpoint=False)
+        st.load_state_dict(sub_sd(g, f"{tag}.w."))
+        close(st.to(DEV)(T(g[f"{tag}.x"]).to(DEV), context=T(g[f"{tag}.ctx"]).to(DEV)), g[f"{tag}.y"], what=f"SpatialTransformer {tag}")
+
+
+def test_resblock_and_resampling_golden():
+    from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import ResBlock, Downsample, Upsample
+    g = load_golden("resblock")
+    for tag, (cin, cout) in {"same": (64, 64), "diff": (96, 64)}.items():
+        rb = ResBlock(cin, 128, 0.0, out_channels=cout, dims=2)
+        rb.load_state_dict(sub_sd(g, f"{tag}.w."))
+        close(rb.to(DEV)(T(g[f"{tag}.x"]).to(DEV), T(g[f"{tag}.emb"]).to(DEV)), g[f"{tag}.y"], what=f"ResBlock {tag}")
+    down = Downsample(64, True, dims=2, out_channels=64)
+    down.load_state_dict(sub_sd(g, "down.w."))
+    down = down.to(DEV)
+    close(down(T(g["down.x"]).to(DEV)), g["down.y"], rl2=6e-3, what="Downsample")
+    close(down(T(g["down.x7"]).to(DEV)), g["down.y7"], rl2=6e-3, what="Downsample odd size")
+    up = Upsample(64, True, dims=2, out_channels=64)
+    up.load_state_dict(sub_sd(g, "up.w."))
+    close(up.to(DEV)(T(g["up.x"]).to(DEV)), g["up.y"], rl2=6e-3, what="Upsample")
+
+
+@pytest.fixture(scope="module")
+def tiny_unet():
+    from util_models import build_tiny_unet
+    g = load_golden("unet_tiny")
+    unet = build_tiny_unet()
+    unet.load_state_dict(sub_sd(g, "w."))
+    return unet.to(DEV), g
+
+
+def test_unet_tiny_golden(tiny_unet):
+    unet, g = tiny_unet
+    y = unet(T(g["x"]).to(DEV), T(g["t"]).to(DEV), context=T(g["ctx"]).to(DEV))
+    close(y, g["y"], what="tiny UNet 8x8")
+    y16 = unet(T(g["x16"]).to(DEV), T(g["t"])[:1].to(DEV), context=T(g["ctx"])[:1].to(DEV))
+    close(y16, g["y16"], what="tiny UNet 16x16")
+
+
+def test_unet_batch_independence_bit_exact(tiny_unet):
+    """Sharding invariance (the multi-GPU data-parallel contract): a sample's output does not depend on what else is in
+    the batch — bit-exact."""
+    unet, g = tiny_unet
+    x, t, ctx = T(g["x"]).to(DEV), T(g["t"]).to(DEV), T(g["ctx"]).to(DEV)
+    full = unet(x, t, context=ctx)
+    for i in range(3):
+        one = unet(x[i:i + 1], t[i:i + 1], context=ctx[i:i + 1])
+        assert torch.equal(one[0], full[i]), f"sample {i} differs between batch-of-3 and batch-of-1"
+
+
+def test_unet_kv_cache_and_determinism(tiny_unet):
+    unet, g = tiny_unet
+    x, t, ctx = T(g["x"]).to(DEV), T(g["t"]).to(DEV), T(g["ctx"]).to(DEV)
+    rows = unet.context_rows(ctx)
+    cache = {}
+    a = unet.forward_rows(x, t, rows, kv_cache=cache)
+    b = unet.forward_rows(x, t, rows, kv_cache=cache)  # second call hits the cached K|V projections
+    c = unet.forward_rows(x, t, rows)
+    assert len(cache) == 7 and torch.equal(a, b) and torch.equal(a, c)
+
+
+def _tiny_ldm(unet):
+    from anyedit_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    return LatentDiffusion(unet, conditioning_key="hybrid", timesteps=1000, linear_start=0.00085, linear_end=0.0120).to(DEV)
+
+
+def test_apply_model_q_sample_mse(tiny_unet):
+    unet, _ = tiny_unet
+    g = load_golden("ddim_tiny")
+    ldm = _tiny_ldm(unet)
+    cond = {"c_concat": [T(g["img_lat"]).to(DEV)], "c_crossattn": [T(g["ctx"]).to(DEV)]}
+    t = T(g["apply.t"]).to(DEV)
+    close(ldm.apply_model(T(g["x_T"]).to(DEV), t, cond), g["apply.y"], what="apply_model hybrid")
+    qs = ldm.q_sample(T(g["x_T"]).to(DEV), t, T(g["qs.noise"]).to(DEV))
+    assert torch.equal(qs.cpu(), T(g["qs.y"])), "q_sample must be bit-exact (unfused fp32)"
+    loss, _ = ldm.p_losses(T(g["x_T"]).to(DEV), cond, t, noise=T(g["qs.noise"]).to(DEV))
+    assert abs(float(loss) - float(g["ploss.loss_simple"])) <= 2e-2 * float(g["ploss.loss_simple"])
+
+
+def test_ddim_sampler_golden(tiny_unet):
+    """Full sampler runs (CFG, mask/x0, eta=0) vs the reference's own sampler output; CPU noise stream replayed (G11)."""
+    from anyedit_amd.ldm.models.diffusion.ddim import DDIMSampler
+    unet, _ = tiny_unet
+    g = load_golden("ddim_tiny")
+    ldm = _tiny_ldm(unet)
+    sampler = DDIMSampler(ldm)
+    sampler.randn = lambda shape, device=None: torch.randn(shape).to(device)  # replay the CPU RNG stream of the golden run
+    dev = lambda k: T(g[k]).to(DEV)
+    cond = {"c_concat": [dev("img_lat")], "c_crossattn": [dev("ctx")]}
+    uncond = {"c_concat": [dev("img_lat")], "c_crossattn": [dev("null_ctx")]}
+    for tag, S, scale, use_mask, tol in (("s5_nocfg", 5, 1.0, False, 3e-2), ("s5_cfg", 5, 7.5, False, 6e-2),
+                                         ("s20_cfg", 20, 7.5, False, 8e-2), ("s7_cfg_mask", 7, 3.0, True, 6e-2)):
+        kw = dict(mask=dev(f"{tag}.mask"), x0=dev(f"{tag}.x0")) if use_mask else {}
+        torch.manual_seed(1234)
+        samples, inter = sampler.sample(S, 2, (4, 8, 8), cond, eta=0.0, x_T=dev("x_T"), verbose=False,
+                                        unconditional_guidance_scale=scale,
+                                        unconditional_conditioning=uncond if scale != 1.0 else None, log_every_t=1, **kw)
+        assert np.array_equal(sampler.ddim_timesteps, g[f"{tag}.ddim_timesteps"])      # integer bookkeeping: bit-exact
+        assert len(inter["x_inter"]) == g[f"{tag}.x_inter"].shape[0]
+        close(samples, g[f"{tag}.samples"], rl2=tol, db=26.0, what=f"DDIM {tag}")       # CFG amplifies bf16 noise x7.5
+
+
+def test_ddim_sampler_vs_oracle_same_eps():
+    """With the SAME eps fed to both, the HIP sampler arithmetic is bit-identical to the oracle's fp32 loop."""
+    from anyedit_amd.ldm.models.diffusion.ddim import DDIMSampler
+    from oracle import ddim_ref as D, schedule_ref as S
+
+    class FakeModel:
+        parameterization = "eps"
+
+        def __init__(self, dev):
+            b = S.register_schedule("linear", 1000, 0.00085, 0.0120)
+            self.num_timesteps = 1000
+            for k, v in b.items():
+                if isinstance(v, torch.Tensor):
+                    setattr(self, k, v.to(dev))
+            self.device = torch.device(dev)
+
+        def apply_model(self, x, t, c):
+            # deterministic "network": a fixed elementwise function of (x, t, c) computed in fp32 on the CPU, so both sides see
+            # bit-identical eps
+            xc = x.detach().float().cpu()
+            out = torch.sin(xc * 1.7 + t.cpu().float()[:, None, None, None] * 0.01) * 0.5 + c.cpu().float()[:, :, None, None] * xc
+            return out.to(x.device)
+
+    B = 2
+    x_T = torch.randn(B, 4, 8, 8, generator=torch.Generator().manual_seed(3))
+    c, uc = torch.full((B, 1), 0.3), torch.full((B, 1), -0.2)
+    m_cpu = FakeModel("cpu")
+    buffers = S.register_schedule("linear", 1000, 0.00085, 0.0120)
+    torch.manual_seed(99)
+    ref, _, _ = D.ddim_sample(m_cpu.apply_model, buffers, 50, tuple(x_T.shape), c, eta=0.3, x_T=x_T, scale=5.0, uc=uc)
+    m = FakeModel(DEV)
+    s = DDIMSampler(m)
+    s.randn = lambda shape, device=None: torch.randn(shape).to(device)
+    torch.manual_seed(99)
+    got, _ = s.sample(50, B, (4, 8, 8), c.to(DEV), eta=0.3, x_T=x_T.to(DEV), verbose=False, unconditional_guidance_scale=5.0,
+                      unconditional_conditioning=uc.to(DEV))
+    # torch-CPU sqrt of the schedule scalars may differ from the correctly rounded one by 1 ulp (see test_host_logic), which
+    # perturbs the trajectory at the 1e-7 level; everything else is bit-identical arithmetic
+    assert float((got.cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())

@@ -111,13 +111,13 @@ def test_ddpm_buffers_and_sampler_schedule_on_cpu():
 
 def test_weight_packing_layouts():
     from anyedit_amd import ops
-    w = torch.arange(2 * 3 * 9, dtype=torch.float32).reshape(2, 3, 3, 3)
+    w = (torch.arange(2 * 3 * 9, dtype=torch.float32) % 97).reshape(2, 3, 3, 3)
     p = ops.pack_conv3x3(w).float().reshape(2, 9, 64)
     for ky in range(3):
         for kx in range(3):
             assert torch.equal(p[:, ky * 3 + kx, :3], w[:, :, ky, kx]) and p[:, ky * 3 + kx, 3:].abs().sum() == 0
     inner = 32
-    wg = torch.arange(2 * inner * 8, dtype=torch.float32).reshape(2 * inner, 8)
+    wg = (torch.arange(2 * inner * 8, dtype=torch.float32) % 101).reshape(2 * inner, 8)
     bg = torch.arange(2 * inner, dtype=torch.float32)
     wp, bp = ops.pack_geglu(wg, bg)
     wp = wp.float()
