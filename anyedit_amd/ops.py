@@ -361,29 +361,29 @@ def _wrap_profiled(fn, label_fn):
     return wrapped
 
 
-def _gemm_label(out, a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue=EPI_NONE, out_f32=False, a2=None, **_):
+def _gemm_label(_r, a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue=EPI_NONE, out_f32=False, a2=None, **_):
     M, (N, K) = a.shape[0], w.shape
-    nb = 2 * (M * K + N * K) + out.numel() * out.element_size() + (2 * M * N if residual is not None else 0)
+    nb = 2 * (M * K + N * K) + _r.numel() * _r.element_size() + (2 * M * N if residual is not None else 0)
     return f"gemm_kernel<{_tile_label(M, N)},dense>", 2.0 * M * N * K, float(nb)
 
 
-def _conv_label(out, x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2x=False, out_f32=False, **_):
-    y = out[0]
+def _conv_label(_r, x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2x=False, out_f32=False, **_):
+    y = _r[0]
     M, Cout, Cin = y.shape[0], w.shape[0], x.shape[1]
     nb = 2 * (x.numel() + 9 * Cin * Cout) + y.numel() * y.element_size() + (2 * y.numel() if residual is not None else 0)
     return f"gemm_kernel<{_tile_label(M, Cout)},conv3x3>", 2.0 * M * Cout * 9 * Cin, float(nb)
 
 
-def _attn_label(out, q, k, v, B, H, Nq, Nk, D, *a, **_):
+def _attn_label(_r, q, k, v, B, H, Nq, Nk, D, *a, **_):
     return f"attn_kernel<D={D}>", 4.0 * B * H * Nq * Nk * D, 2.0 * B * H * D * (2 * Nq + 2 * Nk)
 
 
-def _gn_label(out, x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, **_):
-    return "groupnorm(stats+apply)", 0.0, 2.0 * out.numel() * 2  # 1 read + 1 write algorithmic
+def _gn_label(_r, x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, **_):
+    return "groupnorm(stats+apply)", 0.0, 2.0 * _r.numel() * 2  # 1 read + 1 write algorithmic
 
 
-def _ln_label(out, x, *a, **_):
-    return "layernorm_kernel", 0.0, 2.0 * out.numel() * 2
+def _ln_label(_r, x, *a, **_):
+    return "layernorm_kernel", 0.0, 2.0 * _r.numel() * 2
 
 
 gemm = _wrap_profiled(gemm, _gemm_label)
