@@ -4,11 +4,13 @@
 //   A1/A2  ldm/modules/attention.py:163-194  CrossAttention.forward (self + cross; fp32 logits, optional bool mask)
 //          and the xformers call it swaps in at attention.py:222-233;
 //   A10    segment_anything/.../image_encoder.py:224-240 Attention.forward with the decomposed relative-position
-//          bias of :325-361 added as rel_h[q, key/kW] + rel_w[q, key%kW] (computed from the UNSCALED q, G13).
+//          bias of :325-361 added as rel_h[q, key/kW] + rel_w[q, key%kW] (computed from the UNSCALED q, G13);
+//   A9     the decoupled expert attention of our AnySD spec: out += gate_b * Attn(q, K_ip, V_ip) (accumulate mode).
 //
 // Design (wave64, flash-style online softmax, never materialises the [N,N] logits):
 //   * 256 threads = 4 waves; each wave owns 16*QF query rows and keeps Q in registers as MFMA operands;
-//   * K/V are streamed in 64-key tiles through LDS, global loads issued one tile ahead (register staged);
+//   * K/V are streamed in 64-key tiles through LDS (double-buffered when it fits: one barrier per tile), global
+//     loads issued one tile ahead into registers, branch-free (row indices clamped instead of predicated);
 //   * logits are computed TRANSPOSED, S^T = K Q^T with v_mfma_f32_16x16x32_bf16, so a lane holds 16 logits of
 //     ONE query row per tile: row max / row sum need 2 cross-lane steps, and the exponentiated P registers are
 //     already laid out as the B operand of the O^T = V^T P^T MFMA (contraction slots permuted consistently on
@@ -17,8 +19,9 @@
 //     16-byte ds_read_b128);
 //   * head_dim is padded inside the kernel (40 -> 64 for QK^T, 48 for PV); q/k/v/out are addressed through
 //     (batch, head, row) strides, so the 'b n (h d) -> (b h) n d' rearranges of the reference never happen;
-//   * softmax in fp32, exp2 domain; bf16 P; fp32 accumulation of O.
+//   * softmax in fp32, exp2 domain; bf16 P (v_cvt_pk_bf16_f32); fp32 accumulation of O.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -42,7 +45,7 @@ __device__ __forceinline__ int vt_pos(int key) {  // key = 16 f + 4 g + r  ->  1
     return ((key >> 2) & 3) * 16 + (key >> 4) * 4 + (key & 3);
 }
 
-template <int D, int QF, bool HAS_BIAS>
+template <int D, int QF, bool DBUF, bool HAS_BIAS, bool HAS_MASK>
 __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
     constexpr int DQK = (D + 31) / 32 * 32;
     constexpr int DV = (D + 15) / 16 * 16;
@@ -53,10 +56,13 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
     constexpr int VROW = KT + 8;
     constexpr int KCH = (KT * DCH + NT - 1) / NT;
     constexpr int VCH = ((KT / 2) * DCH + NT - 1) / NT;
+    constexpr int NBUF = DBUF ? 2 : 1;
+    constexpr int KSZ = KT * KROW, VSZ = DV * VROW;
     static_assert(D % 8 == 0, "head_dim must be a multiple of 8");
 
-    __shared__ __attribute__((aligned(16))) bf16_t sK[KT * KROW];
-    __shared__ __attribute__((aligned(16))) bf16_t sVt[DV * VROW];
+    __shared__ __attribute__((aligned(16))) bf16_t smem[NBUF * (KSZ + VSZ)];
+    bf16_t* const sK = smem;
+    bf16_t* const sVt = smem + NBUF * KSZ;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -72,25 +78,27 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
     const bf16_t* vp = p.v + (long)b * p.v_sb + (long)h * p.v_sh;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-    // zero the pad columns of K (d in [D, DQK)) and pad rows of V^T (d in [D, DV)) once
+    // zero the pad columns of K (d in [D, DQK)) and pad rows of V^T (d in [D, DV)) once, in every buffer
     if (DQK > D) {
-        for (int i = tid; i < KT * (DQK - D); i += NT) sK[(i / (DQK - D)) * KROW + D + i % (DQK - D)] = 0;
+        for (int i = tid; i < NBUF * KT * (DQK - D); i += NT) sK[(i / (DQK - D)) * KROW + D + i % (DQK - D)] = 0;
     }
     if (DV > D) {
-        for (int i = tid; i < (DV - D) * VROW; i += NT) sVt[D * VROW + i] = 0;
+        for (int i = tid; i < NBUF * (DV - D) * VROW; i += NT) {
+            const int bufi = i / ((DV - D) * VROW), r = i % ((DV - D) * VROW);
+            sVt[bufi * VSZ + D * VROW + r] = 0;
+        }
     }
 
-    // ---- Q fragments (B operand of S^T = K Q^T): lane (q = l15, g) holds Q[q][32c + 8g .. +8]
+    // ---- Q fragments (B operand of S^T = K Q^T): lane (q = l15, g) holds Q[q][32c + 8g .. +8]; rows clamped, pad zeroed
     bf16x8_t qf[QF][NC];
 #pragma unroll
     for (int a = 0; a < QF; ++a) {
-        const int qrow = q0 + a * 16 + l15;
+        const int qrow = min(q0 + a * 16 + l15, p.Nq - 1);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int d = c * 32 + lg * 8;
-            u32x4 t = zero4;
-            if (qrow < p.Nq && d < D) t = *reinterpret_cast<const u32x4*>(qp + (long)qrow * p.q_sn + d);
-            qf[a][c] = as_bf16x8(t);
+            const u32x4 t = *reinterpret_cast<const u32x4*>(qp + (long)qrow * p.q_sn + (d < D ? d : 0));
+            qf[a][c] = as_bf16x8(d < D ? t : zero4);
         }
     }
 
@@ -104,38 +112,45 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
         for (int df = 0; df < NDF; ++df) o[a][df] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    u32x4 rk[KCH], rv[VCH][2];
-    auto load_kv = [&](int k0) {
+    // ---- staging: per-thread (row, chunk) assignments are loop invariant
+    int k_key[KCH], k_c[KCH], v_pr[VCH], v_c[VCH];
 #pragma unroll
-        for (int i = 0; i < KCH; ++i) {
-            const int id = tid + i * NT;
-            const int key = id / DCH, c = id - key * DCH;
-            rk[i] = (id < KT * DCH && k0 + key < p.Nk)
-                        ? *reinterpret_cast<const u32x4*>(kp + (long)(k0 + key) * p.k_sn + c * 8) : zero4;
-        }
+    for (int i = 0; i < KCH; ++i) {
+        const int id = min(tid + i * NT, KT * DCH - 1);
+        k_key[i] = id / DCH;
+        k_c[i] = id - k_key[i] * DCH;
+    }
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+        const int id = min(tid + i * NT, (KT / 2) * DCH - 1);
+        v_pr[i] = id / DCH;
+        v_c[i] = id - v_pr[i] * DCH;
+    }
+    u32x4 rk[KCH], rv[VCH][2];
+    const int last_key = p.Nk - 1;
+    auto load_kv = [&](int k0) {  // no branches: out-of-range keys read the last valid row (their P is forced to 0)
+#pragma unroll
+        for (int i = 0; i < KCH; ++i)
+            rk[i] = *reinterpret_cast<const u32x4*>(kp + (long)min(k0 + k_key[i], last_key) * p.k_sn + k_c[i] * 8);
 #pragma unroll
         for (int i = 0; i < VCH; ++i) {
-            const int id = tid + i * NT;
-            const int pr = id / DCH, c = id - pr * DCH;
-            const int key = 2 * pr;
-            const bool in = id < (KT / 2) * DCH;
-            rv[i][0] = (in && k0 + key < p.Nk) ? *reinterpret_cast<const u32x4*>(vp + (long)(k0 + key) * p.v_sn + c * 8) : zero4;
-            rv[i][1] = (in && k0 + key + 1 < p.Nk) ? *reinterpret_cast<const u32x4*>(vp + (long)(k0 + key + 1) * p.v_sn + c * 8) : zero4;
+            const int key = k0 + 2 * v_pr[i];
+            rv[i][0] = *reinterpret_cast<const u32x4*>(vp + (long)min(key, last_key) * p.v_sn + v_c[i] * 8);
+            rv[i][1] = *reinterpret_cast<const u32x4*>(vp + (long)min(key + 1, last_key) * p.v_sn + v_c[i] * 8);
         }
     };
-    auto store_kv = [&]() {
+    auto store_kv = [&](int buf) {
+        bf16_t* dK = sK + buf * KSZ;
+        bf16_t* dV = sVt + buf * VSZ;
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
-            const int id = tid + i * NT;
-            const int key = id / DCH, c = id - key * DCH;
-            if (id < KT * DCH) *reinterpret_cast<u32x4*>(sK + key * KROW + c * 8) = rk[i];
+            if (KT * DCH % NT == 0 || tid + i * NT < KT * DCH)
+                *reinterpret_cast<u32x4*>(dK + k_key[i] * KROW + k_c[i] * 8) = rk[i];
         }
 #pragma unroll
         for (int i = 0; i < VCH; ++i) {
-            const int id = tid + i * NT;
-            const int pr = id / DCH, c = id - pr * DCH;
-            if (id < (KT / 2) * DCH) {
-                const int pos = vt_pos(2 * pr);  // even; key 2pr+1 lands at pos+1
+            if ((KT / 2) * DCH % NT == 0 || tid + i * NT < (KT / 2) * DCH) {
+                const int pos = vt_pos(2 * v_pr[i]);  // even; key 2pr+1 lands at pos+1
                 const uint32_t a0[4] = {rv[i][0].x, rv[i][0].y, rv[i][0].z, rv[i][0].w};
                 const uint32_t a1[4] = {rv[i][1].x, rv[i][1].y, rv[i][1].z, rv[i][1].w};
 #pragma unroll
@@ -143,8 +158,8 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
                     // d = c*8 + 2e (low halves) and c*8 + 2e + 1 (high halves)
                     const uint32_t lo = (a0[e] & 0xffffu) | (a1[e] << 16);
                     const uint32_t hi = (a0[e] >> 16) | (a1[e] & 0xffff0000u);
-                    *reinterpret_cast<uint32_t*>(sVt + (c * 8 + 2 * e) * VROW + pos) = lo;
-                    *reinterpret_cast<uint32_t*>(sVt + (c * 8 + 2 * e + 1) * VROW + pos) = hi;
+                    *reinterpret_cast<uint32_t*>(dV + (v_c[i] * 8 + 2 * e) * VROW + pos) = lo;
+                    *reinterpret_cast<uint32_t*>(dV + (v_c[i] * 8 + 2 * e + 1) * VROW + pos) = hi;
                 }
             }
         }
@@ -153,13 +168,16 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
     const float c2 = p.scale * LOG2E;
     const int ntiles = (p.Nk + KT - 1) / KT;
     load_kv(0);
-    __syncthreads();  // pad zero-fill visible / ordered before the first tile write (disjoint addresses, cheap)
-    store_kv();
+    __syncthreads();  // pad zero-fill ordered before the first tile write
+    store_kv(0);
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
         const int k0 = t * KT;
+        const int cur = DBUF ? (t & 1) : 0;
         if (t + 1 < ntiles) load_kv(k0 + KT);
+        const bf16_t* cK = sK + cur * KSZ;
+        const bf16_t* cV = sVt + cur * VSZ;
 
         // ---- S^T = K Q^T : lane holds S^T[key = 16f + 4g + r][q = l15] --------------------------
         f32x4 s[QF][4];
@@ -169,7 +187,7 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
             for (int a = 0; a < QF; ++a) s[a][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const bf16x8_t kf = as_bf16x8(*reinterpret_cast<const u32x4*>(sK + (f * 16 + l15) * KROW + c * 32 + lg * 8));
+                const bf16x8_t kf = as_bf16x8(*reinterpret_cast<const u32x4*>(cK + (f * 16 + l15) * KROW + c * 32 + lg * 8));
 #pragma unroll
                 for (int a = 0; a < QF; ++a) s[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[a][c], s[a][f], 0, 0, 0);
             }
@@ -180,51 +198,56 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
         bf16x8_t pb[QF][2];
 #pragma unroll
         for (int a = 0; a < QF; ++a) {
-            const int qrow = q0 + a * 16 + l15;
-            const int qc = qrow < p.Nq ? qrow : p.Nq - 1;
             float mx = NEG_BIG;
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 const int kb = k0 + f * 16 + lg * 4;
-                float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-                if (HAS_BIAS) {
-                    const float* rh = p.rel_h + ((long)bh * p.Nq + qc) * p.kH;
-                    const float* rw = p.rel_w + ((long)bh * p.Nq + qc) * p.kW;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kb + r;
-                        if (key < p.Nk) {
-                            const int khh = key / p.kW;
-                            bias4[r] = (rh[khh] + rw[key - khh * p.kW]) * LOG2E;
-                        }
-                    }
-                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = s[a][f][r] * c2 + bias4[r];
-                    const int key = kb + r;
-                    if (p.key_mask && key < p.Nk && p.key_mask[(long)b * p.Nk + key] == 0) v = NEG_BIG;
-                    if (tail && key >= p.Nk) v = NEG_BIG;
+                    float v = s[a][f][r] * c2;
+                    if (HAS_BIAS) {
+                        const int qc = min(q0 + a * 16 + l15, p.Nq - 1);
+                        const int key = min(kb + r, last_key);
+                        const int khh = key / p.kW;
+                        v += (p.rel_h[((long)bh * p.Nq + qc) * p.kH + khh] + p.rel_w[((long)bh * p.Nq + qc) * p.kW + (key - khh * p.kW)]) * LOG2E;
+                    }
+                    if (HAS_MASK) {
+                        if (p.key_mask[(long)b * p.Nk + min(kb + r, last_key)] == 0) v = NEG_BIG;
+                    }
                     s[a][f][r] = v;
-                    mx = fmaxf(mx, v);
                 }
             }
+            if (tail) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + f * 16 + lg * 4 + r >= p.Nk) s[a][f][r] = NEG_BIG;
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) mx = fmaxf(mx, fmaxf(fmaxf(s[a][f][0], s[a][f][1]), fmaxf(s[a][f][2], s[a][f][3])));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run[a], mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run[a] - m_new);
             m_run[a] = m_new;
             float rs = 0.f;
-            float pv[4][4];
 #pragma unroll
             for (int f = 0; f < 4; ++f)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float e = __builtin_amdgcn_exp2f(s[a][f][r] - m_new);
-                    if (tail && (k0 + f * 16 + lg * 4 + r) >= p.Nk) e = 0.f;
-                    pv[f][r] = e;
-                    rs += e;
+                    const float e = __builtin_amdgcn_exp2f(s[a][f][r] - m_new);
+                    s[a][f][r] = e;
                 }
+            if (tail) {  // padding keys never contribute (also when a whole row is masked -> uniform over REAL keys only)
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + f * 16 + lg * 4 + r >= p.Nk) s[a][f][r] = 0.f;
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) rs += (s[a][f][0] + s[a][f][1]) + (s[a][f][2] + s[a][f][3]);
             l_run[a] = l_run[a] * alpha + rs;
 #pragma unroll
             for (int df = 0; df < NDF; ++df) {
@@ -233,10 +256,10 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 u32x4 w;
-                w.x = pack_bf16x2(pv[2 * j][0], pv[2 * j][1]);
-                w.y = pack_bf16x2(pv[2 * j][2], pv[2 * j][3]);
-                w.z = pack_bf16x2(pv[2 * j + 1][0], pv[2 * j + 1][1]);
-                w.w = pack_bf16x2(pv[2 * j + 1][2], pv[2 * j + 1][3]);
+                w.x = pack_bf16x2(s[a][2 * j][0], s[a][2 * j][1]);
+                w.y = pack_bf16x2(s[a][2 * j][2], s[a][2 * j][3]);
+                w.z = pack_bf16x2(s[a][2 * j + 1][0], s[a][2 * j + 1][1]);
+                w.w = pack_bf16x2(s[a][2 * j + 1][2], s[a][2 * j + 1][3]);
                 pb[a][j] = as_bf16x8(w);
             }
         }
@@ -246,16 +269,21 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
         for (int df = 0; df < NDF; ++df) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const bf16x8_t vf = as_bf16x8(*reinterpret_cast<const u32x4*>(sVt + (df * 16 + l15) * VROW + lg * 16 + j * 8));
+                const bf16x8_t vf = as_bf16x8(*reinterpret_cast<const u32x4*>(cV + (df * 16 + l15) * VROW + lg * 16 + j * 8));
 #pragma unroll
                 for (int a = 0; a < QF; ++a) o[a][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[a][j], o[a][df], 0, 0, 0);
             }
         }
 
-        __syncthreads();  // every wave is done reading this tile
-        if (t + 1 < ntiles) {
-            store_kv();
+        if (DBUF) {
+            if (t + 1 < ntiles) store_kv(cur ^ 1);
             __syncthreads();
+        } else {
+            __syncthreads();  // every wave is done reading this tile
+            if (t + 1 < ntiles) {
+                store_kv(0);
+                __syncthreads();
+            }
         }
     }
 
@@ -285,14 +313,21 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
     }
 }
 
-template <int D, int QF>
+template <int D, int QF, bool DBUF>
 int launch_attn(const AttnArgs& a, hipStream_t stream) {
     constexpr int QB = 4 * 16 * QF;
     const long blocks = (long)((a.Nq + QB - 1) / QB) * a.B * a.H;
     dim3 grid((unsigned)blocks), block(NT);
-    if (a.rel_h) hipLaunchKernelGGL((attn_kernel<D, QF, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((attn_kernel<D, QF, false>), grid, block, 0, stream, a);
+    if (a.rel_h && a.key_mask) { ae_set_error("ae_attn_fwd_bf16: rel-pos bias together with key_mask is not supported"); return AE_ERR_UNSUPPORTED; }
+    if (a.rel_h) hipLaunchKernelGGL((attn_kernel<D, QF, DBUF, true, false>), grid, block, 0, stream, a);
+    else if (a.key_mask) hipLaunchKernelGGL((attn_kernel<D, QF, DBUF, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((attn_kernel<D, QF, DBUF, false, false>), grid, block, 0, stream, a);
     return ae_check_launch("ae_attn_fwd_bf16");
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
 }
 
 }  // namespace
@@ -318,17 +353,18 @@ extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
     a.scale = scale; a.rel_h = rel_h; a.rel_w = rel_w; a.kH = kH; a.kW = kW; a.key_mask = key_mask;
     a.out_scale = out_scale; a.accum = accumulate;
     hipStream_t s = (hipStream_t)stream;
+    static const int qf40 = env_int("AE_ATTN_QF40", 4);  // tuning knob (A/B on hardware): query fragments per wave for D=40
     switch (D) {
-        case 8: return launch_attn<8, 2>(a, s);
-        case 16: return launch_attn<16, 2>(a, s);
-        case 32: return launch_attn<32, 2>(a, s);
-        case 40: return launch_attn<40, 2>(a, s);
-        case 48: return launch_attn<48, 2>(a, s);
-        case 64: return launch_attn<64, 2>(a, s);
-        case 80: return launch_attn<80, 2>(a, s);
-        case 96: return launch_attn<96, 2>(a, s);
-        case 128: return launch_attn<128, 2>(a, s);
-        case 160: return launch_attn<160, 2>(a, s);
+        case 8: return launch_attn<8, 2, true>(a, s);
+        case 16: return launch_attn<16, 2, true>(a, s);
+        case 32: return launch_attn<32, 2, true>(a, s);
+        case 40: return (qf40 == 2 || Nq <= 1024) ? launch_attn<40, 2, true>(a, s) : launch_attn<40, 4, true>(a, s);
+        case 48: return launch_attn<48, 2, true>(a, s);
+        case 64: return launch_attn<64, 2, true>(a, s);
+        case 80: return launch_attn<80, 2, true>(a, s);
+        case 96: return launch_attn<96, 2, true>(a, s);
+        case 128: return launch_attn<128, 2, false>(a, s);
+        case 160: return launch_attn<160, 2, false>(a, s);
         default:
             ae_set_error("ae_attn_fwd_bf16: unsupported head_dim %d (supported: 8,16,32,40,48,64,80,96,128,160)", D);
             return AE_ERR_UNSUPPORTED;

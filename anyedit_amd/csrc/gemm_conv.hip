@@ -55,40 +55,38 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
     const int tile = xcd_remap(blockIdx.x, ntm * ntn);
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
 
-    // ---- per-thread staging descriptors -------------------------------------------------
-    bool a_ok[A_CH];
-    long a_base[A_CH];            // dense: element offset of (row, chunk) at k=0 ; conv: pixel base of the batch
-    int a_iy[A_CH], a_ix[A_CH];   // conv: top-left tap coordinate in the (virtual) input
+    // ---- per-thread staging descriptors (loads are branch-free: indices are clamped, never predicated) --------
+    long a_base[A_CH];            // dense: element offset of the (clamped) row ; conv: pixel base of the batch
+    int a_iy[A_CH], a_ix[A_CH];   // conv: top-left tap coordinate in the (virtual) input; out-of-range rows get a far-away
+                                  // coordinate so every tap is "halo" (zero)
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-        const int id = tid + i * NT, row = id >> 3, c = id & 7;
+        const int row = (tid + i * NT) >> 3;
         const int m = m0 + row;
-        a_ok[i] = m < p.M;
+        const int mc = min(m, p.M - 1);
         if (AMODE == A_DENSE) {
-            a_base[i] = (long)m * p.lda + c * 8;
+            a_base[i] = (long)mc;
             a_iy[i] = a_ix[i] = 0;
         } else {
             const int hw = p.Ho * p.Wo;
-            const int mm = a_ok[i] ? m : 0;
-            const int b = mm / hw, rem = mm - b * hw;
+            const int b = mc / hw, rem = mc - b * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             a_base[i] = (long)b * p.H * p.Wd;
-            a_iy[i] = oy * p.stride - 1;
+            a_iy[i] = (m < p.M) ? oy * p.stride - 1 : -100000;
             a_ix[i] = ox * p.stride - 1;
         }
     }
-    bool b_ok[B_CH];
     long b_base[B_CH];
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-        const int id = tid + i * NT, row = id >> 3, c = id & 7;
-        b_ok[i] = (n0 + row) < p.N;
-        b_base[i] = (long)(n0 + row) * p.ldw + c * 8;
+        const int row = (tid + i * NT) >> 3;
+        b_base[i] = (long)min(n0 + row, p.N - 1) * p.ldw;
     }
 
     u32x4 ra[A_CH], rb[B_CH];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     const int KT = (p.K + BK - 1) / BK;
+    const int klast = p.K - 8;
     int ld_tap = 0, ld_ci = 0;  // conv: tap / channel offset of the NEXT tile to load
 
     auto load_tile = [&](int kt) {
@@ -96,10 +94,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
         if (AMODE == A_DENSE) {
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
-                const int id = tid + i * NT, row = id >> 3, c = id & 7;
-                const int k = k0 + c * 8;
-                const bf16_t* src = (k >= p.Ksplit) ? p.A2 + (long)(m0 + row) * p.lda2 + (k - p.Ksplit) : p.A + a_base[i] + k0;
-                ra[i] = (a_ok[i] && k < p.K) ? *reinterpret_cast<const u32x4*>(src) : zero4;
+                const int c = (tid + i * NT) & 7;
+                const int k = min(k0 + c * 8, klast);  // K tail: valid (finite) data, multiplied by the zeroed W tail
+                const bf16_t* src = (k >= p.Ksplit) ? p.A2 + a_base[i] * p.lda2 + (k - p.Ksplit) : p.A + a_base[i] * p.lda + k;
+                ra[i] = *reinterpret_cast<const u32x4*>(src);
             }
         } else {
             const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
@@ -109,17 +107,21 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
                 const int c = (tid + i * NT) & 7;
                 const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
                 const int ci = ld_ci + c * 8;
-                const bool ok = a_ok[i] && (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv && ci < p.Cin;
-                const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
-                const bf16_t* src = p.A + (a_base[i] + (long)sy * p.Wd + sx) * p.Cin + ci;
-                ra[i] = ok ? *reinterpret_cast<const u32x4*>(src) : zero4;
+                const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv && ci < p.Cin;
+                const int cy = min(max(iy, 0), Hv - 1), cx = min(max(ix, 0), Wv - 1);
+                const int sy = p.ups ? (cy >> 1) : cy, sx = p.ups ? (cx >> 1) : cx;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(p.A + (a_base[i] + (long)sy * p.Wd + sx) * p.Cin + min(ci, p.Cin - 8));
+                ra[i] = ok ? v : zero4;  // zero padding of the conv halo (select, not a branch)
             }
             ld_ci += BK;
             if (ld_ci >= p.CinPad) { ld_ci = 0; ++ld_tap; }
         }
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i)
-            rb[i] = (b_ok[i] && (k0 + (int)((tid + i * NT) & 7) * 8) < p.K) ? *reinterpret_cast<const u32x4*>(p.W + b_base[i] + k0) : zero4;
+        for (int i = 0; i < B_CH; ++i) {
+            const int k = k0 + ((tid + i * NT) & 7) * 8;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(p.W + b_base[i] + min(k, klast));
+            rb[i] = (k < p.K) ? v : zero4;
+        }
     };
 
     auto store_tile = [&](int buf) {

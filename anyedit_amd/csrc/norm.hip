@@ -18,7 +18,8 @@ struct GNArgs {
     int C1;
     const float* gamma; const float* beta;
     bf16_t* y;
-    float* part;  // [B][nchunk][groups][2]
+    float* part;   // [B][nchunk][groups][2]  partial (sum, sumsq)
+    float* coef;   // [B][2][C]               per-channel scale / shift
     int B, HW, C, groups, rows_per_chunk, nchunk, act;
     float eps;
 };
@@ -29,7 +30,8 @@ __device__ __forceinline__ u32x4 gn_load(const GNArgs& p, long row, int cc) {
     return *reinterpret_cast<const u32x4*>(p.x2 + row * (p.C - p.C1) + (ch - p.C1));
 }
 
-// blockDim.x = ncc * rpp  (ncc = C/8 column chunks, rpp rows in flight); grid = (nchunk, B)
+// (1) partial sums.  blockDim.x = ncc * rpp (ncc = C/8 column chunks, rpp rows in flight); grid = (nchunk, B).
+// Each thread owns ONE 8-channel column chunk for the whole block: no index arithmetic in the row loop.
 __global__ void gn_stats_kernel(const GNArgs p) {
     extern __shared__ float lds[];  // [2*C]
     const int ncc = p.C / 8;
@@ -43,6 +45,7 @@ __global__ void gn_stats_kernel(const GNArgs p) {
     const int r0 = chunk * p.rows_per_chunk;
     const int r1 = min(r0 + p.rows_per_chunk, p.HW);
     if (rr < rpp) {
+#pragma unroll 4
         for (int r = r0 + rr; r < r1; r += rpp) {
             const u32x4 v = gn_load(p, (long)b * p.HW + r, cc);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -73,50 +76,70 @@ __global__ void gn_stats_kernel(const GNArgs p) {
     }
 }
 
-__global__ void gn_apply_kernel(const GNArgs p) {
-    extern __shared__ float lds[];  // scale[C], shift[C], mean[groups], rstd[groups]
-    float* scale = lds;
-    float* shift = lds + p.C;
-    float* mean = lds + 2 * p.C;
-    float* rstd = mean + p.groups;
-    const int b = blockIdx.y, chunk = blockIdx.x;
-    const int cpg = p.C / p.groups;
-    if (threadIdx.x < p.groups) {
+// (2) finalize: one block per batch element folds the partials (fixed order -> deterministic) into per-channel
+// scale = gamma * rstd, shift = beta - mean * scale.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const GNArgs p) {
+    __shared__ float red[2][8][64];
+    __shared__ float mean[64], rstd[64];
+    const int b = blockIdx.x;
+    const int g = threadIdx.x % 32, part = threadIdx.x / 32;  // 8 parts x 32 lanes; groups > 32 handled by the g loop
+    for (int g0 = 0; g0 < p.groups; g0 += 32) {
+        const int gg = g0 + g;
         float a = 0.f, c = 0.f;
-        const float* src = p.part + ((long)b * p.nchunk * p.groups + threadIdx.x) * 2;
-        for (int i = 0; i < p.nchunk; ++i) {  // fixed order -> deterministic
-            a += src[(long)i * p.groups * 2];
-            c += src[(long)i * p.groups * 2 + 1];
+        if (gg < p.groups) {
+            for (int i = part; i < p.nchunk; i += 8) {
+                const float* src = p.part + (((long)b * p.nchunk + i) * p.groups + gg) * 2;
+                a += src[0];
+                c += src[1];
+            }
         }
-        const float n = (float)cpg * (float)p.HW;
-        const float mu = a / n;
-        const float var = fmaxf(c / n - mu * mu, 0.f);
-        mean[threadIdx.x] = mu;
-        rstd[threadIdx.x] = rsqrtf(var + p.eps);
+        red[0][part][g] = a;
+        red[1][part][g] = c;
+        __syncthreads();
+        if (part == 0 && gg < p.groups) {
+            float sa = 0.f, sc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sa += red[0][j][g]; sc += red[1][j][g]; }
+            const float n = (float)(p.C / p.groups) * (float)p.HW;
+            const float mu = sa / n;
+            const float var = fmaxf(sc / n - mu * mu, 0.f);
+            mean[gg] = mu;
+            rstd[gg] = rsqrtf(var + p.eps);
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    const int cpg = p.C / p.groups;
     for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
-        const int g = c / cpg;
-        const float sc = p.gamma[c] * rstd[g];
-        scale[c] = sc;
-        shift[c] = p.beta[c] - mean[g] * sc;
+        const int gi = c / cpg;
+        const float sc = p.gamma[c] * rstd[gi];
+        p.coef[((long)b * 2 + 0) * p.C + c] = sc;
+        p.coef[((long)b * 2 + 1) * p.C + c] = p.beta[c] - mean[gi] * sc;
     }
-    __syncthreads();
+}
+
+// (3) apply: pure streaming.  Same thread layout as (1): a thread keeps its 8 scales + 8 shifts in registers.
+__global__ void gn_apply_kernel(const GNArgs p) {
     const int ncc = p.C / 8;
-    const int r0 = chunk * p.rows_per_chunk;
+    const int cc = threadIdx.x % ncc, rr = threadIdx.x / ncc, rpp = blockDim.x / ncc;
+    if (rr >= rpp) return;
+    const int b = blockIdx.y;
+    const float* cs = p.coef + ((long)b * 2) * p.C + cc * 8;
+    const f32x4 sc0 = *reinterpret_cast<const f32x4*>(cs), sc1 = *reinterpret_cast<const f32x4*>(cs + 4);
+    const f32x4 sh0 = *reinterpret_cast<const f32x4*>(cs + p.C), sh1 = *reinterpret_cast<const f32x4*>(cs + p.C + 4);
+    const float sc[8] = {sc0[0], sc0[1], sc0[2], sc0[3], sc1[0], sc1[1], sc1[2], sc1[3]};
+    const float sh[8] = {sh0[0], sh0[1], sh0[2], sh0[3], sh1[0], sh1[1], sh1[2], sh1[3]};
+    const int r0 = blockIdx.x * p.rows_per_chunk;
     const int r1 = min(r0 + p.rows_per_chunk, p.HW);
-    const int total = (r1 - r0) * ncc;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
-        const int r = r0 + i / ncc, cc = i % ncc;
+#pragma unroll 4
+    for (int r = r0 + rr; r < r1; r += rpp) {
         const long row = (long)b * p.HW + r;
         const u32x4 v = gn_load(p, row, cc);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         uint32_t o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int c0 = cc * 8 + 2 * e;
-            float a = bf16lo(w[e]) * scale[c0] + shift[c0];
-            float c = bf16hi(w[e]) * scale[c0 + 1] + shift[c0 + 1];
+            float a = bf16lo(w[e]) * sc[2 * e] + sh[2 * e];
+            float c = bf16hi(w[e]) * sc[2 * e + 1] + sh[2 * e + 1];
             if (p.act == 1) { a = silu_f(a); c = silu_f(c); }
             o[e] = pack_bf16x2(a, c);
         }
@@ -180,42 +203,51 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, const f
 }  // namespace
 
 extern "C" int ae_groupnorm_rows_per_chunk(int HW) {
-    // at most 64 chunks per image so the apply prologue stays short; at least 8 rows per chunk
-    int r = (HW + 63) / 64;
-    return r < 8 ? (HW < 8 ? HW : 8) : r;
+    // small row chunks -> thousands of blocks at the 64x64 levels (memory-level parallelism), >= 1 row
+    int r = 16;
+    if (HW < r) r = HW;
+    return r;
 }
 
 extern "C" long ae_groupnorm_workspace_floats(int B, int HW, int groups) {
     const int rpc = ae_groupnorm_rows_per_chunk(HW);
     const int nchunk = (HW + rpc - 1) / rpc;
-    return (long)B * nchunk * groups * 2;
+    return (long)B * nchunk * groups * 2 + (long)B * 2 * 8192;  // partials + per-channel scale/shift (C <= 8192)
 }
 
 extern "C" int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y,
                                       int B, int HW, int C, int groups, float eps, int act, float* workspace, void* stream) {
     AE_REQUIRE(x && gamma && beta && y && workspace, "ae_groupnorm_nhwc_bf16: null pointer");
     AE_REQUIRE(B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, "ae_groupnorm_nhwc_bf16: bad shape C=%d groups=%d", C, groups);
-    AE_REQUIRE(C % 8 == 0 && C / 8 <= 1024, "ae_groupnorm_nhwc_bf16: C=%d must be a multiple of 8 and <= 8192", C);
+    AE_REQUIRE(C % 8 == 0 && C <= 8192, "ae_groupnorm_nhwc_bf16: C=%d must be a multiple of 8 and <= 8192", C);
     AE_REQUIRE(groups <= 64, "ae_groupnorm_nhwc_bf16: groups=%d > 64 unsupported", groups);
     AE_REQUIRE(act == 0 || act == 1, "ae_groupnorm_nhwc_bf16: act must be 0 (none) or 1 (SiLU)");
+    AE_REQUIRE(B <= 65535, "ae_groupnorm_nhwc_bf16: batch too large");
     if (x2) AE_REQUIRE(C1 > 0 && C1 < C && C1 % 8 == 0, "ae_groupnorm_nhwc_bf16: bad concat split C1=%d C=%d", C1, C);
-    AE_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)x2 & 15) == 0, "ae_groupnorm_nhwc_bf16: 16-byte alignment");
+    AE_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)x2 & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
+               "ae_groupnorm_nhwc_bf16: 16-byte alignment");
     GNArgs p{};
     p.x = (const bf16_t*)x; p.x2 = (const bf16_t*)x2; p.C1 = x2 ? C1 : C;
-    p.gamma = gamma; p.beta = beta; p.y = (bf16_t*)y; p.part = workspace;
+    p.gamma = gamma; p.beta = beta; p.y = (bf16_t*)y;
     p.B = B; p.HW = HW; p.C = C; p.groups = groups; p.act = act; p.eps = eps;
     p.rows_per_chunk = ae_groupnorm_rows_per_chunk(HW);
     p.nchunk = (HW + p.rows_per_chunk - 1) / p.rows_per_chunk;
+    p.part = workspace;
+    p.coef = workspace + (((long)B * p.nchunk * groups * 2 + 3) / 4) * 4;
     const int ncc = C / 8;
     int rpp = 256 / ncc;
     if (rpp < 1) rpp = 1;
     int threads = ncc * rpp;
-    if (threads < 64) threads = 64;  // need >= groups threads for the group fold (rr >= rpp lanes idle)
+    if (threads < 64) threads = 64;
     dim3 grid(p.nchunk, B);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), 2 * C * sizeof(float), (hipStream_t)stream, p);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), 2 * C * sizeof(float), s, p);
     int rc = ae_check_launch("ae_groupnorm_nhwc_bf16(stats)");
     if (rc) return rc;
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), (2 * C + 2 * groups) * sizeof(float), (hipStream_t)stream, p);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, p);
+    rc = ae_check_launch("ae_groupnorm_nhwc_bf16(finalize)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(threads), 0, s, p);
     return ae_check_launch("ae_groupnorm_nhwc_bf16(apply)");
 }
 
