@@ -22,10 +22,11 @@ SIGNATURES = {
     "ae_device_info": [ctypes.POINTER(c_int), ctypes.POINTER(c_long), ctypes.POINTER(c_int)],
     "ae_gemm_bf16": [c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int,
                      c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_void_p],
+    "ae_conv3x3_workspace_floats": [c_int, c_int, c_int, c_int, c_int, c_int, c_int],
     "ae_conv3x3_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                        c_int, c_int, c_void_p],
-    "ae_groupnorm_rows_per_chunk": [c_int],
-    "ae_groupnorm_workspace_floats": [c_int, c_int, c_int],
+                        c_int, c_int, c_void_p, c_void_p],
+    "ae_groupnorm_rows_per_chunk": [c_int, c_int],
+    "ae_groupnorm_workspace_floats": [c_int, c_int, c_int, c_int],
     "ae_groupnorm_nhwc_bf16": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                c_int, c_void_p, c_void_p],
     "ae_layernorm_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
@@ -48,7 +49,7 @@ SIGNATURES = {
     "ae_mse_f32": [c_void_p, c_void_p, c_void_p, c_long, c_void_p],
     "ae_task_gate": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
 }
-_RESTYPES = {"ae_last_error": ctypes.c_char_p, "ae_groupnorm_workspace_floats": c_long}
+_RESTYPES = {"ae_last_error": ctypes.c_char_p, "ae_groupnorm_workspace_floats": c_long, "ae_conv3x3_workspace_floats": c_long}
 
 
 class AnyEditHipError(RuntimeError):

@@ -353,7 +353,7 @@ extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
     a.scale = scale; a.rel_h = rel_h; a.rel_w = rel_w; a.kH = kH; a.kW = kW; a.key_mask = key_mask;
     a.out_scale = out_scale; a.accum = accumulate;
     hipStream_t s = (hipStream_t)stream;
-    static const int qf40 = env_int("AE_ATTN_QF40", 4);  // tuning knob (A/B on hardware): query fragments per wave for D=40
+    static const int qf40 = env_int("AE_ATTN_QF40", 2);  // tuning knob (A/B on hardware): query fragments per wave for D=40
     switch (D) {
         case 8: return launch_attn<8, 2, true>(a, s);
         case 16: return launch_attn<16, 2, true>(a, s);

@@ -38,10 +38,12 @@ struct GemmArgs {
     long lda, lda2, ldw, ldc, ldr;
     int epi, out_f32, rows_per_batch;
     int H, Wd, Cin, CinPad, Ho, Wo, stride, ups;  // conv3x3: Cin = channels in memory, CinPad = per-tap K extent
+    int splitk;      // > 1: K is cut into `splitk` ranges, each block writes raw fp32 partials (small-M, huge-K convs)
+    float* partial;  // [splitk][M][N] fp32
 };
 
 template <int BM, int BN, int AMODE>
-__global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs p) {
     constexpr int FM = BM / 32, FN = BN / 32;  // 16x16 fragments per wave (waves tiled 2x2)
     constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT;
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];
@@ -52,7 +54,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, lg = lane >> 4;
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
-    const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+    const int ntiles = ntm * ntn;
+    const int split = blockIdx.x / ntiles;
+    const int tile = xcd_remap(blockIdx.x % ntiles, ntiles);
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
 
     // ---- per-thread staging descriptors (loads are branch-free: indices are clamped, never predicated) --------
@@ -83,14 +87,18 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
         b_base[i] = (long)min(n0 + row, p.N - 1) * p.ldw;
     }
 
-    u32x4 ra[A_CH], rb[B_CH];
+    u32x4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];  // two register sets: tiles t+1 and t+2 in flight
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    const int KT = (p.K + BK - 1) / BK;
+    const int KT_all = (p.K + BK - 1) / BK;
+    const int kt_per = (KT_all + p.splitk - 1) / p.splitk;
+    const int kt_begin = split * kt_per;
+    const int KT = max(min(KT_all - kt_begin, kt_per), 0);  // K tiles of this block
     const int klast = p.K - 8;
-    int ld_tap = 0, ld_ci = 0;  // conv: tap / channel offset of the NEXT tile to load
+    // conv: tap / channel offset of the NEXT tile to load
+    int ld_tap = (kt_begin * BK) / (AMODE == A_CONV3 ? p.CinPad : 1 << 30), ld_ci = (AMODE == A_CONV3) ? (kt_begin * BK) % p.CinPad : 0;
 
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
+    auto load_tile = [&](int kt, u32x4 (&ra)[A_CH], u32x4 (&rb)[B_CH]) {
+        const int k0 = (kt_begin + kt) * BK;
         if (AMODE == A_DENSE) {
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
         }
     };
 
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const u32x4 (&ra)[A_CH], const u32x4 (&rb)[B_CH]) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
             const int id = tid + i * NT, row = id >> 3, c = id & 7;
@@ -143,13 +151,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) load_tile(kt + 1);  // global loads in flight under the MFMAs below
+    auto compute_tile = [&](int cur) {
         const bf16_t* cA = sA + cur * BM * BK + (wm * (BM / 2)) * BK;
         const bf16_t* cB = sB + cur * BN * BK + (wn * (BN / 2)) * BK;
 #pragma unroll
@@ -173,11 +175,42 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
                     // D[n][m]: lane holds m = l15, n = 4*lg + r  (operands swapped on purpose)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < KT) store_tile(cur ^ 1);
+    };
+
+    // Software pipeline, two tiles deep in registers: while tile t is multiplied out of LDS, tile t+1 sits in one register
+    // set (landed or landing) and tile t+2 is being fetched into the other; the LDS write of t+1 waits only for ITS loads
+    // (in-order return -> counted vmcnt), so ~2 tiles per block stay in flight: K = 320 GEMMs are otherwise latency-bound.
+    load_tile(0, ra0, rb0);
+    if (KT > 1) load_tile(1, ra1, rb1);
+    store_tile(0, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; kt += 2) {
+        if (kt + 2 < KT) load_tile(kt + 2, ra0, rb0);
+        compute_tile(0);
+        if (kt + 1 < KT) store_tile(1, ra1, rb1);
+        __syncthreads();
+        if (kt + 1 >= KT) break;
+        if (kt + 3 < KT) load_tile(kt + 3, ra1, rb1);
+        compute_tile(1);
+        if (kt + 2 < KT) store_tile(0, ra0, rb0);
         __syncthreads();
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
+    if (p.splitk > 1) {  // raw fp32 partials; bias / vector / residual are applied by splitk_reduce_kernel
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 16 + l15;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
+                if (n >= p.N) continue;
+                *reinterpret_cast<f32x4*>(p.partial + ((long)split * p.M + m) * p.N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * (BM / 2) + i * 16 + l15;
@@ -229,23 +262,72 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
     }
 }
 
+// out[m][n] = sum_s partial[s][m][n] + bias[n] + addvec[m / rows_per_batch][n] (+ residual), fixed summation order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
+    const long total = (long)p.M * p.N / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long e = i * 4;
+        const int m = (int)(e / p.N), n = (int)(e % p.N);
+        f32x4 v = *reinterpret_cast<const f32x4*>(p.partial + e);
+        for (int s2 = 1; s2 < p.splitk; ++s2) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(p.partial + (long)s2 * p.M * p.N + e);
+            v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+        }
+        float o[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (p.bias) o[r] += p.bias[n + r];
+            if (p.addvec) o[r] += p.addvec[(long)(m / p.rows_per_batch) * p.N + n + r];
+        }
+        if (p.res) {
+            const u32x2 rr = *reinterpret_cast<const u32x2*>(p.res + (long)m * p.ldr + n);
+            o[0] += bf16lo(rr.x); o[1] += bf16hi(rr.x); o[2] += bf16lo(rr.y); o[3] += bf16hi(rr.y);
+        }
+        if (p.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = (f32x4){o[0], o[1], o[2], o[3]};
+        else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) = (u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+    }
+}
+
+// tile choice: the largest tile that still fills the 256 CUs and does not waste >10% of N
+int pick_tile(int M, int N) {
+    const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    for (int c = 0; c < 3; ++c) {
+        const long tm = (M + cand[c][0] - 1) / cand[c][0], tn = (N + cand[c][1] - 1) / cand[c][1];
+        const double waste = (double)(tn * cand[c][1]) / (double)N;
+        if (tm * tn >= 256 && waste <= 1.10) return c;
+    }
+    return 2;
+}
+
+// split-K factor for launches that cannot fill the chip with output tiles alone (8x8 / 16x16 levels: M = 768 .. 3072)
+int pick_splitk(int M, int N, int K) {
+    const int c = pick_tile(M, N);
+    if (c != 2) return 1;
+    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+    const int kt = (K + BK - 1) / BK;
+    if (tiles >= 384 || kt < 32) return 1;
+    int s = (int)((768 + tiles - 1) / tiles);
+    if (s > 8) s = 8;
+    if (s > kt / 8) s = kt / 8;
+    return s < 2 ? 1 : s;
+}
+
 template <int AMODE>
 int launch(const GemmArgs& a, hipStream_t stream) {
-    // tile choice: the largest tile that still fills the 256 CUs and does not waste >10% of N
     const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-    int pick = 2;
-    for (int c = 0; c < 3; ++c) {
-        const long tm = (a.M + cand[c][0] - 1) / cand[c][0], tn = (a.N + cand[c][1] - 1) / cand[c][1];
-        const double waste = (double)(tn * cand[c][1]) / (double)a.N;
-        if (tm * tn >= 256 && waste <= 1.10) { pick = c; break; }
-    }
+    const int pick = pick_tile(a.M, a.N);
     const int BM = cand[pick][0], BN = cand[pick][1];
     const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    dim3 grid((unsigned)tiles), block(NT);
+    dim3 grid((unsigned)(tiles * a.splitk)), block(NT);
     if (pick == 0) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE>), grid, block, 0, stream, a);
     else if (pick == 1) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((gemm_kernel<64, 64, AMODE>), grid, block, 0, stream, a);
-    return ae_check_launch(AMODE == A_DENSE ? "ae_gemm_bf16" : "ae_conv3x3_bf16");
+    int rc = ae_check_launch(AMODE == A_DENSE ? "ae_gemm_bf16" : "ae_conv3x3_bf16");
+    if (rc || a.splitk <= 1) return rc;
+    long nb = ((long)a.M * a.N / 4 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a);
+    return ae_check_launch("ae_conv3x3_bf16(split-K reduce)");
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -277,12 +359,22 @@ extern "C" int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, 
     a.M = M; a.N = N; a.K = K; a.Ksplit = A2 ? Ksplit : K;
     a.lda = lda; a.lda2 = lda2; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
     a.epi = epilogue; a.out_f32 = out_f32; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+    a.splitk = 1; a.partial = nullptr;
     return launch<A_DENSE>(a, (hipStream_t)stream);
+}
+
+extern "C" long ae_conv3x3_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride, int upsample2x) {
+    const int Hv = upsample2x ? 2 * H : H, Wv = upsample2x ? 2 * W : W;
+    const int Ho = (Hv + 2 - 3) / stride + 1, Wo = (Wv + 2 - 3) / stride + 1;
+    const int CinPad = (Cin + BK - 1) / BK * BK;
+    const long M = (long)B * Ho * Wo;
+    const int s = pick_splitk((int)M, Cout, 9 * CinPad);
+    return s > 1 ? (long)s * M * Cout : 0;
 }
 
 extern "C" int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float* addvec, const void* residual,
                                void* y, int B, int H, int W, int Cin, int Cout, int stride, int upsample2x, int out_f32,
-                               void* stream) {
+                               float* workspace, void* stream) {
     AE_REQUIRE(x && w && y, "ae_conv3x3_bf16: null pointer");
     AE_REQUIRE(B > 0 && H > 0 && W > 0, "ae_conv3x3_bf16: bad shape B=%d H=%d W=%d", B, H, W);
     AE_REQUIRE(Cin % 8 == 0, "ae_conv3x3_bf16: Cin=%d must be a multiple of 8", Cin);
@@ -300,5 +392,7 @@ extern "C" int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, 
     a.lda = 0; a.lda2 = 0; a.ldw = 9L * CinPad; a.ldc = Cout; a.ldr = Cout;
     a.epi = EPI_NONE; a.out_f32 = out_f32; a.rows_per_batch = Ho * Wo;
     a.H = H; a.Wd = W; a.Cin = Cin; a.CinPad = CinPad; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.ups = upsample2x;
+    a.splitk = workspace ? pick_splitk(a.M, a.N, a.K) : 1;  // without a workspace the kernel runs unsplit
+    a.partial = workspace;
     return launch<A_CONV3>(a, (hipStream_t)stream);
 }

@@ -5,13 +5,16 @@
 // (openaimodel.py:200-204, 224-231, 726-730); nn.LayerNorm in BasicTransformerBlock (attention.py:263-265) and in the
 // SAM Block (image_encoder.py:166-182, eps 1e-6).  Statistics are fp32 exactly as the reference forces them.
 //
-// GroupNorm is two launches: (1) per-(batch, row-chunk) partial sums for all 32 groups, deterministic (no float
-// atomics to global memory); (2) apply: each block folds the partials into mean/rstd, builds per-channel
-// scale/shift in LDS and streams rows with 16-byte loads/stores, SiLU fused.  The input may be the channel-concat
+// GroupNorm is three launches: (1) per-(batch, row-chunk) partial sums for all groups, deterministic (no float atomics
+// to global memory); (2) finalize: one block per batch element folds the partials into per-channel scale/shift;
+// (3) apply: pure streaming, every thread keeps its 8 scales/shifts in registers and all of its rows in flight
+// (16-byte loads/stores), SiLU fused.  The input may be the channel-concat
 // of two tensors (decoder skip connections, openaimodel.py:780) — read in place, never materialised.
 #include "common.hpp"
 
 namespace {
+
+constexpr int GN_MAXR = 8;  // rows per thread kept in flight
 
 struct GNArgs {
     const bf16_t* x; const bf16_t* x2;  // x: channels [0, C1), x2: channels [C1, C)
@@ -45,13 +48,16 @@ __global__ void gn_stats_kernel(const GNArgs p) {
     const int r0 = chunk * p.rows_per_chunk;
     const int r1 = min(r0 + p.rows_per_chunk, p.HW);
     if (rr < rpp) {
-#pragma unroll 4
-        for (int r = r0 + rr; r < r1; r += rpp) {
-            const u32x4 v = gn_load(p, (long)b * p.HW + r, cc);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        u32x4 v[GN_MAXR];  // all of this thread's rows in flight at once (rows_per_chunk <= GN_MAXR * rpp)
+#pragma unroll
+        for (int j = 0; j < GN_MAXR; ++j) v[j] = gn_load(p, (long)b * p.HW + min(r0 + rr + j * rpp, r1 - 1), cc);
+#pragma unroll
+        for (int j = 0; j < GN_MAXR; ++j) {
+            const float keep = (r0 + rr + j * rpp < r1) ? 1.f : 0.f;
+            const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float a = bf16lo(w[e]), c = bf16hi(w[e]);
+                const float a = bf16lo(w[e]) * keep, c = bf16hi(w[e]) * keep;
                 s[2 * e] += a; ss[2 * e] += a * a;
                 s[2 * e + 1] += c; ss[2 * e + 1] += c * c;
             }
@@ -130,10 +136,15 @@ __global__ void gn_apply_kernel(const GNArgs p) {
     const float sh[8] = {sh0[0], sh0[1], sh0[2], sh0[3], sh1[0], sh1[1], sh1[2], sh1[3]};
     const int r0 = blockIdx.x * p.rows_per_chunk;
     const int r1 = min(r0 + p.rows_per_chunk, p.HW);
-#pragma unroll 4
-    for (int r = r0 + rr; r < r1; r += rpp) {
+    u32x4 vv[GN_MAXR];
+#pragma unroll
+    for (int j = 0; j < GN_MAXR; ++j) vv[j] = gn_load(p, (long)b * p.HW + min(r0 + rr + j * rpp, r1 - 1), cc);
+#pragma unroll
+    for (int j = 0; j < GN_MAXR; ++j) {
+        const int r = r0 + rr + j * rpp;
+        if (r >= r1) break;
         const long row = (long)b * p.HW + r;
-        const u32x4 v = gn_load(p, row, cc);
+        const u32x4 v = vv[j];
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         uint32_t o[4];
 #pragma unroll
@@ -202,17 +213,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, const f
 
 }  // namespace
 
-extern "C" int ae_groupnorm_rows_per_chunk(int HW) {
-    // small row chunks -> thousands of blocks at the 64x64 levels (memory-level parallelism), >= 1 row
-    int r = 16;
-    if (HW < r) r = HW;
+extern "C" int ae_groupnorm_rows_per_chunk(int HW, int C) {
+    // every thread keeps all its rows in flight (GN_MAXR 16-byte loads); ~6 blocks per CU at the 64x64 levels
+    const int ncc = C / 8;
+    int rpp = 256 / ncc;
+    if (rpp < 1) rpp = 1;
+    int r = GN_MAXR * rpp;
+    if (r > 32) r = 32;
+    if (r > HW) r = HW;
     return r;
 }
 
-extern "C" long ae_groupnorm_workspace_floats(int B, int HW, int groups) {
-    const int rpc = ae_groupnorm_rows_per_chunk(HW);
+extern "C" long ae_groupnorm_workspace_floats(int B, int HW, int C, int groups) {
+    const int rpc = ae_groupnorm_rows_per_chunk(HW, C);
     const int nchunk = (HW + rpc - 1) / rpc;
-    return (long)B * nchunk * groups * 2 + (long)B * 2 * 8192;  // partials + per-channel scale/shift (C <= 8192)
+    return (((long)B * nchunk * groups * 2 + 3) / 4) * 4 + (long)B * 2 * C;  // partials + per-channel scale/shift
 }
 
 extern "C" int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y,
@@ -230,7 +245,7 @@ extern "C" int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, con
     p.x = (const bf16_t*)x; p.x2 = (const bf16_t*)x2; p.C1 = x2 ? C1 : C;
     p.gamma = gamma; p.beta = beta; p.y = (bf16_t*)y;
     p.B = B; p.HW = HW; p.C = C; p.groups = groups; p.act = act; p.eps = eps;
-    p.rows_per_chunk = ae_groupnorm_rows_per_chunk(HW);
+    p.rows_per_chunk = ae_groupnorm_rows_per_chunk(HW, C);
     p.nchunk = (HW + p.rows_per_chunk - 1) / p.rows_per_chunk;
     p.part = workspace;
     p.coef = workspace + (((long)B * p.nchunk * groups * 2 + 3) / 4) * 4;

@@ -106,8 +106,10 @@ def conv3x3(x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2
         _chk(residual, BF16, "conv3x3.residual", 2)
         if residual.shape != (B * Ho * Wo, Cout) or not residual.is_contiguous():
             raise ValueError("conv3x3: residual shape mismatch")
+    nws = lib.ae_conv3x3_workspace_floats(B, H, W, Cin, Cout, stride, 1 if upsample2x else 0)
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws > 0 else None  # split-K partials (small-M layers)
     check(lib.ae_conv3x3_bf16(_p(x), _p(w), _p(bias), _p(addvec), _p(residual), _p(out), B, H, W, Cin, Cout, stride,
-                              1 if upsample2x else 0, 1 if out_f32 else 0, _s()), "ae_conv3x3_bf16")
+                              1 if upsample2x else 0, 1 if out_f32 else 0, _p(ws), _s()), "ae_conv3x3_bf16")
     return out, Ho, Wo
 
 
@@ -121,7 +123,7 @@ def groupnorm(x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, out=No
         raise ValueError("groupnorm: inputs must be contiguous")
     if out is None:
         out = torch.empty(B * HW, C, dtype=BF16, device=x.device)
-    ws = torch.empty(lib.ae_groupnorm_workspace_floats(B, HW, groups), dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.ae_groupnorm_workspace_floats(B, HW, C, groups), dtype=torch.float32, device=x.device)
     check(lib.ae_groupnorm_nhwc_bf16(_p(x), _p(x2), C1, _p(gamma), _p(beta), _p(out), B, HW, C, groups, eps,
                                      1 if silu else 0, _p(ws), _s()), "ae_groupnorm_nhwc_bf16")
     return out

@@ -49,14 +49,18 @@ int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, int Ksplit,
  * Downsample stride 2 :157-159, Upsample nearest-x2 + conv :108-118 via upsample2x=1).
  *   x [B,H,W,Cin] bf16 channels-last (Cin % 8 == 0), w [Cout, 9*CinPad] bf16 packed (ky,kx,cin) with CinPad = Cin
  *   rounded up to 64 (zero filled), y [B,Ho,Wo,Cout];
- *   addvec fp32 [B,Cout] (time-embedding add, openaimodel.py:262-272), residual bf16 [B,Ho,Wo,Cout] (skip, :274).         */
+ *   addvec fp32 [B,Cout] (time-embedding add, openaimodel.py:262-272), residual bf16 [B,Ho,Wo,Cout] (skip, :274).
+ *   workspace: NULL or ae_conv3x3_workspace_floats(...) fp32 elements (0 = not needed): enables split-K for the small-M,
+ *   huge-K layers (8x8 / 16x16 latents) that cannot fill 256 CUs with output tiles alone.                                  */
+long ae_conv3x3_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride, int upsample2x);
 int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float* addvec, const void* residual, void* y,
-                    int B, int H, int W, int Cin, int Cout, int stride, int upsample2x, int out_f32, void* stream);
+                    int B, int H, int W, int Cin, int Cout, int stride, int upsample2x, int out_f32, float* workspace,
+                    void* stream);
 
 /* GroupNorm32 (+SiLU) (util.py:217-219 eps 1e-5; attention.py:88-89 eps 1e-6); input may be the channel-concat [x | x2].
- * workspace: fp32, ae_groupnorm_workspace_floats(B,HW,groups) elements.  act: 0 none, 1 SiLU.                              */
-int ae_groupnorm_rows_per_chunk(int HW);
-long ae_groupnorm_workspace_floats(int B, int HW, int groups);
+ * workspace: fp32, ae_groupnorm_workspace_floats(B,HW,C,groups) elements.  act: 0 none, 1 SiLU.                              */
+int ae_groupnorm_rows_per_chunk(int HW, int C);
+long ae_groupnorm_workspace_floats(int B, int HW, int C, int groups);
 int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y, int B, int HW,
                            int C, int groups, float eps, int act, float* workspace, void* stream);
 
