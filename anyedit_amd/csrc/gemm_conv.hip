@@ -43,7 +43,7 @@ struct GemmArgs {
 };
 
 template <int BM, int BN, int AMODE>
-__global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
     constexpr int FM = BM / 32, FN = BN / 32;  // 16x16 fragments per wave (waves tiled 2x2)
     constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT;
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs p) {
         b_base[i] = (long)min(n0 + row, p.N - 1) * p.ldw;
     }
 
-    u32x4 ra0[A_CH], rb0[B_CH], ra1[A_CH], rb1[B_CH];  // two register sets: tiles t+1 and t+2 in flight
+    u32x4 ra[A_CH], rb[B_CH];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     const int KT_all = (p.K + BK - 1) / BK;
     const int kt_per = (KT_all + p.splitk - 1) / p.splitk;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs p) {
     // conv: tap / channel offset of the NEXT tile to load
     int ld_tap = (kt_begin * BK) / (AMODE == A_CONV3 ? p.CinPad : 1 << 30), ld_ci = (AMODE == A_CONV3) ? (kt_begin * BK) % p.CinPad : 0;
 
-    auto load_tile = [&](int kt, u32x4 (&ra)[A_CH], u32x4 (&rb)[B_CH]) {
+    auto load_tile = [&](int kt) {
         const int k0 = (kt_begin + kt) * BK;
         if (AMODE == A_DENSE) {
 #pragma unroll
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs p) {
         }
     };
 
-    auto store_tile = [&](int buf, const u32x4 (&ra)[A_CH], const u32x4 (&rb)[B_CH]) {
+    auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
             const int id = tid + i * NT, row = id >> 3, c = id & 7;
@@ -177,22 +177,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs p) {
         }
     };
 
-    // Software pipeline, two tiles deep in registers: while tile t is multiplied out of LDS, tile t+1 sits in one register
-    // set (landed or landing) and tile t+2 is being fetched into the other; the LDS write of t+1 waits only for ITS loads
-    // (in-order return -> counted vmcnt), so ~2 tiles per block stay in flight: K = 320 GEMMs are otherwise latency-bound.
-    load_tile(0, ra0, rb0);
-    if (KT > 1) load_tile(1, ra1, rb1);
-    store_tile(0, ra0, rb0);
+    // Software pipeline: global loads of tile t+1 are issued into registers before tile t is multiplied out of LDS
+    // (issue-early / write-late), one barrier per K tile.  (A two-tile-deep register ring was measured slower: it pushes
+    // the 128x128 variant to 256 VGPRs + spills.)
+    load_tile(0);
+    store_tile(0);
     __syncthreads();
-    for (int kt = 0; kt < KT; kt += 2) {
-        if (kt + 2 < KT) load_tile(kt + 2, ra0, rb0);
-        compute_tile(0);
-        if (kt + 1 < KT) store_tile(1, ra1, rb1);
-        __syncthreads();
-        if (kt + 1 >= KT) break;
-        if (kt + 3 < KT) load_tile(kt + 3, ra1, rb1);
-        compute_tile(1);
-        if (kt + 2 < KT) store_tile(0, ra0, rb0);
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) load_tile(kt + 1);
+        compute_tile(cur);
+        if (kt + 1 < KT) store_tile(cur ^ 1);
         __syncthreads();
     }
 
@@ -211,6 +206,86 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs p) {
         }
         return;
     }
+
+    // ---- coalesced epilogue: the MFMA layout gives a lane 4 columns of 16 different rows (8-byte stores scattered over 16
+    // rows: store-issue bound on the short-K GEMMs).  Stage the wave's fp32 tile through its private LDS slice (the A/B
+    // buffers are free now; 16-byte chunks XOR-swizzled by row) and write 16-byte row-contiguous pieces: 8 lanes = one
+    // 128-byte line; the residual is read the same way.
+    {
+        constexpr int WM = BM / 2, WN = BN / 2, NCH = WN / 4;  // fp32 16-byte chunks per staged row
+        const bool geglu = p.epi == EPI_GEGLU;
+        const int n_out = geglu ? p.N / 2 : p.N;
+        const bool staged = (n_out % 8 == 0) && (p.ldc % 8 == 0) && (!p.res || (p.ldr % 8 == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0));
+        if (staged) {
+            float* st = reinterpret_cast<float*>(smem) + wave * (WM * WN);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int rl = i * 16 + l15;
+                const int m = min(m0 + wm * WM + rl, p.M - 1);
+                const float* av = p.addvec ? p.addvec + (long)(m / p.rows_per_batch) * p.N : nullptr;
+                if (geglu) {
+#pragma unroll
+                    for (int j = 0; j < FN; j += 2) {
+                        const int na = min(n0 + wn * WN + j * 16 + lg * 4, p.N - 20);
+                        f32x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float a = acc[i][j][r] + (p.bias ? p.bias[na + r] : 0.f);
+                            const float g = acc[i][j + 1][r] + (p.bias ? p.bias[na + 16 + r] : 0.f);
+                            o[r] = a * gelu_erf_f(g);
+                        }
+                        const int ch = (j / 2) * 4 + lg;
+                        *reinterpret_cast<f32x4*>(st + rl * WN + ((ch ^ (rl & (NCH - 1))) << 2)) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        const int n = min(n0 + wn * WN + j * 16 + lg * 4, p.N - 4);
+                        f32x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = acc[i][j][r];
+                            if (p.bias) v += p.bias[n + r];
+                            if (av) v += av[n + r];
+                            if (p.epi == EPI_SILU) v = silu_f(v);
+                            else if (p.epi == EPI_GELU) v = gelu_erf_f(v);
+                            o[r] = v;
+                        }
+                        const int ch = j * 4 + lg;
+                        *reinterpret_cast<f32x4*>(st + rl * WN + ((ch ^ (rl & (NCH - 1))) << 2)) = o;
+                    }
+                }
+            }
+            __syncthreads();
+            const int ow = geglu ? WN / 2 : WN;      // output columns of this wave's tile
+            const int och = ow / 8;                  // 8-column output chunks per row
+            const int nbase = geglu ? (n0 + wn * WN) / 2 : n0 + wn * WN;
+            for (int it = lane; it < WM * och; it += 64) {
+                const int rl = it / och, oc = it - rl * och;
+                const int m = m0 + wm * WM + rl, n = nbase + oc * 8;
+                if (m >= p.M || n >= n_out) continue;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + rl * WN + (((2 * oc) ^ (rl & (NCH - 1))) << 2));
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + rl * WN + (((2 * oc + 1) ^ (rl & (NCH - 1))) << 2));
+                float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (p.res) {
+                    const u32x4 rr = *reinterpret_cast<const u32x4*>(p.res + (long)m * p.ldr + n);
+                    o[0] += bf16lo(rr.x); o[1] += bf16hi(rr.x); o[2] += bf16lo(rr.y); o[3] += bf16hi(rr.y);
+                    o[4] += bf16lo(rr.z); o[5] += bf16hi(rr.z); o[6] += bf16lo(rr.w); o[7] += bf16hi(rr.w);
+                }
+                if (p.out_f32) {
+                    float* dst = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+                    *reinterpret_cast<f32x4*>(dst) = (f32x4){o[0], o[1], o[2], o[3]};
+                    *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+                } else {
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) =
+                        (u32x4){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+                }
+            }
+            return;
+        }
+    }
+
+    // ---- direct epilogue (fallback for N % 8 != 0 or unaligned rows, e.g. the 320 -> 4 output conv) ---------------------
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * (BM / 2) + i * 16 + l15;

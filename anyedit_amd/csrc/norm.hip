@@ -36,12 +36,10 @@ __device__ __forceinline__ u32x4 gn_load(const GNArgs& p, long row, int cc) {
 // (1) partial sums.  blockDim.x = ncc * rpp (ncc = C/8 column chunks, rpp rows in flight); grid = (nchunk, B).
 // Each thread owns ONE 8-channel column chunk for the whole block: no index arithmetic in the row loop.
 __global__ void gn_stats_kernel(const GNArgs p) {
-    extern __shared__ float lds[];  // [2*C]
+    extern __shared__ float lds[];  // [rpp][2][C]: one slot per (row slice, channel) -> fixed-order, deterministic fold
     const int ncc = p.C / 8;
     const int cc = threadIdx.x % ncc, rr = threadIdx.x / ncc, rpp = blockDim.x / ncc;
     const int b = blockIdx.y, chunk = blockIdx.x;
-    for (int i = threadIdx.x; i < 2 * p.C; i += blockDim.x) lds[i] = 0.f;
-    __syncthreads();
     float s[8], ss[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = ss[e] = 0.f;
@@ -62,20 +60,21 @@ __global__ void gn_stats_kernel(const GNArgs p) {
                 s[2 * e + 1] += c; ss[2 * e + 1] += c * c;
             }
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            atomicAdd(&lds[cc * 8 + e], s[e]);
-            atomicAdd(&lds[p.C + cc * 8 + e], ss[e]);
-        }
+        float* d0 = lds + (long)rr * 2 * p.C + cc * 8;
+        *reinterpret_cast<f32x4*>(d0) = (f32x4){s[0], s[1], s[2], s[3]};
+        *reinterpret_cast<f32x4*>(d0 + 4) = (f32x4){s[4], s[5], s[6], s[7]};
+        *reinterpret_cast<f32x4*>(d0 + p.C) = (f32x4){ss[0], ss[1], ss[2], ss[3]};
+        *reinterpret_cast<f32x4*>(d0 + p.C + 4) = (f32x4){ss[4], ss[5], ss[6], ss[7]};
     }
     __syncthreads();
     const int cpg = p.C / p.groups;
     if (threadIdx.x < p.groups) {
         float a = 0.f, c = 0.f;
-        for (int i = 0; i < cpg; ++i) {
-            a += lds[threadIdx.x * cpg + i];
-            c += lds[p.C + threadIdx.x * cpg + i];
-        }
+        for (int j = 0; j < rpp; ++j)
+            for (int i = 0; i < cpg; ++i) {
+                a += lds[(long)j * 2 * p.C + threadIdx.x * cpg + i];
+                c += lds[(long)j * 2 * p.C + p.C + threadIdx.x * cpg + i];
+            }
         float* dst = p.part + (((long)b * p.nchunk + chunk) * p.groups + threadIdx.x) * 2;
         dst[0] = a;
         dst[1] = c;
@@ -256,7 +255,7 @@ extern "C" int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, con
     if (threads < 64) threads = 64;
     dim3 grid(p.nchunk, B);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), 2 * C * sizeof(float), s, p);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), (size_t)(threads / ncc) * 2 * C * sizeof(float), s, p);
     int rc = ae_check_launch("ae_groupnorm_nhwc_bf16(stats)");
     if (rc) return rc;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, p);
