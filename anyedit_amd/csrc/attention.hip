@@ -22,6 +22,7 @@
 //   * softmax in fp32, exp2 domain; bf16 P (v_cvt_pk_bf16_f32); fp32 accumulation of O.
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -172,10 +173,9 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
     store_kv(0);
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
-        const int k0 = t * KT;
-        const int cur = DBUF ? (t & 1) : 0;
-        if (t + 1 < ntiles) load_kv(k0 + KT);
+    // One K/V tile: S^T = K Q^T, online softmax, O^T += V^T P^T.  TAIL = the (only) tile that contains padding keys.
+    auto tile_body = [&](int k0, int cur, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
         const bf16_t* cK = sK + cur * KSZ;
         const bf16_t* cV = sVt + cur * VSZ;
 
@@ -193,66 +193,67 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
             }
         }
 
-        // ---- online softmax (fp32, exp2 domain) ---------------------------------------------------
-        const bool tail = (k0 + KT > p.Nk);
+        // ---- online softmax (fp32, exp2 domain).  Fast path (no bias / mask / padding): logits stay raw, the scale is
+        // folded into one fma per element, and O / l are rescaled only when some row's running max actually moves (exact:
+        // otherwise the factor is 1) — a wave-uniform branch that is almost never taken after the first tiles.
         bf16x8_t pb[QF][2];
 #pragma unroll
         for (int a = 0; a < QF; ++a) {
-            float mx = NEG_BIG;
+            constexpr bool PLAIN = !HAS_BIAS && !HAS_MASK && !TAIL;
+            if (!PLAIN) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const int kb = k0 + f * 16 + lg * 4;
+                for (int f = 0; f < 4; ++f) {
+                    const int kb = k0 + f * 16 + lg * 4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = s[a][f][r] * c2;
-                    if (HAS_BIAS) {
-                        const int qc = min(q0 + a * 16 + l15, p.Nq - 1);
-                        const int key = min(kb + r, last_key);
-                        const int khh = key / p.kW;
-                        v += (p.rel_h[((long)bh * p.Nq + qc) * p.kH + khh] + p.rel_w[((long)bh * p.Nq + qc) * p.kW + (key - khh * p.kW)]) * LOG2E;
+                    for (int r = 0; r < 4; ++r) {
+                        float v = s[a][f][r] * c2;
+                        if (HAS_BIAS) {
+                            const int qc = min(q0 + a * 16 + l15, p.Nq - 1);
+                            const int key = min(kb + r, last_key);
+                            const int khh = key / p.kW;
+                            v += (p.rel_h[((long)bh * p.Nq + qc) * p.kH + khh] + p.rel_w[((long)bh * p.Nq + qc) * p.kW + (key - khh * p.kW)]) * LOG2E;
+                        }
+                        if (HAS_MASK) {
+                            if (p.key_mask[(long)b * p.Nk + min(kb + r, last_key)] == 0) v = NEG_BIG;
+                        }
+                        if (TAIL) {
+                            if (kb + r >= p.Nk) v = NEG_BIG;
+                        }
+                        s[a][f][r] = v;
                     }
-                    if (HAS_MASK) {
-                        if (p.key_mask[(long)b * p.Nk + min(kb + r, last_key)] == 0) v = NEG_BIG;
-                    }
-                    s[a][f][r] = v;
                 }
             }
-            if (tail) {
-#pragma unroll
-                for (int f = 0; f < 4; ++f)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (k0 + f * 16 + lg * 4 + r >= p.Nk) s[a][f][r] = NEG_BIG;
-            }
+            float mx = NEG_BIG;
 #pragma unroll
             for (int f = 0; f < 4; ++f) mx = fmaxf(mx, fmaxf(fmaxf(s[a][f][0], s[a][f][1]), fmaxf(s[a][f][2], s[a][f][3])));
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[a], mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[a] - m_new);
-            m_run[a] = m_new;
-            float rs = 0.f;
+            if (PLAIN) mx *= c2;  // scale > 0
+            if (__any(mx > m_run[a])) {
+                const float m_new = fmaxf(m_run[a], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[a] - m_new);
+                m_run[a] = m_new;
+                l_run[a] *= alpha;
+#pragma unroll
+                for (int df = 0; df < NDF; ++df) {
+                    o[a][df][0] *= alpha; o[a][df][1] *= alpha; o[a][df][2] *= alpha; o[a][df][3] *= alpha;
+                }
+            }
+            const float neg_m = -m_run[a];
 #pragma unroll
             for (int f = 0; f < 4; ++f)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(s[a][f][r] - m_new);
+                    float e = PLAIN ? __builtin_amdgcn_exp2f(fmaf(s[a][f][r], c2, neg_m)) : __builtin_amdgcn_exp2f(s[a][f][r] + neg_m);
+                    if (TAIL) {  // padding keys never contribute (also when a whole row is masked -> uniform over REAL keys)
+                        if (k0 + f * 16 + lg * 4 + r >= p.Nk) e = 0.f;
+                    }
                     s[a][f][r] = e;
                 }
-            if (tail) {  // padding keys never contribute (also when a whole row is masked -> uniform over REAL keys only)
-#pragma unroll
-                for (int f = 0; f < 4; ++f)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (k0 + f * 16 + lg * 4 + r >= p.Nk) s[a][f][r] = 0.f;
-            }
+            float rs = 0.f;
 #pragma unroll
             for (int f = 0; f < 4; ++f) rs += (s[a][f][0] + s[a][f][1]) + (s[a][f][2] + s[a][f][3]);
-            l_run[a] = l_run[a] * alpha + rs;
-#pragma unroll
-            for (int df = 0; df < NDF; ++df) {
-                o[a][df][0] *= alpha; o[a][df][1] *= alpha; o[a][df][2] *= alpha; o[a][df][3] *= alpha;
-            }
+            l_run[a] += rs;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 u32x4 w;
@@ -274,7 +275,14 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
                 for (int a = 0; a < QF; ++a) o[a][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[a][j], o[a][df], 0, 0, 0);
             }
         }
+    };
 
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * KT;
+        const int cur = DBUF ? (t & 1) : 0;
+        if (t + 1 < ntiles) load_kv(k0 + KT);
+        if (k0 + KT > p.Nk) tile_body(k0, cur, std::true_type{});
+        else tile_body(k0, cur, std::false_type{});
         if (DBUF) {
             if (t + 1 < ntiles) store_kv(cur ^ 1);
             __syncthreads();

@@ -17,11 +17,11 @@
 //     +residual, bf16 or fp32 output;
 //   * XCD-aware bijective tile remap so tiles sharing an A panel run on the same XCD's L2.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BK = 64;  // 64 bf16 = 128 B per tile row = 8 chunks of 16 B
-constexpr int NT = 256;
 
 enum { A_DENSE = 0, A_CONV3 = 1 };
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GEGLU = 2, EPI_SILU = 3 };
@@ -42,16 +42,18 @@ struct GemmArgs {
     float* partial;  // [splitk][M][N] fp32
 };
 
-template <int BM, int BN, int AMODE>
-__global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
-    constexpr int FM = BM / 32, FN = BN / 32;  // 16x16 fragments per wave (waves tiled 2x2)
+template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const GemmArgs p) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
+    constexpr int FM = WM / 16, FN = WN / 16;            // 16x16 fragments per wave
     constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT;
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];
     bf16_t* sA = smem;
     bf16_t* sB = smem + 2 * BM * BK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l15 = lane & 15, lg = lane >> 4;
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
     const int ntiles = ntm * ntn;
@@ -152,8 +154,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto compute_tile = [&](int cur) {
-        const bf16_t* cA = sA + cur * BM * BK + (wm * (BM / 2)) * BK;
-        const bf16_t* cB = sB + cur * BN * BK + (wn * (BN / 2)) * BK;
+        const bf16_t* cA = sA + cur * BM * BK + (wm * WM) * BK;
+        const bf16_t* cB = sB + cur * BN * BK + (wn * WN) * BK;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8_t af[FM], bfr[FN];
@@ -195,11 +197,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
     if (p.splitk > 1) {  // raw fp32 partials; bias / vector / residual are applied by splitk_reduce_kernel
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const int m = m0 + wm * (BM / 2) + i * 16 + l15;
+            const int m = m0 + wm * WM + i * 16 + l15;
             if (m >= p.M) continue;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
+                const int n = n0 + wn * WN + j * 16 + lg * 4;
                 if (n >= p.N) continue;
                 *reinterpret_cast<f32x4*>(p.partial + ((long)split * p.M + m) * p.N + n) = acc[i][j];
             }
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
     // buffers are free now; 16-byte chunks XOR-swizzled by row) and write 16-byte row-contiguous pieces: 8 lanes = one
     // 128-byte line; the residual is read the same way.
     {
-        constexpr int WM = BM / 2, WN = BN / 2, NCH = WN / 4;  // fp32 16-byte chunks per staged row
+        constexpr int NCH = WN / 4;  // fp32 16-byte chunks per staged row
         const bool geglu = p.epi == EPI_GEGLU;
         const int n_out = geglu ? p.N / 2 : p.N;
         const bool staged = (n_out % 8 == 0) && (p.ldc % 8 == 0) && (!p.res || (p.ldr % 8 == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0));
@@ -288,13 +290,13 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
     // ---- direct epilogue (fallback for N % 8 != 0 or unaligned rows, e.g. the 320 -> 4 output conv) ---------------------
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * (BM / 2) + i * 16 + l15;
+        const int m = m0 + wm * WM + i * 16 + l15;
         if (m >= p.M) continue;
         const float* av = p.addvec ? p.addvec + (long)(m / p.rows_per_batch) * p.N : nullptr;
         if (p.epi == EPI_GEGLU) {
 #pragma unroll
             for (int j = 0; j < FN; j += 2) {
-                const int na = n0 + wn * (BN / 2) + j * 16 + lg * 4;  // packed 'a' rows; gate rows at +16
+                const int na = n0 + wn * WN + j * 16 + lg * 4;  // packed 'a' rows; gate rows at +16
                 if (na >= p.N) continue;
                 float o[4];
 #pragma unroll
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
                     const float g = acc[i][j + 1][r] + (p.bias ? p.bias[na + 16 + r] : 0.f);
                     o[r] = a * gelu_erf_f(g);
                 }
-                const int nc = (n0 + wn * (BN / 2) + j * 16) / 2 + lg * 4;
+                const int nc = (n0 + wn * WN + j * 16) / 2 + lg * 4;
                 u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
                 *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + nc) = pk;
             }
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs p) {
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
+            const int n = n0 + wn * WN + j * 16 + lg * 4;
             if (n >= p.N) continue;
             float o[4];
 #pragma unroll
@@ -393,10 +395,14 @@ int launch(const GemmArgs& a, hipStream_t stream) {
     const int pick = pick_tile(a.M, a.N);
     const int BM = cand[pick][0], BN = cand[pick][1];
     const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    dim3 grid((unsigned)(tiles * a.splitk)), block(NT);
-    if (pick == 0) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE>), grid, block, 0, stream, a);
-    else if (pick == 1) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((gemm_kernel<64, 64, AMODE>), grid, block, 0, stream, a);
+    dim3 grid((unsigned)(tiles * a.splitk));
+    static const int w8 = getenv("AE_GEMM_W8") ? atoi(getenv("AE_GEMM_W8")) : 0;  // tuning knob: 8-wave blocks (A/B on hardware)
+    if (pick == 0 && w8 == 1) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE, 2, 4>), grid, dim3(512), 0, stream, a);
+    else if (pick == 0 && w8 == 2) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE, 4, 2>), grid, dim3(512), 0, stream, a);
+    else if (pick == 0) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE>), grid, dim3(256), 0, stream, a);
+    else if (pick == 1 && w8) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE, 4, 2>), grid, dim3(512), 0, stream, a);
+    else if (pick == 1) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((gemm_kernel<64, 64, AMODE>), grid, dim3(256), 0, stream, a);
     int rc = ae_check_launch(AMODE == A_DENSE ? "ae_gemm_bf16" : "ae_conv3x3_bf16");
     if (rc || a.splitk <= 1) return rc;
     long nb = ((long)a.M * a.N / 4 + 255) / 256;
