@@ -396,11 +396,15 @@ int launch(const GemmArgs& a, hipStream_t stream) {
     const int BM = cand[pick][0], BN = cand[pick][1];
     const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     dim3 grid((unsigned)(tiles * a.splitk));
-    static const int w8 = getenv("AE_GEMM_W8") ? atoi(getenv("AE_GEMM_W8")) : 0;  // tuning knob: 8-wave blocks (A/B on hardware)
+    // 8-wave (4x2) blocks: twice the waves per CU at the same LDS footprint -> twice the latency tolerance of the
+    // one-tile-ahead pipeline.  Measured on MI355X (profiles/r01_kbench_w8.txt): dense GEMMs -15..-25 % time, the 128x64 conv
+    // unchanged (+-2 %), so that one keeps 4 waves (larger wave tile, fewer LDS reads per MFMA).  AE_GEMM_W8=0 forces 4 waves.
+    static const int w8 = getenv("AE_GEMM_W8") ? atoi(getenv("AE_GEMM_W8")) : 2;
+    const bool conv = AMODE == A_CONV3;
     if (pick == 0 && w8 == 1) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE, 2, 4>), grid, dim3(512), 0, stream, a);
     else if (pick == 0 && w8 == 2) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE, 4, 2>), grid, dim3(512), 0, stream, a);
     else if (pick == 0) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE>), grid, dim3(256), 0, stream, a);
-    else if (pick == 1 && w8) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE, 4, 2>), grid, dim3(512), 0, stream, a);
+    else if (pick == 1 && w8 && !conv) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE, 4, 2>), grid, dim3(512), 0, stream, a);
     else if (pick == 1) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((gemm_kernel<64, 64, AMODE>), grid, dim3(256), 0, stream, a);
     int rc = ae_check_launch(AMODE == A_DENSE ? "ae_gemm_bf16" : "ae_conv3x3_bf16");
