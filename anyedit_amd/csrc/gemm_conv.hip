@@ -48,7 +48,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
     constexpr int FM = WM / 16, FN = WN / 16;            // 16x16 fragments per wave
     constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BM + BN) * BK];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];  // 2 * (BM + BN) * BK bf16 (dynamic: > 64 KiB for 128x160)
+    bf16_t* const smem = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* sA = smem;
     bf16_t* sB = smem + 2 * BM * BK;
 
@@ -215,72 +216,83 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     // 128-byte line; the residual is read the same way.
     {
         constexpr int NCH = WN / 4;  // fp32 16-byte chunks per staged row
+        // staging must fit in the main-loop LDS: split the wave tile's rows into passes if it does not (128x160 tile)
+        constexpr int PASSES = (WAVES_M * WAVES_N * WM * WN * 4 > 2 * (BM + BN) * BK * 2) ? 2 : 1;
+        constexpr int FMP = FM / PASSES, WMP = WM / PASSES;
+        static_assert(FM % PASSES == 0, "epilogue passes must divide the fragment rows");
         const bool geglu = p.epi == EPI_GEGLU;
         const int n_out = geglu ? p.N / 2 : p.N;
         const bool staged = (n_out % 8 == 0) && (p.ldc % 8 == 0) && (!p.res || (p.ldr % 8 == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0));
         if (staged) {
-            float* st = reinterpret_cast<float*>(smem) + wave * (WM * WN);
+            float* st = reinterpret_cast<float*>(smem_raw) + wave * (WMP * WN);
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int rl = i * 16 + l15;
-                const int m = min(m0 + wm * WM + rl, p.M - 1);
-                const float* av = p.addvec ? p.addvec + (long)(m / p.rows_per_batch) * p.N : nullptr;
-                if (geglu) {
+            for (int ps = 0; ps < PASSES; ++ps) {
+                if (ps > 0) __syncthreads();
 #pragma unroll
-                    for (int j = 0; j < FN; j += 2) {
-                        const int na = min(n0 + wn * WN + j * 16 + lg * 4, p.N - 20);
-                        f32x4 o;
+                for (int ii = 0; ii < FMP; ++ii) {
+                    const int i = ps * FMP + ii;
+                    const int rl = ii * 16 + l15;  // row inside this pass
+                    const int m = min(m0 + wm * WM + i * 16 + l15, p.M - 1);
+                    const float* av = p.addvec ? p.addvec + (long)(m / p.rows_per_batch) * p.N : nullptr;
+                    if (geglu) {
+                        if constexpr (FN % 2 == 0) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float a = acc[i][j][r] + (p.bias ? p.bias[na + r] : 0.f);
-                            const float g = acc[i][j + 1][r] + (p.bias ? p.bias[na + 16 + r] : 0.f);
-                            o[r] = a * gelu_erf_f(g);
+                            for (int j = 0; j < FN; j += 2) {
+                                const int na = min(n0 + wn * WN + j * 16 + lg * 4, p.N - 20);
+                                f32x4 o;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float a = acc[i][j][r] + (p.bias ? p.bias[na + r] : 0.f);
+                                    const float g = acc[i][j + 1][r] + (p.bias ? p.bias[na + 16 + r] : 0.f);
+                                    o[r] = a * gelu_erf_f(g);
+                                }
+                                const int ch = (j / 2) * 4 + lg;
+                                *reinterpret_cast<f32x4*>(st + rl * WN + (((ch + rl) % NCH) << 2)) = o;
+                            }
                         }
-                        const int ch = (j / 2) * 4 + lg;
-                        *reinterpret_cast<f32x4*>(st + rl * WN + ((ch ^ (rl & (NCH - 1))) << 2)) = o;
-                    }
-                } else {
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        const int n = min(n0 + wn * WN + j * 16 + lg * 4, p.N - 4);
-                        f32x4 o;
+                        for (int j = 0; j < FN; ++j) {
+                            const int n = min(n0 + wn * WN + j * 16 + lg * 4, p.N - 4);
+                            f32x4 o;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float v = acc[i][j][r];
-                            if (p.bias) v += p.bias[n + r];
-                            if (av) v += av[n + r];
-                            if (p.epi == EPI_SILU) v = silu_f(v);
-                            else if (p.epi == EPI_GELU) v = gelu_erf_f(v);
-                            o[r] = v;
+                            for (int r = 0; r < 4; ++r) {
+                                float v = acc[i][j][r];
+                                if (p.bias) v += p.bias[n + r];
+                                if (av) v += av[n + r];
+                                if (p.epi == EPI_SILU) v = silu_f(v);
+                                else if (p.epi == EPI_GELU) v = gelu_erf_f(v);
+                                o[r] = v;
+                            }
+                            const int ch = j * 4 + lg;
+                            *reinterpret_cast<f32x4*>(st + rl * WN + (((ch + rl) % NCH) << 2)) = o;
                         }
-                        const int ch = j * 4 + lg;
-                        *reinterpret_cast<f32x4*>(st + rl * WN + ((ch ^ (rl & (NCH - 1))) << 2)) = o;
                     }
                 }
-            }
-            __syncthreads();
-            const int ow = geglu ? WN / 2 : WN;      // output columns of this wave's tile
-            const int och = ow / 8;                  // 8-column output chunks per row
-            const int nbase = geglu ? (n0 + wn * WN) / 2 : n0 + wn * WN;
-            for (int it = lane; it < WM * och; it += 64) {
-                const int rl = it / och, oc = it - rl * och;
-                const int m = m0 + wm * WM + rl, n = nbase + oc * 8;
-                if (m >= p.M || n >= n_out) continue;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + rl * WN + (((2 * oc) ^ (rl & (NCH - 1))) << 2));
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + rl * WN + (((2 * oc + 1) ^ (rl & (NCH - 1))) << 2));
-                float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                if (p.res) {
-                    const u32x4 rr = *reinterpret_cast<const u32x4*>(p.res + (long)m * p.ldr + n);
-                    o[0] += bf16lo(rr.x); o[1] += bf16hi(rr.x); o[2] += bf16lo(rr.y); o[3] += bf16hi(rr.y);
-                    o[4] += bf16lo(rr.z); o[5] += bf16hi(rr.z); o[6] += bf16lo(rr.w); o[7] += bf16hi(rr.w);
-                }
-                if (p.out_f32) {
-                    float* dst = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
-                    *reinterpret_cast<f32x4*>(dst) = (f32x4){o[0], o[1], o[2], o[3]};
-                    *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){o[4], o[5], o[6], o[7]};
-                } else {
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) =
-                        (u32x4){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+                __syncthreads();
+                const int ow = geglu ? WN / 2 : WN;      // output columns of this wave's tile
+                const int och = ow / 8;                  // 8-column output chunks per row
+                const int nbase = geglu ? (n0 + wn * WN) / 2 : n0 + wn * WN;
+                for (int it = lane; it < WMP * och; it += 64) {
+                    const int rl = it / och, oc = it - rl * och;
+                    const int m = m0 + wm * WM + ps * WMP + rl, n = nbase + oc * 8;
+                    if (m >= p.M || n >= n_out) continue;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + rl * WN + (((2 * oc + rl) % NCH) << 2));
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + rl * WN + (((2 * oc + 1 + rl) % NCH) << 2));
+                    float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    if (p.res) {
+                        const u32x4 rr = *reinterpret_cast<const u32x4*>(p.res + (long)m * p.ldr + n);
+                        o[0] += bf16lo(rr.x); o[1] += bf16hi(rr.x); o[2] += bf16lo(rr.y); o[3] += bf16hi(rr.y);
+                        o[4] += bf16lo(rr.z); o[5] += bf16hi(rr.z); o[6] += bf16lo(rr.w); o[7] += bf16hi(rr.w);
+                    }
+                    if (p.out_f32) {
+                        float* dst = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+                        *reinterpret_cast<f32x4*>(dst) = (f32x4){o[0], o[1], o[2], o[3]};
+                        *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+                    } else {
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) =
+                            (u32x4){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+                    }
                 }
             }
             return;
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
         const float* av = p.addvec ? p.addvec + (long)(m / p.rows_per_batch) * p.N : nullptr;
         if (p.epi == EPI_GEGLU) {
 #pragma unroll
-            for (int j = 0; j < FN; j += 2) {
+            for (int j = 0; j + 1 < FN; j += 2) {
                 const int na = n0 + wn * WN + j * 16 + lg * 4;  // packed 'a' rows; gate rows at +16
                 if (na >= p.N) continue;
                 float o[4];
@@ -368,6 +380,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 // tile choice: the largest tile that still fills the 256 CUs and does not waste >10% of N
 int pick_tile(int M, int N) {
     const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    // 128x160 divides every channel count of this UNet (320, 640, 960, 1280, 1920, ...); prefer it where 128x128 would
+    // pad N (320, 960): 2.5x the A-tile reuse of 128x64
+    if (N % 160 == 0 && N % 128 != 0 && (long)((M + 127) / 128) * (N / 160) >= 256) return 3;
     for (int c = 0; c < 3; ++c) {
         const long tm = (M + cand[c][0] - 1) / cand[c][0], tn = (N + cand[c][1] - 1) / cand[c][1];
         const double waste = (double)(tn * cand[c][1]) / (double)N;
@@ -391,8 +406,10 @@ int pick_splitk(int M, int N, int K) {
 
 template <int AMODE>
 int launch(const GemmArgs& a, hipStream_t stream) {
-    const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-    const int pick = pick_tile(a.M, a.N);
+    const int cand[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}};
+    static const int t160 = getenv("AE_GEMM_T160") ? atoi(getenv("AE_GEMM_T160")) : 1;  // tuning knob: 128x160 tile
+    int pick = pick_tile(a.M, a.N);
+    if (pick == 3 && (!t160 || a.epi == EPI_GEGLU || a.splitk > 1)) pick = 1;
     const int BM = cand[pick][0], BN = cand[pick][1];
     const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     dim3 grid((unsigned)(tiles * a.splitk));
@@ -401,12 +418,23 @@ int launch(const GemmArgs& a, hipStream_t stream) {
     // unchanged (+-2 %), so that one keeps 4 waves (larger wave tile, fewer LDS reads per MFMA).  AE_GEMM_W8=0 forces 4 waves.
     static const int w8 = getenv("AE_GEMM_W8") ? atoi(getenv("AE_GEMM_W8")) : 2;
     const bool conv = AMODE == A_CONV3;
-    if (pick == 0 && w8 == 1) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE, 2, 4>), grid, dim3(512), 0, stream, a);
-    else if (pick == 0 && w8 == 2) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE, 4, 2>), grid, dim3(512), 0, stream, a);
-    else if (pick == 0) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE>), grid, dim3(256), 0, stream, a);
-    else if (pick == 1 && w8 && !conv) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE, 4, 2>), grid, dim3(512), 0, stream, a);
-    else if (pick == 1) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((gemm_kernel<64, 64, AMODE>), grid, dim3(256), 0, stream, a);
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t);
+    if (pick == 3) {
+        static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<128, 160, AMODE, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                ae_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", lds);
+                return AE_ERR_LAUNCH;
+            }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm_kernel<128, 160, AMODE, 2, 2>), grid, dim3(256), lds, stream, a);
+    } else if (pick == 0 && w8 == 1) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE, 2, 4>), grid, dim3(512), lds, stream, a);
+    else if (pick == 0 && w8 == 2) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE, 4, 2>), grid, dim3(512), lds, stream, a);
+    else if (pick == 0) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE>), grid, dim3(256), lds, stream, a);
+    else if (pick == 1 && w8 && !conv) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE, 4, 2>), grid, dim3(512), lds, stream, a);
+    else if (pick == 1) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE>), grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((gemm_kernel<64, 64, AMODE>), grid, dim3(256), lds, stream, a);
     int rc = ae_check_launch(AMODE == A_DENSE ? "ae_gemm_bf16" : "ae_conv3x3_bf16");
     if (rc || a.splitk <= 1) return rc;
     long nb = ((long)a.M * a.N / 4 + 255) / 256;
