@@ -38,6 +38,7 @@ struct GemmArgs {
     long lda, lda2, ldw, ldc, ldr;
     int epi, out_f32, rows_per_batch;
     int H, Wd, Cin, CinPad, Ho, Wo, stride, ups;  // conv3x3: Cin = channels in memory, CinPad = per-tap K extent
+    unsigned a_bytes, a2_bytes, w_bytes;  // buffer extents (bytes) for the bounds-checked fast loaders
     int splitk;      // > 1: K is cut into `splitk` ranges, each block writes raw fp32 partials (small-M, huge-K convs)
     float* partial;  // [splitk][M][N] fp32
 };
@@ -90,6 +91,47 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
         b_base[i] = (long)min(n0 + row, p.N - 1) * p.ldw;
     }
 
+    // ---- fast loaders: raw buffer loads with 32-bit byte offsets.  An offset past the descriptor's extent returns 0 in
+    // hardware, so tails and the conv halo cost no clamps / selects / 64-bit address math (the gather was VALU-bound:
+    // ~10 VALU per MFMA, profiles/r01_pmc_conv128x64.txt).  Tiles that need per-chunk decisions fall back to the generic loader.
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : 0u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, (int)p.w_bytes, 0x00020000);
+    constexpr int OOB = (int)0x80000000;  // any offset >= 2 GiB is out of range for every tensor on this path
+    int fa_off[A_CH], fa2_off[A_CH], fb_off[B_CH];
+    unsigned fa_mask[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int id = tid + i * NT, row = id >> 3, c = id & 7;
+        const int m = m0 + row;
+        fa_mask[i] = 0u;
+        if (AMODE == A_DENSE) {
+            fa_off[i] = (m < p.M) ? (int)((long)m * p.lda * 2) + c * 16 : OOB;
+            fa2_off[i] = (m < p.M) ? (int)((long)m * p.lda2 * 2) + c * 16 : OOB;
+        } else {
+            fa2_off[i] = OOB;
+            const int hw = p.Ho * p.Wo;
+            const int mc = min(m, p.M - 1);
+            const int b = mc / hw, rem = mc - b * hw;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int iy0 = oy * p.stride - 1, ix0 = ox * p.stride - 1;
+            fa_off[i] = (int)(((long)(b * p.H + iy0) * p.Wd + ix0) * p.Cin + c * 8) * 2;
+            if (m < p.M) {
+#pragma unroll
+                for (int t9 = 0; t9 < 9; ++t9) {
+                    const int iy = iy0 + t9 / 3, ix = ix0 + t9 % 3;
+                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd) fa_mask[i] |= 1u << t9;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        const int id = tid + i * NT, row = id >> 3, c = id & 7;
+        fb_off[i] = (n0 + row < p.N) ? (int)((long)(n0 + row) * p.ldw * 2) + c * 16 : OOB;
+    }
+    const bool conv_fast = (AMODE == A_CONV3) && !p.ups && p.Cin == p.CinPad;
+
     u32x4 ra[A_CH], rb[B_CH];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     const int KT_all = (p.K + BK - 1) / BK;
@@ -102,6 +144,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
 
     auto load_tile = [&](int kt) {
         const int k0 = (kt_begin + kt) * BK;
+        const bool full_k = k0 + BK <= p.K;
+        if (AMODE == A_DENSE && full_k && (k0 + BK <= p.Ksplit || k0 >= p.Ksplit)) {
+            if (k0 < p.Ksplit) {
+#pragma unroll
+                for (int i = 0; i < A_CH; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, fa_off[i] + k0 * 2, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < A_CH; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA2, fa2_off[i] + (k0 - p.Ksplit) * 2, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, fb_off[i] + k0 * 2, 0, 0);
+            return;
+        }
+        if (conv_fast) {
+            const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
+            const int tap_off = ((ky * p.Wd + kx) * p.Cin + ld_ci) * 2;  // wave-uniform
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                const int off = ((fa_mask[i] >> ld_tap) & 1u) ? fa_off[i] + tap_off : OOB;  // halo / tail rows -> hardware zero
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
+            }
+            ld_ci += BK;
+            if (ld_ci >= p.CinPad) { ld_ci = 0; ++ld_tap; }
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, fb_off[i] + k0 * 2, 0, 0);
+            return;
+        }
         if (AMODE == A_DENSE) {
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
@@ -409,7 +478,8 @@ int launch(const GemmArgs& a, hipStream_t stream) {
     const int cand[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}};
     static const int t160 = getenv("AE_GEMM_T160") ? atoi(getenv("AE_GEMM_T160")) : 1;  // tuning knob: 128x160 tile
     int pick = pick_tile(a.M, a.N);
-    if (pick == 3 && (!t160 || a.epi == EPI_GEGLU || a.splitk > 1)) pick = 1;
+    // measured (profiles/r01_kbench_t160.txt): 128x160 wins on the N=320 convs (-8..-17 %), loses on dense (4 vs 8 waves)
+    if (pick == 3 && (!t160 || AMODE == A_DENSE || a.epi == EPI_GEGLU || a.splitk > 1)) pick = 1;
     const int BM = cand[pick][0], BN = cand[pick][1];
     const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     dim3 grid((unsigned)(tiles * a.splitk));
@@ -473,6 +543,11 @@ extern "C" int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, 
     a.lda = lda; a.lda2 = lda2; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
     a.epi = epilogue; a.out_f32 = out_f32; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
     a.splitk = 1; a.partial = nullptr;
+    a.a_bytes = (unsigned)((((long)M - 1) * lda + (A2 ? Ksplit : K)) * 2);
+    a.a2_bytes = A2 ? (unsigned)((((long)M - 1) * lda2 + (K - Ksplit)) * 2) : 0u;
+    a.w_bytes = (unsigned)((((long)N - 1) * ldw + K) * 2);
+    AE_REQUIRE(((long)M * lda * 2) < (1L << 31) && ((long)N * ldw * 2) < (1L << 31) && (!A2 || ((long)M * lda2 * 2) < (1L << 31)),
+               "ae_gemm_bf16: operands must be smaller than 2 GiB");
     return launch<A_DENSE>(a, (hipStream_t)stream);
 }
 
@@ -505,6 +580,8 @@ extern "C" int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, 
     a.lda = 0; a.lda2 = 0; a.ldw = 9L * CinPad; a.ldc = Cout; a.ldr = Cout;
     a.epi = EPI_NONE; a.out_f32 = out_f32; a.rows_per_batch = Ho * Wo;
     a.H = H; a.Wd = W; a.Cin = Cin; a.CinPad = CinPad; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.ups = upsample2x;
+    a.a_bytes = (unsigned)((long)B * H * W * Cin * 2); a.a2_bytes = 0u; a.w_bytes = (unsigned)((long)Cout * 9 * CinPad * 2);
+    AE_REQUIRE((long)B * H * W * Cin * 2 < (1L << 31) && (long)Cout * 9 * CinPad * 2 < (1L << 31), "ae_conv3x3_bf16: operands must be smaller than 2 GiB");
     a.splitk = workspace ? pick_splitk(a.M, a.N, a.K) : 1;  // without a workspace the kernel runs unsplit
     a.partial = workspace;
     return launch<A_CONV3>(a, (hipStream_t)stream);
