@@ -21,10 +21,10 @@ SIGNATURES = {
     "ae_device_arch": [ctypes.c_char_p, c_int],
     "ae_device_info": [ctypes.POINTER(c_int), ctypes.POINTER(c_long), ctypes.POINTER(c_int)],
     "ae_gemm_bf16": [c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int,
-                     c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_void_p],
+                     c_void_p, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p],
     "ae_conv3x3_workspace_floats": [c_int, c_int, c_int, c_int, c_int, c_int, c_int],
-    "ae_conv3x3_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                        c_int, c_int, c_void_p, c_void_p],
+    "ae_conv3x3_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                        c_int, c_int, c_int, c_void_p, c_void_p],
     "ae_groupnorm_rows_per_chunk": [c_int, c_int],
     "ae_groupnorm_workspace_floats": [c_int, c_int, c_int, c_int],
     "ae_groupnorm_nhwc_bf16": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,

@@ -12,6 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libanyedit_hip.so")
 SOURCES = ["c_api.hip", "gemm_conv.hip", "attention.hip", "norm.hip", "elementwise.hip", "gate.hip"]
+# attention: no NaN/Inf semantics are relied on (masked logits are a finite -1e30) -> lets fmaxf compile to bare v_max/v_max3
+EXTRA = {"attention.hip": ["-ffinite-math-only"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 
 
@@ -27,7 +29,7 @@ def _digest():
     for name in sorted(os.listdir(CSRC)):
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode() + f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update((" ".join(FLAGS) + repr(sorted(EXTRA.items()))).encode())
     return h.hexdigest()
 
 
@@ -42,7 +44,7 @@ def build_library(force=False, verbose=True):
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     objs = []
     for src, obj, p in procs:

@@ -47,7 +47,7 @@ __device__ __forceinline__ int vt_pos(int key) {  // key = 16 f + 4 g + r  ->  1
 }
 
 template <int D, int QF, bool DBUF, bool HAS_BIAS, bool HAS_MASK>
-__global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(NT, (D <= 96 ? 2 : 1)) void attn_kernel(const AttnArgs p) {
     constexpr int DQK = (D + 31) / 32 * 32;
     constexpr int DV = (D + 15) / 16 * 16;
     constexpr int NC = DQK / 32;   // QK^T MFMAs per (key frag, q frag)
@@ -129,15 +129,24 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
     }
     u32x4 rk[KCH], rv[VCH][2];
     const int last_key = p.Nk - 1;
-    auto load_kv = [&](int k0) {  // no branches: out-of-range keys read the last valid row (their P is forced to 0)
+    // Bounds-checked buffer loads, 32-bit byte offsets: one add per load in the loop; keys >= Nk fall past the descriptor's
+    // extent and read as 0 in hardware (their P is forced to 0 anyway).  Extent = this (batch, head)'s rows [0, Nk).
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kp), 0, (int)(((long)last_key * p.k_sn + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vp), 0, (int)(((long)last_key * p.v_sn + D) * 2), 0x00020000);
+    int k_off[KCH], v_off[VCH];
 #pragma unroll
-        for (int i = 0; i < KCH; ++i)
-            rk[i] = *reinterpret_cast<const u32x4*>(kp + (long)min(k0 + k_key[i], last_key) * p.k_sn + k_c[i] * 8);
+    for (int i = 0; i < KCH; ++i) k_off[i] = (int)((long)k_key[i] * p.k_sn + k_c[i] * 8) * 2;
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) v_off[i] = (int)((long)(2 * v_pr[i]) * p.v_sn + v_c[i] * 8) * 2;
+    const int k_tile_bytes = (int)(KT * p.k_sn * 2), v_tile_bytes = (int)(KT * p.v_sn * 2), v_row_bytes = (int)(p.v_sn * 2);
+    auto load_kv = [&](int k0) {
+        const int tk = (k0 / KT) * k_tile_bytes, tv = (k0 / KT) * v_tile_bytes;  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, k_off[i] + tk, 0, 0);
 #pragma unroll
         for (int i = 0; i < VCH; ++i) {
-            const int key = k0 + 2 * v_pr[i];
-            rv[i][0] = *reinterpret_cast<const u32x4*>(vp + (long)min(key, last_key) * p.v_sn + v_c[i] * 8);
-            rv[i][1] = *reinterpret_cast<const u32x4*>(vp + (long)min(key + 1, last_key) * p.v_sn + v_c[i] * 8);
+            rv[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsV, v_off[i] + tv, 0, 0);
+            rv[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsV, v_off[i] + tv + v_row_bytes, 0, 0);
         }
     };
     auto store_kv = [&](int buf) {
@@ -157,8 +166,8 @@ __global__ __launch_bounds__(NT) void attn_kernel(const AttnArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     // d = c*8 + 2e (low halves) and c*8 + 2e + 1 (high halves)
-                    const uint32_t lo = (a0[e] & 0xffffu) | (a1[e] << 16);
-                    const uint32_t hi = (a0[e] >> 16) | (a1[e] & 0xffff0000u);
+                    const uint32_t lo = __builtin_amdgcn_perm(a1[e], a0[e], 0x05040100u);  // {a0.lo16, a1.lo16}: one v_perm_b32
+                    const uint32_t hi = __builtin_amdgcn_perm(a1[e], a0[e], 0x07060302u);  // {a0.hi16, a1.hi16}
                     *reinterpret_cast<uint32_t*>(dV + (v_c[i] * 8 + 2 * e) * VROW + pos) = lo;
                     *reinterpret_cast<uint32_t*>(dV + (v_c[i] * 8 + 2 * e + 1) * VROW + pos) = hi;
                 }

@@ -35,7 +35,7 @@ struct GemmArgs {
     const bf16_t* res;
     const float* addvec;
     int M, N, K, Ksplit;
-    long lda, lda2, ldw, ldc, ldr;
+    long lda, lda2, ldw, ldc, ldr, ldav;  // ldav: row stride of addvec (a column slice of a batched projection)
     int epi, out_f32, rows_per_batch;
     int H, Wd, Cin, CinPad, Ho, Wo, stride, ups;  // conv3x3: Cin = channels in memory, CinPad = per-tap K extent
     unsigned a_bytes, a2_bytes, w_bytes;  // buffer extents (bytes) for the bounds-checked fast loaders
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
                     const int i = ps * FMP + ii;
                     const int rl = ii * 16 + l15;  // row inside this pass
                     const int m = min(m0 + wm * WM + i * 16 + l15, p.M - 1);
-                    const float* av = p.addvec ? p.addvec + (long)(m / p.rows_per_batch) * p.N : nullptr;
+                    const float* av = p.addvec ? p.addvec + (long)(m / p.rows_per_batch) * p.ldav : nullptr;
                     if (geglu) {
                         if constexpr (FN % 2 == 0) {
 #pragma unroll
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * WM + i * 16 + l15;
         if (m >= p.M) continue;
-        const float* av = p.addvec ? p.addvec + (long)(m / p.rows_per_batch) * p.N : nullptr;
+        const float* av = p.addvec ? p.addvec + (long)(m / p.rows_per_batch) * p.ldav : nullptr;
         if (p.epi == EPI_GEGLU) {
 #pragma unroll
             for (int j = 0; j + 1 < FN; j += 2) {
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (p.bias) o[r] += p.bias[n + r];
-            if (p.addvec) o[r] += p.addvec[(long)(m / p.rows_per_batch) * p.N + n + r];
+            if (p.addvec) o[r] += p.addvec[(long)(m / p.rows_per_batch) * p.ldav + n + r];
         }
         if (p.res) {
             const u32x2 rr = *reinterpret_cast<const u32x2*>(p.res + (long)m * p.ldr + n);
@@ -519,7 +519,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 extern "C" int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, int Ksplit, const void* W, long ldw,
                             void* C, long ldc, int M, int N, int K, const float* bias, const void* residual, long ldr,
-                            const float* addvec, int rows_per_batch, int epilogue, int out_f32, void* stream) {
+                            const float* addvec, long addvec_ld, int rows_per_batch, int epilogue, int out_f32, void* stream) {
     AE_REQUIRE(A && W && C, "ae_gemm_bf16: null pointer");
     AE_REQUIRE(M > 0 && N > 0 && K > 0, "ae_gemm_bf16: M,N,K must be positive (got %d,%d,%d)", M, N, K);
     AE_REQUIRE(K % 8 == 0, "ae_gemm_bf16: K=%d must be a multiple of 8", K);
@@ -540,7 +540,7 @@ extern "C" int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, 
     a.A = (const bf16_t*)A; a.A2 = (const bf16_t*)A2; a.W = (const bf16_t*)W; a.C = C;
     a.bias = bias; a.res = (const bf16_t*)residual; a.addvec = addvec;
     a.M = M; a.N = N; a.K = K; a.Ksplit = A2 ? Ksplit : K;
-    a.lda = lda; a.lda2 = lda2; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
+    a.lda = lda; a.lda2 = lda2; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.ldav = addvec_ld > 0 ? addvec_ld : N;
     a.epi = epilogue; a.out_f32 = out_f32; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
     a.splitk = 1; a.partial = nullptr;
     a.a_bytes = (unsigned)((((long)M - 1) * lda + (A2 ? Ksplit : K)) * 2);
@@ -560,9 +560,9 @@ extern "C" long ae_conv3x3_workspace_floats(int B, int H, int W, int Cin, int Co
     return s > 1 ? (long)s * M * Cout : 0;
 }
 
-extern "C" int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float* addvec, const void* residual,
-                               void* y, int B, int H, int W, int Cin, int Cout, int stride, int upsample2x, int out_f32,
-                               float* workspace, void* stream) {
+extern "C" int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float* addvec, long addvec_ld,
+                               const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int stride, int upsample2x,
+                               int out_f32, float* workspace, void* stream) {
     AE_REQUIRE(x && w && y, "ae_conv3x3_bf16: null pointer");
     AE_REQUIRE(B > 0 && H > 0 && W > 0, "ae_conv3x3_bf16: bad shape B=%d H=%d W=%d", B, H, W);
     AE_REQUIRE(Cin % 8 == 0, "ae_conv3x3_bf16: Cin=%d must be a multiple of 8", Cin);
@@ -577,7 +577,7 @@ extern "C" int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, 
     a.bias = bias; a.res = (const bf16_t*)residual; a.addvec = addvec;
     const int CinPad = (Cin + BK - 1) / BK * BK;  // weights are packed [Cout, 9*CinPad], zero padded per tap
     a.M = B * Ho * Wo; a.N = Cout; a.K = 9 * CinPad; a.Ksplit = a.K;
-    a.lda = 0; a.lda2 = 0; a.ldw = 9L * CinPad; a.ldc = Cout; a.ldr = Cout;
+    a.lda = 0; a.lda2 = 0; a.ldw = 9L * CinPad; a.ldc = Cout; a.ldr = Cout; a.ldav = addvec_ld > 0 ? addvec_ld : Cout;
     a.epi = EPI_NONE; a.out_f32 = out_f32; a.rows_per_batch = Ho * Wo;
     a.H = H; a.Wd = W; a.Cin = Cin; a.CinPad = CinPad; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.ups = upsample2x;
     a.a_bytes = (unsigned)((long)B * H * W * Cin * 2); a.a2_bytes = 0u; a.w_bytes = (unsigned)((long)Cout * 9 * CinPad * 2);

@@ -41,6 +41,14 @@ class Feat:
         return self.t
 
 
+class EmbPack:
+    """SiLU(emb) plus the emb_layers projections of ALL ResBlocks computed by one batched GEMM (22 M=12 launches -> 1)."""
+    __slots__ = ("silu", "all", "offsets")
+
+    def __init__(self, silu, all_out=None, offsets=None):
+        self.silu, self.all, self.offsets = silu, all_out, offsets or {}
+
+
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
     """openaimodel.py:73-87."""
 
@@ -148,7 +156,12 @@ class ResBlock(TimestepBlock):
     def rows(self, f, emb_silu):
         """f: Feat (possibly with a pending concat); emb_silu: bf16 [B, emb_channels] = SiLU(emb)."""
         B, H, W = f.B, f.H, f.W
-        emb_out = self.emb_layers[1].rows(emb_silu, out_f32=True)  # [B, Cout] fp32
+        if isinstance(emb_silu, EmbPack) and id(self) in emb_silu.offsets:
+            off = emb_silu.offsets[id(self)]
+            emb_out = emb_silu.all[:, off:off + self.out_channels]  # column slice of the batched projection (fp32, strided rows)
+        else:
+            silu = emb_silu.silu if isinstance(emb_silu, EmbPack) else emb_silu
+            emb_out = self.emb_layers[1].rows(silu, out_f32=True)  # [B, Cout] fp32
         h = self.in_layers[0].rows(f.t, B, H * W, silu=True, x2=f.t2)
         h, _, _ = self.in_layers[2].rows(h, B, H, W, addvec=emb_out)
         h = self.out_layers[0].rows(h, B, H * W, silu=True)
@@ -282,9 +295,26 @@ class UNetModel(nn.Module):
     # ------------------------------------------------------------------------------------------------ forward
     def repack(self):
         """Drop cached packed weights (call after load_state_dict / optimizer steps on UNet parameters)."""
+        self._emb_pk = None
         for m in self.modules():
             if m is not self and hasattr(m, "repack"):
                 m.repack()
+
+    def _emb_pack(self, emb_silu):
+        """All ResBlock.emb_layers Linears as ONE GEMM: W = cat over blocks [sum(Cout), 4*mc]; each block reads its column slice."""
+        pk = getattr(self, "_emb_pk", None)
+        if pk is None or pk[0].device != emb_silu.device:
+            blocks = [m for m in self.modules() if isinstance(m, ResBlock)]
+            w = torch.cat([ops.pack_linear(b.emb_layers[1].weight) for b in blocks], 0).contiguous()
+            bias = torch.cat([b.emb_layers[1].bias.detach().float() for b in blocks], 0).contiguous()
+            offsets, off = {}, 0
+            for b in blocks:
+                offsets[id(b)] = off
+                off += b.out_channels
+            pk = (w, bias, offsets)
+            self._emb_pk = pk
+        w, bias, offsets = pk
+        return EmbPack(emb_silu, ops.gemm(emb_silu, w, bias, out_f32=True), offsets)
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
@@ -303,6 +333,7 @@ class UNetModel(nn.Module):
         t_emb = ops.timestep_embedding(timesteps, self.model_channels)                 # bf16 [B, mc]
         emb = self.time_embed[0].rows(t_emb, epilogue=ops.EPI_SILU)                   # Linear + SiLU fused
         emb_silu = self.time_embed[2].rows(emb, epilogue=ops.EPI_SILU)                # SiLU(emb): what every ResBlock consumes
+        emb_silu = self._emb_pack(emb_silu)
         f = Feat(ops.nchw_to_rows(x, (C + 7) // 8 * 8), B, H, W)
         hs = []
         for module in self.input_blocks:

@@ -83,7 +83,8 @@ def gemm(a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue
         _chk(addvec, torch.float32, "gemm.addvec", 2)
     check(lib.ae_gemm_bf16(_p(a), a.stride(0), _p(a2), a2.stride(0) if a2 is not None else 0, K1, _p(w), w.stride(0),
                            _p(out), out.stride(0), M, N, K, _p(bias), _p(residual),
-                           residual.stride(0) if residual is not None else 0, _p(addvec), rows_per_batch, epilogue,
+                           residual.stride(0) if residual is not None else 0, _p(addvec),
+                           addvec.stride(0) if addvec is not None else 0, rows_per_batch, epilogue,
                            1 if out_f32 else 0, _s()), "ae_gemm_bf16")
     return out
 
@@ -108,8 +109,9 @@ def conv3x3(x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2
             raise ValueError("conv3x3: residual shape mismatch")
     nws = lib.ae_conv3x3_workspace_floats(B, H, W, Cin, Cout, stride, 1 if upsample2x else 0)
     ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws > 0 else None  # split-K partials (small-M layers)
-    check(lib.ae_conv3x3_bf16(_p(x), _p(w), _p(bias), _p(addvec), _p(residual), _p(out), B, H, W, Cin, Cout, stride,
-                              1 if upsample2x else 0, 1 if out_f32 else 0, _p(ws), _s()), "ae_conv3x3_bf16")
+    check(lib.ae_conv3x3_bf16(_p(x), _p(w), _p(bias), _p(addvec), addvec.stride(0) if addvec is not None else 0, _p(residual),
+                              _p(out), B, H, W, Cin, Cout, stride, 1 if upsample2x else 0, 1 if out_f32 else 0, _p(ws), _s()),
+          "ae_conv3x3_bf16")
     return out, Ho, Wo
 
 
@@ -339,8 +341,10 @@ class OpProfiler:
 _PROF = None
 
 
-def _tile_label(M, N):
+def _tile_label(M, N, conv=False):
     """Mirror of the tile choice in csrc/gemm_conv.hip::launch (for labelling only)."""
+    if conv and N % 160 == 0 and N % 128 != 0 and -(-M // 128) * (N // 160) >= 256:
+        return "128x160"
     for bm, bn in ((128, 128), (128, 64), (64, 64)):
         tm, tn = -(-M // bm), -(-N // bn)
         if tm * tn >= 256 and tn * bn / N <= 1.10:
@@ -373,7 +377,7 @@ def _conv_label(_r, x, w, bias, B, H, W, addvec=None, residual=None, stride=1, u
     y = _r[0]
     M, Cout, Cin = y.shape[0], w.shape[0], x.shape[1]
     nb = 2 * (x.numel() + 9 * Cin * Cout) + y.numel() * y.element_size() + (2 * y.numel() if residual is not None else 0)
-    return f"gemm_kernel<{_tile_label(M, Cout)},conv3x3>", 2.0 * M * Cout * 9 * Cin, float(nb)
+    return f"gemm_kernel<{_tile_label(M, Cout, True)},conv3x3>", 2.0 * M * Cout * 9 * Cin, float(nb)
 
 
 def _attn_label(_r, q, k, v, B, H, Nq, Nk, D, *a, **_):

@@ -40,9 +40,10 @@ int ae_device_info(int* cus, long* hbm_bytes, int* clock_khz);
 /* nn.Linear / 1x1 nn.Conv2d on channels-last rows (util.py:202-238 factories; attention.py:154-161 to_q/to_k/to_v/to_out,
  * :49-76 FeedForward/GEGLU, :296-318 proj_in/proj_out; openaimodel.py:233-240 skip 1x1, :526-531 time_embed, :214-219 emb_layers).
  *   C[M,N] = epi(A[M,K] @ W[N,K]^T); A2 != NULL: columns [Ksplit,K) of A come from A2 (skip-concat, openaimodel.py:780).
- *   K % 8 == 0, N % 4 == 0, rows 16-byte aligned.  addvec: fp32 [M/rows_per_batch, N].  out_f32: C is fp32.          */
+ *   K % 8 == 0, N % 4 == 0, rows 16-byte aligned.  addvec: fp32 [M/rows_per_batch, N] with row stride addvec_ld (0 = N).
+ *   out_f32: C is fp32.                                                                                                   */
 int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, int Ksplit, const void* W, long ldw, void* C, long ldc,
-                 int M, int N, int K, const float* bias, const void* residual, long ldr, const float* addvec,
+                 int M, int N, int K, const float* bias, const void* residual, long ldr, const float* addvec, long addvec_ld,
                  int rows_per_batch, int epilogue, int out_f32, void* stream);
 
 /* 3x3 convolution, padding 1, as implicit GEMM (ResBlock in/out convs openaimodel.py:200-231, stem :536-542, head :726-730,
@@ -53,8 +54,8 @@ int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, int Ksplit,
  *   workspace: NULL or ae_conv3x3_workspace_floats(...) fp32 elements (0 = not needed): enables split-K for the small-M,
  *   huge-K layers (8x8 / 16x16 latents) that cannot fill 256 CUs with output tiles alone.                                  */
 long ae_conv3x3_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride, int upsample2x);
-int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float* addvec, const void* residual, void* y,
-                    int B, int H, int W, int Cin, int Cout, int stride, int upsample2x, int out_f32, float* workspace,
+int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float* addvec, long addvec_ld, const void* residual,
+                    void* y, int B, int H, int W, int Cin, int Cout, int stride, int upsample2x, int out_f32, float* workspace,
                     void* stream);
 
 /* GroupNorm32 (+SiLU) (util.py:217-219 eps 1e-5; attention.py:88-89 eps 1e-6); input may be the channel-concat [x | x2].

@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_error_reporting_without_gpu():
     from anyedit_amd import _lib
-    rc = _lib.lib.ae_gemm_bf16(None, 0, None, 0, 0, None, 0, None, 0, 1, 4, 64, None, None, 0, None, 0, 0, 0, None)
+    rc = _lib.lib.ae_gemm_bf16(None, 0, None, 0, 0, None, 0, None, 0, 1, 4, 64, None, None, 0, None, 0, 0, 0, 0, None)
     assert rc == -1 and b"null pointer" in _lib.lib.ae_last_error()
     rc = _lib.lib.ae_ddim_step_f32(1, 1, None, 1, None, None, 10, 7, 0, 0, 0, 0, 0, 0, 0, 0, None)
     assert rc == -1 and b"branches" in _lib.lib.ae_last_error()
