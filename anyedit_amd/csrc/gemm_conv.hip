@@ -43,8 +43,8 @@ struct GemmArgs {
     float* partial;  // [splitk][M][N] fp32
 };
 
-template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const GemmArgs p) {
+template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool DEEP = false>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (DEEP ? 4 : 1)) void gemm_kernel(const GemmArgs p) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
     constexpr int FM = WM / 16, FN = WN / 16;            // 16x16 fragments per wave
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     const bool conv_fast = (AMODE == A_CONV3) && !p.ups && p.Cin == p.CinPad;
 
     u32x4 ra[A_CH], rb[B_CH];
+    u32x4 ra1[DEEP ? A_CH : 1], rb1[DEEP ? B_CH : 1];  // DEEP: second register set (tile t+2 in flight)
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     const int KT_all = (p.K + BK - 1) / BK;
     const int kt_per = (KT_all + p.splitk - 1) / p.splitk;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     // conv: tap / channel offset of the NEXT tile to load
     int ld_tap = (kt_begin * BK) / (AMODE == A_CONV3 ? p.CinPad : 1 << 30), ld_ci = (AMODE == A_CONV3) ? (kt_begin * BK) % p.CinPad : 0;
 
-    auto load_tile = [&](int kt) {
+    auto load_tile_into = [&](int kt, u32x4* ra, u32x4* rb) {
         const int k0 = (kt_begin + kt) * BK;
         const bool full_k = k0 + BK <= p.K;
         if (AMODE == A_DENSE && full_k && (k0 + BK <= p.Ksplit || k0 >= p.Ksplit)) {
@@ -204,7 +205,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
         }
     };
 
-    auto store_tile = [&](int buf) {
+    auto load_tile = [&](int kt) { load_tile_into(kt, ra, rb); };
+
+    auto store_tile_from = [&](int buf, const u32x4* ra, const u32x4* rb) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
             const int id = tid + i * NT, row = id >> 3, c = id & 7;
@@ -216,6 +219,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
             *reinterpret_cast<u32x4*>(sB + buf * BN * BK + row * BK + ((c ^ (row & 7)) << 3)) = rb[i];
         }
     };
+
+    auto store_tile = [&](int buf) { store_tile_from(buf, ra, rb); };
 
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -252,15 +257,35 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     // Software pipeline: global loads of tile t+1 are issued into registers before tile t is multiplied out of LDS
     // (issue-early / write-late), one barrier per K tile.  (A two-tile-deep register ring was measured slower: it pushes
     // the 128x128 variant to 256 VGPRs + spills.)
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) load_tile(kt + 1);
-        compute_tile(cur);
-        if (kt + 1 < KT) store_tile(cur ^ 1);
+    if (!DEEP) {
+        load_tile(0);
+        store_tile(0);
         __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < KT) load_tile(kt + 1);
+            compute_tile(cur);
+            if (kt + 1 < KT) store_tile(cur ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // two tiles in flight per thread (8-wave blocks: only 2+2 staging chunks per thread, so the second register set is
+        // cheap): the LDS write of tile t+1 waits for ITS loads only (in-order return -> counted vmcnt), tile t+2 keeps flying
+        load_tile_into(0, ra, rb);
+        if (KT > 1) load_tile_into(1, ra1, rb1);
+        store_tile_from(0, ra, rb);
+        __syncthreads();
+        for (int kt = 0; kt < KT; kt += 2) {
+            if (kt + 2 < KT) load_tile_into(kt + 2, ra, rb);
+            compute_tile(0);
+            if (kt + 1 < KT) store_tile_from(1, ra1, rb1);
+            __syncthreads();
+            if (kt + 1 >= KT) break;
+            if (kt + 3 < KT) load_tile_into(kt + 3, ra1, rb1);
+            compute_tile(1);
+            if (kt + 2 < KT) store_tile_from(0, ra, rb);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
@@ -488,6 +513,7 @@ int launch(const GemmArgs& a, hipStream_t stream) {
     // unchanged (+-2 %), so that one keeps 4 waves (larger wave tile, fewer LDS reads per MFMA).  AE_GEMM_W8=0 forces 4 waves.
     static const int w8 = getenv("AE_GEMM_W8") ? atoi(getenv("AE_GEMM_W8")) : 2;
     const bool conv = AMODE == A_CONV3;
+    static const int deep = getenv("AE_GEMM_DEEP") ? atoi(getenv("AE_GEMM_DEEP")) : 0;  // tuning knob: 2-tile-deep register ring
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t);
     if (pick == 3) {
         static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
@@ -500,8 +526,10 @@ int launch(const GemmArgs& a, hipStream_t stream) {
         }
         hipLaunchKernelGGL((gemm_kernel<128, 160, AMODE, 2, 2>), grid, dim3(256), lds, stream, a);
     } else if (pick == 0 && w8 == 1) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE, 2, 4>), grid, dim3(512), lds, stream, a);
+    else if (pick == 0 && w8 == 2 && deep) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE, 4, 2, true>), grid, dim3(512), lds, stream, a);
     else if (pick == 0 && w8 == 2) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE, 4, 2>), grid, dim3(512), lds, stream, a);
     else if (pick == 0) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE>), grid, dim3(256), lds, stream, a);
+    else if (pick == 1 && w8 && !conv && deep) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE, 4, 2, true>), grid, dim3(512), lds, stream, a);
     else if (pick == 1 && w8 && !conv) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE, 4, 2>), grid, dim3(512), lds, stream, a);
     else if (pick == 1) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE>), grid, dim3(256), lds, stream, a);
     else hipLaunchKernelGGL((gemm_kernel<64, 64, AMODE>), grid, dim3(256), lds, stream, a);
