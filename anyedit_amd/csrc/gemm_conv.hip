@@ -43,8 +43,8 @@ struct GemmArgs {
     float* partial;  // [splitk][M][N] fp32
 };
 
-template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool DEEP = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (DEEP ? 4 : 1)) void gemm_kernel(const GemmArgs p) {
+template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const GemmArgs p) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
     constexpr int FM = WM / 16, FN = WN / 16;            // 16x16 fragments per wave
@@ -102,7 +102,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (DEEP ? 4 : 1)) void gemm_k
     unsigned fa_mask[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-        const int id = tid + i * NT, row = id >> 3, c = id & 7;
+        const int id = tid + i * NT, row = id >> 3;
+        const int c = GLDS ? ((id & 7) ^ (row & 7)) : (id & 7);  // GLDS: lane's LDS slot is fixed (lane-linear), pick the chunk that lives there
         const int m = m0 + row;
         fa_mask[i] = 0u;
         if (AMODE == A_DENSE) {
@@ -127,13 +128,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (DEEP ? 4 : 1)) void gemm_k
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-        const int id = tid + i * NT, row = id >> 3, c = id & 7;
+        const int id = tid + i * NT, row = id >> 3;
+        const int c = GLDS ? ((id & 7) ^ (row & 7)) : (id & 7);
         fb_off[i] = (n0 + row < p.N) ? (int)((long)(n0 + row) * p.ldw * 2) + c * 16 : OOB;
     }
     const bool conv_fast = (AMODE == A_CONV3) && !p.ups && p.Cin == p.CinPad;
 
     u32x4 ra[A_CH], rb[B_CH];
-    u32x4 ra1[DEEP ? A_CH : 1], rb1[DEEP ? B_CH : 1];  // DEEP: second register set (tile t+2 in flight)
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     const int KT_all = (p.K + BK - 1) / BK;
     const int kt_per = (KT_all + p.splitk - 1) / p.splitk;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (DEEP ? 4 : 1)) void gemm_k
     // conv: tap / channel offset of the NEXT tile to load
     int ld_tap = (kt_begin * BK) / (AMODE == A_CONV3 ? p.CinPad : 1 << 30), ld_ci = (AMODE == A_CONV3) ? (kt_begin * BK) % p.CinPad : 0;
 
-    auto load_tile_into = [&](int kt, u32x4* ra, u32x4* rb) {
+    auto load_tile = [&](int kt) {
         const int k0 = (kt_begin + kt) * BK;
         const bool full_k = k0 + BK <= p.K;
         if (AMODE == A_DENSE && full_k && (k0 + BK <= p.Ksplit || k0 >= p.Ksplit)) {
@@ -205,9 +206,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (DEEP ? 4 : 1)) void gemm_k
         }
     };
 
-    auto load_tile = [&](int kt) { load_tile_into(kt, ra, rb); };
-
-    auto store_tile_from = [&](int buf, const u32x4* ra, const u32x4* rb) {
+    auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
             const int id = tid + i * NT, row = id >> 3, c = id & 7;
@@ -219,8 +218,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (DEEP ? 4 : 1)) void gemm_k
             *reinterpret_cast<u32x4*>(sB + buf * BN * BK + row * BK + ((c ^ (row & 7)) << 3)) = rb[i];
         }
     };
-
-    auto store_tile = [&](int buf) { store_tile_from(buf, ra, rb); };
 
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -257,7 +254,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (DEEP ? 4 : 1)) void gemm_k
     // Software pipeline: global loads of tile t+1 are issued into registers before tile t is multiplied out of LDS
     // (issue-early / write-late), one barrier per K tile.  (A two-tile-deep register ring was measured slower: it pushes
     // the 128x128 variant to 256 VGPRs + spills.)
-    if (!DEEP) {
+    if (!GLDS) {
         load_tile(0);
         store_tile(0);
         __syncthreads();
@@ -269,21 +266,44 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (DEEP ? 4 : 1)) void gemm_k
             __syncthreads();
         }
     } else {
-        // two tiles in flight per thread (8-wave blocks: only 2+2 staging chunks per thread, so the second register set is
-        // cheap): the LDS write of tile t+1 waits for ITS loads only (in-order return -> counted vmcnt), tile t+2 keeps flying
-        load_tile_into(0, ra, rb);
-        if (KT > 1) load_tile_into(1, ra1, rb1);
-        store_tile_from(0, ra, rb);
+        // LDS-DMA pipeline: `buffer_load_dwordx4 ... lds` moves each 1-KiB piece (8 tile rows x 128 B) straight into the next
+        // LDS stage — no staging VGPRs, no ds_write_b128 pass (the slowest LDS instruction, ~79 B/clk/CU).  The LDS image is
+        // lane-linear, so the XOR swizzle is applied to the per-lane SOURCE chunk instead (same involution as the ds_read
+        // side).  hipcc drains the DMA (vmcnt(0)) in front of each __syncthreads().
+        auto dma_tile = [&](int kt, int buf) {
+            const int k0 = (kt_begin + kt) * BK;
+            if (AMODE == A_DENSE) {
+                const bool second = k0 >= p.Ksplit;
+#pragma unroll
+                for (int i = 0; i < A_CH; ++i) {
+                    bf16_t* dst = sA + buf * BM * BK + (wave + (NT / 64) * i) * 8 * BK;
+                    if (!second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, fa_off[i] + k0 * 2, 0, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (__attribute__((address_space(3))) void*)dst, 16, fa2_off[i] + (k0 - p.Ksplit) * 2, 0, 0, 0);
+                }
+            } else {
+                const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
+                const int tap_off = ((ky * p.Wd + kx) * p.Cin + ld_ci) * 2;  // wave-uniform
+#pragma unroll
+                for (int i = 0; i < A_CH; ++i) {
+                    bf16_t* dst = sA + buf * BM * BK + (wave + (NT / 64) * i) * 8 * BK;
+                    const int off = ((fa_mask[i] >> ld_tap) & 1u) ? fa_off[i] + tap_off : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
+                }
+                ld_ci += BK;
+                if (ld_ci >= p.CinPad) { ld_ci = 0; ++ld_tap; }
+            }
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i) {
+                bf16_t* dst = sB + buf * BN * BK + (wave + (NT / 64) * i) * 8 * BK;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, fb_off[i] + k0 * 2, 0, 0, 0);
+            }
+        };
+        dma_tile(0, 0);
         __syncthreads();
-        for (int kt = 0; kt < KT; kt += 2) {
-            if (kt + 2 < KT) load_tile_into(kt + 2, ra, rb);
-            compute_tile(0);
-            if (kt + 1 < KT) store_tile_from(1, ra1, rb1);
-            __syncthreads();
-            if (kt + 1 >= KT) break;
-            if (kt + 3 < KT) load_tile_into(kt + 3, ra1, rb1);
-            compute_tile(1);
-            if (kt + 2 < KT) store_tile_from(0, ra, rb);
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < KT) dma_tile(kt + 1, cur ^ 1);  // stage cur^1 was last read before the previous barrier
+            compute_tile(cur);
             __syncthreads();
         }
     }
@@ -513,26 +533,33 @@ int launch(const GemmArgs& a, hipStream_t stream) {
     // unchanged (+-2 %), so that one keeps 4 waves (larger wave tile, fewer LDS reads per MFMA).  AE_GEMM_W8=0 forces 4 waves.
     static const int w8 = getenv("AE_GEMM_W8") ? atoi(getenv("AE_GEMM_W8")) : 2;
     const bool conv = AMODE == A_CONV3;
-    static const int deep = getenv("AE_GEMM_DEEP") ? atoi(getenv("AE_GEMM_DEEP")) : 0;  // tuning knob: 2-tile-deep register ring
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t);
+    // LDS-DMA loaders need whole-tile decisions: no K tail, no mixed-source tile, no upsample gather / padded channels
+    static const int glds_env = getenv("AE_GEMM_GLDS") ? atoi(getenv("AE_GEMM_GLDS")) : 1;  // tuning knob (A/B on hardware)
+    const bool glds = glds_env && (conv ? (!a.ups && a.Cin == a.CinPad) : (a.K % BK == 0 && (!a.A2 || a.Ksplit % BK == 0)));
+#define AE_LAUNCH(BM_, BN_, WM_, WN_, THREADS)                                                                              \
+    do {                                                                                                                    \
+        if (glds) hipLaunchKernelGGL((gemm_kernel<BM_, BN_, AMODE, WM_, WN_, true>), grid, dim3(THREADS), lds, stream, a);   \
+        else hipLaunchKernelGGL((gemm_kernel<BM_, BN_, AMODE, WM_, WN_, false>), grid, dim3(THREADS), lds, stream, a);      \
+    } while (0)
     if (pick == 3) {
         static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
         if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<128, 160, AMODE, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<128, 160, AMODE, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<128, 160, AMODE, 2, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
                 ae_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", lds);
                 return AE_ERR_LAUNCH;
             }
             attr_set = true;
         }
-        hipLaunchKernelGGL((gemm_kernel<128, 160, AMODE, 2, 2>), grid, dim3(256), lds, stream, a);
-    } else if (pick == 0 && w8 == 1) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE, 2, 4>), grid, dim3(512), lds, stream, a);
-    else if (pick == 0 && w8 == 2 && deep) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE, 4, 2, true>), grid, dim3(512), lds, stream, a);
-    else if (pick == 0 && w8 == 2) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE, 4, 2>), grid, dim3(512), lds, stream, a);
-    else if (pick == 0) hipLaunchKernelGGL((gemm_kernel<128, 128, AMODE>), grid, dim3(256), lds, stream, a);
-    else if (pick == 1 && w8 && !conv && deep) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE, 4, 2, true>), grid, dim3(512), lds, stream, a);
-    else if (pick == 1 && w8 && !conv) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE, 4, 2>), grid, dim3(512), lds, stream, a);
-    else if (pick == 1) hipLaunchKernelGGL((gemm_kernel<128, 64, AMODE>), grid, dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL((gemm_kernel<64, 64, AMODE>), grid, dim3(256), lds, stream, a);
+        AE_LAUNCH(128, 160, 2, 2, 256);
+    } else if (pick == 0 && w8 == 1) AE_LAUNCH(128, 128, 2, 4, 512);
+    else if (pick == 0 && w8 == 2) AE_LAUNCH(128, 128, 4, 2, 512);
+    else if (pick == 0) AE_LAUNCH(128, 128, 2, 2, 256);
+    else if (pick == 1 && w8 && !conv) AE_LAUNCH(128, 64, 4, 2, 512);
+    else if (pick == 1) AE_LAUNCH(128, 64, 2, 2, 256);
+    else AE_LAUNCH(64, 64, 2, 2, 256);
+#undef AE_LAUNCH
     int rc = ae_check_launch(AMODE == A_DENSE ? "ae_gemm_bf16" : "ae_conv3x3_bf16");
     if (rc || a.splitk <= 1) return rc;
     long nb = ((long)a.M * a.N / 4 + 255) / 256;
