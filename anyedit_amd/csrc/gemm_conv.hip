@@ -43,6 +43,14 @@ struct GemmArgs {
     float* partial;  // [splitk][M][N] fp32
 };
 
+// LDS-DMA: one wave moves 64 x 16 B from global straight into LDS at (wave-uniform dst) + lane*16.  The builtin exists only
+// in the device pass of this translation unit (the host pass merely needs the kernel's launch stub).
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, bf16_t* lds_dst, int voffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, 0, 0, 0);
+#endif
+}
+
 template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const GemmArgs p) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -277,8 +285,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
 #pragma unroll
                 for (int i = 0; i < A_CH; ++i) {
                     bf16_t* dst = sA + buf * BM * BK + (wave + (NT / 64) * i) * 8 * BK;
-                    if (!second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, fa_off[i] + k0 * 2, 0, 0, 0);
-                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (__attribute__((address_space(3))) void*)dst, 16, fa2_off[i] + (k0 - p.Ksplit) * 2, 0, 0, 0);
+                    if (!second) lds_dma16(rsA, dst, fa_off[i] + k0 * 2);
+                    else lds_dma16(rsA2, dst, fa2_off[i] + (k0 - p.Ksplit) * 2);
                 }
             } else {
                 const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
                 for (int i = 0; i < A_CH; ++i) {
                     bf16_t* dst = sA + buf * BM * BK + (wave + (NT / 64) * i) * 8 * BK;
                     const int off = ((fa_mask[i] >> ld_tap) & 1u) ? fa_off[i] + tap_off : OOB;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)dst, 16, off, 0, 0, 0);
+                    lds_dma16(rsA, dst, off);
                 }
                 ld_ci += BK;
                 if (ld_ci >= p.CinPad) { ld_ci = 0; ++ld_tap; }
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
 #pragma unroll
             for (int i = 0; i < B_CH; ++i) {
                 bf16_t* dst = sB + buf * BN * BK + (wave + (NT / 64) * i) * 8 * BK;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, fb_off[i] + k0 * 2, 0, 0, 0);
+                lds_dma16(rsW, dst, fb_off[i] + k0 * 2);
             }
         };
         dma_tile(0, 0);
