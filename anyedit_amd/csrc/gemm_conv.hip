@@ -125,13 +125,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             const int iy0 = oy * p.stride - 1, ix0 = ox * p.stride - 1;
             fa_off[i] = (int)(((long)(b * p.H + iy0) * p.Wd + ix0) * p.Cin + c * 8) * 2;
+            const int Hv = p.ups ? 2 * p.H : p.H, Wv = p.ups ? 2 * p.Wd : p.Wd;  // virtual (upsampled) input extent
             if (m < p.M) {
 #pragma unroll
                 for (int t9 = 0; t9 < 9; ++t9) {
                     const int iy = iy0 + t9 / 3, ix = ix0 + t9 % 3;
-                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd) fa_mask[i] |= 1u << t9;
+                    if ((unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv) fa_mask[i] |= 1u << t9;
                 }
             }
+
         }
     }
 #pragma unroll
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
         const int c = GLDS ? ((id & 7) ^ (row & 7)) : (id & 7);
         fb_off[i] = (n0 + row < p.N) ? (int)((long)(n0 + row) * p.ldw * 2) + c * 16 : OOB;
     }
-    const bool conv_fast = (AMODE == A_CONV3) && !p.ups && p.Cin == p.CinPad;
+    const bool conv_fast = (AMODE == A_CONV3) && p.Cin == p.CinPad;
 
     u32x4 ra[A_CH], rb[B_CH];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -172,7 +174,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
             const int tap_off = ((ky * p.Wd + kx) * p.Cin + ld_ci) * 2;  // wave-uniform
 #pragma unroll
             for (int i = 0; i < A_CH; ++i) {
-                const int off = ((fa_mask[i] >> ld_tap) & 1u) ? fa_off[i] + tap_off : OOB;  // halo / tail rows -> hardware zero
+                int src = fa_off[i] + tap_off;
+                if (p.ups) {  // nearest-x2 upsample folded into the gather: source pixel = virtual pixel >> 1 (3 of 64 convs per UNet call)
+                    const int cc = GLDS ? (((tid + i * NT) & 7) ^ (((tid + i * NT) >> 3) & 7)) : ((tid + i * NT) & 7);
+                    src = (int)((a_base[i] + (long)(max(a_iy[i] + ky, 0) >> 1) * p.Wd + (max(a_ix[i] + kx, 0) >> 1)) * p.Cin + cc * 8 + ld_ci) * 2;
+                }
+                const int off = ((fa_mask[i] >> ld_tap) & 1u) ? src : OOB;  // halo / tail rows -> hardware zero
                 ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off, 0, 0);
             }
             ld_ci += BK;
@@ -294,7 +301,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
 #pragma unroll
                 for (int i = 0; i < A_CH; ++i) {
                     bf16_t* dst = sA + buf * BM * BK + (wave + (NT / 64) * i) * 8 * BK;
-                    const int off = ((fa_mask[i] >> ld_tap) & 1u) ? fa_off[i] + tap_off : OOB;
+                    int src = fa_off[i] + tap_off;
+                    if (p.ups) {  // nearest-x2 upsample folded into the gather: source pixel = virtual pixel >> 1 (3 of 64 convs per UNet call)
+                    const int cc = GLDS ? (((tid + i * NT) & 7) ^ (((tid + i * NT) >> 3) & 7)) : ((tid + i * NT) & 7);
+                    src = (int)((a_base[i] + (long)(max(a_iy[i] + ky, 0) >> 1) * p.Wd + (max(a_ix[i] + kx, 0) >> 1)) * p.Cin + cc * 8 + ld_ci) * 2;
+                }
+                    const int off = ((fa_mask[i] >> ld_tap) & 1u) ? src : OOB;
                     lds_dma16(rsA, dst, off);
                 }
                 ld_ci += BK;
@@ -531,6 +543,8 @@ int launch(const GemmArgs& a, hipStream_t stream) {
     const int cand[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}};
     static const int t160 = getenv("AE_GEMM_T160") ? atoi(getenv("AE_GEMM_T160")) : 1;  // tuning knob: 128x160 tile
     int pick = pick_tile(a.M, a.N);
+    static const int force_tile = getenv("AE_GEMM_TILE") ? atoi(getenv("AE_GEMM_TILE")) : -1;  // dev knob: 0 128x128, 1 128x64, 2 64x64
+    if (force_tile >= 0 && force_tile <= 2 && a.splitk <= 1) pick = force_tile;
     // measured (profiles/r01_kbench_t160.txt): 128x160 wins on the N=320 convs (-8..-17 %), loses on dense (4 vs 8 waves)
     if (pick == 3 && (!t160 || AMODE == A_DENSE || a.epi == EPI_GEGLU || a.splitk > 1)) pick = 1;
     const int BM = cand[pick][0], BN = cand[pick][1];
@@ -544,7 +558,7 @@ int launch(const GemmArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t);
     // LDS-DMA loaders need whole-tile decisions: no K tail, no mixed-source tile, no upsample gather / padded channels
     static const int glds_env = getenv("AE_GEMM_GLDS") ? atoi(getenv("AE_GEMM_GLDS")) : 1;  // tuning knob (A/B on hardware)
-    const bool glds = glds_env && (conv ? (!a.ups && a.Cin == a.CinPad) : (a.K % BK == 0 && (!a.A2 || a.Ksplit % BK == 0)));
+    const bool glds = glds_env && (conv ? (a.Cin == a.CinPad) : (a.K % BK == 0 && (!a.A2 || a.Ksplit % BK == 0)));
 #define AE_LAUNCH(BM_, BN_, WM_, WN_, THREADS)                                                                              \
     do {                                                                                                                    \
         if (glds) hipLaunchKernelGGL((gemm_kernel<BM_, BN_, AMODE, WM_, WN_, true>), grid, dim3(THREADS), lds, stream, a);   \
