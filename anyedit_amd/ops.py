@@ -322,9 +322,11 @@ class OpProfiler:
         _PROF = None
         torch.cuda.synchronize()
 
-    def summary(self):
+    def summary(self, by_shape=False):
         agg = {}
         for label, flops, nbytes, e0, e1 in self.records:
+            if not by_shape:
+                label = label.split("|")[0]
             ms = e0.elapsed_time(e1)
             a = agg.setdefault(label, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             a["calls"] += 1
@@ -370,26 +372,26 @@ def _wrap_profiled(fn, label_fn):
 def _gemm_label(_r, a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue=EPI_NONE, out_f32=False, a2=None, **_):
     M, (N, K) = a.shape[0], w.shape
     nb = 2 * (M * K + N * K) + _r.numel() * _r.element_size() + (2 * M * N if residual is not None else 0)
-    return f"gemm_kernel<{_tile_label(M, N)},dense>", 2.0 * M * N * K, float(nb)
+    return f"gemm_kernel<{_tile_label(M, N)},dense>|M={M} N={N} K={K}", 2.0 * M * N * K, float(nb)
 
 
 def _conv_label(_r, x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2x=False, out_f32=False, **_):
     y = _r[0]
     M, Cout, Cin = y.shape[0], w.shape[0], x.shape[1]
     nb = 2 * (x.numel() + 9 * Cin * Cout) + y.numel() * y.element_size() + (2 * y.numel() if residual is not None else 0)
-    return f"gemm_kernel<{_tile_label(M, Cout, True)},conv3x3>", 2.0 * M * Cout * 9 * Cin, float(nb)
+    return f"gemm_kernel<{_tile_label(M, Cout, True)},conv3x3>|M={M} Cin={Cin} Cout={Cout} s{stride}{'u' if upsample2x else ''}", 2.0 * M * Cout * 9 * Cin, float(nb)
 
 
 def _attn_label(_r, q, k, v, B, H, Nq, Nk, D, *a, **_):
-    return f"attn_kernel<D={D}>", 4.0 * B * H * Nq * Nk * D, 2.0 * B * H * D * (2 * Nq + 2 * Nk)
+    return f"attn_kernel<D={D}>|Nq={Nq} Nk={Nk}", 4.0 * B * H * Nq * Nk * D, 2.0 * B * H * D * (2 * Nq + 2 * Nk)
 
 
 def _gn_label(_r, x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, **_):
-    return "groupnorm(stats+apply)", 0.0, 2.0 * _r.numel() * 2  # 1 read + 1 write algorithmic
+    return f"groupnorm(stats+apply)|rows={_r.shape[0]} C={_r.shape[1]}", 0.0, 2.0 * _r.numel() * 2  # 1 read + 1 write algorithmic
 
 
 def _ln_label(_r, x, *a, **_):
-    return "layernorm_kernel", 0.0, 2.0 * _r.numel() * 2
+    return f"layernorm_kernel|M={_r.shape[0]} C={_r.shape[1]}", 0.0, 2.0 * _r.numel() * 2
 
 
 gemm = _wrap_profiled(gemm, _gemm_label)

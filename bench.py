@@ -191,6 +191,10 @@ def main():
                 for _ in range(3):
                     pipe._denoise_static()
             summ = prof.summary()
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "kernels_by_shape.json"), "w") as f:  # per-shape table for the tuning loop
+                json.dump({k: {"calls": v["calls"] // 3, "avg_us": v["avg_us"], "tflops": v["tflops"], "gbps": v["gbps"]}
+                           for k, v in sorted(prof.summary(by_shape=True).items(), key=lambda kv: -kv[1]["ms"])}, f, indent=1)
             dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
             name, a = dom
             mfma = a["flops"] > 0
