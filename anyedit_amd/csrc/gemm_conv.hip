@@ -525,24 +525,31 @@ int pick_tile(int M, int N) {
     return 2;
 }
 
-// split-K factor for launches that cannot fill the chip with output tiles alone (8x8 / 16x16 levels: M = 768 .. 3072)
-int pick_splitk(int M, int N, int K) {
-    const int c = pick_tile(M, N);
-    if (c != 2) return 1;
-    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+// (tile, split-K) plan.  Launches that cannot fill the chip with 128x128 output tiles alone (16x16 / 8x8 latent levels:
+// M = 3072 / 768 with K = 11520..23040) keep the big tile and cut K instead of shrinking the tile: fp32 partials + a
+// fixed-order reduce.  tile: 0 128x128, 1 128x64, 2 64x64, 3 128x160.
+struct Plan { int tile, splitk; };
+Plan make_plan(int M, int N, int K, bool can_split) {
+    const int t = pick_tile(M, N);
     const int kt = (K + BK - 1) / BK;
-    if (tiles >= 384 || kt < 32) return 1;
-    int s = (int)((768 + tiles - 1) / tiles);
-    if (s > 8) s = 8;
-    if (s > kt / 8) s = kt / 8;
-    return s < 2 ? 1 : s;
+    static const int force_s = getenv("AE_GEMM_SPLITK") ? atoi(getenv("AE_GEMM_SPLITK")) : 0;  // dev knob
+    if (!can_split || kt < 32 || t == 0 || t == 3) return {t, 1};
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const double waste128 = (double)(((N + 127) / 128) * 128) / (double)N;
+    if (waste128 <= 1.10 && t128 < 256) {
+        int s = force_s > 0 ? force_s : (int)((480 + t128 - 1) / t128);
+        if (s > 8) s = 8;
+        if (s > kt / 8) s = kt / 8;
+        if (s >= 2) return {0, s};
+    }
+    return {t, 1};
 }
 
 template <int AMODE>
 int launch(const GemmArgs& a, hipStream_t stream) {
     const int cand[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}};
     static const int t160 = getenv("AE_GEMM_T160") ? atoi(getenv("AE_GEMM_T160")) : 1;  // tuning knob: 128x160 tile
-    int pick = pick_tile(a.M, a.N);
+    int pick = a.splitk > 1 ? 0 : pick_tile(a.M, a.N);  // a split plan always uses the 128x128 tile (make_plan)
     static const int force_tile = getenv("AE_GEMM_TILE") ? atoi(getenv("AE_GEMM_TILE")) : -1;  // dev knob: 0 128x128, 1 128x64, 2 64x64
     if (force_tile >= 0 && force_tile <= 2 && a.splitk <= 1) pick = force_tile;
     // measured (profiles/r01_kbench_t160.txt): 128x160 wins on the N=320 convs (-8..-17 %), loses on dense (4 vs 8 waves)
@@ -633,7 +640,7 @@ extern "C" long ae_conv3x3_workspace_floats(int B, int H, int W, int Cin, int Co
     const int Ho = (Hv + 2 - 3) / stride + 1, Wo = (Wv + 2 - 3) / stride + 1;
     const int CinPad = (Cin + BK - 1) / BK * BK;
     const long M = (long)B * Ho * Wo;
-    const int s = pick_splitk((int)M, Cout, 9 * CinPad);
+    const int s = make_plan((int)M, Cout, 9 * CinPad, true).splitk;
     return s > 1 ? (long)s * M * Cout : 0;
 }
 
@@ -659,7 +666,7 @@ extern "C" int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, 
     a.H = H; a.Wd = W; a.Cin = Cin; a.CinPad = CinPad; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.ups = upsample2x;
     a.a_bytes = (unsigned)((long)B * H * W * Cin * 2); a.a2_bytes = 0u; a.w_bytes = (unsigned)((long)Cout * 9 * CinPad * 2);
     AE_REQUIRE((long)B * H * W * Cin * 2 < (1L << 31) && (long)Cout * 9 * CinPad * 2 < (1L << 31), "ae_conv3x3_bf16: operands must be smaller than 2 GiB");
-    a.splitk = workspace ? pick_splitk(a.M, a.N, a.K) : 1;  // without a workspace the kernel runs unsplit
+    a.splitk = workspace ? make_plan(a.M, a.N, a.K, true).splitk : 1;  // without a workspace the kernel runs unsplit
     a.partial = workspace;
     return launch<A_CONV3>(a, (hipStream_t)stream);
 }
