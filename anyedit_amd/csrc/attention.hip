@@ -26,7 +26,6 @@
 
 namespace {
 
-constexpr int NT = 256;
 constexpr int KT = 64;  // keys per tile
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;  // finite "masked" logit: behaves like masked_fill(-finfo.max) (attention.py:186-187)
@@ -46,8 +45,12 @@ __device__ __forceinline__ int vt_pos(int key) {  // key = 16 f + 4 g + r  ->  1
     return ((key >> 2) & 3) * 16 + (key >> 4) * 4 + (key & 3);
 }
 
-template <int D, int QF, bool DBUF, bool HAS_BIAS, bool HAS_MASK>
-__global__ __launch_bounds__(NT, (D <= 96 ? 2 : 1)) void attn_kernel(const AttnArgs p) {
+// NW waves per block, QF 16-row query fragments per wave.  (NW=4,QF=2) and (NW=8,QF=1) cover the same 128 query rows per
+// block with the same LDS; the latter halves the per-wave register state (4 instead of 2 waves per SIMD -> the exp-bound
+// softmax of one wave overlaps the MFMAs of three others) at the price of twice the K/V fragment reads per FLOP.
+template <int D, int QF, int NW, bool DBUF, bool HAS_BIAS, bool HAS_MASK>
+__global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void attn_kernel(const AttnArgs p) {
+    constexpr int NT = 64 * NW;
     constexpr int DQK = (D + 31) / 32 * 32;
     constexpr int DV = (D + 15) / 16 * 16;
     constexpr int NC = DQK / 32;   // QK^T MFMAs per (key frag, q frag)
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(NT, (D <= 96 ? 2 : 1)) void attn_kernel(const AttnA
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
-    constexpr int QB = 4 * 16 * QF;  // query rows per block
+    constexpr int QB = NW * 16 * QF;  // query rows per block
     const int nqb = (p.Nq + QB - 1) / QB;
     const int vb = xcd_remap(blockIdx.x, nqb * p.B * p.H);
     const int bh = vb / nqb, qb = vb % nqb;
@@ -330,15 +333,16 @@ __global__ __launch_bounds__(NT, (D <= 96 ? 2 : 1)) void attn_kernel(const AttnA
     }
 }
 
-template <int D, int QF, bool DBUF>
+template <int D, int QF, bool DBUF, int NW = 4>
 int launch_attn(const AttnArgs& a, hipStream_t stream) {
-    constexpr int QB = 4 * 16 * QF;
+    constexpr int QB = NW * 16 * QF;
+    constexpr int NT = 64 * NW;
     const long blocks = (long)((a.Nq + QB - 1) / QB) * a.B * a.H;
     dim3 grid((unsigned)blocks), block(NT);
     if (a.rel_h && a.key_mask) { ae_set_error("ae_attn_fwd_bf16: rel-pos bias together with key_mask is not supported"); return AE_ERR_UNSUPPORTED; }
-    if (a.rel_h) hipLaunchKernelGGL((attn_kernel<D, QF, DBUF, true, false>), grid, block, 0, stream, a);
-    else if (a.key_mask) hipLaunchKernelGGL((attn_kernel<D, QF, DBUF, false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((attn_kernel<D, QF, DBUF, false, false>), grid, block, 0, stream, a);
+    if (a.rel_h) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, true, false>), grid, block, 0, stream, a);
+    else if (a.key_mask) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, false, false>), grid, block, 0, stream, a);
     return ae_check_launch("ae_attn_fwd_bf16");
 }
 
@@ -371,14 +375,17 @@ extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
     a.out_scale = out_scale; a.accum = accumulate;
     hipStream_t s = (hipStream_t)stream;
     static const int qf40 = env_int("AE_ATTN_QF40", 2);  // tuning knob (A/B on hardware): query fragments per wave for D=40
+    static const int w8 = env_int("AE_ATTN_W8", 0);      // tuning knob: 8 waves x 1 query fragment instead of 4 x 2
     switch (D) {
         case 8: return launch_attn<8, 2, true>(a, s);
         case 16: return launch_attn<16, 2, true>(a, s);
         case 32: return launch_attn<32, 2, true>(a, s);
-        case 40: return (qf40 == 2 || Nq <= 1024) ? launch_attn<40, 2, true>(a, s) : launch_attn<40, 4, true>(a, s);
+        case 40:
+            if (w8) return launch_attn<40, 1, true, 8>(a, s);
+            return (qf40 == 2 || Nq <= 1024) ? launch_attn<40, 2, true>(a, s) : launch_attn<40, 4, true>(a, s);
         case 48: return launch_attn<48, 2, true>(a, s);
         case 64: return launch_attn<64, 2, true>(a, s);
-        case 80: return launch_attn<80, 2, true>(a, s);
+        case 80: return w8 ? launch_attn<80, 1, true, 8>(a, s) : launch_attn<80, 2, true>(a, s);
         case 96: return launch_attn<96, 2, true>(a, s);
         case 128: return launch_attn<128, 2, false>(a, s);
         case 160: return launch_attn<160, 2, false>(a, s);
