@@ -32,7 +32,8 @@ SIGNATURES = {
     "ae_layernorm_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "ae_attn_fwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                          c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long,
-                         c_float, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
+                         c_float, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
+                         c_void_p, c_void_p, c_int, c_long, c_long, c_long, c_long, c_long, c_long, c_void_p, c_void_p],
     "ae_transpose_last2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ae_concat_channels_bf16": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_void_p],
     "ae_timestep_embedding": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],

@@ -39,6 +39,11 @@ struct AttnArgs {
     const uint8_t* key_mask;                               // optional [B, Nk], 0 = masked
     const float* out_scale;                                // optional [B]: out = (accum ? out : 0) + out_scale[b] * result
     int accum;
+    // optional second key/value segment with its OWN softmax (decoupled adapter attention fused into the same launch):
+    // out = Attn(q,K,V) + scale2[b] * Attn(q,K2,V2)   — Q is read once, O is written once
+    const bf16_t* k2; const bf16_t* v2; int Nk2;
+    long k2_sb, k2_sh, k2_sn, v2_sb, v2_sh, v2_sn;
+    const float* scale2;
 };
 
 __device__ __forceinline__ int vt_pos(int key) {  // key = 16 f + 4 g + r  ->  16 g + 4 f + r
@@ -48,7 +53,7 @@ __device__ __forceinline__ int vt_pos(int key) {  // key = 16 f + 4 g + r  ->  1
 // NW waves per block, QF 16-row query fragments per wave.  (NW=4,QF=2) and (NW=8,QF=1) cover the same 128 query rows per
 // block with the same LDS; the latter halves the per-wave register state (4 instead of 2 waves per SIMD -> the exp-bound
 // softmax of one wave overlaps the MFMAs of three others) at the price of twice the K/V fragment reads per FLOP.
-template <int D, int QF, int NW, bool DBUF, bool HAS_BIAS, bool HAS_MASK>
+template <int D, int QF, int NW, bool DBUF, bool HAS_BIAS, bool HAS_MASK, bool SEG2 = false>
 __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void attn_kernel(const AttnArgs p) {
     constexpr int NT = 64 * NW;
     constexpr int DQK = (D + 31) / 32 * 32;
@@ -116,193 +121,218 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
         for (int df = 0; df < NDF; ++df) o[a][df] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    // ---- staging: per-thread (row, chunk) assignments are loop invariant
-    int k_key[KCH], k_c[KCH], v_pr[VCH], v_c[VCH];
-#pragma unroll
-    for (int i = 0; i < KCH; ++i) {
-        const int id = min(tid + i * NT, KT * DCH - 1);
-        k_key[i] = id / DCH;
-        k_c[i] = id - k_key[i] * DCH;
-    }
-#pragma unroll
-    for (int i = 0; i < VCH; ++i) {
-        const int id = min(tid + i * NT, (KT / 2) * DCH - 1);
-        v_pr[i] = id / DCH;
-        v_c[i] = id - v_pr[i] * DCH;
-    }
-    u32x4 rk[KCH], rv[VCH][2];
-    const int last_key = p.Nk - 1;
-    // Bounds-checked buffer loads, 32-bit byte offsets: one add per load in the loop; keys >= Nk fall past the descriptor's
-    // extent and read as 0 in hardware (their P is forced to 0 anyway).  Extent = this (batch, head)'s rows [0, Nk).
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kp), 0, (int)(((long)last_key * p.k_sn + D) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vp), 0, (int)(((long)last_key * p.v_sn + D) * 2), 0x00020000);
-    int k_off[KCH], v_off[VCH];
-#pragma unroll
-    for (int i = 0; i < KCH; ++i) k_off[i] = (int)((long)k_key[i] * p.k_sn + k_c[i] * 8) * 2;
-#pragma unroll
-    for (int i = 0; i < VCH; ++i) v_off[i] = (int)((long)(2 * v_pr[i]) * p.v_sn + v_c[i] * 8) * 2;
-    const int k_tile_bytes = (int)(KT * p.k_sn * 2), v_tile_bytes = (int)(KT * p.v_sn * 2), v_row_bytes = (int)(p.v_sn * 2);
-    auto load_kv = [&](int k0) {
-        const int tk = (k0 / KT) * k_tile_bytes, tv = (k0 / KT) * v_tile_bytes;  // wave-uniform
-#pragma unroll
-        for (int i = 0; i < KCH; ++i) rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, k_off[i] + tk, 0, 0);
-#pragma unroll
-        for (int i = 0; i < VCH; ++i) {
-            rv[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsV, v_off[i] + tv, 0, 0);
-            rv[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsV, v_off[i] + tv + v_row_bytes, 0, 0);
-        }
-    };
-    auto store_kv = [&](int buf) {
-        bf16_t* dK = sK + buf * KSZ;
-        bf16_t* dV = sVt + buf * VSZ;
-#pragma unroll
+    f32x4 o_first[SEG2 ? QF : 1][SEG2 ? NDF : 1];  // normalised result of segment 0 while segment 1 runs
+    constexpr int nseg = SEG2 ? 2 : 1;
+    for (int seg_i = 0; seg_i < nseg; ++seg_i) {
+        const bf16_t* seg_kp = seg_i == 0 ? kp : p.k2 + (long)b * p.k2_sb + (long)h * p.k2_sh;
+        const bf16_t* seg_vp = seg_i == 0 ? vp : p.v2 + (long)b * p.v2_sb + (long)h * p.v2_sh;
+        const int seg_Nk = seg_i == 0 ? p.Nk : p.Nk2;
+        const long seg_ksn = seg_i == 0 ? p.k_sn : p.k2_sn, seg_vsn = seg_i == 0 ? p.v_sn : p.v2_sn;
+        // ---- staging: per-thread (row, chunk) assignments are loop invariant
+        int k_key[KCH], k_c[KCH], v_pr[VCH], v_c[VCH];
+    #pragma unroll
         for (int i = 0; i < KCH; ++i) {
-            if (KT * DCH % NT == 0 || tid + i * NT < KT * DCH)
-                *reinterpret_cast<u32x4*>(dK + k_key[i] * KROW + k_c[i] * 8) = rk[i];
+            const int id = min(tid + i * NT, KT * DCH - 1);
+            k_key[i] = id / DCH;
+            k_c[i] = id - k_key[i] * DCH;
         }
-#pragma unroll
+    #pragma unroll
         for (int i = 0; i < VCH; ++i) {
-            if ((KT / 2) * DCH % NT == 0 || tid + i * NT < (KT / 2) * DCH) {
-                const int pos = vt_pos(2 * v_pr[i]);  // even; key 2pr+1 lands at pos+1
-                const uint32_t a0[4] = {rv[i][0].x, rv[i][0].y, rv[i][0].z, rv[i][0].w};
-                const uint32_t a1[4] = {rv[i][1].x, rv[i][1].y, rv[i][1].z, rv[i][1].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    // d = c*8 + 2e (low halves) and c*8 + 2e + 1 (high halves)
-                    const uint32_t lo = __builtin_amdgcn_perm(a1[e], a0[e], 0x05040100u);  // {a0.lo16, a1.lo16}: one v_perm_b32
-                    const uint32_t hi = __builtin_amdgcn_perm(a1[e], a0[e], 0x07060302u);  // {a0.hi16, a1.hi16}
-                    *reinterpret_cast<uint32_t*>(dV + (v_c[i] * 8 + 2 * e) * VROW + pos) = lo;
-                    *reinterpret_cast<uint32_t*>(dV + (v_c[i] * 8 + 2 * e + 1) * VROW + pos) = hi;
-                }
-            }
+            const int id = min(tid + i * NT, (KT / 2) * DCH - 1);
+            v_pr[i] = id / DCH;
+            v_c[i] = id - v_pr[i] * DCH;
         }
-    };
-
-    const float c2 = p.scale * LOG2E;
-    const int ntiles = (p.Nk + KT - 1) / KT;
-    load_kv(0);
-    __syncthreads();  // pad zero-fill ordered before the first tile write
-    store_kv(0);
-    __syncthreads();
-
-    // One K/V tile: S^T = K Q^T, online softmax, O^T += V^T P^T.  TAIL = the (only) tile that contains padding keys.
-    auto tile_body = [&](int k0, int cur, auto tail_tag) {
-        constexpr bool TAIL = decltype(tail_tag)::value;
-        const bf16_t* cK = sK + cur * KSZ;
-        const bf16_t* cV = sVt + cur * VSZ;
-
-        // ---- S^T = K Q^T : lane holds S^T[key = 16f + 4g + r][q = l15] --------------------------
-        f32x4 s[QF][4];
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-#pragma unroll
-            for (int a = 0; a < QF; ++a) s[a][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const bf16x8_t kf = as_bf16x8(*reinterpret_cast<const u32x4*>(cK + (f * 16 + l15) * KROW + c * 32 + lg * 8));
-#pragma unroll
-                for (int a = 0; a < QF; ++a) s[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[a][c], s[a][f], 0, 0, 0);
+        u32x4 rk[KCH], rv[VCH][2];
+        const int last_key = seg_Nk - 1;
+        // Bounds-checked buffer loads, 32-bit byte offsets: one add per load in the loop; keys >= Nk fall past the descriptor's
+        // extent and read as 0 in hardware (their P is forced to 0 anyway).  Extent = this (batch, head)'s rows [0, Nk).
+        const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(seg_kp), 0, (int)(((long)last_key * seg_ksn + D) * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(seg_vp), 0, (int)(((long)last_key * seg_vsn + D) * 2), 0x00020000);
+        int k_off[KCH], v_off[VCH];
+    #pragma unroll
+        for (int i = 0; i < KCH; ++i) k_off[i] = (int)((long)k_key[i] * seg_ksn + k_c[i] * 8) * 2;
+    #pragma unroll
+        for (int i = 0; i < VCH; ++i) v_off[i] = (int)((long)(2 * v_pr[i]) * seg_vsn + v_c[i] * 8) * 2;
+        const int k_tile_bytes = (int)(KT * seg_ksn * 2), v_tile_bytes = (int)(KT * seg_vsn * 2), v_row_bytes = (int)(seg_vsn * 2);
+        auto load_kv = [&](int k0) {
+            const int tk = (k0 / KT) * k_tile_bytes, tv = (k0 / KT) * v_tile_bytes;  // wave-uniform
+    #pragma unroll
+            for (int i = 0; i < KCH; ++i) rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, k_off[i] + tk, 0, 0);
+    #pragma unroll
+            for (int i = 0; i < VCH; ++i) {
+                rv[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsV, v_off[i] + tv, 0, 0);
+                rv[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsV, v_off[i] + tv + v_row_bytes, 0, 0);
             }
-        }
-
-        // ---- online softmax (fp32, exp2 domain).  Fast path (no bias / mask / padding): logits stay raw, the scale is
-        // folded into one fma per element, and O / l are rescaled only when some row's running max actually moves (exact:
-        // otherwise the factor is 1) — a wave-uniform branch that is almost never taken after the first tiles.
-        bf16x8_t pb[QF][2];
-#pragma unroll
-        for (int a = 0; a < QF; ++a) {
-            constexpr bool PLAIN = !HAS_BIAS && !HAS_MASK && !TAIL;
-            if (!PLAIN) {
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    const int kb = k0 + f * 16 + lg * 4;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = s[a][f][r] * c2;
-                        if (HAS_BIAS) {
-                            const int qc = min(q0 + a * 16 + l15, p.Nq - 1);
-                            const int key = min(kb + r, last_key);
-                            const int khh = key / p.kW;
-                            v += (p.rel_h[((long)bh * p.Nq + qc) * p.kH + khh] + p.rel_w[((long)bh * p.Nq + qc) * p.kW + (key - khh * p.kW)]) * LOG2E;
-                        }
-                        if (HAS_MASK) {
-                            if (p.key_mask[(long)b * p.Nk + min(kb + r, last_key)] == 0) v = NEG_BIG;
-                        }
-                        if (TAIL) {
-                            if (kb + r >= p.Nk) v = NEG_BIG;
-                        }
-                        s[a][f][r] = v;
+        };
+        auto store_kv = [&](int buf) {
+            bf16_t* dK = sK + buf * KSZ;
+            bf16_t* dV = sVt + buf * VSZ;
+    #pragma unroll
+            for (int i = 0; i < KCH; ++i) {
+                if (KT * DCH % NT == 0 || tid + i * NT < KT * DCH)
+                    *reinterpret_cast<u32x4*>(dK + k_key[i] * KROW + k_c[i] * 8) = rk[i];
+            }
+    #pragma unroll
+            for (int i = 0; i < VCH; ++i) {
+                if ((KT / 2) * DCH % NT == 0 || tid + i * NT < (KT / 2) * DCH) {
+                    const int pos = vt_pos(2 * v_pr[i]);  // even; key 2pr+1 lands at pos+1
+                    const uint32_t a0[4] = {rv[i][0].x, rv[i][0].y, rv[i][0].z, rv[i][0].w};
+                    const uint32_t a1[4] = {rv[i][1].x, rv[i][1].y, rv[i][1].z, rv[i][1].w};
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // d = c*8 + 2e (low halves) and c*8 + 2e + 1 (high halves)
+                        const uint32_t lo = __builtin_amdgcn_perm(a1[e], a0[e], 0x05040100u);  // {a0.lo16, a1.lo16}: one v_perm_b32
+                        const uint32_t hi = __builtin_amdgcn_perm(a1[e], a0[e], 0x07060302u);  // {a0.hi16, a1.hi16}
+                        *reinterpret_cast<uint32_t*>(dV + (v_c[i] * 8 + 2 * e) * VROW + pos) = lo;
+                        *reinterpret_cast<uint32_t*>(dV + (v_c[i] * 8 + 2 * e + 1) * VROW + pos) = hi;
                     }
                 }
             }
-            float mx = NEG_BIG;
+        };
+
+        const float c2 = p.scale * LOG2E;
+        const int ntiles = (seg_Nk + KT - 1) / KT;
+        load_kv(0);
+        __syncthreads();  // pad zero-fill ordered before the first tile write
+        store_kv(0);
+        __syncthreads();
+
+        // One K/V tile: S^T = K Q^T, online softmax, O^T += V^T P^T.  TAIL = the (only) tile that contains padding keys.
+        auto tile_body = [&](int k0, int cur, auto tail_tag) {
+            constexpr bool TAIL = decltype(tail_tag)::value;
+            const bf16_t* cK = sK + cur * KSZ;
+            const bf16_t* cV = sVt + cur * VSZ;
+
+            // ---- S^T = K Q^T : lane holds S^T[key = 16f + 4g + r][q = l15] --------------------------
+            f32x4 s[QF][4];
+    #pragma unroll
+            for (int f = 0; f < 4; ++f) {
+    #pragma unroll
+                for (int a = 0; a < QF; ++a) s[a][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const bf16x8_t kf = as_bf16x8(*reinterpret_cast<const u32x4*>(cK + (f * 16 + l15) * KROW + c * 32 + lg * 8));
+    #pragma unroll
+                    for (int a = 0; a < QF; ++a) s[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[a][c], s[a][f], 0, 0, 0);
+                }
+            }
+
+            // ---- online softmax (fp32, exp2 domain).  Fast path (no bias / mask / padding): logits stay raw, the scale is
+            // folded into one fma per element, and O / l are rescaled only when some row's running max actually moves (exact:
+            // otherwise the factor is 1) — a wave-uniform branch that is almost never taken after the first tiles.
+            bf16x8_t pb[QF][2];
+    #pragma unroll
+            for (int a = 0; a < QF; ++a) {
+                constexpr bool PLAIN = !HAS_BIAS && !HAS_MASK && !TAIL;
+                if (!PLAIN) {
+    #pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        const int kb = k0 + f * 16 + lg * 4;
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = s[a][f][r] * c2;
+                            if (HAS_BIAS) {
+                                const int qc = min(q0 + a * 16 + l15, p.Nq - 1);
+                                const int key = min(kb + r, last_key);
+                                const int khh = key / p.kW;
+                                v += (p.rel_h[((long)bh * p.Nq + qc) * p.kH + khh] + p.rel_w[((long)bh * p.Nq + qc) * p.kW + (key - khh * p.kW)]) * LOG2E;
+                            }
+                            if (HAS_MASK) {
+                                if (p.key_mask[(long)b * seg_Nk + min(kb + r, last_key)] == 0) v = NEG_BIG;
+                            }
+                            if (TAIL) {
+                                if (kb + r >= seg_Nk) v = NEG_BIG;
+                            }
+                            s[a][f][r] = v;
+                        }
+                    }
+                }
+                float mx = NEG_BIG;
+    #pragma unroll
+                for (int f = 0; f < 4; ++f) mx = fmaxf(mx, fmaxf(fmaxf(s[a][f][0], s[a][f][1]), fmaxf(s[a][f][2], s[a][f][3])));
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                if (PLAIN) mx *= c2;  // scale > 0
+                if (__any(mx > m_run[a])) {
+                    const float m_new = fmaxf(m_run[a], mx);
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[a] - m_new);
+                    m_run[a] = m_new;
+                    l_run[a] *= alpha;
+    #pragma unroll
+                    for (int df = 0; df < NDF; ++df) {
+                        o[a][df][0] *= alpha; o[a][df][1] *= alpha; o[a][df][2] *= alpha; o[a][df][3] *= alpha;
+                    }
+                }
+                const float neg_m = -m_run[a];
+    #pragma unroll
+                for (int f = 0; f < 4; ++f)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float e = PLAIN ? __builtin_amdgcn_exp2f(fmaf(s[a][f][r], c2, neg_m)) : __builtin_amdgcn_exp2f(s[a][f][r] + neg_m);
+                        if (TAIL) {  // padding keys never contribute (also when a whole row is masked -> uniform over REAL keys)
+                            if (k0 + f * 16 + lg * 4 + r >= seg_Nk) e = 0.f;
+                        }
+                        s[a][f][r] = e;
+                    }
+                float rs = 0.f;
+    #pragma unroll
+                for (int f = 0; f < 4; ++f) rs += (s[a][f][0] + s[a][f][1]) + (s[a][f][2] + s[a][f][3]);
+                l_run[a] += rs;
+    #pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    u32x4 w;
+                    w.x = pack_bf16x2(s[a][2 * j][0], s[a][2 * j][1]);
+                    w.y = pack_bf16x2(s[a][2 * j][2], s[a][2 * j][3]);
+                    w.z = pack_bf16x2(s[a][2 * j + 1][0], s[a][2 * j + 1][1]);
+                    w.w = pack_bf16x2(s[a][2 * j + 1][2], s[a][2 * j + 1][3]);
+                    pb[a][j] = as_bf16x8(w);
+                }
+            }
+
+            // ---- O^T += V^T P^T : lane holds O^T[d = 16 df + 4g + r][q = l15] -------------------------
+    #pragma unroll
+            for (int df = 0; df < NDF; ++df) {
+    #pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8_t vf = as_bf16x8(*reinterpret_cast<const u32x4*>(cV + (df * 16 + l15) * VROW + lg * 16 + j * 8));
+    #pragma unroll
+                    for (int a = 0; a < QF; ++a) o[a][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[a][j], o[a][df], 0, 0, 0);
+                }
+            }
+        };
+
+        for (int t = 0; t < ntiles; ++t) {
+            const int k0 = t * KT;
+            const int cur = DBUF ? (t & 1) : 0;
+            if (t + 1 < ntiles) load_kv(k0 + KT);
+            if (k0 + KT > seg_Nk) tile_body(k0, cur, std::true_type{});
+            else tile_body(k0, cur, std::false_type{});
+            if (DBUF) {
+                if (t + 1 < ntiles) store_kv(cur ^ 1);
+                __syncthreads();
+            } else {
+                __syncthreads();  // every wave is done reading this tile
+                if (t + 1 < ntiles) {
+                    store_kv(0);
+                    __syncthreads();
+                }
+            }
+        }
+
+        if (SEG2 && seg_i == 0) {  // park segment 0's normalised output, restart the online softmax
 #pragma unroll
-            for (int f = 0; f < 4; ++f) mx = fmaxf(mx, fmaxf(fmaxf(s[a][f][0], s[a][f][1]), fmaxf(s[a][f][2], s[a][f][3])));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            if (PLAIN) mx *= c2;  // scale > 0
-            if (__any(mx > m_run[a])) {
-                const float m_new = fmaxf(m_run[a], mx);
-                const float alpha = __builtin_amdgcn_exp2f(m_run[a] - m_new);
-                m_run[a] = m_new;
-                l_run[a] *= alpha;
+            for (int a = 0; a < QF; ++a) {
+                float l = l_run[a];
+                l += __shfl_xor(l, 16, 64);
+                l += __shfl_xor(l, 32, 64);
+                const float inv = 1.0f / l;
 #pragma unroll
                 for (int df = 0; df < NDF; ++df) {
-                    o[a][df][0] *= alpha; o[a][df][1] *= alpha; o[a][df][2] *= alpha; o[a][df][3] *= alpha;
+                    o_first[SEG2 ? a : 0][SEG2 ? df : 0] = (f32x4){o[a][df][0] * inv, o[a][df][1] * inv, o[a][df][2] * inv, o[a][df][3] * inv};
+                    o[a][df] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-            }
-            const float neg_m = -m_run[a];
-#pragma unroll
-            for (int f = 0; f < 4; ++f)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float e = PLAIN ? __builtin_amdgcn_exp2f(fmaf(s[a][f][r], c2, neg_m)) : __builtin_amdgcn_exp2f(s[a][f][r] + neg_m);
-                    if (TAIL) {  // padding keys never contribute (also when a whole row is masked -> uniform over REAL keys)
-                        if (k0 + f * 16 + lg * 4 + r >= p.Nk) e = 0.f;
-                    }
-                    s[a][f][r] = e;
-                }
-            float rs = 0.f;
-#pragma unroll
-            for (int f = 0; f < 4; ++f) rs += (s[a][f][0] + s[a][f][1]) + (s[a][f][2] + s[a][f][3]);
-            l_run[a] += rs;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                u32x4 w;
-                w.x = pack_bf16x2(s[a][2 * j][0], s[a][2 * j][1]);
-                w.y = pack_bf16x2(s[a][2 * j][2], s[a][2 * j][3]);
-                w.z = pack_bf16x2(s[a][2 * j + 1][0], s[a][2 * j + 1][1]);
-                w.w = pack_bf16x2(s[a][2 * j + 1][2], s[a][2 * j + 1][3]);
-                pb[a][j] = as_bf16x8(w);
-            }
-        }
-
-        // ---- O^T += V^T P^T : lane holds O^T[d = 16 df + 4g + r][q = l15] -------------------------
-#pragma unroll
-        for (int df = 0; df < NDF; ++df) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bf16x8_t vf = as_bf16x8(*reinterpret_cast<const u32x4*>(cV + (df * 16 + l15) * VROW + lg * 16 + j * 8));
-#pragma unroll
-                for (int a = 0; a < QF; ++a) o[a][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[a][j], o[a][df], 0, 0, 0);
-            }
-        }
-    };
-
-    for (int t = 0; t < ntiles; ++t) {
-        const int k0 = t * KT;
-        const int cur = DBUF ? (t & 1) : 0;
-        if (t + 1 < ntiles) load_kv(k0 + KT);
-        if (k0 + KT > p.Nk) tile_body(k0, cur, std::true_type{});
-        else tile_body(k0, cur, std::false_type{});
-        if (DBUF) {
-            if (t + 1 < ntiles) store_kv(cur ^ 1);
-            __syncthreads();
-        } else {
-            __syncthreads();  // every wave is done reading this tile
-            if (t + 1 < ntiles) {
-                store_kv(0);
-                __syncthreads();
+                m_run[a] = NEG_BIG;
+                l_run[a] = 0.f;
             }
         }
     }
@@ -314,7 +344,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
         float l = l_run[a];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
-        const float inv = (p.out_scale ? p.out_scale[b] : 1.0f) / l;
+        const float inv = (SEG2 ? p.scale2[b] : (p.out_scale ? p.out_scale[b] : 1.0f)) / l;
         const int qrow = q0 + a * 16 + l15;
         if (qrow >= p.Nq) continue;
 #pragma unroll
@@ -322,6 +352,10 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
             const int d = df * 16 + lg * 4;
             if (d < D) {
                 float r0 = o[a][df][0] * inv, r1 = o[a][df][1] * inv, r2 = o[a][df][2] * inv, r3 = o[a][df][3] * inv;
+                if (SEG2) {
+                    const f32x4 f0 = o_first[SEG2 ? a : 0][SEG2 ? df : 0];
+                    r0 += f0[0]; r1 += f0[1]; r2 += f0[2]; r3 += f0[3];
+                }
                 u32x2* dst = reinterpret_cast<u32x2*>(op + (long)qrow * p.o_sn + d);
                 if (p.accum) {  // decoupled adapter attention: out += gate * Attn(q, K_ip, V_ip)
                     const u32x2 prev = *dst;
@@ -340,7 +374,9 @@ int launch_attn(const AttnArgs& a, hipStream_t stream) {
     const long blocks = (long)((a.Nq + QB - 1) / QB) * a.B * a.H;
     dim3 grid((unsigned)blocks), block(NT);
     if (a.rel_h && a.key_mask) { ae_set_error("ae_attn_fwd_bf16: rel-pos bias together with key_mask is not supported"); return AE_ERR_UNSUPPORTED; }
-    if (a.rel_h) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, true, false>), grid, block, 0, stream, a);
+    if (a.k2) {
+        if constexpr (D <= 96) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, false, false, true>), grid, block, 0, stream, a);
+    } else if (a.rel_h) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, true, false>), grid, block, 0, stream, a);
     else if (a.key_mask) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, false, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, false, false>), grid, block, 0, stream, a);
     return ae_check_launch("ae_attn_fwd_bf16");
@@ -357,7 +393,8 @@ extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
                                 long q_sb, long q_sh, long q_sn, long k_sb, long k_sh, long k_sn,
                                 long v_sb, long v_sh, long v_sn, long o_sb, long o_sh, long o_sn, float scale,
                                 const float* rel_h, const float* rel_w, int kH, int kW, const unsigned char* key_mask,
-                                const float* out_scale, int accumulate, void* stream) {
+                                const float* out_scale, int accumulate, const void* k2, const void* v2, int Nk2, long k2_sb,
+                                long k2_sh, long k2_sn, long v2_sb, long v2_sh, long v2_sn, const float* scale2, void* stream) {
     AE_REQUIRE(q && k && v && out, "ae_attn_fwd_bf16: null pointer");
     AE_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0, "ae_attn_fwd_bf16: bad sizes B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
     AE_REQUIRE((q_sb | q_sh | q_sn | k_sb | k_sh | k_sn | v_sb | v_sh | v_sn) % 8 == 0 && (o_sb | o_sh | o_sn) % 4 == 0,
@@ -373,6 +410,14 @@ extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
     a.v_sb = v_sb; a.v_sh = v_sh; a.v_sn = v_sn; a.o_sb = o_sb; a.o_sh = o_sh; a.o_sn = o_sn;
     a.scale = scale; a.rel_h = rel_h; a.rel_w = rel_w; a.kH = kH; a.kW = kW; a.key_mask = key_mask;
     a.out_scale = out_scale; a.accum = accumulate;
+    if (k2) {
+        AE_REQUIRE(v2 && scale2 && Nk2 > 0 && D <= 96, "ae_attn_fwd_bf16: second segment needs v2, scale2, Nk2 > 0 and head_dim <= 96");
+        AE_REQUIRE(!rel_h && !key_mask && !accumulate && !out_scale, "ae_attn_fwd_bf16: second segment excludes bias / mask / accumulate / out_scale");
+        AE_REQUIRE((k2_sb | k2_sh | k2_sn | v2_sb | v2_sh | v2_sn) % 8 == 0 && ((uintptr_t)k2 & 15) == 0 && ((uintptr_t)v2 & 15) == 0,
+                   "ae_attn_fwd_bf16: second segment alignment");
+    }
+    a.k2 = (const bf16_t*)k2; a.v2 = (const bf16_t*)v2; a.Nk2 = Nk2; a.k2_sb = k2_sb; a.k2_sh = k2_sh; a.k2_sn = k2_sn;
+    a.v2_sb = v2_sb; a.v2_sh = v2_sh; a.v2_sn = v2_sn; a.scale2 = scale2;
     hipStream_t s = (hipStream_t)stream;
     static const int qf40 = env_int("AE_ATTN_QF40", 2);  // tuning knob (A/B on hardware): query fragments per wave for D=40
     static const int w8 = env_int("AE_ATTN_W8", 0);      // tuning knob: 8 waves x 1 query fragment instead of 4 x 2

@@ -141,13 +141,22 @@ class CrossAttention(nn.Module):
             Nk = kv.shape[0] // B
             qs = (N * inner, d, inner)
             ks = (Nk * 2 * inner, d, 2 * inner)
-            o = ops.attention(q, kv, kv[:, inner:], B, h, N, Nk, d, self.scale, qs, ks, ks, key_mask=key_mask)
-            if adapter is not None:
+            if adapter is not None and d <= 96 and key_mask is None:
+                # both softmaxes in ONE launch: Q read once, O written once (the 4-token expert segment used to cost as much
+                # as the 77-token text segment because it re-read Q and read-modify-wrote O)
                 kv_ip, gate = adapter
                 T_ip = kv_ip.shape[0] // B
                 ks_ip = (T_ip * 2 * inner, d, 2 * inner)
-                ops.attention(q, kv_ip, kv_ip[:, inner:], B, h, N, T_ip, d, self.scale, qs, ks_ip, ks_ip, out=o,
-                              out_scale=gate, accumulate=True)
+                seg2 = (kv_ip.data_ptr(), kv_ip[:, inner:].data_ptr(), T_ip, *ks_ip, *ks_ip, gate.data_ptr())
+                o = ops.attention(q, kv, kv[:, inner:], B, h, N, Nk, d, self.scale, qs, ks, ks, seg2=seg2)
+            else:
+                o = ops.attention(q, kv, kv[:, inner:], B, h, N, Nk, d, self.scale, qs, ks, ks, key_mask=key_mask)
+                if adapter is not None:
+                    kv_ip, gate = adapter
+                    T_ip = kv_ip.shape[0] // B
+                    ks_ip = (T_ip * 2 * inner, d, 2 * inner)
+                    ops.attention(q, kv_ip, kv_ip[:, inner:], B, h, N, T_ip, d, self.scale, qs, ks_ip, ks_ip, out=o,
+                                  out_scale=gate, accumulate=True)
         return self.to_out[0].rows(o.reshape(B * N, inner), residual=residual)
 
     def forward(self, x, context=None, mask=None):

@@ -144,14 +144,14 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
 
 # --------------------------------------------------------------------------- attention
 def attention(q, k, v, B, H, Nq, Nk, D, scale, q_strides, k_strides, v_strides, out=None, rel_h=None, rel_w=None,
-              kH=0, kW=0, key_mask=None, out_scale=None, accumulate=False):
+              kH=0, kW=0, key_mask=None, out_scale=None, accumulate=False, seg2=None):
     """q/k/v: bf16 tensors (any shape) addressed via (batch, head, row) element strides; out: [B, Nq, H*D] bf16."""
     if out is None:
         out = torch.empty(B, Nq, H * D, dtype=BF16, device=q.device)
     o_strides = (Nq * H * D, D, H * D)
     check(lib.ae_attn_fwd_bf16(_p(q), _p(k), _p(v), _p(out), B, H, Nq, Nk, D, *q_strides, *k_strides, *v_strides, *o_strides,
-                               scale, _p(rel_h), _p(rel_w), kH, kW, _p(key_mask), _p(out_scale), 1 if accumulate else 0, _s()),
-          "ae_attn_fwd_bf16")
+                               scale, _p(rel_h), _p(rel_w), kH, kW, _p(key_mask), _p(out_scale), 1 if accumulate else 0,
+                               *(seg2 if seg2 is not None else (None, None, 0, 0, 0, 0, 0, 0, 0, None)), _s()), "ae_attn_fwd_bf16")
     return out
 
 
@@ -164,7 +164,8 @@ def attention_bhnd(q, k, v, scale=None, key_mask=None):
     out = torch.empty(BH, Nq, D, dtype=BF16, device=q.device)
     scale = scale if scale is not None else D ** -0.5
     check(lib.ae_attn_fwd_bf16(_p(q), _p(k), _p(v), _p(out), BH, 1, Nq, Nk, D, Nq * D, 0, D, Nk * D, 0, D, Nk * D, 0, D,
-                               Nq * D, 0, D, scale, None, None, 0, 0, _p(key_mask), None, 0, _s()), "ae_attn_fwd_bf16")
+                               Nq * D, 0, D, scale, None, None, 0, 0, _p(key_mask), None, 0, None, None, 0, 0, 0, 0, 0, 0, 0, None, _s()),
+          "ae_attn_fwd_bf16")
     return out
 
 

@@ -73,11 +73,15 @@ int ae_layernorm_bf16(const void* x, const float* gamma, const float* beta, void
  * (batch, head, row); head_dim D in {8,16,32,40,48,64,80,96,128,160}.  rel_h/rel_w: optional fp32 [B*H,Nq,kH] / [B*H,Nq,kW]
  * decomposed relative-position bias (image_encoder.py:325-361), Nk == kH*kW.  key_mask: optional uint8 [B,Nk], 0 = masked
  * (attention.py:183-187).  out_scale: optional fp32 [B]; accumulate != 0: out += out_scale[b] * result (decoupled adapter
- * attention, ip_adapter/attention_processor.py:141-173 — the shape template of AnySD's expert K/V).           */
+ * attention, ip_adapter/attention_processor.py:141-173 — the shape template of AnySD's expert K/V, SURVEY.md A9).
+ * k2/v2 (optional, head_dim <= 96): a second key/value segment with its own softmax fused into the same launch:
+ * out = Attn(q,k,v) + scale2[b] * Attn(q,k2,v2).                                                                           */
 int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int D,
                      long q_sb, long q_sh, long q_sn, long k_sb, long k_sh, long k_sn, long v_sb, long v_sh, long v_sn,
                      long o_sb, long o_sh, long o_sn, float scale, const float* rel_h, const float* rel_w, int kH, int kW,
-                     const unsigned char* key_mask, const float* out_scale, int accumulate, void* stream);
+                     const unsigned char* key_mask, const float* out_scale, int accumulate, const void* k2, const void* v2,
+                     int Nk2, long k2_sb, long k2_sh, long k2_sn, long v2_sb, long v2_sh, long v2_sn, const float* scale2,
+                     void* stream);
 
 /* out[b,y,x] = in[b,x,y], inner dim zero-padded to Xpad: NCHW <-> channels-last at the UNet boundary
  * ('b c h w -> b (h w) c', attention.py:329,337).                                                                           */
