@@ -81,44 +81,41 @@ __global__ void gn_stats_kernel(const GNArgs p) {
     }
 }
 
-// (2) finalize: one block per batch element folds the partials (fixed order -> deterministic) into per-channel
-// scale = gamma * rstd, shift = beta - mean * scale.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const GNArgs p) {
-    __shared__ float red[2][8][64];
+// (2) finalize: one 1024-thread block per batch element folds the partials (fixed order -> deterministic) into per-channel
+// scale = gamma * rstd, shift = beta - mean * scale.  16 slices x 64 group lanes so the partial loads run in parallel.
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const GNArgs p) {
+    __shared__ float red[2][16][64];
     __shared__ float mean[64], rstd[64];
     const int b = blockIdx.x;
-    const int g = threadIdx.x % 32, part = threadIdx.x / 32;  // 8 parts x 32 lanes; groups > 32 handled by the g loop
-    for (int g0 = 0; g0 < p.groups; g0 += 32) {
-        const int gg = g0 + g;
-        float a = 0.f, c = 0.f;
-        if (gg < p.groups) {
-            for (int i = part; i < p.nchunk; i += 8) {
-                const float* src = p.part + (((long)b * p.nchunk + i) * p.groups + gg) * 2;
-                a += src[0];
-                c += src[1];
-            }
+    const int g = threadIdx.x & 63, part = threadIdx.x >> 6;  // 16 parts x 64 group lanes (groups <= 64)
+    float a = 0.f, c = 0.f;
+    if (g < p.groups) {
+        for (int i = part; i < p.nchunk; i += 16) {
+            const float* src = p.part + (((long)b * p.nchunk + i) * p.groups + g) * 2;
+            a += src[0];
+            c += src[1];
         }
-        red[0][part][g] = a;
-        red[1][part][g] = c;
-        __syncthreads();
-        if (part == 0 && gg < p.groups) {
-            float sa = 0.f, sc = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { sa += red[0][j][g]; sc += red[1][j][g]; }
-            const float n = (float)(p.C / p.groups) * (float)p.HW;
-            const float mu = sa / n;
-            const float var = fmaxf(sc / n - mu * mu, 0.f);
-            mean[gg] = mu;
-            rstd[gg] = rsqrtf(var + p.eps);
-        }
-        __syncthreads();
     }
+    red[0][part][g] = a;
+    red[1][part][g] = c;
+    __syncthreads();
+    if (part == 0 && g < p.groups) {
+        float sa = 0.f, sc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { sa += red[0][j][g]; sc += red[1][j][g]; }
+        const float n = (float)(p.C / p.groups) * (float)p.HW;
+        const float mu = sa / n;
+        const float var = fmaxf(sc / n - mu * mu, 0.f);
+        mean[g] = mu;
+        rstd[g] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
     const int cpg = p.C / p.groups;
-    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
-        const int gi = c / cpg;
-        const float sc = p.gamma[c] * rstd[gi];
-        p.coef[((long)b * 2 + 0) * p.C + c] = sc;
-        p.coef[((long)b * 2 + 1) * p.C + c] = p.beta[c] - mean[gi] * sc;
+    for (int ch = threadIdx.x; ch < p.C; ch += blockDim.x) {
+        const int gi = ch / cpg;
+        const float sc = p.gamma[ch] * rstd[gi];
+        p.coef[((long)b * 2 + 0) * p.C + ch] = sc;
+        p.coef[((long)b * 2 + 1) * p.C + ch] = p.beta[ch] - mean[gi] * sc;
     }
 }
 
@@ -258,7 +255,7 @@ extern "C" int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, con
     hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), (size_t)(threads / ncc) * 2 * C * sizeof(float), s, p);
     int rc = ae_check_launch("ae_groupnorm_nhwc_bf16(stats)");
     if (rc) return rc;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(1024), 0, s, p);
     rc = ae_check_launch("ae_groupnorm_nhwc_bf16(finalize)");
     if (rc) return rc;
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(threads), 0, s, p);

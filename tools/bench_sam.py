@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""SAM ViT-H image-encoder latency on MI355X (row A10; BASELINE.md §2: 5.96 TFLOP per 1024^2 image).
+    python tools/bench_sam.py [--batch 1] [--iters 5]
+Random-init weights of the build_sam_vit_h geometry (no checkpoints exist on the box), synthetic normalised image."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from anyedit_amd import ops  # noqa: E402
+from anyedit_amd.segment_anything.modeling.image_encoder import build_sam_vit_h_encoder  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--iters", type=int, default=5)
+    a = ap.parse_args()
+    dev = "cuda"
+    torch.manual_seed(0)
+    with torch.device(dev):
+        enc = build_sam_vit_h_encoder()
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if "rel_pos" in n or "pos_embed" in n:
+                p.normal_(0, 0.02)
+    enc.eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(5)
+    x = ((torch.rand(a.batch, 3, 1024, 1024, generator=g) * 255 - 120.0) / 58.0).to(dev)
+    with torch.no_grad():
+        y = enc(x)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(a.iters):
+            t0 = time.perf_counter()
+            y = enc(x)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        with ops.OpProfiler() as prof:
+            enc(x)
+        summ = prof.summary()
+    ts.sort()
+    med = ts[len(ts) // 2]
+    assert y.shape == (a.batch, 256, 64, 64) and torch.isfinite(y).all()
+    out = {"what": "SAM ViT-H image encoder, 1024x1024", "batch": a.batch, "latency_ms_p50": 1e3 * med,
+           "images_per_s": a.batch / med, "tflops": 5.96 * a.batch / med,
+           "kernels": {k: {"calls": v["calls"], "ms": v["ms"], "tflops": v["tflops"], "gbps": v["gbps"]}
+                       for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
