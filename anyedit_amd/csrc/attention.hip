@@ -56,9 +56,13 @@ __device__ __forceinline__ int vt_pos(int key) {  // key = 16 f + 4 g + r  ->  1
 template <int D, int QF, int NW, bool DBUF, bool HAS_BIAS, bool HAS_MASK, bool SEG2 = false>
 __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void attn_kernel(const AttnArgs p) {
     constexpr int NT = 64 * NW;
-    constexpr int DQK = (D + 31) / 32 * 32;
+    constexpr int NC = D / 32;                 // full K=32 MFMAs per (key frag, q frag)
+    constexpr bool TAIL16 = (D % 32) != 0;     // head-dim remainder (8 or 16) goes through ONE K=16 MFMA instead of padding to 32
+    static_assert(D % 32 == 0 || D % 32 == 8 || D % 32 == 16, "head_dim % 32 must be 0, 8 or 16");
+    constexpr int DQK = NC * 32 + (TAIL16 ? 16 : 0);
     constexpr int DV = (D + 15) / 16 * 16;
-    constexpr int NC = DQK / 32;   // QK^T MFMAs per (key frag, q frag)
+    constexpr bool ONES = DV > D;  // a free padding row of V^T holds 1.0: the PV MFMA then also produces sum_k P[q][k] (the softmax
+                                   // denominator, rescaled together with O) and the 32 VALU adds per tile disappear
     constexpr int NDF = DV / 16;   // 16-row fragments of O^T
     constexpr int DCH = D / 8;     // 16-byte chunks per K/V row
     constexpr int KROW = DQK + 8;  // LDS row strides (elements), +16 B pad
@@ -94,20 +98,23 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
     if (DV > D) {
         for (int i = tid; i < NBUF * (DV - D) * VROW; i += NT) {
             const int bufi = i / ((DV - D) * VROW), r = i % ((DV - D) * VROW);
-            sVt[bufi * VSZ + D * VROW + r] = 0;
+            sVt[bufi * VSZ + D * VROW + r] = (ONES && r < VROW) ? (bf16_t)0x3F80 : (bf16_t)0;  // row D = ones
         }
     }
 
     // ---- Q fragments (B operand of S^T = K Q^T): lane (q = l15, g) holds Q[q][32c + 8g .. +8]; rows clamped, pad zeroed
-    bf16x8_t qf[QF][NC];
+    bf16x8_t qf[QF][NC > 0 ? NC : 1];
+    s16x4_t qt[QF];  // K=16 tail operand: lane (q = l15, g) holds Q[q][32 NC + 4g .. +4]
 #pragma unroll
     for (int a = 0; a < QF; ++a) {
         const int qrow = min(q0 + a * 16 + l15, p.Nq - 1);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int d = c * 32 + lg * 8;
-            const u32x4 t = *reinterpret_cast<const u32x4*>(qp + (long)qrow * p.q_sn + (d < D ? d : 0));
-            qf[a][c] = as_bf16x8(d < D ? t : zero4);
+        for (int c = 0; c < NC; ++c)
+            qf[a][c] = as_bf16x8(*reinterpret_cast<const u32x4*>(qp + (long)qrow * p.q_sn + c * 32 + lg * 8));
+        if (TAIL16) {
+            const int d = NC * 32 + lg * 4;
+            const u32x2 t = *reinterpret_cast<const u32x2*>(qp + (long)qrow * p.q_sn + (d < D ? d : 0));
+            qt[a] = as_s16x4(d < D ? t : (u32x2){0u, 0u});
         }
     }
 
@@ -120,6 +127,18 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
 #pragma unroll
         for (int df = 0; df < NDF; ++df) o[a][df] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+
+    // softmax denominator of query fragment a, replicated over the 4 lane groups of its row
+    auto row_sum = [&](int a) -> float {
+        if (ONES) {  // O^T[d = D][q] lives in lane group (D % 16) / 4, register D % 4 of fragment D / 16
+            const float v = o[a][D / 16][D % 4];
+            return __shfl(v, l15 + 16 * ((D % 16) / 4), 64);
+        }
+        float l = l_run[a];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        return l;
+    };
 
     f32x4 o_first[SEG2 ? QF : 1][SEG2 ? NDF : 1];  // normalised result of segment 0 while segment 1 runs
     constexpr int nseg = SEG2 ? 2 : 1;
@@ -215,6 +234,11 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
     #pragma unroll
                     for (int a = 0; a < QF; ++a) s[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[a][c], s[a][f], 0, 0, 0);
                 }
+                if (TAIL16) {  // d in [32 NC, 32 NC + 16): K pad columns and Q pad lanes are zero
+                    const s16x4_t kt = as_s16x4(*reinterpret_cast<const u32x2*>(cK + (f * 16 + l15) * KROW + NC * 32 + lg * 4));
+    #pragma unroll
+                    for (int a = 0; a < QF; ++a) s[a][f] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt, qt[a], s[a][f], 0, 0, 0);
+                }
             }
 
             // ---- online softmax (fp32, exp2 domain).  Fast path (no bias / mask / padding): logits stay raw, the scale is
@@ -274,10 +298,12 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
                         }
                         s[a][f][r] = e;
                     }
+                if (!ONES) {
                 float rs = 0.f;
     #pragma unroll
                 for (int f = 0; f < 4; ++f) rs += (s[a][f][0] + s[a][f][1]) + (s[a][f][2] + s[a][f][3]);
                 l_run[a] += rs;
+                }
     #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     u32x4 w;
@@ -322,10 +348,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
         if (SEG2 && seg_i == 0) {  // park segment 0's normalised output, restart the online softmax
 #pragma unroll
             for (int a = 0; a < QF; ++a) {
-                float l = l_run[a];
-                l += __shfl_xor(l, 16, 64);
-                l += __shfl_xor(l, 32, 64);
-                const float inv = 1.0f / l;
+                const float inv = 1.0f / row_sum(a);
 #pragma unroll
                 for (int df = 0; df < NDF; ++df) {
                     o_first[SEG2 ? a : 0][SEG2 ? df : 0] = (f32x4){o[a][df][0] * inv, o[a][df][1] * inv, o[a][df][2] * inv, o[a][df][3] * inv};
@@ -341,10 +364,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
     bf16_t* op = p.o + (long)b * p.o_sb + (long)h * p.o_sh;
 #pragma unroll
     for (int a = 0; a < QF; ++a) {
-        float l = l_run[a];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const float inv = (SEG2 ? p.scale2[b] : (p.out_scale ? p.out_scale[b] : 1.0f)) / l;
+        const float inv = (SEG2 ? p.scale2[b] : (p.out_scale ? p.out_scale[b] : 1.0f)) / row_sum(a);
         const int qrow = q0 + a * 16 + l15;
         if (qrow >= p.Nq) continue;
 #pragma unroll

@@ -50,6 +50,13 @@ __device__ __forceinline__ bf16x8_t as_bf16x8(u32x4 v) {
     return c.b;
 }
 
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;  // MFMA 16x16x16 bf16 A/B operand (2 VGPRs)
+__device__ __forceinline__ s16x4_t as_s16x4(u32x2 v) {
+    union { u32x2 u; s16x4_t s; } c;
+    c.u = v;
+    return c.s;
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
