@@ -224,20 +224,30 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
 
             // ---- S^T = K Q^T : lane holds S^T[key = 16f + 4g + r][q = l15] --------------------------
             f32x4 s[QF][4];
+            // K=16 remainder (d in [32 NC, 32 NC + 16); K pad columns / Q pad lanes are zero) first, for ALL key fragments, then
+            // the K=32 chain.  A 16x16x16 and a 16x16x32 MFMA issued close together on one accumulator lose updates on gfx950 in
+            // either order (measured; the compiler's dependency spacing is not enough), so the two shapes are kept 4 QF - 1
+            // MFMAs apart and the scheduler may not mix the groups.  tests/test_hip_ops.py covers every head dim with a tail.
     #pragma unroll
             for (int f = 0; f < 4; ++f) {
+                if (TAIL16) {
+                    const s16x4_t kt = as_s16x4(*reinterpret_cast<const u32x2*>(cK + (f * 16 + l15) * KROW + NC * 32 + lg * 4));
     #pragma unroll
-                for (int a = 0; a < QF; ++a) s[a][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int a = 0; a < QF; ++a)
+                        s[a][f] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt, qt[a], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                } else {
+    #pragma unroll
+                    for (int a = 0; a < QF; ++a) s[a][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            if (TAIL16) __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+            for (int f = 0; f < 4; ++f) {
     #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     const bf16x8_t kf = as_bf16x8(*reinterpret_cast<const u32x4*>(cK + (f * 16 + l15) * KROW + c * 32 + lg * 8));
     #pragma unroll
                     for (int a = 0; a < QF; ++a) s[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[a][c], s[a][f], 0, 0, 0);
-                }
-                if (TAIL16) {  // d in [32 NC, 32 NC + 16): K pad columns and Q pad lanes are zero
-                    const s16x4_t kt = as_s16x4(*reinterpret_cast<const u32x2*>(cK + (f * 16 + l15) * KROW + NC * 32 + lg * 4));
-    #pragma unroll
-                    for (int a = 0; a < QF; ++a) s[a][f] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt, qt[a], s[a][f], 0, 0, 0);
                 }
             }
 
