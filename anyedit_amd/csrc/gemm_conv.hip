@@ -51,12 +51,20 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, bf16_t* lds
 #endif
 }
 
+// smallest divisor of FM (16-row fragments per wave) whose share of the fp32 tile fits the main-loop LDS
+constexpr int epilogue_passes(int FM, int bytes_per_frag_row, int lds_bytes) {
+    for (int ps = 1; ps <= FM; ++ps)
+        if (FM % ps == 0 && (FM / ps) * bytes_per_frag_row <= lds_bytes) return ps;
+    return FM;
+}
+
 template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const GemmArgs p) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
     constexpr int FM = WM / 16, FN = WN / 16;            // 16x16 fragments per wave
     constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT;
+    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile / thread-count combination not supported");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];  // 2 * (BM + BN) * BK bf16 (dynamic: > 64 KiB for 128x160)
     bf16_t* const smem = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* sA = smem;
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     {
         constexpr int NCH = WN / 4;  // fp32 16-byte chunks per staged row
         // staging must fit in the main-loop LDS: split the wave tile's rows into passes if it does not (128x160 tile)
-        constexpr int PASSES = (WAVES_M * WAVES_N * WM * WN * 4 > 2 * (BM + BN) * BK * 2) ? 2 : 1;
+        constexpr int PASSES = epilogue_passes(FM, WAVES_M * WAVES_N * 16 * WN * 4, 2 * (BM + BN) * BK * 2);
         constexpr int FMP = FM / PASSES, WMP = WM / PASSES;
         static_assert(FM % PASSES == 0, "epilogue passes must divide the fragment rows");
         const bool geglu = p.epi == EPI_GEGLU;
@@ -571,6 +579,35 @@ int launch(const GemmArgs& a, hipStream_t stream) {
         if (glds) hipLaunchKernelGGL((gemm_kernel<BM_, BN_, AMODE, WM_, WN_, true>), grid, dim3(THREADS), lds, stream, a);   \
         else hipLaunchKernelGGL((gemm_kernel<BM_, BN_, AMODE, WM_, WN_, false>), grid, dim3(THREADS), lds, stream, a);      \
     } while (0)
+    // 192x320 tile, one block per CU (128 KiB LDS), 8 waves with 96x80 (or 48x160 for the GEGLU column pairing) wave tiles:
+    // 0.37-0.43 LDS fragment reads per MFMA instead of 0.75.  Used when the tile grid fills whole rounds of 256 CUs.
+    static const int t320 = getenv("AE_GEMM_T320") ? atoi(getenv("AE_GEMM_T320")) : 2;  // tuning knob: 0 off, 1 conv only, 2 conv + GEGLU GEMMs (other dense shapes measured neutral)
+    if (t320 && glds && a.splitk <= 1 && a.N % 320 == 0 && (conv || (t320 >= 2 && a.K >= 640 && a.epi == EPI_GEGLU))) {
+        auto fill_of = [&](int bm) {
+            const long t = (long)((a.M + bm - 1) / bm) * (a.N / 320);
+            return (double)t / (double)(((t + 255) / 256) * 256) * ((double)a.M / (double)(((a.M + bm - 1) / bm) * bm));
+        };
+        const bool geglu = a.epi == EPI_GEGLU;
+        // 192x320 waves 2x4, or 4x2 for GEGLU (pairs of 16-column fragments must sit in one wave).  A 96x320 variant for the
+        // 32x32 level (M = 12288) measured 9-13 % slower than the 128x128 tile there and was dropped.
+        if (fill_of(192) >= 0.85) {
+            const size_t ldsb = (size_t)2 * (192 + 320) * BK * sizeof(bf16_t);
+            const long t = (long)((a.M + 191) / 192) * (a.N / 320);
+            static bool attr_done[2] = {false, false};
+            const void* fn = geglu ? reinterpret_cast<const void*>(&gemm_kernel<192, 320, AMODE, 4, 2, true>)
+                                   : reinterpret_cast<const void*>(&gemm_kernel<192, 320, AMODE, 2, 4, true>);
+            if (!attr_done[geglu]) {
+                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) {
+                    ae_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", ldsb);
+                    return AE_ERR_LAUNCH;
+                }
+                attr_done[geglu] = true;
+            }
+            if (geglu) hipLaunchKernelGGL((gemm_kernel<192, 320, AMODE, 4, 2, true>), dim3((unsigned)t), dim3(512), ldsb, stream, a);
+            else hipLaunchKernelGGL((gemm_kernel<192, 320, AMODE, 2, 4, true>), dim3((unsigned)t), dim3(512), ldsb, stream, a);
+            return ae_check_launch(conv ? "ae_conv3x3_bf16" : "ae_gemm_bf16");
+        }
+    }
     if (pick == 3) {
         static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
         if (!attr_set) {

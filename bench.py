@@ -107,6 +107,20 @@ def cpu_baseline_and_parity(unet, device, max_seconds=40.0):
     return cpu, parity
 
 
+def traffic_for(kernel):
+    """HBM-side bytes per launch of `kernel` (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes over this same
+    workload: tools/traffic.sh -> profiles/r*_traffic.json).  PMC passes cannot run inside the timed process, so the figure
+    comes from the newest committed collection; None when there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    k = json.load(open(files[-1])).get("kernels", {}).get(kernel)
+    if not k or k.get("fetch_bytes") is None or k.get("write_bytes") is None:
+        return None
+    return k["fetch_bytes"] + k["write_bytes"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,7 +217,7 @@ def main():
                 "achieved": a["tflops"] if mfma else a["gbps"], "peak": PEAK_BF16_TFLOPS if mfma else PEAK_HBM_GBPS,
                 "unit": "TFLOP/s" if mfma else "GB/s",
                 "frac": (a["tflops"] / PEAK_BF16_TFLOPS) if mfma else (a["gbps"] / PEAK_HBM_GBPS),
-                "traffic": None, "avg_launch_us": a["avg_us"], "launches_per_unet_step": a["calls"] // 3,
+                "traffic": traffic_for(name), "avg_launch_us": a["avg_us"], "launches_per_unet_step": a["calls"] // 3,
                 "share_of_unet_step": a["ms"] / sum(v["ms"] for v in summ.values()),
             }
             result["kernels"] = {k: {"calls_per_step": v["calls"] // 3, "ms_per_step": v["ms"] / 3, "avg_us": v["avg_us"],
