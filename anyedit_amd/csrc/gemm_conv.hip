@@ -45,9 +45,13 @@ struct GemmArgs {
 
 // LDS-DMA: one wave moves 64 x 16 B from global straight into LDS at (wave-uniform dst) + lane*16.  The builtin exists only
 // in the device pass of this translation unit (the host pass merely needs the kernel's launch stub).
-__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, bf16_t* lds_dst, int voffset) {
+// `soffset` is the wave-uniform part of the address (the K position): it rides in an SGPR, so the per-lane voffset is loop
+// invariant and the K loop issues no address VALU at all (VALU and MFMA share the SIMD's vector pipe on gfx950: measured
+// 2.3 cycles per VALU instruction ADDED to the MFMA time, tools/ubench/issue_model.hip).  The bounds check covers voffset only,
+// so an out-of-range voffset (halo / tail rows) still reads as zero whatever soffset is.
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, bf16_t* lds_dst, int voffset, int soffset = 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, soffset, 0, 0);
 #endif
 }
 
@@ -58,8 +62,9 @@ constexpr int epilogue_passes(int FM, int bytes_per_frag_row, int lds_bytes) {
     return FM;
 }
 
-template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false>
+template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false, int STAGES = 2>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const GemmArgs p) {
+    static_assert(STAGES == 2 || GLDS, "the deep LDS ring exists only for the LDS-DMA loader");
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
     constexpr int FM = WM / 16, FN = WN / 16;            // 16x16 fragments per wave
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];  // 2 * (BM + BN) * BK bf16 (dynamic: > 64 KiB for 128x160)
     bf16_t* const smem = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* sA = smem;
-    bf16_t* sB = smem + 2 * BM * BK;
+    bf16_t* sB = smem + STAGES * BM * BK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -293,6 +298,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
         // LDS stage — no staging VGPRs, no ds_write_b128 pass (the slowest LDS instruction, ~79 B/clk/CU).  The LDS image is
         // lane-linear, so the XOR swizzle is applied to the per-lane SOURCE chunk instead (same involution as the ds_read
         // side).  hipcc drains the DMA (vmcnt(0)) in front of each __syncthreads().
+        int fa_cur[A_CH];  // conv: this tap's per-lane gather offset (OOB for halo pixels)
         auto dma_tile = [&](int kt, int buf) {
             const int k0 = (kt_begin + kt) * BK;
             if (AMODE == A_DENSE) {
@@ -300,22 +306,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
 #pragma unroll
                 for (int i = 0; i < A_CH; ++i) {
                     bf16_t* dst = sA + buf * BM * BK + (wave + (NT / 64) * i) * 8 * BK;
-                    if (!second) lds_dma16(rsA, dst, fa_off[i] + k0 * 2);
-                    else lds_dma16(rsA2, dst, fa2_off[i] + (k0 - p.Ksplit) * 2);
+                    if (!second) lds_dma16(rsA, dst, fa_off[i], k0 * 2);
+                    else lds_dma16(rsA2, dst, fa2_off[i], (k0 - p.Ksplit) * 2);
                 }
             } else {
                 const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
-                const int tap_off = ((ky * p.Wd + kx) * p.Cin + ld_ci) * 2;  // wave-uniform
+                if (ld_ci == 0 || kt == 0) {  // a new tap: the per-lane part (halo mask, upsample source pixel) changes only here
+#pragma unroll
+                    for (int i = 0; i < A_CH; ++i) {
+                        int src = fa_off[i] + ((ky * p.Wd + kx) * p.Cin) * 2;  // >= 0 for every in-image tap (voffset is bounds-checked unsigned)
+                        if (p.ups) {  // nearest-x2 upsample folded into the gather: source pixel = virtual pixel >> 1 (3 of 64 convs per UNet call)
+                            const int cc = ((tid + i * NT) & 7) ^ (((tid + i * NT) >> 3) & 7);
+                            src = (int)((a_base[i] + (long)(max(a_iy[i] + ky, 0) >> 1) * p.Wd + (max(a_ix[i] + kx, 0) >> 1)) * p.Cin + cc * 8) * 2;
+                        }
+                        fa_cur[i] = ((fa_mask[i] >> ld_tap) & 1u) ? src : OOB;
+                    }
+                }
+                const int tap_off = ld_ci * 2;  // wave-uniform -> SGPR offset
 #pragma unroll
                 for (int i = 0; i < A_CH; ++i) {
                     bf16_t* dst = sA + buf * BM * BK + (wave + (NT / 64) * i) * 8 * BK;
-                    int src = fa_off[i] + tap_off;
-                    if (p.ups) {  // nearest-x2 upsample folded into the gather: source pixel = virtual pixel >> 1 (3 of 64 convs per UNet call)
-                    const int cc = GLDS ? (((tid + i * NT) & 7) ^ (((tid + i * NT) >> 3) & 7)) : ((tid + i * NT) & 7);
-                    src = (int)((a_base[i] + (long)(max(a_iy[i] + ky, 0) >> 1) * p.Wd + (max(a_ix[i] + kx, 0) >> 1)) * p.Cin + cc * 8 + ld_ci) * 2;
-                }
-                    const int off = ((fa_mask[i] >> ld_tap) & 1u) ? src : OOB;
-                    lds_dma16(rsA, dst, off);
+                    lds_dma16(rsA, dst, fa_cur[i], tap_off);
                 }
                 ld_ci += BK;
                 if (ld_ci >= p.CinPad) { ld_ci = 0; ++ld_tap; }
@@ -323,16 +334,42 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
 #pragma unroll
             for (int i = 0; i < B_CH; ++i) {
                 bf16_t* dst = sB + buf * BN * BK + (wave + (NT / 64) * i) * 8 * BK;
-                lds_dma16(rsW, dst, fb_off[i] + k0 * 2);
+                lds_dma16(rsW, dst, fb_off[i], k0 * 2);
             }
         };
-        dma_tile(0, 0);
-        __syncthreads();
-        for (int kt = 0; kt < KT; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < KT) dma_tile(kt + 1, cur ^ 1);  // stage cur^1 was last read before the previous barrier
-            compute_tile(cur);
+        if constexpr (STAGES == 2) {
+            dma_tile(0, 0);
             __syncthreads();
+            for (int kt = 0; kt < KT; ++kt) {
+                const int cur = kt & 1;
+                if (kt + 1 < KT) dma_tile(kt + 1, cur ^ 1);  // stage cur^1 was last read before the previous barrier
+                compute_tile(cur);
+                __syncthreads();
+            }
+        } else {
+            // Deep ring: STAGES - 1 tiles in flight.  HBM/L3-sourced operands (the dense GEMMs) take far longer to land than one
+            // tile's MFMAs, so a one-tile prefetch leaves every iteration waiting on the DMA.  Ordering follows the LDS-DMA rules:
+            // each wave waits (counted vmcnt: only the OLDEST tile must have landed) for its own pieces, then a raw s_barrier
+            // makes every wave's pieces visible and proves all waves are done with the stage that is refilled next.
+            // __syncthreads() is not used here: its fence would drain the whole DMA queue (vmcnt(0)).
+            constexpr int PIECES = A_CH + B_CH;  // DMA instructions per tile per wave
+            constexpr int AHEAD = STAGES - 1;
+#pragma unroll
+            for (int t = 0; t < AHEAD; ++t)
+                if (t < KT) dma_tile(t, t);
+            int cur = 0, nxt = AHEAD % STAGES;
+            for (int kt = 0; kt < KT; ++kt) {
+                const int younger = min(KT - 1 - kt, AHEAD - 1);  // tiles issued after tile kt and still allowed in flight
+                if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (kt + AHEAD < KT) dma_tile(kt + AHEAD, nxt);  // refills the stage read in iteration kt - 1
+                compute_tile(cur);
+                cur = cur + 1 == STAGES ? 0 : cur + 1;
+                nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+            }
+            __builtin_amdgcn_s_barrier();  // the epilogue reuses the ring as fp32 staging
         }
     }
 
@@ -359,7 +396,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     {
         constexpr int NCH = WN / 4;  // fp32 16-byte chunks per staged row
         // staging must fit in the main-loop LDS: split the wave tile's rows into passes if it does not (128x160 tile)
-        constexpr int PASSES = epilogue_passes(FM, WAVES_M * WAVES_N * 16 * WN * 4, 2 * (BM + BN) * BK * 2);
+        constexpr int PASSES = epilogue_passes(FM, WAVES_M * WAVES_N * 16 * WN * 4, STAGES * (BM + BN) * BK * 2);
         constexpr int FMP = FM / PASSES, WMP = WM / PASSES;
         static_assert(FM % PASSES == 0, "epilogue passes must divide the fragment rows");
         const bool geglu = p.epi == EPI_GEGLU;
@@ -553,6 +590,27 @@ Plan make_plan(int M, int N, int K, bool can_split) {
     return {t, 1};
 }
 
+// Launch one instantiation; kernels that need more than 64 KiB of dynamic LDS get the opt-in attribute once.
+template <typename Kern>
+int launch_kernel(Kern kern, unsigned grid, int threads, size_t lds, hipStream_t stream, const GemmArgs& a, const char* what) {
+    if (lds > 64 * 1024) {
+        static const void* done[32];
+        static int ndone = 0;
+        const void* fn = reinterpret_cast<const void*>(kern);
+        bool seen = false;
+        for (int i = 0; i < ndone; ++i) seen |= done[i] == fn;
+        if (!seen) {
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                ae_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", lds);
+                return AE_ERR_LAUNCH;
+            }
+            if (ndone < 32) done[ndone++] = fn;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, a);
+    return ae_check_launch(what);
+}
+
 template <int AMODE>
 int launch(const GemmArgs& a, hipStream_t stream) {
     const int cand[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}};
@@ -562,71 +620,53 @@ int launch(const GemmArgs& a, hipStream_t stream) {
     if (force_tile >= 0 && force_tile <= 2 && a.splitk <= 1) pick = force_tile;
     // measured (profiles/r01_kbench_t160.txt): 128x160 wins on the N=320 convs (-8..-17 %), loses on dense (4 vs 8 waves)
     if (pick == 3 && (!t160 || AMODE == A_DENSE || a.epi == EPI_GEGLU || a.splitk > 1)) pick = 1;
-    const int BM = cand[pick][0], BN = cand[pick][1];
-    const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    dim3 grid((unsigned)(tiles * a.splitk));
     // 8-wave (4x2) blocks: twice the waves per CU at the same LDS footprint -> twice the latency tolerance of the
     // one-tile-ahead pipeline.  Measured on MI355X (profiles/r01_kbench_w8.txt): dense GEMMs -15..-25 % time, the 128x64 conv
     // unchanged (+-2 %), so that one keeps 4 waves (larger wave tile, fewer LDS reads per MFMA).  AE_GEMM_W8=0 forces 4 waves.
     static const int w8 = getenv("AE_GEMM_W8") ? atoi(getenv("AE_GEMM_W8")) : 2;
+    static const int stages = getenv("AE_GEMM_STAGES") ? atoi(getenv("AE_GEMM_STAGES")) : 2;  // tuning knob: LDS ring depth (2, 3, 4)
     const bool conv = AMODE == A_CONV3;
-    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16_t);
+    const char* what = conv ? "ae_conv3x3_bf16" : "ae_gemm_bf16";
     // LDS-DMA loaders need whole-tile decisions: no K tail, no mixed-source tile, no upsample gather / padded channels
     static const int glds_env = getenv("AE_GEMM_GLDS") ? atoi(getenv("AE_GEMM_GLDS")) : 1;  // tuning knob (A/B on hardware)
     const bool glds = glds_env && (conv ? (a.Cin == a.CinPad) : (a.K % BK == 0 && (!a.A2 || a.Ksplit % BK == 0)));
-#define AE_LAUNCH(BM_, BN_, WM_, WN_, THREADS)                                                                              \
-    do {                                                                                                                    \
-        if (glds) hipLaunchKernelGGL((gemm_kernel<BM_, BN_, AMODE, WM_, WN_, true>), grid, dim3(THREADS), lds, stream, a);   \
-        else hipLaunchKernelGGL((gemm_kernel<BM_, BN_, AMODE, WM_, WN_, false>), grid, dim3(THREADS), lds, stream, a);      \
-    } while (0)
+    auto lds_of = [](int bm, int bn, int st) { return (size_t)st * (bm + bn) * BK * sizeof(bf16_t); };
+    int rc = 0;
+
     // 192x320 tile, one block per CU (128 KiB LDS), 8 waves with 96x80 (or 48x160 for the GEGLU column pairing) wave tiles:
     // 0.37-0.43 LDS fragment reads per MFMA instead of 0.75.  Used when the tile grid fills whole rounds of 256 CUs.
     static const int t320 = getenv("AE_GEMM_T320") ? atoi(getenv("AE_GEMM_T320")) : 2;  // tuning knob: 0 off, 1 conv only, 2 conv + GEGLU GEMMs (other dense shapes measured neutral)
+    bool done = false;
     if (t320 && glds && a.splitk <= 1 && a.N % 320 == 0 && (conv || (t320 >= 2 && a.K >= 640 && a.epi == EPI_GEGLU))) {
-        auto fill_of = [&](int bm) {
-            const long t = (long)((a.M + bm - 1) / bm) * (a.N / 320);
-            return (double)t / (double)(((t + 255) / 256) * 256) * ((double)a.M / (double)(((a.M + bm - 1) / bm) * bm));
-        };
-        const bool geglu = a.epi == EPI_GEGLU;
+        const long t = (long)((a.M + 191) / 192) * (a.N / 320);
+        const double fill = (double)t / (double)(((t + 255) / 256) * 256) * ((double)a.M / (double)(((a.M + 191) / 192) * 192));
         // 192x320 waves 2x4, or 4x2 for GEGLU (pairs of 16-column fragments must sit in one wave).  A 96x320 variant for the
         // 32x32 level (M = 12288) measured 9-13 % slower than the 128x128 tile there and was dropped.
-        if (fill_of(192) >= 0.85) {
-            const size_t ldsb = (size_t)2 * (192 + 320) * BK * sizeof(bf16_t);
-            const long t = (long)((a.M + 191) / 192) * (a.N / 320);
-            static bool attr_done[2] = {false, false};
-            const void* fn = geglu ? reinterpret_cast<const void*>(&gemm_kernel<192, 320, AMODE, 4, 2, true>)
-                                   : reinterpret_cast<const void*>(&gemm_kernel<192, 320, AMODE, 2, 4, true>);
-            if (!attr_done[geglu]) {
-                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) {
-                    ae_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", ldsb);
-                    return AE_ERR_LAUNCH;
-                }
-                attr_done[geglu] = true;
-            }
-            if (geglu) hipLaunchKernelGGL((gemm_kernel<192, 320, AMODE, 4, 2, true>), dim3((unsigned)t), dim3(512), ldsb, stream, a);
-            else hipLaunchKernelGGL((gemm_kernel<192, 320, AMODE, 2, 4, true>), dim3((unsigned)t), dim3(512), ldsb, stream, a);
-            return ae_check_launch(conv ? "ae_conv3x3_bf16" : "ae_gemm_bf16");
+        if (fill >= 0.85) {
+            if (a.epi == EPI_GEGLU) rc = launch_kernel(gemm_kernel<192, 320, AMODE, 4, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
+            else rc = launch_kernel(gemm_kernel<192, 320, AMODE, 2, 4, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
+            done = true;
         }
     }
-    if (pick == 3) {
-        static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<128, 160, AMODE, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<128, 160, AMODE, 2, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-                ae_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", lds);
-                return AE_ERR_LAUNCH;
-            }
-            attr_set = true;
-        }
-        AE_LAUNCH(128, 160, 2, 2, 256);
-    } else if (pick == 0 && w8 == 1) AE_LAUNCH(128, 128, 2, 4, 512);
-    else if (pick == 0 && w8 == 2) AE_LAUNCH(128, 128, 4, 2, 512);
-    else if (pick == 0) AE_LAUNCH(128, 128, 2, 2, 256);
-    else if (pick == 1 && w8 && !conv) AE_LAUNCH(128, 64, 4, 2, 512);
-    else if (pick == 1) AE_LAUNCH(128, 64, 2, 2, 256);
-    else AE_LAUNCH(64, 64, 2, 2, 256);
+    if (!done) {
+        const int BM = cand[pick][0], BN = cand[pick][1];
+        const unsigned grid = (unsigned)((long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.splitk);
+#define AE_LAUNCH(BM_, BN_, WM_, WN_, THREADS)                                                                                            \
+    do {                                                                                                                                  \
+        if (glds && stages == 3) rc = launch_kernel(gemm_kernel<BM_, BN_, AMODE, WM_, WN_, true, 3>, grid, THREADS, lds_of(BM_, BN_, 3), stream, a, what); \
+        else if (glds && stages == 4) rc = launch_kernel(gemm_kernel<BM_, BN_, AMODE, WM_, WN_, true, 4>, grid, THREADS, lds_of(BM_, BN_, 4), stream, a, what); \
+        else if (glds) rc = launch_kernel(gemm_kernel<BM_, BN_, AMODE, WM_, WN_, true>, grid, THREADS, lds_of(BM_, BN_, 2), stream, a, what); \
+        else rc = launch_kernel(gemm_kernel<BM_, BN_, AMODE, WM_, WN_, false>, grid, THREADS, lds_of(BM_, BN_, 2), stream, a, what);       \
+    } while (0)
+        if (pick == 3) AE_LAUNCH(128, 160, 2, 2, 256);
+        else if (pick == 0 && w8 == 1) AE_LAUNCH(128, 128, 2, 4, 512);
+        else if (pick == 0 && w8 == 2) AE_LAUNCH(128, 128, 4, 2, 512);
+        else if (pick == 0) AE_LAUNCH(128, 128, 2, 2, 256);
+        else if (pick == 1 && w8 && !conv) AE_LAUNCH(128, 64, 4, 2, 512);
+        else if (pick == 1) AE_LAUNCH(128, 64, 2, 2, 256);
+        else AE_LAUNCH(64, 64, 2, 2, 256);
 #undef AE_LAUNCH
-    int rc = ae_check_launch(AMODE == A_DENSE ? "ae_gemm_bf16" : "ae_conv3x3_bf16");
+    }
     if (rc || a.splitk <= 1) return rc;
     long nb = ((long)a.M * a.N / 4 + 255) / 256;
     if (nb > 2048) nb = 2048;
