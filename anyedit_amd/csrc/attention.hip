@@ -53,11 +53,8 @@ __device__ __forceinline__ int vt_pos(int key) {  // key = 16 f + 4 g + r  ->  1
 // NW waves per block, QF 16-row query fragments per wave.  (NW=4,QF=2) and (NW=8,QF=1) cover the same 128 query rows per
 // block with the same LDS; the latter halves the per-wave register state (4 instead of 2 waves per SIMD -> the exp-bound
 // softmax of one wave overlaps the MFMAs of three others) at the price of twice the K/V fragment reads per FLOP.
-// PRE: the caller folded scale * log2(e) into Q (c2 == 1).  The running max then enters the QK^T MFMA as its C operand, so the
-// logits come out of the matrix core already shifted (s - m) and the per-element scale/shift fma disappears from the VALU.
-template <int D, int QF, int NW, bool DBUF, bool HAS_BIAS, bool HAS_MASK, bool SEG2 = false, bool PRE = false>
+template <int D, int QF, int NW, bool DBUF, bool HAS_BIAS, bool HAS_MASK, bool SEG2 = false>
 __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void attn_kernel(const AttnArgs p) {
-    static_assert(!PRE || (!HAS_BIAS && !HAS_MASK), "PRE is a plain / two-segment variant");
     constexpr int NT = 64 * NW;
     constexpr int NC = D / 32;                 // full K=32 MFMAs per (key frag, q frag)
     constexpr bool TAIL16 = (D % 32) != 0;     // head-dim remainder (8 or 16) goes through ONE K=16 MFMA instead of padding to 32
@@ -123,7 +120,6 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
 
     f32x4 o[QF][NDF];
     float m_run[QF], l_run[QF];
-    f32x4 negm[PRE ? QF : 1];  // PRE: -m_run splat, the C operand of the first QK^T MFMA of a chain
 #pragma unroll
     for (int a = 0; a < QF; ++a) {
         m_run[a] = NEG_BIG;
@@ -213,7 +209,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
             }
         };
 
-        const float c2 = PRE ? 1.0f : p.scale * LOG2E;
+        const float c2 = p.scale * LOG2E;
         const int ntiles = (seg_Nk + KT - 1) / KT;
         load_kv(0);
         __syncthreads();  // pad zero-fill ordered before the first tile write
@@ -221,10 +217,8 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
         __syncthreads();
 
         // One K/V tile: S^T = K Q^T, online softmax, O^T += V^T P^T.  TAIL = the (only) tile that contains padding keys.
-        auto tile_body = [&](int k0, int cur, auto tail_tag, auto first_tag) {
+        auto tile_body = [&](int k0, int cur, auto tail_tag) {
             constexpr bool TAIL = decltype(tail_tag)::value;
-            // PRE fast tiles: every tile but the first (m_run is still -inf there) and the padded last one
-            constexpr bool CINIT = PRE && !TAIL && !decltype(first_tag)::value;
             const bf16_t* cK = sK + cur * KSZ;
             const bf16_t* cV = sVt + cur * VSZ;
 
@@ -240,10 +234,10 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
                     const s16x4_t kt = as_s16x4(*reinterpret_cast<const u32x2*>(cK + (f * 16 + l15) * KROW + NC * 32 + lg * 4));
     #pragma unroll
                     for (int a = 0; a < QF; ++a)
-                        s[a][f] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt, qt[a], CINIT ? negm[PRE ? a : 0] : (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        s[a][f] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt, qt[a], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 } else {
     #pragma unroll
-                    for (int a = 0; a < QF; ++a) s[a][f] = CINIT ? negm[PRE ? a : 0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int a = 0; a < QF; ++a) s[a][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
             if (TAIL16) __builtin_amdgcn_sched_barrier(0);
@@ -292,44 +286,23 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
                 for (int f = 0; f < 4; ++f) mx = fmaxf(mx, fmaxf(fmaxf(s[a][f][0], s[a][f][1]), fmaxf(s[a][f][2], s[a][f][3])));
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                if (CINIT) {
-                    // s already holds logit - m_run: the row maximum moved iff some element is positive (rare after the first tiles)
-                    if (__any(mx > 0.f)) {
-                        const float dlt = fmaxf(mx, 0.f);
-                        const float alpha = __builtin_amdgcn_exp2f(-dlt);
-                        m_run[a] += dlt;
-                        negm[PRE ? a : 0] = (f32x4){-m_run[a], -m_run[a], -m_run[a], -m_run[a]};
-                        l_run[a] *= alpha;
-    #pragma unroll
-                        for (int df = 0; df < NDF; ++df) {
-                            o[a][df][0] *= alpha; o[a][df][1] *= alpha; o[a][df][2] *= alpha; o[a][df][3] *= alpha;
-                        }
-    #pragma unroll
-                        for (int f = 0; f < 4; ++f) {
-                            s[a][f][0] -= dlt; s[a][f][1] -= dlt; s[a][f][2] -= dlt; s[a][f][3] -= dlt;
-                        }
-                    }
-                } else {
                 if (PLAIN) mx *= c2;  // scale > 0
                 if (__any(mx > m_run[a])) {
                     const float m_new = fmaxf(m_run[a], mx);
                     const float alpha = __builtin_amdgcn_exp2f(m_run[a] - m_new);
                     m_run[a] = m_new;
-                    if (PRE) negm[PRE ? a : 0] = (f32x4){-m_new, -m_new, -m_new, -m_new};
                     l_run[a] *= alpha;
     #pragma unroll
                     for (int df = 0; df < NDF; ++df) {
                         o[a][df][0] *= alpha; o[a][df][1] *= alpha; o[a][df][2] *= alpha; o[a][df][3] *= alpha;
                     }
                 }
-                }
                 const float neg_m = -m_run[a];
     #pragma unroll
                 for (int f = 0; f < 4; ++f)
     #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float e = CINIT ? __builtin_amdgcn_exp2f(s[a][f][r])
-                                  : PLAIN ? __builtin_amdgcn_exp2f(fmaf(s[a][f][r], c2, neg_m)) : __builtin_amdgcn_exp2f(s[a][f][r] + neg_m);
+                        float e = PLAIN ? __builtin_amdgcn_exp2f(fmaf(s[a][f][r], c2, neg_m)) : __builtin_amdgcn_exp2f(s[a][f][r] + neg_m);
                         if (TAIL) {  // padding keys never contribute (also when a whole row is masked -> uniform over REAL keys)
                             if (k0 + f * 16 + lg * 4 + r >= seg_Nk) e = 0.f;
                         }
@@ -368,9 +341,8 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
             const int k0 = t * KT;
             const int cur = DBUF ? (t & 1) : 0;
             if (t + 1 < ntiles) load_kv(k0 + KT);
-            if (k0 + KT > seg_Nk) tile_body(k0, cur, std::true_type{}, std::false_type{});
-            else if (PRE && t == 0) tile_body(k0, cur, std::false_type{}, std::true_type{});
-            else tile_body(k0, cur, std::false_type{}, std::false_type{});
+            if (k0 + KT > seg_Nk) tile_body(k0, cur, std::true_type{});
+            else tile_body(k0, cur, std::false_type{});
             if (DBUF) {
                 if (t + 1 < ntiles) store_kv(cur ^ 1);
                 __syncthreads();
@@ -432,14 +404,9 @@ int launch_attn(const AttnArgs& a, hipStream_t stream) {
     const long blocks = (long)((a.Nq + QB - 1) / QB) * a.B * a.H;
     dim3 grid((unsigned)blocks), block(NT);
     if (a.rel_h && a.key_mask) { ae_set_error("ae_attn_fwd_bf16: rel-pos bias together with key_mask is not supported"); return AE_ERR_UNSUPPORTED; }
-    const bool pre = fabsf(a.scale * LOG2E - 1.0f) < 1e-6f;  // caller folded scale * log2(e) into Q and passes scale = ln 2
     if (a.k2) {
-        if constexpr (D <= 96) {
-            if (pre) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, false, false, true, true>), grid, block, 0, stream, a);
-            else hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, false, false, true>), grid, block, 0, stream, a);
-        }
-    } else if (!a.rel_h && !a.key_mask && pre) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, false, false, false, true>), grid, block, 0, stream, a);
-    else if (a.rel_h) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, true, false>), grid, block, 0, stream, a);
+        if constexpr (D <= 96) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, false, false, true>), grid, block, 0, stream, a);
+    } else if (a.rel_h) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, true, false>), grid, block, 0, stream, a);
     else if (a.key_mask) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, false, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, false, false>), grid, block, 0, stream, a);
     return ae_check_launch("ae_attn_fwd_bf16");
@@ -482,7 +449,7 @@ extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
     a.k2 = (const bf16_t*)k2; a.v2 = (const bf16_t*)v2; a.Nk2 = Nk2; a.k2_sb = k2_sb; a.k2_sh = k2_sh; a.k2_sn = k2_sn;
     a.v2_sb = v2_sb; a.v2_sh = v2_sh; a.v2_sn = v2_sn; a.scale2 = scale2;
     hipStream_t s = (hipStream_t)stream;
-    static const int qf40 = env_int("AE_ATTN_QF40", 2);  // tuning knob (A/B on hardware): query fragments per wave for D=40
+    static const int qf40 = env_int("AE_ATTN_QF40", 4);  // tuning knob (A/B on hardware): query fragments per wave for D=40
     static const int w8 = env_int("AE_ATTN_W8", 0);      // tuning knob: 8 waves x 1 query fragment instead of 4 x 2
     switch (D) {
         case 8: return launch_attn<8, 2, true>(a, s);
@@ -490,7 +457,9 @@ extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
         case 32: return launch_attn<32, 2, true>(a, s);
         case 40:
             if (w8) return launch_attn<40, 1, true, 8>(a, s);
-            return (qf40 == 2 || Nq <= 1024) ? launch_attn<40, 2, true>(a, s) : launch_attn<40, 4, true>(a, s);
+            // 64 queries per wave halve the K/V staging and K-fragment reads per query (514 vs 547 us at N = 4096); only for long
+            // self-attention: the two-segment variant would spill at 4 fragments, and short K/V has nothing to amortise
+            return (qf40 == 4 && Nq > 1024 && Nk >= 1024 && !k2) ? launch_attn<40, 4, true>(a, s) : launch_attn<40, 2, true>(a, s);
         case 48: return launch_attn<48, 2, true>(a, s);
         case 64: return launch_attn<64, 2, true>(a, s);
         case 80: return w8 ? launch_attn<80, 1, true, 8>(a, s) : launch_attn<80, 2, true>(a, s);

@@ -112,10 +112,7 @@ class CrossAttention(nn.Module):
 
     def _packed(self):
         if self._pk is None or self._pk["dev"] != self.to_q.weight.device:
-            # the softmax scale and log2(e) ride on the query projection (one bf16 rounding of W_q * c, like rounding W_q):
-            # the attention kernel then takes logits straight out of the MFMA in the exp2 domain
-            wq = ops.pack_linear(self.to_q.weight, scale=self.scale * ops.LOG2E)
-            wk, wv = (ops.pack_linear(m.weight) for m in (self.to_k, self.to_v))
+            wq, wk, wv = (ops.pack_linear(m.weight) for m in (self.to_q, self.to_k, self.to_v))
             pk = {"dev": self.to_q.weight.device, "q": wq, "kv": torch.cat([wk, wv], 0).contiguous()}
             if wq.shape[1] == wk.shape[1]:
                 pk["qkv"] = torch.cat([wq, wk, wv], 0).contiguous()
@@ -136,7 +133,7 @@ class CrossAttention(nn.Module):
         if context_rows is None and kv is None:
             qkv = ops.gemm(x, pk["qkv"])  # [B*N, 3*inner]
             s = (N * 3 * inner, d, 3 * inner)
-            o = ops.attention(qkv, qkv[:, inner:], qkv[:, 2 * inner:], B, h, N, N, d, ops.LOGIT_SCALE_FOLDED, s, s, s, key_mask=key_mask)
+            o = ops.attention(qkv, qkv[:, inner:], qkv[:, 2 * inner:], B, h, N, N, d, self.scale, s, s, s, key_mask=key_mask)
         else:
             q = ops.gemm(x, pk["q"])
             if kv is None:
@@ -151,14 +148,14 @@ class CrossAttention(nn.Module):
                 T_ip = kv_ip.shape[0] // B
                 ks_ip = (T_ip * 2 * inner, d, 2 * inner)
                 seg2 = (kv_ip.data_ptr(), kv_ip[:, inner:].data_ptr(), T_ip, *ks_ip, *ks_ip, gate.data_ptr())
-                o = ops.attention(q, kv, kv[:, inner:], B, h, N, Nk, d, ops.LOGIT_SCALE_FOLDED, qs, ks, ks, seg2=seg2)
+                o = ops.attention(q, kv, kv[:, inner:], B, h, N, Nk, d, self.scale, qs, ks, ks, seg2=seg2)
             else:
-                o = ops.attention(q, kv, kv[:, inner:], B, h, N, Nk, d, ops.LOGIT_SCALE_FOLDED, qs, ks, ks, key_mask=key_mask)
+                o = ops.attention(q, kv, kv[:, inner:], B, h, N, Nk, d, self.scale, qs, ks, ks, key_mask=key_mask)
                 if adapter is not None:
                     kv_ip, gate = adapter
                     T_ip = kv_ip.shape[0] // B
                     ks_ip = (T_ip * 2 * inner, d, 2 * inner)
-                    ops.attention(q, kv_ip, kv_ip[:, inner:], B, h, N, T_ip, d, ops.LOGIT_SCALE_FOLDED, qs, ks_ip, ks_ip, out=o,
+                    ops.attention(q, kv_ip, kv_ip[:, inner:], B, h, N, T_ip, d, self.scale, qs, ks_ip, ks_ip, out=o,
                                   out_scale=gate, accumulate=True)
         return self.to_out[0].rows(o.reshape(B * N, inner), residual=residual)
 

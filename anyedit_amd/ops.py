@@ -31,18 +31,9 @@ def _chk(t, dtype, name, dims=None):
 
 
 # --------------------------------------------------------------------------- weight packing (host side, once)
-def pack_linear(w, scale=None):
-    """nn.Linear / 1x1 conv weight -> bf16 [N, K] contiguous.  `scale` multiplies the fp32 weight before the single bf16
-    rounding (used to fold the softmax scale * log2(e) into the query projection, see LOGIT_SCALE_FOLDED)."""
-    w = w.detach().reshape(w.shape[0], -1)
-    if scale is not None:
-        w = w.float() * scale
-    return w.to(BF16).contiguous()
-
-
-LOG2E = 1.4426950408889634
-LOGIT_SCALE_FOLDED = math.log(2.0)  # pass as `scale` to attention() when Q already carries dim_head**-0.5 * log2(e):
-                                    # softmax(q'k * ln 2) = 2**(q'k) / sum, and the kernel skips the per-logit multiply
+def pack_linear(w):
+    """nn.Linear / 1x1 conv weight -> bf16 [N, K] contiguous."""
+    return w.detach().reshape(w.shape[0], -1).to(BF16).contiguous()
 
 
 def pack_conv3x3(w, cin_pad=None):

@@ -51,7 +51,7 @@ def main():
         qkv = rnd(B * N, 3 * C)
         s = (N * 3 * C, d, 3 * C)
         case(f"attn self N={N} d={d} BH={B * h}",
-             lambda qkv=qkv, s=s, N=N, C=C, d=d: ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B, h, N, N, d, d ** -0.5 if os.environ.get("KB_EXACT_SCALE") else ops.LOGIT_SCALE_FOLDED, s, s, s),
+             lambda qkv=qkv, s=s, N=N, C=C, d=d: ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B, h, N, N, d, d ** -0.5, s, s, s),
              4.0 * B * h * N * N * d, 2.0 * B * h * d * 4 * N)
         q = rnd(B * N, C)
         kv = rnd(B * 78, 2 * C)
