@@ -344,8 +344,15 @@ class OpProfiler:
 _PROF = None
 
 
-def _tile_label(M, N, conv=False):
-    """Mirror of the tile choice in csrc/gemm_conv.hip::launch (for labelling only)."""
+def _tile_label(M, N, conv=False, K=0, geglu=False, dma_ok=True):
+    """Mirror of the tile choice in csrc/gemm_conv.hip::launch / make_plan (for labelling only)."""
+    if dma_ok and N % 320 == 0 and (conv or (geglu and K >= 640)):
+        tm = -(-M // 192)
+        t = tm * (N // 320)
+        if t / (-(-t // 256) * 256) * (M / (tm * 192)) >= 0.85 and not (conv and _conv_splitk(M, N, K) > 1):
+            return "192x320"
+    if conv and _conv_splitk(M, N, K) > 1:
+        return "128x128,splitK"
     if conv and N % 160 == 0 and N % 128 != 0 and -(-M // 128) * (N // 160) >= 256:
         return "128x160"
     for bm, bn in ((128, 128), (128, 64), (64, 64)):
@@ -353,6 +360,19 @@ def _tile_label(M, N, conv=False):
         if tm * tn >= 256 and tn * bn / N <= 1.10:
             return f"{bm}x{bn}"
     return "64x64"
+
+
+def _conv_splitk(M, N, K):
+    kt = -(-K // 64)
+    t128 = -(-M // 128) * -(-N // 128)
+    picked_big = any(-(-M // bm) * -(-N // bn) >= 256 and -(-N // bn) * bn / N <= 1.10 for bm, bn in ((128, 128),))
+    is160 = N % 160 == 0 and N % 128 != 0 and -(-M // 128) * (N // 160) >= 256
+    if kt < 32 or picked_big or is160:
+        return 1
+    if -(-N // 128) * 128 / N <= 1.10 and t128 < 256:
+        s_ = min(-(-480 // t128), 8, kt // 8)
+        return s_ if s_ >= 2 else 1
+    return 1
 
 
 def _wrap_profiled(fn, label_fn):
@@ -373,14 +393,14 @@ def _wrap_profiled(fn, label_fn):
 def _gemm_label(_r, a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue=EPI_NONE, out_f32=False, a2=None, **_):
     M, (N, K) = a.shape[0], w.shape
     nb = 2 * (M * K + N * K) + _r.numel() * _r.element_size() + (2 * M * N if residual is not None else 0)
-    return f"gemm_kernel<{_tile_label(M, N)},dense>|M={M} N={N} K={K}", 2.0 * M * N * K, float(nb)
+    return f"gemm_kernel<{_tile_label(M, N, False, K, epilogue == EPI_GEGLU, K % 64 == 0 and a2 is None)},dense>|M={M} N={N} K={K}", 2.0 * M * N * K, float(nb)
 
 
 def _conv_label(_r, x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2x=False, out_f32=False, **_):
     y = _r[0]
     M, Cout, Cin = y.shape[0], w.shape[0], x.shape[1]
     nb = 2 * (x.numel() + 9 * Cin * Cout) + y.numel() * y.element_size() + (2 * y.numel() if residual is not None else 0)
-    return f"gemm_kernel<{_tile_label(M, Cout, True)},conv3x3>|M={M} Cin={Cin} Cout={Cout} s{stride}{'u' if upsample2x else ''}", 2.0 * M * Cout * 9 * Cin, float(nb)
+    return f"gemm_kernel<{_tile_label(M, Cout, True, 9 * (-(-Cin // 64) * 64), False, Cin % 64 == 0)},conv3x3>|M={M} Cin={Cin} Cout={Cout} s{stride}{'u' if upsample2x else ''}", 2.0 * M * Cout * 9 * Cin, float(nb)
 
 
 def _attn_label(_r, q, k, v, B, H, Nq, Nk, D, *a, **_):
