@@ -14,7 +14,7 @@ if [ "${SKIP_BENCH:-0}" != "1" ]; then
   ( timeout 1500 python bench.py --steps ${BENCH_STEPS:-1} --warmup 1 ${BENCH_ARGS:-} ) > $OUT/bench.log 2>&1; echo "bench rc=$?"; tail -3 $OUT/bench.log | cut -c1-3000
 fi
 if [ "${SKIP_PROF:-0}" != "1" ]; then
-  cd /tmp && ( timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 1 --ddim-steps ${PROF_DDIM_STEPS:-10} --no-cpu-baseline ) > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?"; cd $OLDPWD
+  cd /tmp && ( timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $OLDPWD/bench.py --steps 1 --warmup 1 --ddim-steps ${PROF_DDIM_STEPS:-10} --no-cpu-baseline ) > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?"; cd $OLDPWD
   find $OUT/prof -name "*kernel_stats*" | head -3
   f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" | cut -c1-200
 fi
