@@ -33,7 +33,25 @@ SIGNATURES = {
     "ae_attn_fwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                          c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long,
                          c_float, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
-                         c_void_p, c_void_p, c_int, c_long, c_long, c_long, c_long, c_long, c_long, c_void_p, c_void_p],
+                         c_void_p, c_void_p, c_int, c_long, c_long, c_long, c_long, c_long, c_long, c_void_p, c_void_p, c_void_p,
+                         c_void_p],
+    "ae_attn_bwd_bf16": [c_void_p] * 9 + [c_int] * 5 + [c_long] * 21 + [c_float, c_void_p, c_int, c_void_p],
+    "ae_groupnorm_bwd_workspace_floats": [c_int, c_int, c_int, c_int],
+    "ae_groupnorm_bwd_nhwc_bf16": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_int, c_float, c_int, c_void_p, c_void_p],
+    "ae_layernorm_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "ae_layernorm_param_grad_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "ae_add_bf16": [c_void_p, c_void_p, c_void_p, c_long, c_void_p],
+    "ae_geglu_fwd_bf16": [c_void_p, c_void_p, c_long, c_int, c_void_p],
+    "ae_geglu_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
+    "ae_sumpool2x2_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "ae_colsum_bf16_f32": [c_void_p, c_void_p, c_int, c_int, c_long, c_void_p],
+    "ae_mse_grad_f32": [c_void_p, c_void_p, c_void_p, c_long, c_float, c_void_p],
+    "ae_adamw_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float, c_float, c_int, c_float,
+                     c_void_p],
+    "ae_rowsum_f32": [c_void_p, c_void_p, c_int, c_long, c_void_p],
+    "ae_scatter_add_rows_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "ae_task_gate_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "ae_transpose_last2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ae_concat_channels_bf16": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_void_p],
     "ae_timestep_embedding": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
@@ -50,7 +68,8 @@ SIGNATURES = {
     "ae_mse_f32": [c_void_p, c_void_p, c_void_p, c_long, c_void_p],
     "ae_task_gate": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
 }
-_RESTYPES = {"ae_last_error": ctypes.c_char_p, "ae_groupnorm_workspace_floats": c_long, "ae_conv3x3_workspace_floats": c_long}
+_RESTYPES = {"ae_last_error": ctypes.c_char_p, "ae_groupnorm_workspace_floats": c_long, "ae_conv3x3_workspace_floats": c_long,
+             "ae_groupnorm_bwd_workspace_floats": c_long}
 
 
 class AnyEditHipError(RuntimeError):

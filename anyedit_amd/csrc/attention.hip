@@ -44,6 +44,8 @@ struct AttnArgs {
     const bf16_t* k2; const bf16_t* v2; int Nk2;
     long k2_sb, k2_sh, k2_sn, v2_sb, v2_sh, v2_sn;
     const float* scale2;
+    // optional [B, H, Nq] fp32 outputs for the backward pass: log2-domain log-sum-exp of each segment's softmax
+    float* lse; float* lse2;
 };
 
 __device__ __forceinline__ int vt_pos(int key) {  // key = 16 f + 4 g + r  ->  16 g + 4 f + r
@@ -358,7 +360,9 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
         if (SEG2 && seg_i == 0) {  // park segment 0's normalised output, restart the online softmax
 #pragma unroll
             for (int a = 0; a < QF; ++a) {
-                const float inv = 1.0f / row_sum(a);
+                const float rsum0 = row_sum(a);
+                if (p.lse && lg == 0 && q0 + a * 16 + l15 < p.Nq) p.lse[((long)b * p.H + h) * p.Nq + q0 + a * 16 + l15] = m_run[a] + __builtin_amdgcn_logf(rsum0);
+                const float inv = 1.0f / rsum0;
 #pragma unroll
                 for (int df = 0; df < NDF; ++df) {
                     o_first[SEG2 ? a : 0][SEG2 ? df : 0] = (f32x4){o[a][df][0] * inv, o[a][df][1] * inv, o[a][df][2] * inv, o[a][df][3] * inv};
@@ -374,9 +378,12 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
     bf16_t* op = p.o + (long)b * p.o_sb + (long)h * p.o_sh;
 #pragma unroll
     for (int a = 0; a < QF; ++a) {
-        const float inv = (SEG2 ? p.scale2[b] : (p.out_scale ? p.out_scale[b] : 1.0f)) / row_sum(a);
+        const float rsum = row_sum(a);
+        const float inv = (SEG2 ? p.scale2[b] : (p.out_scale ? p.out_scale[b] : 1.0f)) / rsum;
         const int qrow = q0 + a * 16 + l15;
         if (qrow >= p.Nq) continue;
+        float* lse_out = SEG2 ? p.lse2 : p.lse;
+        if (lse_out && lg == 0) lse_out[((long)b * p.H + h) * p.Nq + qrow] = m_run[a] + __builtin_amdgcn_logf(rsum);  // v_log_f32 = log2
 #pragma unroll
         for (int df = 0; df < NDF; ++df) {
             const int d = df * 16 + lg * 4;
@@ -424,7 +431,8 @@ extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
                                 long v_sb, long v_sh, long v_sn, long o_sb, long o_sh, long o_sn, float scale,
                                 const float* rel_h, const float* rel_w, int kH, int kW, const unsigned char* key_mask,
                                 const float* out_scale, int accumulate, const void* k2, const void* v2, int Nk2, long k2_sb,
-                                long k2_sh, long k2_sn, long v2_sb, long v2_sh, long v2_sn, const float* scale2, void* stream) {
+                                long k2_sh, long k2_sn, long v2_sb, long v2_sh, long v2_sn, const float* scale2, float* lse,
+                                float* lse2, void* stream) {
     AE_REQUIRE(q && k && v && out, "ae_attn_fwd_bf16: null pointer");
     AE_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0, "ae_attn_fwd_bf16: bad sizes B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
     AE_REQUIRE((q_sb | q_sh | q_sn | k_sb | k_sh | k_sn | v_sb | v_sh | v_sn) % 8 == 0 && (o_sb | o_sh | o_sn) % 4 == 0,
@@ -448,6 +456,8 @@ extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
     }
     a.k2 = (const bf16_t*)k2; a.v2 = (const bf16_t*)v2; a.Nk2 = Nk2; a.k2_sb = k2_sb; a.k2_sh = k2_sh; a.k2_sn = k2_sn;
     a.v2_sb = v2_sb; a.v2_sh = v2_sh; a.v2_sn = v2_sn; a.scale2 = scale2;
+    a.lse = lse; a.lse2 = lse2;
+    if (lse2) AE_REQUIRE(k2 != nullptr, "ae_attn_fwd_bf16: lse2 needs a second segment");
     hipStream_t s = (hipStream_t)stream;
     static const int qf40 = env_int("AE_ATTN_QF40", 4);  // tuning knob (A/B on hardware): query fragments per wave for D=40
     static const int w8 = env_int("AE_ATTN_W8", 0);      // tuning knob: 8 waves x 1 query fragment instead of 4 x 2

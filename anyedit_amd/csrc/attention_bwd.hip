@@ -1,0 +1,381 @@
+// Attention backward for gfx950 (training step, SURVEY.md §8a row A11: train.py:694-703 back-propagates the eps-MSE through the
+// frozen UNet's self- / cross- / adapter attention, attention.py:163-194, to reach the trainable adapter projections).
+//
+//   S = Q K^T,  P = softmax(scale S),  O = P V      (forward, attention.hip; it also stores L2[q] = log2 sum_k 2^(c2 S[q,k]))
+//   dV = P^T dO      dP = dO V^T      dS = P o (dP - delta) * scale,  delta[q] = sum_k P[q,k] dP[q,k]      dQ = dS K      dK = dS^T Q
+//
+// Two deterministic passes over one kernel template (no float atomics):
+//   MODE_DQ : a block owns 128 query rows (operands Q, dO live in registers), streams 64-key tiles of K / V through LDS and
+//             accumulates  T1 = sum_k (P o dP) K,  T2 = sum_k P K,  delta = rowsum(P o dP);  dQ = g scale (T1 - delta T2).
+//             delta is written out for the second pass (and for the gate gradient of the adapter segment).
+//   MODE_DKV: a block owns 128 key rows (K, V in registers), streams 64-query tiles of Q / dO (+ L2, delta) and accumulates
+//             dV = g sum_q P^T dO,  dK = g scale sum_q dS^T Q.
+// `g` = optional per-batch output scale (the adapter gate: out = Attn(q,K,V) + g_b Attn(q,K_ip,V_ip)); delta is kept UN-scaled.
+// Same MFMA conventions as the forward: the streamed side is the row (A) operand read from LDS, the fixed side the column (B)
+// operand held in registers, so every lane owns one fixed-side row; the second product takes its A operand from a transposed LDS
+// image (key/query slots permuted to the accumulator order) and its B operand straight from the accumulator registers.
+#include "common.hpp"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int ST = 64;  // streamed rows per tile
+constexpr float LOG2E = 1.4426950408889634f;
+enum { MODE_DQ = 0, MODE_DKV = 1 };
+
+struct BwdArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* dO;
+    const float* lse;        // [B, H, Nq] log2-domain log-sum-exp written by the forward
+    float* delta;            // [B, H, Nq] rowsum(P o dP): written by MODE_DQ, read by MODE_DKV
+    const float* out_scale;  // optional [B]
+    bf16_t* dq; bf16_t* dk; bf16_t* dv;
+    int B, H, Nq, Nk;
+    long q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, v_sb, v_sh, v_sn, o_sb, o_sh, o_sn;
+    long dq_sb, dq_sh, dq_sn, dk_sb, dk_sh, dk_sn, dv_sb, dv_sh, dv_sn;
+    float scale;
+    int accum_dq;  // dq += (second segment sharing the same queries)
+};
+
+__device__ __forceinline__ int perm_pos(int r) {  // streamed row 16 f + 4 g + e  ->  slot 16 g + 4 f + e (accumulator order)
+    return ((r >> 2) & 3) * 16 + (r >> 4) * 4 + (r & 3);
+}
+
+template <int D, int QF, int MODE>
+__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdArgs p) {
+    constexpr int NW = 4, NT = 256;
+    constexpr int NC = D / 32;
+    constexpr bool TAIL16 = (D % 32) != 0;
+    static_assert(D % 32 == 0 || D % 32 == 8 || D % 32 == 16, "head_dim % 32 must be 0, 8 or 16");
+    constexpr int DQK = NC * 32 + (TAIL16 ? 16 : 0);
+    constexpr int DV = (D + 15) / 16 * 16;
+    constexpr int NDF = DV / 16;
+    constexpr int DCH = D / 8;
+    constexpr int ROW = DQK + 8;   // row-major images (streamed rows x head dim), +16 B pad
+    constexpr int TROW = ST + 8;   // transposed images (head dim x streamed slots)
+    constexpr int NTR = MODE == MODE_DQ ? 1 : 2;
+    constexpr int FB = NW * 16 * QF;  // fixed-side rows per block
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* const sX = reinterpret_cast<bf16_t*>(smem_raw);          // K (DQ) / Q (DKV), row-major
+    bf16_t* const sY = sX + ST * ROW;                                 // V (DQ) / dO (DKV), row-major
+    bf16_t* const sT0 = sY + ST * ROW;                                // K^T (DQ) / Q^T (DKV)
+    bf16_t* const sT1 = sT0 + DV * TROW;                              // dO^T (DKV only)
+    float* const sStat = reinterpret_cast<float*>(sT0 + NTR * DV * TROW);  // DKV: L2[64], delta[64] of the query tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int nfixed = MODE == MODE_DQ ? p.Nq : p.Nk, nstream = MODE == MODE_DQ ? p.Nk : p.Nq;
+    const int nfb = (nfixed + FB - 1) / FB;
+    const int vb = xcd_remap(blockIdx.x, nfb * p.B * p.H);
+    const int bh = vb / nfb, fb = vb % nfb;
+    const int b = bh / p.H, h = bh % p.H;
+    const int f0 = fb * FB + wave * 16 * QF;
+
+    const bf16_t* qp = p.q + (long)b * p.q_sb + (long)h * p.q_sh;
+    const bf16_t* kp = p.k + (long)b * p.k_sb + (long)h * p.k_sh;
+    const bf16_t* vp = p.v + (long)b * p.v_sb + (long)h * p.v_sh;
+    const bf16_t* dop = p.dO + (long)b * p.o_sb + (long)h * p.o_sh;
+    // fixed side (registers): X_f pairs with the streamed X_s in S = X_s X_f^T, Y_f with Y_s in dP = Y_s Y_f^T
+    const bf16_t* xf_p = MODE == MODE_DQ ? qp : kp;   const long xf_sn = MODE == MODE_DQ ? p.q_sn : p.k_sn;
+    const bf16_t* yf_p = MODE == MODE_DQ ? dop : vp;  const long yf_sn = MODE == MODE_DQ ? p.o_sn : p.v_sn;
+    const bf16_t* xs_p = MODE == MODE_DQ ? kp : qp;   const long xs_sn = MODE == MODE_DQ ? p.k_sn : p.q_sn;
+    const bf16_t* ys_p = MODE == MODE_DQ ? vp : dop;  const long ys_sn = MODE == MODE_DQ ? p.v_sn : p.o_sn;
+
+    // zero the pad columns of the row-major images and the pad rows of the transposed ones once
+    if (DQK > D) {
+        for (int i = tid; i < 2 * ST * (DQK - D); i += NT) {
+            const int img = i / (ST * (DQK - D)), r = i % (ST * (DQK - D));
+            (img ? sY : sX)[(r / (DQK - D)) * ROW + D + r % (DQK - D)] = 0;
+        }
+    }
+    if (DV > D) {
+        for (int i = tid; i < NTR * (DV - D) * TROW; i += NT) {
+            const int img = i / ((DV - D) * TROW), r = i % ((DV - D) * TROW);
+            (img ? sT1 : sT0)[D * TROW + r] = 0;
+        }
+    }
+
+    bf16x8_t xf[QF][NC > 0 ? NC : 1], yf[QF][NC > 0 ? NC : 1];
+    s16x4_t xt[QF], yt[QF];
+#pragma unroll
+    for (int a = 0; a < QF; ++a) {
+        const int row = min(f0 + a * 16 + l15, nfixed - 1);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            xf[a][c] = as_bf16x8(*reinterpret_cast<const u32x4*>(xf_p + (long)row * xf_sn + c * 32 + lg * 8));
+            yf[a][c] = as_bf16x8(*reinterpret_cast<const u32x4*>(yf_p + (long)row * yf_sn + c * 32 + lg * 8));
+        }
+        if (TAIL16) {
+            const int d = NC * 32 + lg * 4;
+            const u32x2 t0 = *reinterpret_cast<const u32x2*>(xf_p + (long)row * xf_sn + (d < D ? d : 0));
+            const u32x2 t1 = *reinterpret_cast<const u32x2*>(yf_p + (long)row * yf_sn + (d < D ? d : 0));
+            xt[a] = as_s16x4(d < D ? t0 : (u32x2){0u, 0u});
+            yt[a] = as_s16x4(d < D ? t1 : (u32x2){0u, 0u});
+        }
+    }
+
+    const float c2 = p.scale * LOG2E;
+    const float g = p.out_scale ? p.out_scale[b] : 1.0f;
+    float l2f[QF], dlt[QF];  // MODE_DQ: per-lane L2 of its query row, running delta
+#pragma unroll
+    for (int a = 0; a < QF; ++a) {
+        dlt[a] = 0.f;
+        l2f[a] = MODE == MODE_DQ ? p.lse[((long)b * p.H + h) * p.Nq + min(f0 + a * 16 + l15, p.Nq - 1)] : 0.f;
+    }
+    f32x4 acc0[QF][NDF], acc1[QF][NDF];  // DQ: T1, T2 ; DKV: dK^T, dV^T   (lane: [d = 16 df + 4 lg + r][fixed row l15])
+#pragma unroll
+    for (int a = 0; a < QF; ++a)
+#pragma unroll
+        for (int df = 0; df < NDF; ++df) acc0[a][df] = acc1[a][df] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = (nstream + ST - 1) / ST;
+    for (int t = 0; t < ntiles; ++t) {
+        const int t0 = t * ST;
+        __syncthreads();  // everyone is done with the previous tile's images
+        // ---- stage the streamed tile: pairs of rows -> row-major images + transposed images (slots permuted) -------------
+        for (int i = tid; i < (ST / 2) * DCH; i += NT) {
+            const int pr = i / DCH, c = i - pr * DCH;
+            const int r0 = t0 + 2 * pr, r1 = r0 + 1;
+            const u32x4 z4 = {0u, 0u, 0u, 0u};
+            const u32x4 x0 = r0 < nstream ? *reinterpret_cast<const u32x4*>(xs_p + (long)r0 * xs_sn + c * 8) : z4;
+            const u32x4 x1 = r1 < nstream ? *reinterpret_cast<const u32x4*>(xs_p + (long)r1 * xs_sn + c * 8) : z4;
+            const u32x4 y0 = r0 < nstream ? *reinterpret_cast<const u32x4*>(ys_p + (long)r0 * ys_sn + c * 8) : z4;
+            const u32x4 y1 = r1 < nstream ? *reinterpret_cast<const u32x4*>(ys_p + (long)r1 * ys_sn + c * 8) : z4;
+            *reinterpret_cast<u32x4*>(sX + (2 * pr) * ROW + c * 8) = x0;
+            *reinterpret_cast<u32x4*>(sX + (2 * pr + 1) * ROW + c * 8) = x1;
+            *reinterpret_cast<u32x4*>(sY + (2 * pr) * ROW + c * 8) = y0;
+            *reinterpret_cast<u32x4*>(sY + (2 * pr + 1) * ROW + c * 8) = y1;
+            const int pos = perm_pos(2 * pr);  // even; row 2pr+1 lands at pos+1
+            const uint32_t a0[4] = {x0.x, x0.y, x0.z, x0.w}, a1[4] = {x1.x, x1.y, x1.z, x1.w};
+            const uint32_t b0[4] = {y0.x, y0.y, y0.z, y0.w}, b1[4] = {y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // transposed image of X_s (K^T in DQ mode, Q^T in DKV mode)
+                *reinterpret_cast<uint32_t*>(sT0 + (c * 8 + 2 * e) * TROW + pos) = __builtin_amdgcn_perm(a1[e], a0[e], 0x05040100u);
+                *reinterpret_cast<uint32_t*>(sT0 + (c * 8 + 2 * e + 1) * TROW + pos) = __builtin_amdgcn_perm(a1[e], a0[e], 0x07060302u);
+                if (MODE == MODE_DKV) {  // dO^T
+                    *reinterpret_cast<uint32_t*>(sT1 + (c * 8 + 2 * e) * TROW + pos) = __builtin_amdgcn_perm(b1[e], b0[e], 0x05040100u);
+                    *reinterpret_cast<uint32_t*>(sT1 + (c * 8 + 2 * e + 1) * TROW + pos) = __builtin_amdgcn_perm(b1[e], b0[e], 0x07060302u);
+                }
+            }
+        }
+        if (MODE == MODE_DKV && tid < ST) {
+            const int qrow = t0 + tid;
+            const long si = ((long)b * p.H + h) * p.Nq + min(qrow, p.Nq - 1);
+            sStat[tid] = qrow < p.Nq ? p.lse[si] : 1.0e30f;  // padding queries: P = 2^(s - 1e30) = 0
+            sStat[ST + tid] = qrow < p.Nq ? p.delta[si] : 0.f;
+        }
+        __syncthreads();
+
+        // ---- S_T = X_s X_f^T and dP_T = Y_s Y_f^T : lane holds [streamed row 16 f + 4 lg + r][fixed row l15] -----------------
+        f32x4 s[QF][4], dp[QF][4];
+        // K = 16 head-dim remainder first for all fragments, then the K = 32 chain (mixed-shape accumulate chains issued
+        // close together lose updates on gfx950, see attention.hip)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            if (TAIL16) {
+                const s16x4_t xk = as_s16x4(*reinterpret_cast<const u32x2*>(sX + (f * 16 + l15) * ROW + NC * 32 + lg * 4));
+                const s16x4_t yk = as_s16x4(*reinterpret_cast<const u32x2*>(sY + (f * 16 + l15) * ROW + NC * 32 + lg * 4));
+#pragma unroll
+                for (int a = 0; a < QF; ++a) {
+                    s[a][f] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xk, xt[a], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    dp[a][f] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yk, yt[a], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < QF; ++a) s[a][f] = dp[a][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (TAIL16) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const bf16x8_t xk = as_bf16x8(*reinterpret_cast<const u32x4*>(sX + (f * 16 + l15) * ROW + c * 32 + lg * 8));
+                const bf16x8_t yk = as_bf16x8(*reinterpret_cast<const u32x4*>(sY + (f * 16 + l15) * ROW + c * 32 + lg * 8));
+#pragma unroll
+                for (int a = 0; a < QF; ++a) {
+                    s[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xk, xf[a][c], s[a][f], 0, 0, 0);
+                    dp[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yk, yf[a][c], dp[a][f], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- P and the second-product operands --------------------------------------------------------------------------------
+        bf16x8_t rb0[QF][2], rb1[QF][2];  // DQ: (P o dP, P) ; DKV: (dS, P)
+#pragma unroll
+        for (int a = 0; a < QF; ++a) {
+            float r0v[4][4], r1v[4][4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                f32x4 lrow = {0.f, 0.f, 0.f, 0.f}, drow = {0.f, 0.f, 0.f, 0.f};
+                if (MODE == MODE_DKV) {
+                    lrow = *reinterpret_cast<const f32x4*>(sStat + f * 16 + lg * 4);
+                    drow = *reinterpret_cast<const f32x4*>(sStat + ST + f * 16 + lg * 4);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pv;
+                    if (MODE == MODE_DQ) {
+                        pv = __builtin_amdgcn_exp2f(fmaf(s[a][f][r], c2, -l2f[a]));
+                        if (t0 + f * 16 + lg * 4 + r >= p.Nk) pv = 0.f;  // padding keys
+                        const float w = pv * dp[a][f][r];
+                        dlt[a] += w;
+                        r0v[f][r] = w;
+                        r1v[f][r] = pv;
+                    } else {
+                        pv = __builtin_amdgcn_exp2f(fmaf(s[a][f][r], c2, -lrow[r]));
+                        r0v[f][r] = pv * (dp[a][f][r] - drow[r]);
+                        r1v[f][r] = pv;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                u32x4 w0, w1;
+                w0.x = pack_bf16x2(r0v[2 * j][0], r0v[2 * j][1]); w0.y = pack_bf16x2(r0v[2 * j][2], r0v[2 * j][3]);
+                w0.z = pack_bf16x2(r0v[2 * j + 1][0], r0v[2 * j + 1][1]); w0.w = pack_bf16x2(r0v[2 * j + 1][2], r0v[2 * j + 1][3]);
+                w1.x = pack_bf16x2(r1v[2 * j][0], r1v[2 * j][1]); w1.y = pack_bf16x2(r1v[2 * j][2], r1v[2 * j][3]);
+                w1.z = pack_bf16x2(r1v[2 * j + 1][0], r1v[2 * j + 1][1]); w1.w = pack_bf16x2(r1v[2 * j + 1][2], r1v[2 * j + 1][3]);
+                rb0[a][j] = as_bf16x8(w0);
+                rb1[a][j] = as_bf16x8(w1);
+            }
+        }
+
+        // ---- acc^T[d][fixed] += Z^T[d][streamed] R[streamed][fixed] -------------------------------------------------------------
+#pragma unroll
+        for (int df = 0; df < NDF; ++df) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8_t z0 = as_bf16x8(*reinterpret_cast<const u32x4*>(sT0 + (df * 16 + l15) * TROW + lg * 16 + j * 8));
+                bf16x8_t z1 = z0;  // DQ: both products use K^T ; DKV: dV uses dO^T
+                if (MODE == MODE_DKV) z1 = as_bf16x8(*reinterpret_cast<const u32x4*>(sT1 + (df * 16 + l15) * TROW + lg * 16 + j * 8));
+#pragma unroll
+                for (int a = 0; a < QF; ++a) {
+                    acc0[a][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z0, rb0[a][j], acc0[a][df], 0, 0, 0);
+                    acc1[a][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z1, rb1[a][j], acc1[a][df], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int a = 0; a < QF; ++a) {
+        const int row = f0 + a * 16 + l15;
+        if (MODE == MODE_DQ) {
+            float dsum = dlt[a];
+            dsum += __shfl_xor(dsum, 16, 64);
+            dsum += __shfl_xor(dsum, 32, 64);
+            if (row < p.Nq && lg == 0) p.delta[((long)b * p.H + h) * p.Nq + row] = dsum;
+            if (row >= p.Nq) continue;
+            bf16_t* dst = p.dq + (long)b * p.dq_sb + (long)h * p.dq_sh + (long)row * p.dq_sn;
+            const float gs = g * p.scale;
+#pragma unroll
+            for (int df = 0; df < NDF; ++df) {
+                const int d = df * 16 + lg * 4;
+                if (d >= D) continue;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = gs * (acc0[a][df][r] - dsum * acc1[a][df][r]);
+                if (p.accum_dq) {
+                    const u32x2 old = *reinterpret_cast<const u32x2*>(dst + d);
+                    o[0] += bf16lo(old.x); o[1] += bf16hi(old.x); o[2] += bf16lo(old.y); o[3] += bf16hi(old.y);
+                }
+                *reinterpret_cast<u32x2*>(dst + d) = (u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            }
+        } else {
+            if (row >= p.Nk) continue;
+            bf16_t* dkd = p.dk + (long)b * p.dk_sb + (long)h * p.dk_sh + (long)row * p.dk_sn;
+            bf16_t* dvd = p.dv + (long)b * p.dv_sb + (long)h * p.dv_sh + (long)row * p.dv_sn;
+            const float gs = g * p.scale;
+#pragma unroll
+            for (int df = 0; df < NDF; ++df) {
+                const int d = df * 16 + lg * 4;
+                if (d >= D) continue;
+                *reinterpret_cast<u32x2*>(dkd + d) = (u32x2){pack_bf16x2(gs * acc0[a][df][0], gs * acc0[a][df][1]), pack_bf16x2(gs * acc0[a][df][2], gs * acc0[a][df][3])};
+                *reinterpret_cast<u32x2*>(dvd + d) = (u32x2){pack_bf16x2(g * acc1[a][df][0], g * acc1[a][df][1]), pack_bf16x2(g * acc1[a][df][2], g * acc1[a][df][3])};
+            }
+        }
+    }
+}
+
+template <int D, int QF, int MODE>
+int launch_bwd(const BwdArgs& a, hipStream_t stream) {
+    constexpr int NC = D / 32;
+    constexpr int DQK = NC * 32 + ((D % 32) ? 16 : 0);
+    constexpr int DV = (D + 15) / 16 * 16;
+    constexpr int NTR = MODE == MODE_DQ ? 1 : 2;
+    constexpr size_t lds = (size_t)(2 * ST * (DQK + 8) + NTR * DV * (ST + 8)) * sizeof(bf16_t) + 2 * ST * sizeof(float);
+    constexpr int FB = 4 * 16 * QF;
+    const int nfixed = MODE == MODE_DQ ? a.Nq : a.Nk;
+    const long blocks = (long)((nfixed + FB - 1) / FB) * a.B * a.H;
+    if (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<D, QF, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                ae_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", lds);
+                return AE_ERR_LAUNCH;
+            }
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL((attn_bwd_kernel<D, QF, MODE>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    return ae_check_launch(MODE == MODE_DQ ? "ae_attn_bwd_bf16(dQ)" : "ae_attn_bwd_bf16(dK,dV)");
+}
+
+template <int D, int QF>
+int launch_both(const BwdArgs& a, hipStream_t stream) {
+    int rc = launch_bwd<D, QF, MODE_DQ>(a, stream);
+    if (rc) return rc;
+    if (!a.dk) return 0;  // caller only needs dQ (frozen key/value side)
+    return launch_bwd<D, QF, MODE_DKV>(a, stream);
+}
+
+}  // namespace
+
+// Gradients of ae_attn_fwd_bf16 for one key/value segment.  `lse` is the forward's log2-domain log-sum-exp for THIS segment;
+// `delta` ([B,H,Nq] fp32) is an output (rowsum(P o dP) with the UN-scaled dO: summed over heads and rows it is the gradient of
+// the segment's out_scale).  dk / dv may both be NULL when only dQ is needed.  dq is overwritten, or accumulated if accumulate_dq.
+extern "C" int ae_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dout, const float* lse, float* delta,
+                                void* dq, void* dk, void* dv, int B, int H, int Nq, int Nk, int D,
+                                long q_sb, long q_sh, long q_sn, long k_sb, long k_sh, long k_sn, long v_sb, long v_sh, long v_sn,
+                                long o_sb, long o_sh, long o_sn, long dq_sb, long dq_sh, long dq_sn, long dk_sb, long dk_sh, long dk_sn,
+                                long dv_sb, long dv_sh, long dv_sn, float scale, const float* out_scale, int accumulate_dq,
+                                void* stream) {
+    AE_REQUIRE(q && k && v && dout && lse && delta && dq, "ae_attn_bwd_bf16: null pointer");
+    AE_REQUIRE((dk == nullptr) == (dv == nullptr), "ae_attn_bwd_bf16: dk and dv go together");
+    AE_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0, "ae_attn_bwd_bf16: bad sizes B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
+    AE_REQUIRE((q_sb | q_sh | q_sn | k_sb | k_sh | k_sn | v_sb | v_sh | v_sn | o_sb | o_sh | o_sn) % 8 == 0,
+               "ae_attn_bwd_bf16: input strides must keep rows 16-byte aligned");
+    AE_REQUIRE((dq_sb | dq_sh | dq_sn | dk_sb | dk_sh | dk_sn | dv_sb | dv_sh | dv_sn) % 4 == 0, "ae_attn_bwd_bf16: gradient strides must keep rows 8-byte aligned");
+    AE_REQUIRE(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0 && ((uintptr_t)dout & 15) == 0 &&
+                   ((uintptr_t)dq & 7) == 0 && ((uintptr_t)dk & 7) == 0 && ((uintptr_t)dv & 7) == 0,
+               "ae_attn_bwd_bf16: pointer alignment");
+    BwdArgs a{};
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.dO = (const bf16_t*)dout;
+    a.lse = lse; a.delta = delta; a.out_scale = out_scale;
+    a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk;
+    a.q_sb = q_sb; a.q_sh = q_sh; a.q_sn = q_sn; a.k_sb = k_sb; a.k_sh = k_sh; a.k_sn = k_sn;
+    a.v_sb = v_sb; a.v_sh = v_sh; a.v_sn = v_sn; a.o_sb = o_sb; a.o_sh = o_sh; a.o_sn = o_sn;
+    a.dq_sb = dq_sb; a.dq_sh = dq_sh; a.dq_sn = dq_sn; a.dk_sb = dk_sb; a.dk_sh = dk_sh; a.dk_sn = dk_sn;
+    a.dv_sb = dv_sb; a.dv_sh = dv_sh; a.dv_sn = dv_sn;
+    a.scale = scale; a.accum_dq = accumulate_dq;
+    hipStream_t s = (hipStream_t)stream;
+    switch (D) {
+        case 8: return launch_both<8, 2>(a, s);
+        case 16: return launch_both<16, 2>(a, s);
+        case 32: return launch_both<32, 2>(a, s);
+        case 40: return launch_both<40, 2>(a, s);
+        case 48: return launch_both<48, 2>(a, s);
+        case 64: return launch_both<64, 2>(a, s);
+        case 80: return launch_both<80, 2>(a, s);
+        case 96: return launch_both<96, 1>(a, s);
+        case 128: return launch_both<128, 1>(a, s);
+        case 160: return launch_both<160, 1>(a, s);
+        default:
+            ae_set_error("ae_attn_bwd_bf16: unsupported head_dim %d (supported: 8,16,32,40,48,64,80,96,128,160)", D);
+            return AE_ERR_UNSUPPORTED;
+    }
+}

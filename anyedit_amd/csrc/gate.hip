@@ -39,7 +39,28 @@ __global__ __launch_bounds__(64) void task_gate_kernel(const float* task_emb, co
         if (top1_prob) top1_prob[b] = best;
     }
 }
+// Backward of g_b = softmax(Wg te_b + bg)[top1_b] w.r.t. the task embedding row (argmax is a constant of the step):
+//   dlogit[e] = dg_b * g_b * ((e == top1_b) - probs[b, e]);   dte_b = Wg^T dlogit      (Wg, bg are not trained, train.py:483-485)
+__global__ __launch_bounds__(256) void task_gate_bwd_kernel(const float* probs, const int* top1, const float* dgate, const float* Wg,
+                                                            int Dt, int E, float* dte) {
+    const int b = blockIdx.x;
+    const int t1 = top1[b];
+    const float gb = probs[(long)b * E + t1], dg = dgate[b];
+    for (int i = threadIdx.x; i < Dt; i += 256) {
+        float acc = 0.f;
+        for (int e = 0; e < E; ++e) acc += dg * gb * ((e == t1 ? 1.0f : 0.0f) - probs[(long)b * E + e]) * Wg[(long)e * Dt + i];
+        dte[(long)b * Dt + i] = acc;
+    }
+}
 }  // namespace
+
+extern "C" int ae_task_gate_bwd(const float* probs, const int* top1, const float* dgate, const float* Wg, int B, int Dt, int E,
+                                float* dte, void* stream) {
+    AE_REQUIRE(probs && top1 && dgate && Wg && dte, "ae_task_gate_bwd: null pointer");
+    AE_REQUIRE(B > 0 && Dt > 0 && E > 0 && E <= 64, "ae_task_gate_bwd: bad sizes");
+    hipLaunchKernelGGL(task_gate_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, probs, top1, dgate, Wg, Dt, E, dte);
+    return ae_check_launch("ae_task_gate_bwd");
+}
 
 extern "C" int ae_task_gate(const float* task_emb, const long* edit_code, const float* Wg, const float* bg, int B, int n_tasks, int Dt,
                             int E, float* probs, int* top1, float* top1_prob, void* stream) {

@@ -143,7 +143,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
 #pragma unroll
                 for (int t9 = 0; t9 < 9; ++t9) {
                     const int iy = iy0 + t9 / 3, ix = ix0 + t9 % 3;
-                    if ((unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv) fa_mask[i] |= 1u << t9;
+                    // ups == 2: zero-insert upsampling (adjoint of a stride-2 conv): only even virtual pixels carry data
+                    if ((unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv && (p.ups != 2 || ((iy | ix) & 1) == 0)) fa_mask[i] |= 1u << t9;
                 }
             }
 
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
                 const int c = (tid + i * NT) & 7;
                 const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
                 const int ci = ld_ci + c * 8;
-                const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv && ci < p.Cin;
+                const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv && ci < p.Cin && (p.ups != 2 || ((iy | ix) & 1) == 0);
                 const int cy = min(max(iy, 0), Hv - 1), cx = min(max(ix, 0), Wv - 1);
                 const int sy = p.ups ? (cy >> 1) : cy, sx = p.ups ? (cx >> 1) : cx;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(p.A + (a_base[i] + (long)sy * p.Wd + sx) * p.Cin + min(ci, p.Cin - 8));
@@ -729,6 +730,7 @@ extern "C" int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, 
     AE_REQUIRE(Cin % 8 == 0, "ae_conv3x3_bf16: Cin=%d must be a multiple of 8", Cin);
     AE_REQUIRE(Cout % 4 == 0, "ae_conv3x3_bf16: Cout=%d must be a multiple of 4", Cout);
     AE_REQUIRE(stride == 1 || stride == 2, "ae_conv3x3_bf16: stride must be 1 or 2");
+    AE_REQUIRE(upsample2x >= 0 && upsample2x <= 2, "ae_conv3x3_bf16: upsample2x must be 0, 1 (nearest) or 2 (zero-insert)");
     AE_REQUIRE(!(upsample2x && stride != 1), "ae_conv3x3_bf16: upsample2x requires stride 1");
     AE_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), "ae_conv3x3_bf16: pointers must be 16-byte aligned");
     const int Hv = upsample2x ? 2 * H : H, Wv = upsample2x ? 2 * W : W;

@@ -25,6 +25,11 @@ struct GNArgs {
     float* coef;   // [B][2][C]               per-channel scale / shift
     int B, HW, C, groups, rows_per_chunk, nchunk, act;
     float eps;
+    float* stat;   // optional [B][groups][2] (mean, rstd): written by finalize for the backward pass
+    // backward (ae_groupnorm_bwd_nhwc_bf16)
+    const bf16_t* dy; bf16_t* dx; bf16_t* dx2;
+    float* part2;  // [B][nchunk][groups][2]  partial (sum dz*gamma, sum dz*(z - beta))
+    float* coef2;  // [B][2][C]               per-channel kA, kB of dx = dz*scale + x*kA + kB
 };
 
 __device__ __forceinline__ u32x4 gn_load(const GNArgs& p, long row, int cc) {
@@ -108,6 +113,10 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const GNArgs p) {
         const float var = fmaxf(sc / n - mu * mu, 0.f);
         mean[g] = mu;
         rstd[g] = rsqrtf(var + p.eps);
+        if (p.stat) {
+            p.stat[((long)b * p.groups + g) * 2 + 0] = mu;
+            p.stat[((long)b * p.groups + g) * 2 + 1] = rstd[g];
+        }
     }
     __syncthreads();
     const int cpg = p.C / p.groups;
@@ -152,6 +161,204 @@ __global__ void gn_apply_kernel(const GNArgs p) {
         }
         *reinterpret_cast<u32x4*>(p.y + row * p.C + cc * 8) = (u32x4){o[0], o[1], o[2], o[3]};
     }
+}
+
+// ---- GroupNorm(+SiLU) backward (training step, SURVEY.md row A11: the frozen UNet is differentiated w.r.t. its activations).
+//   z = x*scale + shift, y = act(z);  dz = dy * act'(z);  per (batch, group): m1 = mean(dz*gamma), m2 = mean(dz*gamma*xhat)
+//   dx = rstd * (dz*gamma - m1 - xhat*m2) = dz*scale + x*kA + kB,  kA = -rstd^2 m2,  kB = mu rstd^2 m2 - rstd m1
+// and dz*gamma*xhat = dz*(z - beta): no division by gamma anywhere.  Same launch geometry and fixed-order folds as the forward.
+__device__ __forceinline__ float act_grad(float z, int act) {
+    if (act == 0) return 1.0f;
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+    return sg * (1.0f + z * (1.0f - sg));
+}
+
+__global__ void gnb_partial_kernel(const GNArgs p) {
+    extern __shared__ float lds[];  // [rpp][2][C]
+    const int ncc = p.C / 8;
+    const int cc = threadIdx.x % ncc, rr = threadIdx.x / ncc, rpp = blockDim.x / ncc;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int r0 = chunk * p.rows_per_chunk;
+    const int r1 = min(r0 + p.rows_per_chunk, p.HW);
+    if (rr < rpp) {
+        float t1[8], t2[8], sc[8], sh[8], gm[8], bt[8];
+        const float* cs = p.coef + ((long)b * 2) * p.C + cc * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            t1[e] = t2[e] = 0.f;
+            sc[e] = cs[e]; sh[e] = cs[p.C + e]; gm[e] = p.gamma[cc * 8 + e]; bt[e] = p.beta[cc * 8 + e];
+        }
+        for (int r = r0 + rr; r < r1; r += rpp) {
+            const long row = (long)b * p.HW + r;
+            const u32x4 xv = gn_load(p, row, cc);
+            const u32x4 dv = *reinterpret_cast<const u32x4*>(p.dy + row * p.C + cc * 8);
+            const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z0 = bf16lo(xw[e]) * sc[2 * e] + sh[2 * e], z1 = bf16hi(xw[e]) * sc[2 * e + 1] + sh[2 * e + 1];
+                const float d0 = bf16lo(dw[e]) * act_grad(z0, p.act), d1 = bf16hi(dw[e]) * act_grad(z1, p.act);
+                t1[2 * e] += d0 * gm[2 * e]; t2[2 * e] += d0 * (z0 - bt[2 * e]);
+                t1[2 * e + 1] += d1 * gm[2 * e + 1]; t2[2 * e + 1] += d1 * (z1 - bt[2 * e + 1]);
+            }
+        }
+        float* d0 = lds + (long)rr * 2 * p.C + cc * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { d0[e] = t1[e]; d0[p.C + e] = t2[e]; }
+    }
+    __syncthreads();
+    const int cpg = p.C / p.groups;
+    if (threadIdx.x < p.groups) {
+        float a = 0.f, c = 0.f;
+        for (int j = 0; j < rpp; ++j)
+            for (int i = 0; i < cpg; ++i) {
+                a += lds[(long)j * 2 * p.C + threadIdx.x * cpg + i];
+                c += lds[(long)j * 2 * p.C + p.C + threadIdx.x * cpg + i];
+            }
+        float* dst = p.part2 + (((long)b * p.nchunk + chunk) * p.groups + threadIdx.x) * 2;
+        dst[0] = a;
+        dst[1] = c;
+    }
+}
+
+__global__ __launch_bounds__(1024) void gnb_finalize_kernel(const GNArgs p) {
+    __shared__ float red[2][16][64];
+    __shared__ float kA[64], kB[64];
+    const int b = blockIdx.x;
+    const int g = threadIdx.x & 63, part = threadIdx.x >> 6;
+    float a = 0.f, c = 0.f;
+    if (g < p.groups) {
+        for (int i = part; i < p.nchunk; i += 16) {
+            const float* src = p.part2 + (((long)b * p.nchunk + i) * p.groups + g) * 2;
+            a += src[0];
+            c += src[1];
+        }
+    }
+    red[0][part][g] = a;
+    red[1][part][g] = c;
+    __syncthreads();
+    if (part == 0 && g < p.groups) {
+        float sa = 0.f, sc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { sa += red[0][j][g]; sc += red[1][j][g]; }
+        const float n = (float)(p.C / p.groups) * (float)p.HW;
+        const float m1 = sa / n, m2 = sc / n;
+        const float mu = p.stat[((long)b * p.groups + g) * 2 + 0], rs = p.stat[((long)b * p.groups + g) * 2 + 1];
+        kA[g] = -rs * rs * m2;
+        kB[g] = mu * rs * rs * m2 - rs * m1;
+    }
+    __syncthreads();
+    const int cpg = p.C / p.groups;
+    for (int ch = threadIdx.x; ch < p.C; ch += blockDim.x) {
+        p.coef2[((long)b * 2 + 0) * p.C + ch] = kA[ch / cpg];
+        p.coef2[((long)b * 2 + 1) * p.C + ch] = kB[ch / cpg];
+    }
+}
+
+__global__ void gnb_apply_kernel(const GNArgs p) {
+    const int ncc = p.C / 8;
+    const int cc = threadIdx.x % ncc, rr = threadIdx.x / ncc, rpp = blockDim.x / ncc;
+    if (rr >= rpp) return;
+    const int b = blockIdx.y;
+    float sc[8], sh[8], ka[8], kb[8];
+    const float* cs = p.coef + ((long)b * 2) * p.C + cc * 8;
+    const float* c2 = p.coef2 + ((long)b * 2) * p.C + cc * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = cs[e]; sh[e] = cs[p.C + e]; ka[e] = c2[e]; kb[e] = c2[p.C + e]; }
+    const int r0 = blockIdx.x * p.rows_per_chunk;
+    const int r1 = min(r0 + p.rows_per_chunk, p.HW);
+    const int ch = cc * 8;
+    for (int r = r0 + rr; r < r1; r += rpp) {
+        const long row = (long)b * p.HW + r;
+        const u32x4 xv = gn_load(p, row, cc);
+        const u32x4 dv = *reinterpret_cast<const u32x4*>(p.dy + row * p.C + ch);
+        const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x0 = bf16lo(xw[e]), x1 = bf16hi(xw[e]);
+            const float z0 = x0 * sc[2 * e] + sh[2 * e], z1 = x1 * sc[2 * e + 1] + sh[2 * e + 1];
+            const float d0 = bf16lo(dw[e]) * act_grad(z0, p.act), d1 = bf16hi(dw[e]) * act_grad(z1, p.act);
+            o[e] = pack_bf16x2(d0 * sc[2 * e] + x0 * ka[2 * e] + kb[2 * e], d1 * sc[2 * e + 1] + x1 * ka[2 * e + 1] + kb[2 * e + 1]);
+        }
+        const u32x4 ov = {o[0], o[1], o[2], o[3]};
+        if (ch < p.C1) *reinterpret_cast<u32x4*>(p.dx + row * p.C1 + ch) = ov;
+        else *reinterpret_cast<u32x4*>(p.dx2 + row * (p.C - p.C1) + (ch - p.C1)) = ov;
+    }
+}
+
+// LayerNorm backward w.r.t. the input: t = dy*gamma, dx = rstd * (t - mean(t) - xhat * mean(t*xhat)); one wave per row.
+// Optionally writes (mean, rstd) per row for the parameter-gradient kernel.
+template <int MAXCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* x, const float* gamma, const bf16_t* dy, bf16_t* dx,
+                                                            float* row_stat, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    const int ncc = C / 8;
+    float xv[MAXCH][8], tv[MAXCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int cc = lane + i * 64;
+        if (cc < ncc) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(x + row * C + cc * 8);
+            const u32x4 d = *reinterpret_cast<const u32x4*>(dy + row * C + cc * 8);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w}, dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xv[i][2 * e] = bf16lo(w[e]); xv[i][2 * e + 1] = bf16hi(w[e]);
+                tv[i][2 * e] = bf16lo(dw[e]) * gamma[cc * 8 + 2 * e]; tv[i][2 * e + 1] = bf16hi(dw[e]) * gamma[cc * 8 + 2 * e + 1];
+                s += xv[i][2 * e] + xv[i][2 * e + 1];
+            }
+        }
+    }
+    const float mu = wave_reduce_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i)
+        if (lane + i * 64 < ncc) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float a = xv[i][e] - mu; q += a * a; }
+        }
+    const float rstd = rsqrtf(wave_reduce_sum(q) / (float)C + eps);
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i)
+        if (lane + i * 64 < ncc) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a1 += tv[i][e]; a2 += tv[i][e] * (xv[i][e] - mu) * rstd; }
+        }
+    const float m1 = wave_reduce_sum(a1) / (float)C, m2 = wave_reduce_sum(a2) / (float)C;
+    if (row_stat && lane == 0) { row_stat[row * 2] = mu; row_stat[row * 2 + 1] = rstd; }
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int cc = lane + i * 64;
+        if (cc < ncc) {
+            uint32_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float h0 = (xv[i][2 * e] - mu) * rstd, h1 = (xv[i][2 * e + 1] - mu) * rstd;
+                o[e] = pack_bf16x2(rstd * (tv[i][2 * e] - m1 - h0 * m2), rstd * (tv[i][2 * e + 1] - m1 - h1 * m2));
+            }
+            *reinterpret_cast<u32x4*>(dx + row * C + cc * 8) = (u32x4){o[0], o[1], o[2], o[3]};
+        }
+    }
+}
+
+// dgamma[c] = sum_m dy*xhat, dbeta[c] = sum_m dy (fixed order over rows: deterministic); one thread per channel, small M only
+// (the image-projection LayerNorm of the AnySD adapter: 16 rows).
+__global__ void layernorm_param_grad_kernel(const bf16_t* x, const bf16_t* dy, const float* row_stat, float* dgamma, float* dbeta,
+                                            int M, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float g = 0.f, bsum = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float d = bf16_to_f32(dy[(long)m * C + c]);
+        g += d * (bf16_to_f32(x[(long)m * C + c]) - row_stat[m * 2]) * row_stat[m * 2 + 1];
+        bsum += d;
+    }
+    dgamma[c] = g;
+    dbeta[c] = bsum;
 }
 
 // LayerNorm over the last dim: one wave per row, 16-byte loads, two-pass (mean, then centred variance) in registers.
@@ -276,4 +483,82 @@ extern "C" int ae_layernorm_bf16(const void* x, const float* gamma, const float*
     else if (ncc <= 192) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);
     else hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);
     return ae_check_launch("ae_layernorm_bf16");
+}
+
+extern "C" long ae_groupnorm_bwd_workspace_floats(int B, int HW, int C, int groups) {
+    const int rpc = ae_groupnorm_rows_per_chunk(HW, C);
+    const int nchunk = (HW + rpc - 1) / rpc;
+    const long partials = (((long)B * nchunk * groups * 2 + 3) / 4) * 4;
+    return 2 * partials + 2 * (long)B * 2 * C + (((long)B * groups * 2 + 3) / 4) * 4;
+}
+
+extern "C" int ae_groupnorm_bwd_nhwc_bf16(const void* x, const void* x2, int C1, const float* gamma, const float* beta, const void* dy,
+                                          void* dx, void* dx2, int B, int HW, int C, int groups, float eps, int act,
+                                          float* workspace, void* stream) {
+    AE_REQUIRE(x && gamma && beta && dy && dx && workspace, "ae_groupnorm_bwd_nhwc_bf16: null pointer");
+    AE_REQUIRE(B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, "ae_groupnorm_bwd_nhwc_bf16: bad shape C=%d groups=%d", C, groups);
+    AE_REQUIRE(C % 8 == 0 && C <= 8192 && groups <= 64 && B <= 65535, "ae_groupnorm_bwd_nhwc_bf16: unsupported size");
+    AE_REQUIRE(act == 0 || act == 1, "ae_groupnorm_bwd_nhwc_bf16: act must be 0 (none) or 1 (SiLU)");
+    if (x2) AE_REQUIRE(dx2 && C1 > 0 && C1 < C && C1 % 8 == 0, "ae_groupnorm_bwd_nhwc_bf16: bad concat split C1=%d C=%d", C1, C);
+    AE_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0 && ((uintptr_t)x2 & 15) == 0 &&
+                   ((uintptr_t)dx2 & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
+               "ae_groupnorm_bwd_nhwc_bf16: 16-byte alignment");
+    GNArgs p{};
+    p.x = (const bf16_t*)x; p.x2 = (const bf16_t*)x2; p.C1 = x2 ? C1 : C;
+    p.gamma = gamma; p.beta = beta; p.y = nullptr;
+    p.dy = (const bf16_t*)dy; p.dx = (bf16_t*)dx; p.dx2 = (bf16_t*)dx2;
+    p.B = B; p.HW = HW; p.C = C; p.groups = groups; p.act = act; p.eps = eps;
+    p.rows_per_chunk = ae_groupnorm_rows_per_chunk(HW, C);
+    p.nchunk = (HW + p.rows_per_chunk - 1) / p.rows_per_chunk;
+    const long partials = (((long)B * p.nchunk * groups * 2 + 3) / 4) * 4;
+    p.part = workspace;
+    p.part2 = workspace + partials;
+    p.coef = workspace + 2 * partials;
+    p.coef2 = p.coef + (long)B * 2 * C;
+    p.stat = p.coef2 + (long)B * 2 * C;
+    const int ncc = C / 8;
+    int rpp = 256 / ncc;
+    if (rpp < 1) rpp = 1;
+    int threads = ncc * rpp;
+    if (threads < 64) threads = 64;
+    dim3 grid(p.nchunk, B);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)(threads / ncc) * 2 * C * sizeof(float);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), lds, s, p);
+    int rc = ae_check_launch("ae_groupnorm_bwd_nhwc_bf16(stats)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(1024), 0, s, p);
+    rc = ae_check_launch("ae_groupnorm_bwd_nhwc_bf16(finalize)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gnb_partial_kernel, grid, dim3(threads), lds, s, p);
+    rc = ae_check_launch("ae_groupnorm_bwd_nhwc_bf16(partial)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gnb_finalize_kernel, dim3(B), dim3(1024), 0, s, p);
+    rc = ae_check_launch("ae_groupnorm_bwd_nhwc_bf16(finalize2)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gnb_apply_kernel, grid, dim3(threads), 0, s, p);
+    return ae_check_launch("ae_groupnorm_bwd_nhwc_bf16(apply)");
+}
+
+extern "C" int ae_layernorm_bwd_bf16(const void* x, const float* gamma, const void* dy, void* dx, float* row_stat, int M, int C,
+                                     float eps, void* stream) {
+    AE_REQUIRE(x && gamma && dy && dx, "ae_layernorm_bwd_bf16: null pointer");
+    AE_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "ae_layernorm_bwd_bf16: C=%d must be a multiple of 8 and <= 2048", C);
+    AE_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0, "ae_layernorm_bwd_bf16: 16-byte alignment");
+    dim3 grid((M + 3) / 4), block(256);
+    const int ncc = C / 8;
+    hipStream_t s = (hipStream_t)stream;
+    if (ncc <= 64) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, s, (const bf16_t*)x, gamma, (const bf16_t*)dy, (bf16_t*)dx, row_stat, M, C, eps);
+    else if (ncc <= 128) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, s, (const bf16_t*)x, gamma, (const bf16_t*)dy, (bf16_t*)dx, row_stat, M, C, eps);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, s, (const bf16_t*)x, gamma, (const bf16_t*)dy, (bf16_t*)dx, row_stat, M, C, eps);
+    return ae_check_launch("ae_layernorm_bwd_bf16");
+}
+
+extern "C" int ae_layernorm_param_grad_f32(const void* x, const void* dy, const float* row_stat, float* dgamma, float* dbeta, int M,
+                                           int C, void* stream) {
+    AE_REQUIRE(x && dy && row_stat && dgamma && dbeta, "ae_layernorm_param_grad_f32: null pointer");
+    AE_REQUIRE(M > 0 && M <= 4096 && C > 0, "ae_layernorm_param_grad_f32: M=%d must be in [1, 4096] (small-batch parameter gradients only)", M);
+    hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (const bf16_t*)dy, row_stat, dgamma, dbeta, M, C);
+    return ae_check_launch("ae_layernorm_param_grad_f32");
 }

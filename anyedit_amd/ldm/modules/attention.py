@@ -59,6 +59,12 @@ class GEGLU(nn.Module):
         self._pk = None
 
     def rows(self, x):
+        if ops._TAPE is not None and ops._TAPE.active:
+            # training step: the pre-activation [a | g] is kept for the backward, so the gate runs as its own kernel
+            if getattr(self, "_pk_plain", None) is None or self._pk_plain[0].device != self.proj.weight.device:
+                self._pk_plain = (ops.pack_linear(self.proj.weight), self.proj.bias.detach().float().contiguous())
+            w, b = self._pk_plain
+            return ops.geglu(ops.gemm(x, w, b))
         if self._pk is None or self._pk[0].device != self.proj.weight.device:
             self._pk = ops.pack_geglu(self.proj.weight, self.proj.bias)
         w, b = self._pk
@@ -147,7 +153,7 @@ class CrossAttention(nn.Module):
                 kv_ip, gate = adapter
                 T_ip = kv_ip.shape[0] // B
                 ks_ip = (T_ip * 2 * inner, d, 2 * inner)
-                seg2 = (kv_ip.data_ptr(), kv_ip[:, inner:].data_ptr(), T_ip, *ks_ip, *ks_ip, gate.data_ptr())
+                seg2 = (kv_ip, kv_ip[:, inner:], T_ip, ks_ip, ks_ip, gate)
                 o = ops.attention(q, kv, kv[:, inner:], B, h, N, Nk, d, self.scale, qs, ks, ks, seg2=seg2)
             else:
                 o = ops.attention(q, kv, kv[:, inner:], B, h, N, Nk, d, self.scale, qs, ks, ks, key_mask=key_mask)

@@ -58,6 +58,8 @@ def pack_geglu(w, b):
 # --------------------------------------------------------------------------- GEMM / conv
 def gemm(a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue=EPI_NONE, out_f32=False, a2=None, out=None):
     """out[M,N] = epi(cat([a, a2], 1) @ w^T).  a: [M,K1] bf16 (row stride free), w: [N,K] bf16."""
+    if _TAPE is not None and _TAPE.active:
+        return _TAPE.gemm(a, w, bias=bias, residual=residual, addvec=addvec, rows_per_batch=rows_per_batch, epilogue=epilogue, out_f32=out_f32, a2=a2, out=out)
     _chk(a, BF16, "gemm.a", 2)
     _chk(w, BF16, "gemm.w", 2)
     M, K1 = a.shape
@@ -91,6 +93,8 @@ def gemm(a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue
 
 def conv3x3(x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2x=False, out_f32=False, out=None):
     """x: [B*H*W, Cin] bf16 channels-last, w: packed [Cout, 9*Cin].  Returns ([B*Ho*Wo, Cout], Ho, Wo)."""
+    if _TAPE is not None and _TAPE.active:
+        return _TAPE.conv3x3(x, w, bias, B, H, W, addvec=addvec, residual=residual, stride=stride, upsample2x=upsample2x, out_f32=out_f32, out=out)
     _chk(x, BF16, "conv3x3.x", 2)
     _chk(w, BF16, "conv3x3.w", 2)
     Cin = x.shape[1]
@@ -107,10 +111,10 @@ def conv3x3(x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2
         _chk(residual, BF16, "conv3x3.residual", 2)
         if residual.shape != (B * Ho * Wo, Cout) or not residual.is_contiguous():
             raise ValueError("conv3x3: residual shape mismatch")
-    nws = lib.ae_conv3x3_workspace_floats(B, H, W, Cin, Cout, stride, 1 if upsample2x else 0)
+    nws = lib.ae_conv3x3_workspace_floats(B, H, W, Cin, Cout, stride, int(upsample2x))
     ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws > 0 else None  # split-K partials (small-M layers)
     check(lib.ae_conv3x3_bf16(_p(x), _p(w), _p(bias), _p(addvec), addvec.stride(0) if addvec is not None else 0, _p(residual),
-                              _p(out), B, H, W, Cin, Cout, stride, 1 if upsample2x else 0, 1 if out_f32 else 0, _p(ws), _s()),
+                              _p(out), B, H, W, Cin, Cout, stride, int(upsample2x), 1 if out_f32 else 0, _p(ws), _s()),
           "ae_conv3x3_bf16")
     return out, Ho, Wo
 
@@ -118,6 +122,8 @@ def conv3x3(x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2
 # --------------------------------------------------------------------------- norms
 def groupnorm(x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, out=None):
     """GroupNorm(+SiLU) over channels-last [B*HW, C]; x2: optional second tensor concatenated along channels."""
+    if _TAPE is not None and _TAPE.active:
+        return _TAPE.groupnorm(x, gamma, beta, B, HW, eps, silu=silu, groups=groups, x2=x2, out=out)
     _chk(x, BF16, "groupnorm.x", 2)
     C1 = x.shape[1]
     C = C1 + (x2.shape[1] if x2 is not None else 0)
@@ -132,6 +138,8 @@ def groupnorm(x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, out=No
 
 
 def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    if _TAPE is not None and _TAPE.active:
+        return _TAPE.layernorm(x, gamma, beta, eps=eps, out=out)
     _chk(x, BF16, "layernorm.x", 2)
     if not x.is_contiguous():
         raise ValueError("layernorm: x must be contiguous")
@@ -144,15 +152,39 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
 
 # --------------------------------------------------------------------------- attention
 def attention(q, k, v, B, H, Nq, Nk, D, scale, q_strides, k_strides, v_strides, out=None, rel_h=None, rel_w=None,
-              kH=0, kW=0, key_mask=None, out_scale=None, accumulate=False, seg2=None):
-    """q/k/v: bf16 tensors (any shape) addressed via (batch, head, row) element strides; out: [B, Nq, H*D] bf16."""
+              kH=0, kW=0, key_mask=None, out_scale=None, accumulate=False, seg2=None, lse=None, lse2=None):
+    """q/k/v: bf16 tensors (any shape) addressed via (batch, head, row) element strides; out: [B, Nq, H*D] bf16.
+    seg2 = (k2, v2, Nk2, k2_strides, v2_strides, scale2 [B] fp32): second key/value segment with its own softmax.
+    lse / lse2: optional fp32 [B, H, Nq] outputs (log2-domain log-sum-exp per segment) kept for attention_bwd."""
+    if _TAPE is not None and _TAPE.active:
+        return _TAPE.attention(q, k, v, B, H, Nq, Nk, D, scale, q_strides, k_strides, v_strides, out=out, key_mask=key_mask,
+                               out_scale=out_scale, accumulate=accumulate, seg2=seg2, rel_h=rel_h)
     if out is None:
         out = torch.empty(B, Nq, H * D, dtype=BF16, device=q.device)
     o_strides = (Nq * H * D, D, H * D)
+    if seg2 is not None:
+        k2, v2, Nk2, k2_strides, v2_strides, scale2 = seg2
+        seg_args = (_p(k2), _p(v2), Nk2, *k2_strides, *v2_strides, _p(scale2))
+    else:
+        seg_args = (None, None, 0, 0, 0, 0, 0, 0, 0, None)
     check(lib.ae_attn_fwd_bf16(_p(q), _p(k), _p(v), _p(out), B, H, Nq, Nk, D, *q_strides, *k_strides, *v_strides, *o_strides,
                                scale, _p(rel_h), _p(rel_w), kH, kW, _p(key_mask), _p(out_scale), 1 if accumulate else 0,
-                               *(seg2 if seg2 is not None else (None, None, 0, 0, 0, 0, 0, 0, 0, None)), _s()), "ae_attn_fwd_bf16")
+                               *seg_args, _p(lse), _p(lse2), _s()), "ae_attn_fwd_bf16")
     return out
+
+
+def attention_bwd(q, k, v, dout, lse, B, H, Nq, Nk, D, scale, q_strides, k_strides, v_strides, dq, dk, dv, dq_strides,
+                  dk_strides, dv_strides, out_scale=None, accumulate_dq=False):
+    """Gradients of one attention segment (ae_attn_bwd_bf16).  dq/dk/dv: bf16 tensors written through the given element strides
+    (dk = dv = None when the key/value side needs no gradient).  Returns delta [B, H, Nq] fp32."""
+    delta = torch.empty(B, H, Nq, dtype=torch.float32, device=q.device)
+    o_strides = (Nq * H * D, D, H * D)
+    zero3 = (0, 0, 0)
+    check(lib.ae_attn_bwd_bf16(_p(q), _p(k), _p(v), _p(dout), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, Nq, Nk, D,
+                               *q_strides, *k_strides, *v_strides, *o_strides, *dq_strides, *(dk_strides if dk is not None else zero3),
+                               *(dv_strides if dv is not None else zero3), scale, _p(out_scale), 1 if accumulate_dq else 0, _s()),
+          "ae_attn_bwd_bf16")
+    return delta
 
 
 def attention_bhnd(q, k, v, scale=None, key_mask=None):
@@ -164,7 +196,7 @@ def attention_bhnd(q, k, v, scale=None, key_mask=None):
     out = torch.empty(BH, Nq, D, dtype=BF16, device=q.device)
     scale = scale if scale is not None else D ** -0.5
     check(lib.ae_attn_fwd_bf16(_p(q), _p(k), _p(v), _p(out), BH, 1, Nq, Nk, D, Nq * D, 0, D, Nk * D, 0, D, Nk * D, 0, D,
-                               Nq * D, 0, D, scale, None, None, 0, 0, _p(key_mask), None, 0, None, None, 0, 0, 0, 0, 0, 0, 0, None, _s()),
+                               Nq * D, 0, D, scale, None, None, 0, 0, _p(key_mask), None, 0, None, None, 0, 0, 0, 0, 0, 0, 0, None, None, None, _s()),
           "ae_attn_fwd_bf16")
     return out
 
@@ -182,6 +214,8 @@ def nchw_to_rows(x, c_pad=None):
 
 def rows_to_nchw(x, B, H, W, out_dtype=torch.float32):
     """channels-last [B*H*W, C] (bf16 or fp32) -> [B,C,H,W]."""
+    if _TAPE is not None and _TAPE.active:
+        return _TAPE.rows_to_nchw(x, B, H, W, out_dtype=out_dtype)
     C = x.shape[1]
     x = x.contiguous()
     out = torch.empty(B, C, H, W, dtype=out_dtype, device=x.device)
@@ -191,6 +225,8 @@ def rows_to_nchw(x, B, H, W, out_dtype=torch.float32):
 
 
 def concat_channels(a, b):
+    if _TAPE is not None and _TAPE.active:
+        return _TAPE.concat_channels(a, b)
     out = torch.empty(a.shape[0], a.shape[1] + b.shape[1], dtype=BF16, device=a.device)
     check(lib.ae_concat_channels_bf16(_p(a), a.shape[1], _p(b), b.shape[1], _p(out), a.shape[0], _s()), "ae_concat_channels_bf16")
     return out
@@ -305,6 +341,114 @@ def task_gate(task_emb, edit_code, Wg, bg):
 
 
 # --------------------------------------------------------------------------- per-op profiler (bench.py roofline leg)
+# --------------------------------------------------------------------------- training-step kernels (row A11)
+_TAPE = None  # set by anyedit_amd.autodiff.Tape while a differentiated forward is being recorded
+
+
+def add(a, b, out=None):
+    """a + b, bf16, same shape (gradient accumulation)."""
+    a, b = a.contiguous(), b.contiguous()
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib.ae_add_bf16(_p(a), _p(b), _p(out), a.numel(), _s()), "ae_add_bf16")
+    return out
+
+
+def geglu(h):
+    """h = [a | g] [M, 2F] bf16 -> a * gelu(g) [M, F] (attention.py:49-57, un-fused so that h is kept for the backward)."""
+    if _TAPE is not None and _TAPE.active:
+        return _TAPE.geglu(h)
+    M, F2 = h.shape
+    out = torch.empty(M, F2 // 2, dtype=BF16, device=h.device)
+    check(lib.ae_geglu_fwd_bf16(_p(h.contiguous()), _p(out), M, F2 // 2, _s()), "ae_geglu_fwd_bf16")
+    return out
+
+
+def geglu_bwd(h, dy):
+    dh = torch.empty_like(h)
+    check(lib.ae_geglu_bwd_bf16(_p(h.contiguous()), _p(dy.contiguous()), _p(dh), h.shape[0], h.shape[1] // 2, _s()), "ae_geglu_bwd_bf16")
+    return dh
+
+
+def groupnorm_bwd(x, gamma, beta, dy, B, HW, eps, silu=False, groups=32, x2=None):
+    C1 = x.shape[1]
+    C = C1 + (x2.shape[1] if x2 is not None else 0)
+    dx = torch.empty_like(x)
+    dx2 = torch.empty_like(x2) if x2 is not None else None
+    ws = torch.empty(lib.ae_groupnorm_bwd_workspace_floats(B, HW, C, groups), dtype=torch.float32, device=x.device)
+    check(lib.ae_groupnorm_bwd_nhwc_bf16(_p(x), _p(x2), C1, _p(gamma), _p(beta), _p(dy.contiguous()), _p(dx), _p(dx2), B, HW, C, groups,
+                                         eps, 1 if silu else 0, _p(ws), _s()), "ae_groupnorm_bwd_nhwc_bf16")
+    return dx, dx2
+
+
+def layernorm_bwd(x, gamma, dy, eps=1e-5, want_param_grads=False):
+    M, C = x.shape
+    dx = torch.empty_like(x)
+    stat = torch.empty(M, 2, dtype=torch.float32, device=x.device) if want_param_grads else None
+    dy = dy.contiguous()
+    check(lib.ae_layernorm_bwd_bf16(_p(x), _p(gamma), _p(dy), _p(dx), _p(stat), M, C, eps, _s()), "ae_layernorm_bwd_bf16")
+    if not want_param_grads:
+        return dx, None, None
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    db = torch.empty(C, dtype=torch.float32, device=x.device)
+    check(lib.ae_layernorm_param_grad_f32(_p(x), _p(dy), _p(stat), _p(dg), _p(db), M, C, _s()), "ae_layernorm_param_grad_f32")
+    return dx, dg, db
+
+
+def sumpool2x2(x, B, H, W):
+    """x: [B*2H*2W, C] -> [B*H*W, C] (adjoint of the nearest-x2 upsample)."""
+    out = torch.empty(B * H * W, x.shape[1], dtype=BF16, device=x.device)
+    check(lib.ae_sumpool2x2_bf16(_p(x.contiguous()), _p(out), B, H, W, x.shape[1], _s()), "ae_sumpool2x2_bf16")
+    return out
+
+
+def colsum(x):
+    out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+    check(lib.ae_colsum_bf16_f32(_p(x), _p(out), x.shape[0], x.shape[1], x.stride(0), _s()), "ae_colsum_bf16_f32")
+    return out
+
+
+def mse_grad(pred, target, loss_scale=1.0):
+    pred, target = pred.contiguous(), target.contiguous()
+    out = torch.empty_like(pred)
+    check(lib.ae_mse_grad_f32(_p(pred), _p(target), _p(out), pred.numel(), float(loss_scale), _s()), "ae_mse_grad_f32")
+    return out
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+    """In-place torch.optim.AdamW update of one fp32 parameter tensor."""
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        _chk(t, torch.float32, "adamw")
+        if not t.is_contiguous():
+            raise ValueError("adamw_step: tensors must be contiguous")
+    check(lib.ae_adamw_f32(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0], betas[1], eps, weight_decay,
+                           int(step), float(grad_scale), _s()), "ae_adamw_f32")
+
+
+def rowsum_f32(x):
+    """x [R, n] fp32 -> [R] (fixed-order sums)."""
+    x = x.contiguous()
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    check(lib.ae_rowsum_f32(_p(x), _p(out), x.shape[0], x.shape[1], _s()), "ae_rowsum_f32")
+    return out
+
+
+def scatter_add_rows(src, code, dst):
+    """dst[code[b]] += src[b] (fp32), deterministic."""
+    code = code.to(torch.int32).contiguous()
+    check(lib.ae_scatter_add_rows_f32(_p(src.contiguous()), _p(code), _p(dst), src.shape[0], src.shape[1], dst.shape[0], _s()),
+          "ae_scatter_add_rows_f32")
+    return dst
+
+
+def task_gate_bwd(probs, top1, dgate, Wg):
+    B, E = probs.shape
+    dte = torch.empty(B, Wg.shape[1], dtype=torch.float32, device=probs.device)
+    check(lib.ae_task_gate_bwd(_p(probs.contiguous()), _p(top1.contiguous()), _p(dgate.float().contiguous()), _p(Wg.float().contiguous()),
+                               B, Wg.shape[1], E, _p(dte), _s()), "ae_task_gate_bwd")
+    return dte
+
+
 class OpProfiler:
     """Records (kernel label, algorithmic flops, algorithmic bytes, HIP-event duration) for every GEMM / conv / attention /
     norm launch issued through this module while active.  Events are recorded on torch's current stream, which is the

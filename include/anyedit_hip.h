@@ -81,6 +81,52 @@ int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, void* out, int
                      long o_sb, long o_sh, long o_sn, float scale, const float* rel_h, const float* rel_w, int kH, int kW,
                      const unsigned char* key_mask, const float* out_scale, int accumulate, const void* k2, const void* v2,
                      int Nk2, long k2_sb, long k2_sh, long k2_sn, long v2_sb, long v2_sh, long v2_sn, const float* scale2,
+                     float* lse, float* lse2, void* stream);
+/* lse / lse2 (optional, fp32 [B,H,Nq]): log2-domain log-sum-exp of the first / second segment's softmax, kept for
+ * ae_attn_bwd_bf16.
+ *
+ * ---- training step (SURVEY.md row A11: train.py:625-710; the in-tree restatement is LatentDiffusion.p_losses,
+ * ddpm.py:889-932).  The UNet is frozen: layers are differentiated w.r.t. activations only; Linear / conv data-gradients reuse
+ * ae_gemm_bf16 / ae_conv3x3_bf16 with transposed / rotated packed weights (upsample2x = 2: zero-insert gather = adjoint of the
+ * stride-2 Downsample conv, openaimodel.py:157-159).
+ *
+ * Attention backward for one key/value segment (autograd of attention.py:171-193): delta [B,H,Nq] fp32 is an OUTPUT
+ * (rowsum(P o dP) with the un-scaled dout; its sum over heads and rows is d/d out_scale[b]).  dk, dv may both be NULL.       */
+int ae_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dout, const float* lse, float* delta, void* dq,
+                     void* dk, void* dv, int B, int H, int Nq, int Nk, int D, long q_sb, long q_sh, long q_sn, long k_sb,
+                     long k_sh, long k_sn, long v_sb, long v_sh, long v_sn, long o_sb, long o_sh, long o_sn, long dq_sb,
+                     long dq_sh, long dq_sn, long dk_sb, long dk_sh, long dk_sn, long dv_sb, long dv_sh, long dv_sn,
+                     float scale, const float* out_scale, int accumulate_dq, void* stream);
+/* GroupNorm(+SiLU) backward w.r.t. the input(s) (autograd of util.py:217-219 + nn.SiLU); dx2 receives channels [C1, C).      */
+long ae_groupnorm_bwd_workspace_floats(int B, int HW, int C, int groups);
+int ae_groupnorm_bwd_nhwc_bf16(const void* x, const void* x2, int C1, const float* gamma, const float* beta, const void* dy,
+                               void* dx, void* dx2, int B, int HW, int C, int groups, float eps, int act, float* workspace,
+                               void* stream);
+/* LayerNorm backward w.r.t. the input; row_stat (optional fp32 [M,2]) receives (mean, rstd) for the parameter gradients.    */
+int ae_layernorm_bwd_bf16(const void* x, const float* gamma, const void* dy, void* dx, float* row_stat, int M, int C, float eps,
+                          void* stream);
+int ae_layernorm_param_grad_f32(const void* x, const void* dy, const float* row_stat, float* dgamma, float* dbeta, int M, int C,
+                                void* stream);
+/* y = a + b (gradient accumulation where a layer's input fans out).                                                          */
+int ae_add_bf16(const void* a, const void* b, void* y, long n, void* stream);
+/* GEGLU un-fused for training (attention.py:49-57): h = [a | g] [M, 2F] -> y = a * gelu(g); backward -> dh.                   */
+int ae_geglu_fwd_bf16(const void* h, void* y, long M, int F, void* stream);
+int ae_geglu_bwd_bf16(const void* h, const void* dy, void* dh, long M, int F, void* stream);
+/* adjoint of the nearest-x2 upsample (openaimodel.py:108-118): x [B,2H,2W,C] -> y [B,H,W,C] = 2x2 block sums.                  */
+int ae_sumpool2x2_bf16(const void* x, void* y, int B, int H, int W, int C, void* stream);
+/* out[n] = sum_m x[m, n] (bias gradient of the small trainable Linear layers).                                               */
+int ae_colsum_bf16_f32(const void* x, float* out, int M, int N, long ld, void* stream);
+/* d/dpred mean((pred - target)^2) * loss_scale (train.py:696).                                                               */
+int ae_mse_grad_f32(const float* pred, const float* target, float* out, long n, float loss_scale, void* stream);
+/* torch.optim.AdamW step on fp32 state (train.py:536-541); step counts from 1; grad is multiplied by grad_scale first.       */
+int ae_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* out[r] = sum_j x[r, j] (fp32, fixed order): gate gradient = sum over heads and rows of the adapter segment's delta.     */
+int ae_rowsum_f32(const float* x, float* out, int rows, long n, void* stream);
+/* dst[code[b]] += src[b] in batch order (task-embedding gradient rows).                                                      */
+int ae_scatter_add_rows_f32(const float* src, const int* code, float* dst, int B, int D, int n_rows, void* stream);
+/* Backward of the task-router gate value w.r.t. the task embedding (ae_task_gate).                                           */
+int ae_task_gate_bwd(const float* probs, const int* top1, const float* dgate, const float* Wg, int B, int Dt, int E, float* dte,
                      void* stream);
 
 /* out[b,y,x] = in[b,x,y], inner dim zero-padded to Xpad: NCHW <-> channels-last at the UNet boundary

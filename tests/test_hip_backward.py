@@ -1,0 +1,211 @@
+"""GPU parity tests of the training-step kernels: every backward operator, called through the C ABI, against
+torch.autograd of the oracle's forward restatement (CPU fp32) on the same seeded, bf16-rounded inputs.
+
+Tolerances: gradients are stored in bf16 (one rounding, 2^-9 relative) and accumulate in fp32: relative L2 <= 6e-3 per operator
+(1e-2 for attention, whose recomputed probabilities see bf16 P and bf16 dS), max-abs <= 3e-2 * max|ref|.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+DEV = "cuda"
+
+
+def q(t):
+    return t.to(BF).float()
+
+
+def check_close(got, ref, rl2=6e-3, mabs=3e-2, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    e = rel_l2(got, ref)
+    m = float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+    assert e <= rl2 and m <= mabs, f"{what}: rel_l2={e:.3e} (<= {rl2}), max_abs/max={m:.3e} (<= {mabs})"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from anyedit_amd import ops as o
+    return o
+
+
+# ------------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("B,HW,C,C1,silu,eps", [(2, 64, 64, None, True, 1e-5), (3, 256, 320, None, False, 1e-6), (2, 1024, 320, None, True, 1e-5),
+                                                (2, 64, 960, 640, True, 1e-5), (1, 4096, 320, None, True, 1e-5), (2, 16, 1280, None, True, 1e-5)])
+def test_groupnorm_backward(ops, B, HW, C, C1, silu, eps):
+    from oracle import ldm_ref as L
+    g = torch.Generator().manual_seed(B + HW + C)
+    x = q(torch.randn(B, HW, C, generator=g) * 2 + 0.5)
+    w, b = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    dy = q(torch.randn(B, HW, C, generator=g))
+    xr = x.clone().requires_grad_(True)
+    y = L.group_norm32(xr.permute(0, 2, 1).reshape(B, C, HW, 1), w, b, eps).reshape(B, C, HW).permute(0, 2, 1)
+    if silu:
+        y = F.silu(y)
+    y.backward(dy)
+    rows = x.reshape(B * HW, C).to(DEV, BF)
+    if C1 is None:
+        dx, _ = ops.groupnorm_bwd(rows, w.to(DEV), b.to(DEV), dy.reshape(B * HW, C).to(DEV, BF), B, HW, eps, silu=silu)
+        check_close(dx.reshape(B, HW, C), xr.grad, what="groupnorm dx")
+    else:
+        x1, x2 = rows[:, :C1].contiguous(), rows[:, C1:].contiguous()
+        dx1, dx2 = ops.groupnorm_bwd(x1, w.to(DEV), b.to(DEV), dy.reshape(B * HW, C).to(DEV, BF), B, HW, eps, silu=silu, x2=x2)
+        check_close(torch.cat([dx1, dx2], 1).reshape(B, HW, C), xr.grad, what="groupnorm (concat) dx")
+
+
+@pytest.mark.parametrize("M,C", [(16, 768), (4096, 320), (777, 1280), (10, 64)])
+def test_layernorm_backward(ops, M, C):
+    g = torch.Generator().manual_seed(M + C)
+    x = q(torch.randn(M, C, generator=g) * 3 + 1)
+    w, b = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    dy = q(torch.randn(M, C, generator=g))
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.layer_norm(xr, (C,), wr, br, 1e-5).backward(dy)
+    dx, dg, db = ops.layernorm_bwd(x.to(DEV, BF), w.to(DEV), dy.to(DEV, BF), 1e-5, want_param_grads=True)
+    check_close(dx, xr.grad, what="layernorm dx")
+    check_close(dg, wr.grad, rl2=2e-3, mabs=1e-2, what="layernorm dgamma")
+    check_close(db, br.grad, rl2=2e-3, mabs=1e-2, what="layernorm dbeta")
+
+
+def test_geglu_forward_backward(ops):
+    g = torch.Generator().manual_seed(5)
+    M, Fd = 300, 1280
+    h = q(torch.randn(M, 2 * Fd, generator=g) * 1.5)
+    dy = q(torch.randn(M, Fd, generator=g))
+    hr = h.clone().requires_grad_(True)
+    a, gate = hr.chunk(2, dim=-1)
+    y = a * F.gelu(gate)
+    y.backward(dy)
+    check_close(ops.geglu(h.to(DEV, BF)), y, what="geglu fwd")
+    check_close(ops.geglu_bwd(h.to(DEV, BF), dy.to(DEV, BF)), hr.grad, what="geglu bwd")
+
+
+# ------------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("BH,Nq,Nk,D", [(2, 64, 64, 40), (2, 200, 77, 80), (2, 128, 4, 40), (1, 144, 272, 160), (2, 130, 200, 16),
+                                        (1, 1024, 1024, 40), (2, 256, 256, 80), (2, 70, 129, 64), (1, 33, 65, 48)])
+def test_attention_backward(ops, BH, Nq, Nk, D):
+    from oracle import ldm_ref as L
+    g = torch.Generator().manual_seed(BH + Nq + Nk + D)
+    qq, kk, vv = (q(torch.randn(BH, n, D, generator=g)) for n in (Nq, Nk, Nk))
+    do = q(torch.randn(BH, Nq, D, generator=g))
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (qq, kk, vv))
+    L.sdpa_core(qr, kr, vr, D ** -0.5).backward(do)
+    qd, kd, vd, dod = (t.to(DEV, BF).contiguous() for t in (qq, kk, vv, do))
+    lse = torch.empty(BH, 1, Nq, dtype=torch.float32, device=DEV)
+    sq, sk = (Nq * D, 0, D), (Nk * D, 0, D)
+    out = ops.attention(qd, kd, vd, BH, 1, Nq, Nk, D, D ** -0.5, sq, sk, sk, lse=lse)
+    # the stored log-sum-exp (log2 domain) against the oracle's logits
+    sim = torch.einsum("bid,bjd->bij", qq, kk) * D ** -0.5
+    check_close(lse.reshape(BH, Nq), torch.logsumexp(sim, -1) * 1.4426950408889634, rl2=2e-3, mabs=5e-3, what="lse")
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    delta = ops.attention_bwd(qd, kd, vd, dod, lse, BH, 1, Nq, Nk, D, D ** -0.5, sq, sk, sk, dq, dk, dv, sq, sk, sk)
+    ref_o = L.sdpa_core(qq, kk, vv, D ** -0.5)
+    check_close(delta.reshape(BH, Nq), (do * ref_o).sum(-1), rl2=2e-2, mabs=5e-2, what="delta")
+    check_close(dv, vr.grad, rl2=1e-2, what=f"dV {BH}x{Nq}x{Nk}x{D}")
+    check_close(dk, kr.grad, rl2=1.5e-2, mabs=5e-2, what=f"dK {BH}x{Nq}x{Nk}x{D}")
+    check_close(dq, qr.grad, rl2=1.5e-2, mabs=5e-2, what=f"dQ {BH}x{Nq}x{Nk}x{D}")
+
+
+# ------------------------------------------------------------------------------------------------- tape: GEMM / conv adjoints
+def test_tape_gemm_and_conv_adjoints(ops):
+    """Data-gradients through ops.gemm (two-source K split, residual) and ops.conv3x3 (stride 1, nearest-x2 upsample, stride 2),
+    produced by the tape with the forward kernels on transposed / rotated weights."""
+    from anyedit_amd.autodiff import Tape
+    g = torch.Generator().manual_seed(3)
+    B, H, W, C1, C2, Co = 2, 16, 16, 64, 128, 64
+    x1, x2 = q(torch.randn(B * H * W, C1, generator=g)), q(torch.randn(B * H * W, C2, generator=g))
+    wl = q(torch.randn(Co, C1 + C2, generator=g) / (C1 + C2) ** 0.5)
+    wc = q(torch.randn(Co, Co, 3, 3, generator=g) / (9 * Co) ** 0.5)
+    wu = q(torch.randn(128, Co, 3, 3, generator=g) / (9 * Co) ** 0.5)
+    wd = q(torch.randn(64, 128, 3, 3, generator=g) / (9 * 128) ** 0.5)
+    dy = q(torch.randn(B * H * W, 64, generator=g))
+
+    # oracle: NCHW torch graph
+    x1r, x2r = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    hlin = torch.cat([x1r, x2r], 1) @ wl.t()                                         # 1x1 over the channel concat
+    hn = hlin.reshape(B, H, W, Co).permute(0, 3, 1, 2)
+    h1 = F.conv2d(hn, wc, padding=1) + hn                                           # stride-1 conv + residual
+    h2 = F.conv2d(F.interpolate(h1, scale_factor=2, mode="nearest"), wu, padding=1)  # Upsample
+    h3 = F.conv2d(h2, wd, stride=2, padding=1)                                       # Downsample
+    out_ref = h3.permute(0, 2, 3, 1).reshape(B * H * W, 64)
+    out_ref.backward(dy)
+
+    tape = Tape()
+    x1d, x2d = x1.to(DEV, BF), x2.to(DEV, BF)
+    tape.require(x1d)
+    tape.require(x2d)
+    with tape.recording():
+        hl = ops.gemm(x1d, wl.to(DEV, BF), a2=x2d)
+        c1, _, _ = ops.conv3x3(hl, ops.pack_conv3x3(wc.to(DEV)), None, B, H, W, residual=hl)
+        c2, H2, W2 = ops.conv3x3(c1, ops.pack_conv3x3(wu.to(DEV)), None, B, H, W, upsample2x=True)
+        c3, H3, W3 = ops.conv3x3(c2, ops.pack_conv3x3(wd.to(DEV)), None, B, H2, W2, stride=2)
+    assert (H3, W3) == (H, W)
+    check_close(c3, out_ref, rl2=8e-3, what="tape forward")
+    tape.accumulate(c3, dy.to(DEV, BF))
+    tape.backward()
+    check_close(tape.grad(x1d), x1r.grad, rl2=1.2e-2, what="d x1 through conv chain")
+    check_close(tape.grad(x2d), x2r.grad, rl2=1.2e-2, what="d x2 through conv chain")
+
+
+def test_tape_trainable_linear_and_layernorm(ops):
+    """Parameter gradients of a small trainable Linear (+bias) followed by LayerNorm: the image-projection head of the adapter."""
+    from anyedit_amd.autodiff import Tape
+    g = torch.Generator().manual_seed(4)
+    M, K, N = 4, 1280, 4 * 768
+    x = q(torch.randn(M, K, generator=g))
+    w, b = q(torch.randn(N, K, generator=g) / K ** 0.5), torch.randn(N, generator=g) * 0.1
+    gam, bet = 1 + 0.1 * torch.randn(768, generator=g), 0.1 * torch.randn(768, generator=g)
+    dy = q(torch.randn(M * 4, 768, generator=g))
+    wr, br, gr, ber = (t.clone().requires_grad_(True) for t in (w, b, gam, bet))
+    y = F.layer_norm((x @ wr.t() + br).reshape(M * 4, 768), (768,), gr, ber, 1e-5)
+    y.backward(dy)
+    tape = Tape()
+    wd, bd, gd, bed = w.to(DEV, BF), b.to(DEV), gam.to(DEV), bet.to(DEV)
+    for t, n in ((wd, "w"), (bd, "b"), (gd, "gamma"), (bed, "beta")):
+        tape.mark_trainable(t, n)
+    with tape.recording():
+        h = ops.gemm(x.to(DEV, BF), wd, bd)
+        yy = ops.layernorm(h.reshape(M * 4, 768), gd, bed, 1e-5)
+    check_close(yy, y, what="forward")
+    tape.accumulate(yy, dy.to(DEV, BF))
+    pg = tape.backward()
+    check_close(pg["w"], wr.grad, rl2=1e-2, what="dW")
+    check_close(pg["b"], br.grad, rl2=1e-2, what="db")
+    check_close(pg["gamma"], gr.grad, rl2=1e-2, what="dgamma")
+    check_close(pg["beta"], ber.grad, rl2=1e-2, what="dbeta")
+
+
+# ------------------------------------------------------------------------------------------------- small kernels
+def test_sumpool_add_mse_grad_rowsum(ops):
+    g = torch.Generator().manual_seed(6)
+    x = q(torch.randn(2, 8, 8, 64, generator=g))
+    ref = x.reshape(2, 4, 2, 4, 2, 64).sum((2, 4))
+    check_close(ops.sumpool2x2(x.reshape(-1, 64).to(DEV, BF), 2, 4, 4).reshape(2, 4, 4, 64), ref, what="sumpool2x2")
+    a, b = q(torch.randn(100, 64, generator=g)), q(torch.randn(100, 64, generator=g))
+    assert torch.equal(ops.add(a.to(DEV, BF), b.to(DEV, BF)).float().cpu(), (a + b).to(BF).float())
+    p, t = torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 4, 8, 8, generator=g)
+    pr = p.clone().requires_grad_(True)
+    F.mse_loss(pr, t).backward()
+    check_close(ops.mse_grad(p.to(DEV), t.to(DEV)), pr.grad, rl2=1e-6, mabs=1e-6, what="mse grad")
+    r = torch.randn(3, 5000, generator=g)
+    check_close(ops.rowsum_f32(r.to(DEV)), r.sum(1), rl2=1e-5, mabs=1e-5, what="rowsum")
+
+
+def test_adamw_matches_torch(ops):
+    g = torch.Generator().manual_seed(7)
+    p0 = torch.randn(1000, generator=g)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    pd, m, v = p0.to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for step in range(1, 4):
+        gr = torch.randn(1000, generator=g)
+        pt.grad = gr.clone()
+        opt.step()
+        ops.adamw_step(pd, gr.to(DEV), m, v, step, 1e-3)
+    check_close(pd, pt.detach(), rl2=1e-6, mabs=1e-5, what="adamw")
