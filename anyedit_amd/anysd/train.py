@@ -1,0 +1,183 @@
+"""AnySD training step on MI355X — SURVEY.md §8a row A11 (specification: train.py:625-710; the eps-MSE objective is the in-tree
+LatentDiffusion.p_losses / get_loss restatement, ddpm.py:889-932, 367-380).
+
+    noise ~ N(0, I), t ~ U{0..999}                                  train.py:636-641
+    noisy = sqrt(acp_t) latents + sqrt(1 - acp_t) noise             train.py:643-645  (ddpm.py:356-359)  -> ae_q_sample_f32
+    conditioning dropout from ONE uniform draw per sample           train.py:652-669  -> parallel.conditioning_dropout_masks
+    x = cat([noisy, image_cond_latents], 1)                         train.py:672
+    eps_hat = ip_adapter(x, t, ehs, ref_embeds, edit_code)          train.py:694-695  -> MoE forward on the autodiff tape
+    loss = mean((eps_hat.float() - noise.float())^2)                train.py:696      -> ae_mse_f32 / ae_mse_grad_f32
+    backward; all-reduce adapter grads; AdamW on the adapters       train.py:483-485, 536-541, 703-706
+
+Only `image_proj_model`, `adapter_modules`, `task_embs` are trained; the UNet is frozen and differentiated w.r.t. activations.
+The AnySD source is absent from the reference (row A9: parity unpinned), so gradients are checked against torch.autograd of OUR
+forward specification (oracle/anysd_ref.py), not against reference numbers.
+"""
+import torch
+
+from anyedit_amd import ops
+from anyedit_amd.autodiff import Tape
+from anyedit_amd.parallel import GradientExchange, conditioning_dropout_masks
+
+BF16 = torch.bfloat16
+
+
+class AnySDTrainer:
+    def __init__(self, moe, sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=1e-2, process_group=None, bucket_bytes=25 << 20):
+        self.moe = moe
+        self.sqrt_ac = sqrt_alphas_cumprod.float()
+        self.sqrt_1mac = sqrt_one_minus_alphas_cumprod.float()
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.step_count = 0
+        # fp32 master parameters, in the order train.py:483-485 chains them
+        self.params = {}
+        for n, p in moe.image_proj_model.named_parameters():
+            self.params["image_proj_model." + n] = p
+        for i, p in enumerate(moe.adapter_modules):
+            self.params[f"adapter_modules.{i}"] = p
+        self.params["task_embs"] = moe.task_embs
+        self.state = {}
+        import torch.distributed as dist
+        self.exchange = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+            self.exchange = GradientExchange(list(self.params.values()), bucket_bytes, group=process_group)
+
+    # ------------------------------------------------------------------------------------------------ forward on the tape
+    def forward_loss(self, latents, image_cond, encoder_hidden_states, ref_embeds, edit_code, noise, timesteps, null_ehs=None,
+                     dropout_u=None, dropout_p=0.05):
+        """Returns (loss scalar tensor, tape, leaves) with the forward recorded; call `backward` next."""
+        moe, dev = self.moe, latents.device
+        B = latents.shape[0]
+        sa, s1 = self.sqrt_ac.to(dev)[timesteps], self.sqrt_1mac.to(dev)[timesteps]
+        noisy = ops.q_sample(latents.float(), noise.float(), sa, s1)
+        ehs = encoder_hidden_states
+        if dropout_u is not None:  # train.py:652-669: one draw u per sample decides prompt / image dropout
+            prompt_mask, image_mask = conditioning_dropout_masks(dropout_u, dropout_p)
+            if null_ehs is not None:
+                ehs = torch.where(prompt_mask.view(B, 1, 1), null_ehs.to(ehs.dtype), ehs)
+            image_cond = image_cond * image_mask.view(B, 1, 1, 1).to(image_cond.dtype)
+        x = torch.cat([noisy, image_cond.float()], 1)  # channel concat of two 4-channel latents (plumbing, train.py:672)
+
+        tape = Tape()
+        L, Dc = ehs.shape[1], ehs.shape[2]
+        T_ip = moe.image_proj_model.tokens
+        with torch.no_grad():
+            code = edit_code.long()
+            te = moe.task_embs.detach()[code]                                                   # [B, Dc] lookup
+            context_rows = torch.cat([ehs.float(), te[:, None, :].float()], 1).reshape(B * (L + 1), Dc).to(BF16).contiguous()
+            probs, top1, top1p = moe.route(edit_code)
+            gate = top1p.float().contiguous()
+            experts = top1.long().tolist()
+            tape.require(context_rows)
+            tape.require(gate)
+            # trainable leaves: packed bf16 copies of the fp32 masters
+            ipm = moe.image_proj_model
+            Wp, bp = ops.pack_linear(ipm.proj.weight), ipm.proj.bias.detach().float().contiguous()
+            gam, bet = ipm.norm.weight.detach().float().contiguous(), ipm.norm.bias.detach().float().contiguous()
+            for t, n in ((Wp, "image_proj_model.proj.weight"), (bp, "image_proj_model.proj.bias"),
+                         (gam, "image_proj_model.norm.weight"), (bet, "image_proj_model.norm.bias")):
+                tape.mark_trainable(t, n)
+            cls = ref_embeds[:, 0].to(BF16).contiguous()
+            with tape.recording():
+                y = ops.gemm(cls, Wp, bp)
+                ip_rows = ops.layernorm(y.reshape(B * T_ip, Dc), gam, bet, ipm.norm.eps)
+                kv_cache = {}
+                for li, (blk, W) in enumerate(zip(moe._blocks, moe.adapter_modules)):
+                    attn = blk.attn2
+                    kv_cache[id(attn)] = attn.project_kv(context_rows)
+                    kv_ip = self._expert_kv(tape, ip_rows, W, experts, T_ip, f"adapter_modules.{li}")
+                    kv_cache[("adapter", id(attn))] = (kv_ip, gate)
+                eps_hat = moe.unet.forward_rows(x, timesteps, context_rows, kv_cache=kv_cache)
+            loss = ops.mse(eps_hat, noise.float())
+        leaves = {"context_rows": context_rows, "gate": gate, "probs": probs, "top1": top1, "code": code, "eps_hat": eps_hat,
+                  "noise": noise.float(), "L": L, "B": B, "Dc": Dc}
+        return loss, tape, leaves
+
+    def _expert_kv(self, tape, ip_rows, W, experts, T_ip, name):
+        """kv_ip[b] = ip_rows[b] @ W[expert_b]^T for every sample, one GEMM per expert present; recorded as ONE tape node whose
+        backward gathers the rows per expert again (row gather / scatter is data movement, the arithmetic is ae_gemm_bf16)."""
+        B = len(experts)
+        dev = ip_rows.device
+        Wb = W.detach().to(BF16)
+        kv_ip = torch.empty(B * T_ip, Wb.shape[1], dtype=BF16, device=dev)
+        groups = {}
+        for b, e in enumerate(experts):
+            groups.setdefault(e, []).append(b)
+        index = {e: torch.tensor([b * T_ip + j for b in bs for j in range(T_ip)], device=dev) for e, bs in groups.items()}
+        with tape.paused():
+            for e, idx in index.items():
+                kv_ip[idx] = ops.gemm(ip_rows[idx].contiguous(), Wb[e].contiguous())
+
+        def bwd():
+            dkv = tape.grad(kv_ip)
+            if dkv is None:
+                return
+            d_ip = torch.zeros_like(ip_rows)
+            dW = torch.zeros(W.shape, dtype=torch.float32, device=dev)
+            for e, idx in index.items():
+                dy, a = dkv[idx].contiguous(), ip_rows[idx].contiguous()
+                d_ip[idx] = ops.gemm(dy, Wb[e].t().contiguous())                      # dA = dY W_e
+                M, Mp = dy.shape[0], (dy.shape[0] + 7) // 8 * 8
+                dyt = torch.zeros(dy.shape[1], Mp, dtype=BF16, device=dev)
+                dyt[:, :M] = dy.t()
+                at = torch.zeros(a.shape[1], Mp, dtype=BF16, device=dev)
+                at[:, :M] = a.t()
+                dW[e] = ops.gemm(dyt, at, out_f32=True)                               # dW_e = dY^T A
+            tape.accumulate(ip_rows, d_ip)
+            tape.add_param_grad(name, dW)
+
+        tape.require(kv_ip)
+        tape.keep.extend([kv_ip, ip_rows])
+        tape.nodes.append(bwd)
+        return kv_ip
+
+    # ------------------------------------------------------------------------------------------------ backward
+    def backward(self, tape, leaves, loss_scale=1.0):
+        """Returns {parameter name: fp32 gradient}."""
+        with torch.no_grad():
+            tape.accumulate(leaves["eps_hat"], ops.mse_grad(leaves["eps_hat"], leaves["noise"], loss_scale))
+            grads = dict(tape.backward())
+            B, L, Dc = leaves["B"], leaves["L"], leaves["Dc"]
+            # task embeddings: the (L+1)-th context token of every sample + the router gate
+            dctx = tape.grad(leaves["context_rows"])
+            dte = torch.zeros(B, Dc, dtype=torch.float32, device=leaves["gate"].device)
+            if dctx is not None:
+                dte = dctx.reshape(B, L + 1, Dc)[:, L].float().contiguous()
+            dtask = torch.zeros(self.moe.task_embs.shape, dtype=torch.float32, device=dte.device)
+            ops.scatter_add_rows(dte, leaves["code"], dtask)
+            dgate = tape.grads.get(id(leaves["gate"]))
+            if dgate is not None:
+                ops.scatter_add_rows(ops.task_gate_bwd(leaves["probs"], leaves["top1"], dgate, self.moe.gate.weight.detach()),
+                                     leaves["code"], dtask)
+            grads["task_embs"] = dtask
+            for n, p in self.params.items():  # parameters that received nothing this step (experts not routed to)
+                if n not in grads:
+                    grads[n] = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+                grads[n] = grads[n].reshape(p.shape).contiguous()
+        return grads
+
+    # ------------------------------------------------------------------------------------------------ optimiser
+    def optimizer_step(self, grads, grad_scale=1.0):
+        with torch.no_grad():
+            if self.exchange is not None:  # DDP: one reduce-scatter + all-gather exchange of the adapter gradients per step
+                for n, p in self.params.items():
+                    p.grad = grads[n]
+                self.exchange.reduce()
+                grads = {n: p.grad for n, p in self.params.items()}
+            self.step_count += 1
+            for n, p in self.params.items():
+                st = self.state.get(n)
+                if st is None:
+                    st = self.state[n] = (torch.zeros_like(p.data, dtype=torch.float32), torch.zeros_like(p.data, dtype=torch.float32))
+                if p.data.dtype != torch.float32 or not p.data.is_contiguous():
+                    raise TypeError(f"{n}: trainable parameters are fp32 contiguous masters")
+                ops.adamw_step(p.data, grads[n], st[0], st[1], self.step_count, self.lr, self.betas, self.eps, self.wd, grad_scale)
+        return grads
+
+    def train_step(self, latents, image_cond, encoder_hidden_states, ref_embeds, edit_code, noise, timesteps, **kw):
+        """One optimisation step; returns the fp32 loss (device scalar tensor)."""
+        loss, tape, leaves = self.forward_loss(latents, image_cond, encoder_hidden_states, ref_embeds, edit_code, noise, timesteps, **kw)
+        grads = self.backward(tape, leaves)
+        self.optimizer_step(grads)
+        return loss
