@@ -298,14 +298,21 @@ class Tape:
 
     def attention(self, q, k, v, B, H, Nq, Nk, D, scale, q_strides, k_strides, v_strides, out=None, key_mask=None, out_scale=None,
                   accumulate=False, seg2=None, rel_h=None):
-        if key_mask is not None or rel_h is not None or accumulate or out_scale is not None:
-            raise RuntimeError("autodiff: masked / biased / accumulating attention is not differentiable here")
+        if key_mask is not None or rel_h is not None or (seg2 is not None and (accumulate or out_scale is not None)):
+            raise RuntimeError("autodiff: masked / biased attention is not differentiable here")
+        if accumulate and out is None:
+            raise RuntimeError("autodiff: accumulate=True needs the tensor to accumulate into")
         dev = q.device
         lse = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
         lse2 = torch.empty(B, H, Nq, dtype=torch.float32, device=dev) if seg2 is not None else None
         with self.paused():
-            y = ops.attention(q, k, v, B, H, Nq, Nk, D, scale, q_strides, k_strides, v_strides, out=out, seg2=seg2, lse=lse, lse2=lse2)
+            # accumulate=True: out += out_scale[b] * Attn(q, k, v) in place — `out` keeps its identity, so the gradient that reaches
+            # it later is the gradient of BOTH contributions (the un-fused adapter path for head_dim > 96)
+            y = ops.attention(q, k, v, B, H, Nq, Nk, D, scale, q_strides, k_strides, v_strides, out=out, seg2=seg2, lse=lse, lse2=lse2,
+                              out_scale=out_scale, accumulate=accumulate)
         ins = [q, k, v]
+        if out_scale is not None:
+            ins.append(out_scale)
         if seg2 is not None:
             k2, v2, Nk2, k2_strides, v2_strides, gate = seg2
             ins += [k2, v2, gate]
@@ -333,8 +340,10 @@ class Tape:
                 covered = sum(t.numel() for t in (q, k, v) if id(_base(t)) == bid and (t is q or need_kv))
                 if covered < b.numel():
                     gb.zero_()
-            ops.attention_bwd(q, k, v, dy, lse, B, H, Nq, Nk, D, scale, q_strides, k_strides, v_strides, dq, dk if need_kv else None,
-                              dv if need_kv else None, q_strides, k_strides, v_strides)
+            delta = ops.attention_bwd(q, k, v, dy, lse, B, H, Nq, Nk, D, scale, q_strides, k_strides, v_strides, dq, dk if need_kv else None,
+                                      dv if need_kv else None, q_strides, k_strides, v_strides, out_scale=out_scale)
+            if out_scale is not None and self.needs(out_scale):
+                self.accumulate_f32(out_scale, ops.rowsum_f32(delta.reshape(B, -1)))
             if seg2 is not None:
                 need_kv2 = self.needs(k2) or self.needs(v2)
                 bufs2, (dk2, dv2) = grad_views([k2, v2])

@@ -209,3 +209,48 @@ def test_adamw_matches_torch(ops):
         opt.step()
         ops.adamw_step(pd, gr.to(DEV), m, v, step, 1e-3)
     check_close(pd, pt.detach(), rl2=1e-6, mabs=1e-5, what="adamw")
+
+
+@pytest.mark.parametrize("fused,D", [(True, 40), (False, 160), (False, 40), (True, 80)])
+def test_tape_adapter_attention_two_segments(ops, fused, D):
+    """out = Attn(q, K, V) + g_b * Attn(q, K_ip, V_ip): the fused two-segment launch (head_dim <= 96) and the un-fused
+    accumulate path (head_dim 160), gradients w.r.t. q, the text K|V, the expert K|V and the gate against autograd."""
+    from anyedit_amd.autodiff import Tape
+    from oracle import ldm_ref as L
+    g = torch.Generator().manual_seed(9 + D)
+    B, H, N, Nk, T = 2, 2, 96, 78, 4
+    inner = H * D
+    qq = q(torch.randn(B * N, inner, generator=g))
+    kv = q(torch.randn(B * Nk, 2 * inner, generator=g))
+    kvip = q(torch.randn(B * T, 2 * inner, generator=g))
+    gate = torch.tensor([0.7, 0.3])
+    dy = q(torch.randn(B, N, inner, generator=g))
+
+    def heads(t, n):  # [B*n, inner] -> [B*H, n, D]
+        return t.reshape(B, n, H, D).permute(0, 2, 1, 3).reshape(B * H, n, D)
+
+    qr, kvr, kvipr, gr = (t.clone().requires_grad_(True) for t in (qq, kv, kvip, gate))
+    a1 = L.sdpa_core(heads(qr, N), heads(kvr[:, :inner], Nk), heads(kvr[:, inner:], Nk), D ** -0.5)
+    a2 = L.sdpa_core(heads(qr, N), heads(kvipr[:, :inner], T), heads(kvipr[:, inner:], T), D ** -0.5)
+    out_ref = (a1 + gr.repeat_interleave(H).view(B * H, 1, 1) * a2).reshape(B, H, N, D).permute(0, 2, 1, 3).reshape(B, N, inner)
+    out_ref.backward(dy)
+
+    tape = Tape()
+    qd, kvd, kvipd, gd = qq.to(DEV, BF), kv.to(DEV, BF), kvip.to(DEV, BF), gate.to(DEV)
+    for t in (qd, kvd, kvipd, gd):
+        tape.require(t)
+    qs, ks, ks2 = (N * inner, D, inner), (Nk * 2 * inner, D, 2 * inner), (T * 2 * inner, D, 2 * inner)
+    with tape.recording():
+        if fused:
+            o = ops.attention(qd, kvd, kvd[:, inner:], B, H, N, Nk, D, D ** -0.5, qs, ks, ks,
+                              seg2=(kvipd, kvipd[:, inner:], T, ks2, ks2, gd))
+        else:
+            o = ops.attention(qd, kvd, kvd[:, inner:], B, H, N, Nk, D, D ** -0.5, qs, ks, ks)
+            ops.attention(qd, kvipd, kvipd[:, inner:], B, H, N, T, D, D ** -0.5, qs, ks2, ks2, out=o, out_scale=gd, accumulate=True)
+    check_close(o, out_ref, what="two-segment forward")
+    tape.accumulate(o, dy.to(DEV, BF))
+    tape.backward()
+    check_close(tape.grad(qd), qr.grad, rl2=1.5e-2, mabs=5e-2, what="dq")
+    check_close(tape.grad(kvd), kvr.grad, rl2=1.5e-2, mabs=5e-2, what="d kv (text)")
+    check_close(tape.grad(kvipd), kvipr.grad, rl2=1.5e-2, mabs=5e-2, what="d kv (expert)")
+    check_close(tape.grads[id(gd)], gr.grad, rl2=3e-2, mabs=5e-2, what="d gate")
