@@ -55,8 +55,12 @@ __device__ __forceinline__ int vt_pos(int key) {  // key = 16 f + 4 g + r  ->  1
 // NW waves per block, QF 16-row query fragments per wave.  (NW=4,QF=2) and (NW=8,QF=1) cover the same 128 query rows per
 // block with the same LDS; the latter halves the per-wave register state (4 instead of 2 waves per SIMD -> the exp-bound
 // softmax of one wave overlaps the MFMAs of three others) at the price of twice the K/V fragment reads per FLOP.
-template <int D, int QF, int NW, bool DBUF, bool HAS_BIAS, bool HAS_MASK, bool SEG2 = false>
-__global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void attn_kernel(const AttnArgs p) {
+// BIAS: 0 none; 1 decomposed rel-pos bias, any key grid; 2 the same when one key tile is exactly one key ROW (kW == 64, SAM's
+// global attention on the 64x64 token grid): rel_w[q, kw] of the lane's 16 key slots lives in registers for the whole kernel
+// and rel_h[q, kh] is one value per tile — no per-element index arithmetic or gathers.
+template <int D, int QF, int NW, bool DBUF, int BIAS, bool HAS_MASK, bool SEG2 = false>
+__global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 && BIAS == 0 ? 4 : 2) : 1)) void attn_kernel(const AttnArgs p) {
+    constexpr bool HAS_BIAS = BIAS != 0;
     constexpr int NT = 64 * NW;
     constexpr int NC = D / 32;                 // full K=32 MFMAs per (key frag, q frag)
     constexpr bool TAIL16 = (D % 32) != 0;     // head-dim remainder (8 or 16) goes through ONE K=16 MFMA instead of padding to 32
@@ -120,6 +124,19 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
         }
     }
 
+    f32x4 rw[BIAS == 2 ? QF : 1][4];  // BIAS 2: rel_w[q][16 f + 4 lg + r] * log2(e) of this lane's key slots
+    if (BIAS == 2) {
+#pragma unroll
+        for (int a = 0; a < QF; ++a) {
+            const int qc = min(q0 + a * 16 + l15, p.Nq - 1);
+            const float* row = p.rel_w + ((long)bh * p.Nq + qc) * p.kW;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(row + f * 16 + lg * 4);
+                rw[BIAS == 2 ? a : 0][f] = (f32x4){t[0] * LOG2E, t[1] * LOG2E, t[2] * LOG2E, t[3] * LOG2E};
+            }
+        }
+    }
     f32x4 o[QF][NDF];
     float m_run[QF], l_run[QF];
 #pragma unroll
@@ -223,6 +240,12 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
             constexpr bool TAIL = decltype(tail_tag)::value;
             const bf16_t* cK = sK + cur * KSZ;
             const bf16_t* cV = sVt + cur * VSZ;
+            float rh[BIAS == 2 ? QF : 1];  // BIAS 2: rel_h[q][key row of this tile], issued ahead of the QK^T MFMAs
+            if (BIAS == 2) {
+#pragma unroll
+                for (int a = 0; a < QF; ++a)
+                    rh[BIAS == 2 ? a : 0] = p.rel_h[((long)bh * p.Nq + min(q0 + a * 16 + l15, p.Nq - 1)) * p.kH + k0 / KT] * LOG2E;
+            }
 
             // ---- S^T = K Q^T : lane holds S^T[key = 16f + 4g + r][q = l15] --------------------------
             f32x4 s[QF][4];
@@ -267,7 +290,9 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 ? 4 : 2) : 1)) void at
     #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float v = s[a][f][r] * c2;
-                            if (HAS_BIAS) {
+                            if (BIAS == 2) {
+                                v = fmaf(s[a][f][r], c2, rw[BIAS == 2 ? a : 0][f][r] + rh[BIAS == 2 ? a : 0]);
+                            } else if (HAS_BIAS) {
                                 const int qc = min(q0 + a * 16 + l15, p.Nq - 1);
                                 const int key = min(kb + r, last_key);
                                 const int khh = key / p.kW;
@@ -412,10 +437,11 @@ int launch_attn(const AttnArgs& a, hipStream_t stream) {
     dim3 grid((unsigned)blocks), block(NT);
     if (a.rel_h && a.key_mask) { ae_set_error("ae_attn_fwd_bf16: rel-pos bias together with key_mask is not supported"); return AE_ERR_UNSUPPORTED; }
     if (a.k2) {
-        if constexpr (D <= 96) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, false, false, true>), grid, block, 0, stream, a);
-    } else if (a.rel_h) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, true, false>), grid, block, 0, stream, a);
-    else if (a.key_mask) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, false, false>), grid, block, 0, stream, a);
+        if constexpr (D <= 96) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, 0, false, true>), grid, block, 0, stream, a);
+    } else if (a.rel_h && a.kW == KT && a.Nk % KT == 0) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, 2, false>), grid, block, 0, stream, a);
+    else if (a.rel_h) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, 1, false>), grid, block, 0, stream, a);
+    else if (a.key_mask) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, 0, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, 0, false>), grid, block, 0, stream, a);
     return ae_check_launch("ae_attn_fwd_bf16");
 }
 
@@ -472,7 +498,8 @@ extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
             return (qf40 == 4 && Nq > 1024 && Nk >= 1024 && !k2) ? launch_attn<40, 4, true>(a, s) : launch_attn<40, 2, true>(a, s);
         case 48: return launch_attn<48, 2, true>(a, s);
         case 64: return launch_attn<64, 2, true>(a, s);
-        case 80: return w8 ? launch_attn<80, 1, true, 8>(a, s) : launch_attn<80, 2, true>(a, s);
+        // SAM (rel-pos bias): 8 waves x 1 query fragment keeps the bias registers + softmax state under 256 VGPRs without spills
+        case 80: return (w8 || rel_h) ? launch_attn<80, 1, true, 8>(a, s) : launch_attn<80, 2, true>(a, s);
         case 96: return launch_attn<96, 2, true>(a, s);
         case 128: return launch_attn<128, 2, false>(a, s);
         case 160: return launch_attn<160, 2, false>(a, s);

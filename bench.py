@@ -193,6 +193,17 @@ def main():
             "unet_step_ms": ms_per_step / n_unet_steps,
             "unet_tflops": 3 * B * GFLOP_PER_UNET_SAMPLE * n_unet_steps / (ms_per_step * 1e-3) / 1e3,
         }
+        # BASELINE.json's second metric: UNet-step ms p50 — per-replay HIP-event timing of the captured UNet evaluation
+        if pipe._graph is not None:
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(41)]
+            for e0, e1 in evs:
+                e0.record()
+                pipe._graph.replay()
+                e1.record()
+            torch.cuda.synchronize()
+            ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+            result["unet_step_ms_p50"] = ts[len(ts) // 2]
+            result["unet_step_ms_p90"] = ts[int(len(ts) * 0.9)]
         if not args.no_roofline:
             # eager (un-graphed) UNet evaluation with a HIP-event pair around every kernel launch on the launch stream
             pipe.prepare(img_lat, ehs, null, ref, code)

@@ -44,7 +44,7 @@ def test_relpos_terms_and_biased_attention():
     from anyedit_amd import ops
     from oracle import sam_ref as M, ldm_ref as L
     g = torch.Generator().manual_seed(21)
-    for (B, heads, H, W, d) in ((2, 2, 8, 8, 32), (3, 2, 14, 14, 80), (1, 2, 64, 64, 80)):
+    for (B, heads, H, W, d) in ((2, 2, 8, 8, 32), (3, 2, 14, 14, 80), (1, 2, 64, 64, 80), (2, 2, 3, 64, 32), (1, 3, 5, 64, 40)):
         N = H * W
         q, k, v = (torch.randn(B * heads, N, d, generator=g).to(BF).float() for _ in range(3))
         rph, rpw = torch.randn(2 * H - 1, d, generator=g) * 0.3, torch.randn(2 * W - 1, d, generator=g) * 0.3

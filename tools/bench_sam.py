@@ -43,13 +43,16 @@ def main():
         with ops.OpProfiler() as prof:
             enc(x)
         summ = prof.summary()
+        by_shape = prof.summary(by_shape=True)
     ts.sort()
     med = ts[len(ts) // 2]
     assert y.shape == (a.batch, 256, 64, 64) and torch.isfinite(y).all()
     out = {"what": "SAM ViT-H image encoder, 1024x1024", "batch": a.batch, "latency_ms_p50": 1e3 * med,
            "images_per_s": a.batch / med, "tflops": 5.96 * a.batch / med,
            "kernels": {k: {"calls": v["calls"], "ms": v["ms"], "tflops": v["tflops"], "gbps": v["gbps"]}
-                       for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}}
+                       for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])},
+           "by_shape": {k: {"calls": v["calls"], "avg_us": v["avg_us"], "tflops": v["tflops"]}
+                        for k, v in sorted(by_shape.items(), key=lambda kv: -kv[1]["ms"])[:12]}}
     print(json.dumps(out))
 
 
