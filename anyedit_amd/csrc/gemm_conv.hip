@@ -41,6 +41,8 @@ struct GemmArgs {
     unsigned a_bytes, a2_bytes, w_bytes;  // buffer extents (bytes) for the bounds-checked fast loaders
     int splitk;      // > 1: K is cut into `splitk` ranges, each block writes raw fp32 partials (small-M, huge-K convs)
     float* partial;  // [splitk][M][N] fp32
+    int m_fast;      // tile order inside an XCD's run: 1 = M tiles fastest (tiles sharing a WEIGHT panel are neighbours: small-M layers whose
+                     // weights outweigh the activations), 0 = N tiles fastest (tiles sharing an ACTIVATION panel are neighbours)
 };
 
 // LDS-DMA: one wave moves 64 x 16 B from global straight into LDS at (wave-uniform dst) + lane*16.  The builtin exists only
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     const int ntiles = ntm * ntn;
     const int split = blockIdx.x / ntiles;
     const int tile = xcd_remap(blockIdx.x % ntiles, ntiles);
-    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int m0 = (p.m_fast ? tile % ntm : tile / ntn) * BM, n0 = (p.m_fast ? tile / ntm : tile % ntn) * BN;
 
     // ---- per-thread staging descriptors (loads are branch-free: indices are clamped, never predicated) --------
     long a_base[A_CH];            // dense: element offset of the (clamped) row ; conv: pixel base of the batch
@@ -613,7 +615,14 @@ int launch_kernel(Kern kern, unsigned grid, int threads, size_t lds, hipStream_t
 }
 
 template <int AMODE>
-int launch(const GemmArgs& a, hipStream_t stream) {
+int launch(const GemmArgs& a_in, hipStream_t stream) {
+    GemmArgs a = a_in;
+    // each XCD's L2 sees a contiguous run of tile ids: put the tiles that share the LARGER operand panel next to each other.
+    // Weights dominate at the 16x16 / 8x8 latent levels (M = 3072 / 768 rows against N x 9 Cin weights); the gather's 9x
+    // re-reads of the activation hit L2 either way.
+    static const int mfast_env = getenv("AE_GEMM_MFAST") ? atoi(getenv("AE_GEMM_MFAST")) : -1;  // tuning knob
+    // measured (kbench, MI355X): M = 768 convs +15..17 %, M = 3072 x N = 10240 GEGLU GEMM +7 %; M = 3072 convs -2..-6 %, M = 12288 -3..-12 %
+    a.m_fast = mfast_env >= 0 ? mfast_env : (AMODE == A_CONV3 ? (9L * a.N >= 8L * a.M) : ((long)a.N >= 3L * a.M)) ? 1 : 0;
     const int cand[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}};
     static const int t160 = getenv("AE_GEMM_T160") ? atoi(getenv("AE_GEMM_T160")) : 1;  // tuning knob: 128x160 tile
     int pick = a.splitk > 1 ? 0 : pick_tile(a.M, a.N);  // a split plan always uses the 128x128 tile (make_plan)
