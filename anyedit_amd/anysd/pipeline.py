@@ -54,13 +54,39 @@ class EditPipeline:
         ehs3 = torch.cat([ehs, null_ehs, null_ehs], 0)
         ref3 = torch.cat([ref_embeds, ref_embeds, torch.zeros_like(ref_embeds)], 0)
         code3 = torch.cat([edit_code] * 3, 0)
-        self._ctx_rows, self._kv_cache = self.moe.prepare_conditioning(ehs3, ref3, code3)
+        ctx_rows, kv_cache = self.moe.prepare_conditioning(ehs3, ref3, code3)
         img_cond3 = torch.cat([img_lat, img_lat, torch.zeros_like(img_lat)], 0).float()      # global_tool.py:290-304
         C = img_lat.shape[1]
-        self._x_in = torch.empty(3 * B, 2 * C, *img_lat.shape[2:], dtype=torch.float32, device=img_lat.device)
+        shape_in = (3 * B, 2 * C, *img_lat.shape[2:])
+        if self._same_layout(ctx_rows, kv_cache, shape_in):
+            # same shapes as the captured edit: refresh the graph's static buffers in place (no re-capture: a capture costs
+            # three eager UNet evaluations, ~6 % of a 50-step edit)
+            self._ctx_rows.copy_(ctx_rows)
+            for k, v in kv_cache.items():
+                cur = self._kv_cache[k]
+                if isinstance(v, tuple):
+                    for c, n in zip(cur, v):
+                        c.copy_(n)
+                else:
+                    cur.copy_(v)
+        else:
+            self._ctx_rows, self._kv_cache = ctx_rows, kv_cache
+            self._x_in = torch.empty(shape_in, dtype=torch.float32, device=img_lat.device)
+            self._t = torch.zeros(3 * B, dtype=torch.long, device=img_lat.device)
+            self._graph = None  # buffers changed identity -> recapture
         self._x_in[:, C:] = img_cond3
-        self._t = torch.zeros(3 * B, dtype=torch.long, device=img_lat.device)
-        self._graph = None  # conditioning buffers changed identity -> recapture
+
+    def _same_layout(self, ctx_rows, kv_cache, shape_in):
+        if getattr(self, "_kv_cache", None) is None or getattr(self, "_x_in", None) is None:
+            return False
+        if tuple(self._x_in.shape) != tuple(shape_in) or self._ctx_rows.shape != ctx_rows.shape or self._kv_cache.keys() != kv_cache.keys():
+            return False
+        for k, v in kv_cache.items():
+            cur = self._kv_cache[k]
+            a, b = (cur, v) if isinstance(v, tuple) else ((cur,), (v,))
+            if any(x.shape != y.shape or x.dtype != y.dtype for x, y in zip(a, b)):
+                return False
+        return True
 
     @torch.no_grad()
     def edit(self, x_T, img_lat, ehs, null_ehs, ref_embeds, edit_code, steps=50, s_txt=7.5, s_img=1.5, eta=0.0, mask=None,
