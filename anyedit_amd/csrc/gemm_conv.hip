@@ -64,9 +64,8 @@ constexpr int epilogue_passes(int FM, int bytes_per_frag_row, int lds_bytes) {
     return FM;
 }
 
-template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false, int STAGES = 2>
+template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const GemmArgs p) {
-    static_assert(STAGES == 2 || GLDS, "the deep LDS ring exists only for the LDS-DMA loader");
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
     constexpr int FM = WM / 16, FN = WN / 16;            // 16x16 fragments per wave
@@ -75,7 +74,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];  // 2 * (BM + BN) * BK bf16 (dynamic: > 64 KiB for 128x160)
     bf16_t* const smem = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* sA = smem;
-    bf16_t* sB = smem + STAGES * BM * BK;
+    bf16_t* sB = smem + 2 * BM * BK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -340,40 +339,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
                 lds_dma16(rsW, dst, fb_off[i], k0 * 2);
             }
         };
-        if constexpr (STAGES == 2) {
-            dma_tile(0, 0);
+        dma_tile(0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < KT) dma_tile(kt + 1, cur ^ 1);  // stage cur^1 was last read before the previous barrier
+            compute_tile(cur);
             __syncthreads();
-            for (int kt = 0; kt < KT; ++kt) {
-                const int cur = kt & 1;
-                if (kt + 1 < KT) dma_tile(kt + 1, cur ^ 1);  // stage cur^1 was last read before the previous barrier
-                compute_tile(cur);
-                __syncthreads();
-            }
-        } else {
-            // Deep ring: STAGES - 1 tiles in flight.  HBM/L3-sourced operands (the dense GEMMs) take far longer to land than one
-            // tile's MFMAs, so a one-tile prefetch leaves every iteration waiting on the DMA.  Ordering follows the LDS-DMA rules:
-            // each wave waits (counted vmcnt: only the OLDEST tile must have landed) for its own pieces, then a raw s_barrier
-            // makes every wave's pieces visible and proves all waves are done with the stage that is refilled next.
-            // __syncthreads() is not used here: its fence would drain the whole DMA queue (vmcnt(0)).
-            constexpr int PIECES = A_CH + B_CH;  // DMA instructions per tile per wave
-            constexpr int AHEAD = STAGES - 1;
-#pragma unroll
-            for (int t = 0; t < AHEAD; ++t)
-                if (t < KT) dma_tile(t, t);
-            int cur = 0, nxt = AHEAD % STAGES;
-            for (int kt = 0; kt < KT; ++kt) {
-                const int younger = min(KT - 1 - kt, AHEAD - 1);  // tiles issued after tile kt and still allowed in flight
-                if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
-                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (kt + AHEAD < KT) dma_tile(kt + AHEAD, nxt);  // refills the stage read in iteration kt - 1
-                compute_tile(cur);
-                cur = cur + 1 == STAGES ? 0 : cur + 1;
-                nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
-            }
-            __builtin_amdgcn_s_barrier();  // the epilogue reuses the ring as fp32 staging
         }
+        // (A deeper ring — 3-4 LDS stages, counted vmcnt, raw s_barrier — was built and measured 5-40 % slower on every GEMM
+        // shape of this UNet: it costs the second resident block per CU, which hides more latency than the extra stage.)
     }
 
     // ---- epilogue ---------------------------------------------------------------------------
@@ -399,7 +374,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     {
         constexpr int NCH = WN / 4;  // fp32 16-byte chunks per staged row
         // staging must fit in the main-loop LDS: split the wave tile's rows into passes if it does not (128x160 tile)
-        constexpr int PASSES = epilogue_passes(FM, WAVES_M * WAVES_N * 16 * WN * 4, STAGES * (BM + BN) * BK * 2);
+        constexpr int PASSES = epilogue_passes(FM, WAVES_M * WAVES_N * 16 * WN * 4, 2 * (BM + BN) * BK * 2);
         constexpr int FMP = FM / PASSES, WMP = WM / PASSES;
         static_assert(FM % PASSES == 0, "epilogue passes must divide the fragment rows");
         const bool geglu = p.epi == EPI_GEGLU;
@@ -634,7 +609,6 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // one-tile-ahead pipeline.  Measured on MI355X (profiles/r01_kbench_w8.txt): dense GEMMs -15..-25 % time, the 128x64 conv
     // unchanged (+-2 %), so that one keeps 4 waves (larger wave tile, fewer LDS reads per MFMA).  AE_GEMM_W8=0 forces 4 waves.
     static const int w8 = getenv("AE_GEMM_W8") ? atoi(getenv("AE_GEMM_W8")) : 2;
-    static const int stages = getenv("AE_GEMM_STAGES") ? atoi(getenv("AE_GEMM_STAGES")) : 2;  // tuning knob: LDS ring depth (2, 3, 4)
     const bool conv = AMODE == A_CONV3;
     const char* what = conv ? "ae_conv3x3_bf16" : "ae_gemm_bf16";
     // LDS-DMA loaders need whole-tile decisions: no K tail, no mixed-source tile, no upsample gather / padded channels
@@ -663,9 +637,7 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         const unsigned grid = (unsigned)((long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.splitk);
 #define AE_LAUNCH(BM_, BN_, WM_, WN_, THREADS)                                                                                            \
     do {                                                                                                                                  \
-        if (glds && stages == 3) rc = launch_kernel(gemm_kernel<BM_, BN_, AMODE, WM_, WN_, true, 3>, grid, THREADS, lds_of(BM_, BN_, 3), stream, a, what); \
-        else if (glds && stages == 4) rc = launch_kernel(gemm_kernel<BM_, BN_, AMODE, WM_, WN_, true, 4>, grid, THREADS, lds_of(BM_, BN_, 4), stream, a, what); \
-        else if (glds) rc = launch_kernel(gemm_kernel<BM_, BN_, AMODE, WM_, WN_, true>, grid, THREADS, lds_of(BM_, BN_, 2), stream, a, what); \
+        if (glds) rc = launch_kernel(gemm_kernel<BM_, BN_, AMODE, WM_, WN_, true>, grid, THREADS, lds_of(BM_, BN_, 2), stream, a, what);   \
         else rc = launch_kernel(gemm_kernel<BM_, BN_, AMODE, WM_, WN_, false>, grid, THREADS, lds_of(BM_, BN_, 2), stream, a, what);       \
     } while (0)
         if (pick == 3) AE_LAUNCH(128, 160, 2, 2, 256);

@@ -63,10 +63,10 @@ def build_model(device, seed=0):
     return unet, moe, sched
 
 
-def synthetic_inputs(B, device, rank=0):
+def synthetic_inputs(B, device, rank=0, latent=64):
     g = lambda s: torch.Generator(device="cpu").manual_seed(1000 * rank + s)
-    x_T = torch.randn(B, 4, 64, 64, generator=g(1)).to(device)
-    img_lat = (torch.randn(B, 4, 64, 64, generator=g(2)) * 0.18215).to(device)
+    x_T = torch.randn(B, 4, latent, latent, generator=g(1)).to(device)
+    img_lat = (torch.randn(B, 4, latent, latent, generator=g(2)) * 0.18215).to(device)
     ehs = torch.randn(B, 77, 768, generator=g(3)).to(device)
     null = torch.randn(1, 77, 768, generator=g(6)).to(device)
     ref = torch.randn(B, 257, 1280, generator=g(7)).to(device)
@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--images", type=int, default=4, help="images per GPU per step")
     ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--latent", type=int, default=64, help="latent side (64 = the 512x512 metric; 96 = 768x768, configs[4], informational)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -151,7 +152,7 @@ def main():
     from anyedit_amd.anysd.pipeline import EditPipeline
     unet, moe, sched = build_model(device)
     B = args.images
-    x_T, img_lat, ehs, null, ref, code = synthetic_inputs(B, device, rank)
+    x_T, img_lat, ehs, null, ref, code = synthetic_inputs(B, device, rank, args.latent)
     pipe = EditPipeline(moe, sched, use_graph=not args.no_graph)
 
     def one_step():
@@ -183,7 +184,8 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
         result = {
-            "metric": "edited-images/sec @512x512, 50 DDIM steps", "value": value, "unit": "edited-images/sec",
+            "metric": "edited-images/sec @512x512, 50 DDIM steps" if args.latent == 64 else f"edited-images/sec @{8 * args.latent}x{8 * args.latent}, 50 DDIM steps (informational)",
+            "value": value, "unit": "edited-images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[1]: AnySD (SD-1.5 UNet in=8 + task embedding/expert adapters) 512x512 bf16, "
@@ -191,7 +193,7 @@ def main():
                        "images_per_gpu": B, "ddim_steps": n_unet_steps, "cfg_branches": 3, "hip_graph": not args.no_graph,
                        "parallelism": f"dp{world} (image-sharded, no data-path collective)"},
             "unet_step_ms": ms_per_step / n_unet_steps,
-            "unet_tflops": 3 * B * GFLOP_PER_UNET_SAMPLE * n_unet_steps / (ms_per_step * 1e-3) / 1e3,
+            "unet_tflops": 3 * B * (GFLOP_PER_UNET_SAMPLE if args.latent == 64 else 2148.3 if args.latent == 96 else float("nan")) * n_unet_steps / (ms_per_step * 1e-3) / 1e3,
         }
         # BASELINE.json's second metric: UNet-step ms p50 — per-replay HIP-event timing of the captured UNet evaluation
         if pipe._graph is not None:
@@ -207,7 +209,7 @@ def main():
         if not args.no_roofline:
             # eager (un-graphed) UNet evaluation with a HIP-event pair around every kernel launch on the launch stream
             pipe.prepare(img_lat, ehs, null, ref, code)
-            pipe._x_in[:, :4].view(3, B, 4, 64, 64).copy_(x_T.unsqueeze(0))
+            pipe._x_in[:, :4].view(3, B, 4, args.latent, args.latent).copy_(x_T.unsqueeze(0))
             pipe._t.fill_(501)
             for _ in range(2):
                 pipe._denoise_static()
