@@ -102,6 +102,23 @@ __global__ void ddim_step_kernel(const DdimArgs p) {
     }
 }
 
+// DDIM inversion step (DDIMSampler.encode, ddim.py:253-298): x_next = cx * x + ce * e with e the CFG combination
+// e_uncond + s (e_cond - e_uncond) (ddim.py:277-280; batch order [uncond, cond]); two products and one sum, un-fused, like the
+// reference's xt_weighted + weighted_noise_pred.  cx, ce are computed on the host in float64 exactly as the reference does.
+__global__ void ddim_encode_step_kernel(const float* x, const float* eps, float* x_next, long n, int branches, float scale, float cx,
+                                        float ce) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        float e = eps[i];
+        if (branches == 2) {
+            const float eu = eps[i], ec = eps[n + i];
+            e = eu + scale * (ec - eu);
+        }
+        const float xw = cx * x[i];
+        const float ew = ce * e;
+        x_next[i] = xw + ew;
+    }
+}
+
 // out = (sa*x0 + s1*noise) * mask + (1 - mask) * img   (ddim.py:154-157 with q_sample ddpm.py:356-359);
 // mask is [B,1,H,W] broadcast over C.  order!=0 -> IP2P order: img*mask + q*(1-mask) (global_tool.py:183-184)
 __global__ void mask_blend_kernel(const float* img, const float* x0, const float* noise, const float* mask, float* out,
@@ -256,6 +273,14 @@ extern "C" int ae_ddim_step_f32(const float* x, const float* eps, const float* n
     DdimArgs a{x, eps, noise, x_prev, pred_x0, e_out, n, branches, s0, s1, sqrt_one_minus_at, sqrt_at, sqrt_a_prev, dir_coef, sigma_t, temperature};
     hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, a);
     return ae_check_launch("ae_ddim_step_f32");
+}
+
+extern "C" int ae_ddim_encode_step_f32(const float* x, const float* eps, float* x_next, long n, int branches, float scale, float cx,
+                                       float ce, void* stream) {
+    AE_REQUIRE(x && eps && x_next && n > 0, "ae_ddim_encode_step_f32: null pointer / bad n");
+    AE_REQUIRE(branches == 1 || branches == 2, "ae_ddim_encode_step_f32: branches must be 1 or 2 (got %d)", branches);
+    hipLaunchKernelGGL(ddim_encode_step_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, x, eps, x_next, n, branches, scale, cx, ce);
+    return ae_check_launch("ae_ddim_encode_step_f32");
 }
 
 extern "C" int ae_mask_blend_f32(const float* img, const float* x0, const float* noise, const float* mask, float* out, int B,

@@ -237,5 +237,49 @@ class DDIMSampler(object):
     @torch.no_grad()
     def encode(self, x0, c, t_enc, use_original_steps=False, return_intermediates=None, unconditional_guidance_scale=1.0,
                unconditional_conditioning=None, callback=None):
-        """ddim.py:253-298 (DDIM inversion) — listed as 'next' in SURVEY.md §8f N4; host loop over apply_model."""
-        raise NotImplementedError("DDIMSampler.encode (inversion) is scheduled with SURVEY.md §8(f) N4")
+        """ddim.py:253-298 (DDIM inversion).  Host loop over apply_model; the update x_next = cx*x + ce*e is one fused kernel
+        per step (ae_ddim_encode_step_f32).  Reference quirks kept: t = loop index i (not ddim_timesteps[i]); cx, ce formed in
+        float64 from the fp32 alphas_next and the float64 alphas_prev, rounded to fp32 where they meet the latents."""
+        num_reference_steps = self.ddpm_num_timesteps if use_original_steps else self.ddim_timesteps.shape[0]
+        assert t_enc <= num_reference_steps
+        num_steps = t_enc
+        if use_original_steps:
+            a_next = np.asarray(self.alphas_cumprod[:num_steps].detach().cpu(), dtype=np.float32)
+            a_prev = np.asarray(self.alphas_cumprod_prev[:num_steps].detach().cpu(), dtype=np.float32)  # fp32 buffer in this branch
+        else:
+            a_next = np.asarray(self.ddim_alphas[:num_steps], dtype=np.float32)
+            a_prev = np.asarray(self.ddim_alphas_prev[:num_steps], dtype=np.float64)
+        x_next = x0.float().contiguous()
+        intermediates, inter_steps = [], []
+        cfg = unconditional_guidance_scale != 1.
+        for i in range(num_steps):
+            t = torch.full((x0.shape[0],), i, device=x0.device, dtype=torch.long)
+            if not cfg:
+                eps = self.model.apply_model(x_next, t, c)
+            else:
+                assert unconditional_conditioning is not None
+                eps = self.model.apply_model(torch.cat((x_next, x_next)), torch.cat((t, t)), torch.cat((unconditional_conditioning, c)))
+            an32, ap = np.float32(a_next[i]), a_prev[i]
+            cx = np.float32(np.sqrt(np.float64(an32) / np.float64(ap)) if not use_original_steps else np.sqrt(an32 / np.float32(ap), dtype=np.float32))
+            s_next = np.sqrt(an32, dtype=np.float32)                                   # alphas_next[i].sqrt()          (fp32)
+            r_next = np.sqrt(np.float32(1) / an32 - np.float32(1), dtype=np.float32)   # (1 / alphas_next[i] - 1).sqrt() (fp32)
+            if use_original_steps:
+                r_prev = np.sqrt(np.float32(1) / np.float32(ap) - np.float32(1), dtype=np.float32)
+                ce = np.float32(s_next * (r_next - r_prev))
+            else:
+                r_prev = np.sqrt(1.0 / np.float64(ap) - 1.0)                            # float64
+                ce = np.float32(np.float64(s_next) * (np.float64(r_next) - r_prev))
+            x_next = ops.ddim_encode_step(x_next, eps.float(), float(cx), float(ce), branches=2 if cfg else 1,
+                                          scale=float(unconditional_guidance_scale))
+            if return_intermediates and i % (num_steps // return_intermediates) == 0 and i < num_steps - 1:
+                intermediates.append(x_next)
+                inter_steps.append(i)
+            elif return_intermediates and i >= num_steps - 2:
+                intermediates.append(x_next)
+                inter_steps.append(i)
+            if callback:
+                callback(i)
+        out = {'x_encoded': x_next, 'intermediate_steps': inter_steps}
+        if return_intermediates:
+            out.update({'intermediates': intermediates})
+        return x_next, out

@@ -259,6 +259,17 @@ def ddim_step(x, eps, coeffs, branches, s0=1.0, s1=0.0, noise=None, temperature=
     return x_prev, pred_x0
 
 
+def ddim_encode_step(x, eps, cx, ce, branches=1, scale=1.0):
+    """DDIM inversion update x_next = cx*x + ce*cfg(eps) (ddim.py:253-298); eps holds `branches` stacked predictions."""
+    _chk(x, torch.float32, "ddim_encode_step.x")
+    _chk(eps, torch.float32, "ddim_encode_step.eps")
+    x, eps = x.contiguous(), eps.contiguous()
+    out = torch.empty_like(x)
+    check(lib.ae_ddim_encode_step_f32(_p(x), _p(eps), _p(out), x.numel(), branches, float(scale), float(cx), float(ce), _s()),
+          "ae_ddim_encode_step_f32")
+    return out
+
+
 def mask_blend(img, x0, noise, mask, sqrt_ac, sqrt_one_minus_ac, ip2p_order=False):
     B, C, H, W = img.shape
     out = torch.empty_like(img)

@@ -142,6 +142,10 @@ int ae_timestep_embedding(const long* t_i64, const float* t_f32, void* out_bf16,
 int ae_ddim_step_f32(const float* x, const float* eps, const float* noise, float* x_prev, float* pred_x0, float* e_out, long n,
                      int branches, float s0, float s1, float sqrt_one_minus_at, float sqrt_at, float sqrt_a_prev, float dir_coef,
                      float sigma_t, float temperature, void* stream);
+/* DDIM inversion update (DDIMSampler.encode, ddim.py:253-298): x_next = cx*x + ce*e, e = CFG combination of `branches`
+ * stacked predictions ([uncond, cond]); cx, ce from the host in float64 as the reference computes them.                       */
+int ae_ddim_encode_step_f32(const float* x, const float* eps, float* x_next, long n, int branches, float scale, float cx, float ce,
+                            void* stream);
 /* q_sample (ddpm.py:356-359) fused with the mask blend (ddim.py:154-157; ip2p_order=1: global_tool.py:183-184).               */
 int ae_mask_blend_f32(const float* img, const float* x0, const float* noise, const float* mask, float* out, int B, int C, int HW,
                       float sqrt_ac, float sqrt_one_minus_ac, int ip2p_order, void* stream);

@@ -96,6 +96,43 @@ def stochastic_encode(sched, x0, t, noise):
     return extract(sa, t, x0.shape) * x0 + extract(s1, t, x0.shape) * noise
 
 
+def ddim_encode(apply_model, sched, buffers, x0, c, t_enc, use_original_steps=False, return_intermediates=None, scale=1.0, uc=None):
+    """ddim.py:253-298 (DDIM inversion).  Kept quirks: the network is queried at t = LOOP INDEX i, not at ddim_timesteps[i];
+    alphas_next is the fp32 schedule tensor, alphas the float64 array of previous alphas (G5 dtype mix), so the two
+    coefficients are formed in float64 and rounded to fp32 when they meet the fp32 latents."""
+    num_reference_steps = buffers["alphas_cumprod"].shape[0] if use_original_steps else sched["ddim_timesteps"].shape[0]
+    assert t_enc <= num_reference_steps
+    num_steps = t_enc
+    if use_original_steps:
+        alphas_next = buffers["alphas_cumprod"][:num_steps]
+        alphas = buffers["alphas_cumprod_prev"][:num_steps]
+    else:
+        alphas_next = torch.as_tensor(sched["ddim_alphas"])[:num_steps]
+        alphas = torch.tensor(np.asarray(sched["ddim_alphas_prev"])[:num_steps])
+    x_next = x0
+    intermediates, inter_steps = [], []
+    for i in range(num_steps):
+        t = torch.full((x0.shape[0],), i, dtype=torch.long)
+        if scale == 1.0:
+            noise_pred = apply_model(x_next, t, c)
+        else:
+            e_t_uncond, noise_pred = torch.chunk(apply_model(torch.cat((x_next, x_next)), torch.cat((t, t)), _cat_cond(uc, c)), 2)
+            noise_pred = e_t_uncond + scale * (noise_pred - e_t_uncond)
+        xt_weighted = (alphas_next[i] / alphas[i]).sqrt() * x_next
+        weighted_noise_pred = alphas_next[i].sqrt() * ((1 / alphas_next[i] - 1).sqrt() - (1 / alphas[i] - 1).sqrt()) * noise_pred
+        x_next = xt_weighted + weighted_noise_pred
+        if return_intermediates and i % (num_steps // return_intermediates) == 0 and i < num_steps - 1:
+            intermediates.append(x_next)
+            inter_steps.append(i)
+        elif return_intermediates and i >= num_steps - 2:
+            intermediates.append(x_next)
+            inter_steps.append(i)
+    out = {"x_encoded": x_next, "intermediate_steps": inter_steps}
+    if return_intermediates:
+        out["intermediates"] = intermediates
+    return x_next, out
+
+
 def ddim_decode(apply_model, sched, x_latent, cond, t_start, scale=1.0, uc=None):
     """ddim.py:316-336."""
     timesteps = sched["ddim_timesteps"][:t_start]

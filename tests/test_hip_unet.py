@@ -134,6 +134,42 @@ def test_ddim_sampler_golden(tiny_unet):
         close(samples, g[f"{tag}.samples"], rl2=tol, db=26.0, what=f"DDIM {tag}")       # CFG amplifies bf16 noise x7.5
 
 
+def test_ddim_encode_inversion_golden(tiny_unet):
+    """DDIMSampler.encode on the HIP path vs the reference's inversion output (golden) and its integer bookkeeping."""
+    from anyedit_amd.ldm.models.diffusion.ddim import DDIMSampler
+    unet, _ = tiny_unet
+    g = load_golden("ddim_encode")
+    ldm = _tiny_ldm(unet)
+    sampler = DDIMSampler(ldm)
+    sampler.make_schedule(10, ddim_eta=0.0, verbose=False)
+    dev = lambda k: T(g[k]).to(DEV)
+    cond = {"c_concat": [dev("img_lat")], "c_crossattn": [dev("ctx")]}
+    x_enc, out = sampler.encode(dev("x0"), cond, t_enc=7, return_intermediates=3)
+    assert out["intermediate_steps"] == g["intermediate_steps"].tolist()
+    close(x_enc, g["x_encoded"], rl2=3e-2, db=30.0, what="DDIM inversion (7 of 10 steps)")
+    close(torch.stack(out["intermediates"]), g["intermediates"], rl2=3e-2, db=30.0, what="DDIM inversion intermediates")
+    x_enc2, _ = sampler.encode(dev("x0"), cond, t_enc=20, use_original_steps=True)
+    close(x_enc2, g["x_encoded_original_steps"], rl2=3e-2, db=30.0, what="DDIM inversion (original steps)")
+
+
+def test_ddim_encode_step_bit_exact_vs_oracle_arithmetic():
+    """Same eps on both sides: the fused inversion update reproduces the reference's un-fused fp32 expression bit for bit,
+    including the CFG combination."""
+    from anyedit_amd import ops
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    eps = torch.randn(4, 4, 8, 8, generator=g)
+    a_next = torch.tensor(0.8531, dtype=torch.float32)
+    a_prev = torch.tensor(0.9127, dtype=torch.float64)
+    cx = (a_next / a_prev).sqrt()
+    ce = a_next.sqrt() * ((1 / a_next - 1).sqrt() - (1 / a_prev - 1).sqrt())
+    eu, ec = eps.chunk(2)
+    e = eu + 7.5 * (ec - eu)
+    ref = cx * x + ce * e
+    got = ops.ddim_encode_step(x.to(DEV), eps.to(DEV), float(cx.float()), float(ce.float()), branches=2, scale=7.5)
+    assert torch.equal(got.cpu(), ref.float())
+
+
 def test_ddim_sampler_vs_oracle_same_eps():
     """With the SAME eps fed to both, the HIP sampler arithmetic is bit-identical to the oracle's fp32 loop."""
     from anyedit_amd.ldm.models.diffusion.ddim import DDIMSampler

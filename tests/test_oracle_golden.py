@@ -157,6 +157,21 @@ def test_ddim_sampler():
     close(dec, g["sdedit.dec"], tol=2e-4)
 
 
+def test_ddim_encode_inversion():
+    """DDIMSampler.encode (ddim.py:253-298) restatement against the reference's own inversion run."""
+    g = load_golden("ddim_encode")
+    buffers, apply_model = _tiny_ldm()
+    cond = {"c_concat": [T(g["img_lat"])], "c_crossattn": [T(g["ctx"])]}
+    sched = S.make_ddim_schedule(buffers, 10, "uniform", 0.0)
+    assert np.array_equal(np.asarray(sched["ddim_alphas"]), g["ddim_alphas"]) and np.array_equal(np.asarray(sched["ddim_alphas_prev"]), g["ddim_alphas_prev"])
+    x_enc, out = D.ddim_encode(apply_model, sched, buffers, T(g["x0"]), cond, 7, return_intermediates=3)
+    assert out["intermediate_steps"] == g["intermediate_steps"].tolist()      # integer bookkeeping: exact
+    close(x_enc, g["x_encoded"], tol=2e-4)
+    close(torch.stack(out["intermediates"]), g["intermediates"], tol=2e-4)
+    x_enc2, _ = D.ddim_encode(apply_model, sched, buffers, T(g["x0"]), cond, 20, use_original_steps=True)
+    close(x_enc2, g["x_encoded_original_steps"], tol=2e-4)
+
+
 def test_eps_mse_matches_p_losses():
     g = load_golden("ddim_tiny")
     buffers, apply_model = _tiny_ldm()

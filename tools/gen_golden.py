@@ -392,6 +392,38 @@ def gen_ddim():
 
 
 @torch.no_grad()
+def gen_ddim_encode():
+    """DDIMSampler.encode (DDIM inversion, ddim.py:253-298) on the tiny hybrid model; scale 1.0 (the reference's CFG branch
+    concatenates conditionings with torch.cat and therefore only accepts tensor conditioning, which a hybrid model rejects)."""
+    print("[ddim_encode]")
+    import io
+    import contextlib
+    tiny = build_tiny_unet()
+    ldm = build_ldm(TINY_UNET)
+    ldm.model.diffusion_model.load_state_dict(tiny.state_dict())
+    g = G(61)
+    B = 2
+    x0 = torch.randn(B, 4, 8, 8, generator=g)
+    img_lat = torch.randn(B, 4, 8, 8, generator=g) * 0.18215
+    ctx = torch.randn(B, 5, 16, generator=g)
+    cond = {"c_concat": [img_lat], "c_crossattn": [ctx]}
+    arrs = {"x0": x0, "img_lat": img_lat, "ctx": ctx}
+    sampler = CPUDDIMSampler(ldm)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        sampler.make_schedule(10, ddim_eta=0.0, verbose=False)
+        x_enc, out = sampler.encode(x0, cond, t_enc=7, return_intermediates=3)
+    arrs["x_encoded"] = x_enc
+    arrs["intermediate_steps"] = np.asarray(out["intermediate_steps"], dtype=np.int64)
+    arrs["intermediates"] = torch.stack(out["intermediates"])
+    arrs["ddim_alphas"] = np.asarray(sampler.ddim_alphas)
+    arrs["ddim_alphas_prev"] = np.asarray(sampler.ddim_alphas_prev)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        x_enc2, _ = sampler.encode(x0, cond, t_enc=20, use_original_steps=True)
+    arrs["x_encoded_original_steps"] = x_enc2
+    npz("ddim_encode", **arrs)
+
+
+@torch.no_grad()
 def gen_sam():
     print("[sam]")
     arrs = {}
@@ -461,13 +493,10 @@ def gen_ldm_misc():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    gen_schedule()
-    gen_norms()
-    gen_attention()
-    gen_transformer()
-    gen_resblock()
-    gen_unet()
-    gen_ddim()
-    gen_sam()
-    gen_ldm_misc()
+    only = set(sys.argv[1:])  # e.g. `python tools/gen_golden.py ddim_encode` regenerates one fixture
+    for name, fn in (("schedule", gen_schedule), ("norms", gen_norms), ("attention", gen_attention), ("transformer", gen_transformer),
+                     ("resblock", gen_resblock), ("unet", gen_unet), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode),
+                     ("sam", gen_sam), ("misc", gen_ldm_misc)):
+        if not only or name in only:
+            fn()
     print("done")
