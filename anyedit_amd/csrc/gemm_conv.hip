@@ -619,9 +619,11 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
 
     // 192x320 tile, one block per CU (128 KiB LDS), 8 waves with 96x80 (or 48x160 for the GEGLU column pairing) wave tiles:
     // 0.37-0.43 LDS fragment reads per MFMA instead of 0.75.  Used when the tile grid fills whole rounds of 256 CUs.
-    static const int t320 = getenv("AE_GEMM_T320") ? atoi(getenv("AE_GEMM_T320")) : 2;  // tuning knob: 0 off, 1 conv only, 2 conv + GEGLU GEMMs (other dense shapes measured neutral)
+    static const int t320 = getenv("AE_GEMM_T320") ? atoi(getenv("AE_GEMM_T320")) : 3;  // tuning knob, bit flags: 1 convs, 2 GEGLU GEMMs with K >= 640, 4 GEGLU K = 320, 8 other dense K >= 640.  Isolated (kbench) the
+    // dense flags gain 4..20 %, inside the UNet evaluation (in-situ A/B, one box) 4 and 8 are neutral-to-negative (0.5 %): default 3
     bool done = false;
-    if (t320 && glds && a.splitk <= 1 && a.N % 320 == 0 && (conv || (t320 >= 2 && a.K >= 640 && a.epi == EPI_GEGLU))) {
+    if (t320 && glds && a.splitk <= 1 && a.N % 320 == 0 && ((conv && (t320 & 1)) || (!conv && a.epi == EPI_GEGLU && a.K >= 640 && (t320 & 2)) || (!conv && a.epi == EPI_GEGLU && a.K < 640 && a.K >= 320 && (t320 & 4)) ||
+                                                                     (!conv && a.epi != EPI_GEGLU && a.K >= 640 && (t320 & 8)))) {
         const long t = (long)((a.M + 191) / 192) * (a.N / 320);
         const double fill = (double)t / (double)(((t + 255) / 256) * 256) * ((double)a.M / (double)(((a.M + 191) / 192) * 192));
         // 192x320 waves 2x4, or 4x2 for GEGLU (pairs of 16-column fragments must sit in one wave).  A 96x320 variant for the
