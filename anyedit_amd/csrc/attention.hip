@@ -124,6 +124,47 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 && BIAS == 0 ? 4 : 2) 
         }
     }
 
+    // BIAS 1: this lane's rows of the two bias tables (32-bit indexing inside a row)
+    const float* rh_row[BIAS == 1 ? QF : 1];
+    const float* rw_row[BIAS == 1 ? QF : 1];
+    const float inv_kw = BIAS == 1 ? 1.0f / (float)p.kW : 0.f;
+    // small key grids (SAM's 14x14 windows): the block's bias rows [query][kH + kW] are copied into LDS once — the per-key
+    // lookups are index-dependent, and as global loads each one exposed a full memory round trip (3x the kernel time)
+    constexpr int BIAS_LDS_W = 32;                 // kH, kW <= 32 each
+    constexpr int BQ = NW * 16 * QF;               // queries per block
+    __shared__ float sBiasH[BIAS == 1 ? BQ * BIAS_LDS_W : 1];
+    __shared__ float sBiasW[BIAS == 1 ? BQ * BIAS_LDS_W : 1];
+    const bool bias_in_lds = BIAS == 1 && p.kH <= BIAS_LDS_W && p.kW <= BIAS_LDS_W;
+    if (BIAS == 1) {
+        if (bias_in_lds) {
+            // the block's rows of each table are one contiguous range: straight coalesced copies, all loads in flight at once
+            const int qfirst = qb * BQ;
+            const int nq = min(BQ, p.Nq - qfirst);
+            const float* gh = p.rel_h + ((long)bh * p.Nq + qfirst) * p.kH;
+            const float* gw = p.rel_w + ((long)bh * p.Nq + qfirst) * p.kW;
+            constexpr int IT = (BQ * BIAS_LDS_W + NT - 1) / NT;
+            float th[IT], tw[IT];
+#pragma unroll
+            for (int j = 0; j < IT; ++j) {
+                const int i = tid + j * NT;
+                th[j] = i < nq * p.kH ? gh[i] : 0.f;
+                tw[j] = i < nq * p.kW ? gw[i] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < IT; ++j) {
+                const int i = tid + j * NT;
+                if (i < BQ * p.kH) sBiasH[i] = th[j];
+                if (i < BQ * p.kW) sBiasW[i] = tw[j];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int a = 0; a < QF; ++a) {
+            const long qc = (long)bh * p.Nq + min(q0 + a * 16 + l15, p.Nq - 1);
+            rh_row[BIAS == 1 ? a : 0] = p.rel_h + qc * p.kH;
+            rw_row[BIAS == 1 ? a : 0] = p.rel_w + qc * p.kW;
+        }
+    }
     f32x4 rw[BIAS == 2 ? QF : 1][4];  // BIAS 2: rel_w[q][16 f + 4 lg + r] * log2(e) of this lane's key slots
     if (BIAS == 2) {
 #pragma unroll
@@ -284,6 +325,25 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 && BIAS == 0 ? 4 : 2) 
             for (int a = 0; a < QF; ++a) {
                 constexpr bool PLAIN = !HAS_BIAS && !HAS_MASK && !TAIL;
                 if (!PLAIN) {
+                    float bval[BIAS == 1 ? 4 : 1][4];  // BIAS 1: all 16 lookups are issued before any is consumed
+                    if (BIAS == 1) {
+    #pragma unroll
+                        for (int f = 0; f < 4; ++f)
+    #pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                // key -> (row, column) of the key grid without an integer division: (key + 0.5) / kW is never
+                                // closer than 0.5 / kW to an integer, far above the fp32 error for any grid that fits a kernel
+                                const int key = min(k0 + f * 16 + lg * 4 + r, last_key);
+                                const int khh = (int)(((float)key + 0.5f) * inv_kw);
+                                const int kww = key - khh * p.kW;
+                                if (bias_in_lds) {
+                                    const int ql = wave * 16 * QF + a * 16 + l15;
+                                    bval[BIAS == 1 ? f : 0][r] = sBiasH[ql * p.kH + khh] + sBiasW[ql * p.kW + kww];
+                                } else {
+                                    bval[BIAS == 1 ? f : 0][r] = rh_row[BIAS == 1 ? a : 0][khh] + rw_row[BIAS == 1 ? a : 0][kww];
+                                }
+                            }
+                    }
     #pragma unroll
                     for (int f = 0; f < 4; ++f) {
                         const int kb = k0 + f * 16 + lg * 4;
@@ -293,10 +353,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 && BIAS == 0 ? 4 : 2) 
                             if (BIAS == 2) {
                                 v = fmaf(s[a][f][r], c2, rw[BIAS == 2 ? a : 0][f][r] + rh[BIAS == 2 ? a : 0]);
                             } else if (HAS_BIAS) {
-                                const int qc = min(q0 + a * 16 + l15, p.Nq - 1);
-                                const int key = min(kb + r, last_key);
-                                const int khh = key / p.kW;
-                                v += (p.rel_h[((long)bh * p.Nq + qc) * p.kH + khh] + p.rel_w[((long)bh * p.Nq + qc) * p.kW + (key - khh * p.kW)]) * LOG2E;
+                                v = fmaf(bval[BIAS == 1 ? f : 0][r], LOG2E, v);
                             }
                             if (HAS_MASK) {
                                 if (p.key_mask[(long)b * seg_Nk + min(kb + r, last_key)] == 0) v = NEG_BIG;
