@@ -203,6 +203,57 @@ __global__ void relpos_kernel(const bf16_t* q, long q_sb, long q_sh, long q_sn, 
     }
 }
 
+// Same contraction, one block per (batch*head, query row y) [PART 0: rel_h] or (batch*head, query column x) [PART 1: rel_w]: the
+// qW (qH) queries of that line share one [kH, D] (resp. [kW, D]) slice of the table, so both operands are staged in LDS once by
+// coalesced loads and every thread produces several outputs (the per-query kernel above launched 65k 128-thread blocks with
+// strided table reads: 112 us per SAM block vs ~15 us of traffic).  Limits: line length, kH/kW <= 64, D % 8 == 0, D <= 160.
+template <int PART>
+__global__ __launch_bounds__(256) void relpos_line_kernel(const bf16_t* q, long q_sb, long q_sh, long q_sn, const float* Rh, const float* Rw,
+                                                          float* rel_h, float* rel_w, int Hh, int qH, int qW, int kH, int kW, int D) {
+    extern __shared__ float smem_rp[];
+    const int LD = D + 4;
+    const int nline = PART == 0 ? qH : qW;          // lines per (b, h)
+    const int Lq = PART == 0 ? qW : qH;             // queries on this line
+    const int K = PART == 0 ? kH : kW;
+    float* sQ = smem_rp;                            // [Lq][LD]
+    float* sR = smem_rp + 64 * LD;                  // [K][LD]
+    const int bh = blockIdx.x / nline, line = blockIdx.x % nline;
+    const int b = bh / Hh, h = bh % Hh;
+    const bf16_t* qb = q + (long)b * q_sb + (long)h * q_sh;
+    const float* R = PART == 0 ? Rh + (long)line * kH * D : Rw + (long)line * kW * D;
+    const int d8 = D / 8;
+    for (int i = threadIdx.x; i < Lq * d8; i += 256) {
+        const int qi = i / d8, c = (i - qi * d8) * 8;
+        const int n = PART == 0 ? line * qW + qi : qi * qW + line;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(qb + (long)n * q_sn + c);
+        float* d = sQ + qi * LD + c;
+        d[0] = bf16lo(v.x); d[1] = bf16hi(v.x); d[2] = bf16lo(v.y); d[3] = bf16hi(v.y);
+        d[4] = bf16lo(v.z); d[5] = bf16hi(v.z); d[6] = bf16lo(v.w); d[7] = bf16hi(v.w);
+    }
+    for (int i = threadIdx.x; i < K * D / 4; i += 256) {
+        const int k = (i * 4) / D, c = i * 4 - k * D;
+        *reinterpret_cast<f32x4*>(sR + k * LD + c) = *reinterpret_cast<const f32x4*>(R + (long)i * 4);
+    }
+    __syncthreads();
+    const long N = (long)qH * qW;
+    float* out = PART == 0 ? rel_h : rel_w;
+    for (int o = threadIdx.x; o < Lq * K; o += 256) {
+        const int qi = o / K, k = o - qi * K;
+        const float* a = sQ + qi * LD;
+        const float* r = sR + k * LD;
+        float acc = 0.f;
+        for (int c = 0; c < D; c += 4) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(a + c), rv = *reinterpret_cast<const f32x4*>(r + c);
+            acc += av[0] * rv[0];
+            acc += av[1] * rv[1];
+            acc += av[2] * rv[2];
+            acc += av[3] * rv[3];
+        }
+        const int n = PART == 0 ? line * qW + qi : qi * qW + line;
+        out[((long)bh * N + n) * K + k] = acc;
+    }
+}
+
 // PatchEmbed im2col: x [B,Cin,H,W] fp32 -> patches [B*(H/P)*(W/P), Cin*P*P] bf16, K order (c, ky, kx) = conv weight order
 __global__ void patchify_kernel(const float* x, bf16_t* y, int B, int Cin, int H, int W, int P) {
     const int gh = H / P, gw = W / P, K = Cin * P * P;
@@ -330,6 +381,23 @@ extern "C" int ae_sam_relpos_terms(const void* q, long q_sb, long q_sh, long q_s
                                    float* rel_w, int B, int heads, int qH, int qW, int kH, int kW, int D, void* stream) {
     AE_REQUIRE(q && Rh && Rw && rel_h && rel_w && B > 0 && heads > 0 && D > 0, "ae_sam_relpos_terms: bad arguments");
     AE_REQUIRE((long)B * heads <= 65535, "ae_sam_relpos_terms: B*heads too large for grid.y");
+    if (qH <= 64 && qW <= 64 && kH <= 64 && kW <= 64 && D % 8 == 0 && D <= 160 && (q_sn % 8) == 0 && (q_sb % 8) == 0 && (q_sh % 8) == 0 &&
+        (reinterpret_cast<uintptr_t>(q) & 15) == 0 && (reinterpret_cast<uintptr_t>(Rh) & 15) == 0 && (reinterpret_cast<uintptr_t>(Rw) & 15) == 0) {
+        const size_t lds = (size_t)2 * 64 * (D + 4) * sizeof(float);
+        static bool attr_done = false;
+        if (lds > 64 * 1024 && !attr_done) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&relpos_line_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&relpos_line_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(relpos_line_kernel<0>, dim3(B * heads * qH), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, q_sb, q_sh, q_sn,
+                           Rh, Rw, rel_h, rel_w, heads, qH, qW, kH, kW, D);
+        int rc = ae_check_launch("ae_sam_relpos_terms(rel_h)");
+        if (rc) return rc;
+        hipLaunchKernelGGL(relpos_line_kernel<1>, dim3(B * heads * qW), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q, q_sb, q_sh, q_sn,
+                           Rh, Rw, rel_h, rel_w, heads, qH, qW, kH, kW, D);
+        return ae_check_launch("ae_sam_relpos_terms(rel_w)");
+    }
     dim3 grid(qH * qW, B * heads);
     hipLaunchKernelGGL(relpos_kernel, grid, dim3(128), D * sizeof(float), (hipStream_t)stream, (const bf16_t*)q, q_sb, q_sh, q_sn, Rh, Rw,
                        rel_h, rel_w, B, heads, qH, qW, kH, kW, D);

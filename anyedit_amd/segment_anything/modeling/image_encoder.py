@@ -201,6 +201,35 @@ class ImageEncoderViT(nn.Module):
                                   Conv2d(out_chans, out_chans, kernel_size=3, padding=1, bias=False), LayerNorm2d(out_chans))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if getattr(self, "use_hip_graph", False) and x.is_cuda:
+            return self._forward_graphed(x)
+        return self._forward_eager(x)
+
+    @torch.no_grad()
+    def _forward_graphed(self, x):
+        """The encoder is ~330 launches of fixed shape: captured once per input shape as a HIP graph (torch.cuda.CUDAGraph) and
+        replayed on a static input buffer — removes the host launch gaps (SamPredictor.set_torch_image always feeds 1024x1024)."""
+        key = (tuple(x.shape), x.dtype, x.device)
+        st = getattr(self, "_graph_state", None)
+        if st is None or st["key"] != key:
+            xin = x.clone()
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(2):  # warm-up outside capture (weight packing, allocator pools)
+                    self._forward_eager(xin)
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._forward_eager(xin)
+            st = self._graph_state = {"key": key, "graph": g, "xin": xin, "out": out}
+        st["xin"].copy_(x)
+        st["graph"].replay()
+        return st["out"].clone()
+
+    def _forward_eager(self, x: torch.Tensor) -> torch.Tensor:
         B = x.shape[0]
         h, gh, gw = self.patch_embed.rows(x)
         if self.pos_embed is not None:
