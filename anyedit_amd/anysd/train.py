@@ -99,15 +99,15 @@ class AnySDTrainer:
         backward gathers the rows per expert again (row gather / scatter is data movement, the arithmetic is ae_gemm_bf16)."""
         B = len(experts)
         dev = ip_rows.device
-        Wb = W.detach().to(BF16)
-        kv_ip = torch.empty(B * T_ip, Wb.shape[1], dtype=BF16, device=dev)
+        kv_ip = torch.empty(B * T_ip, W.shape[1], dtype=BF16, device=dev)
         groups = {}
         for b, e in enumerate(experts):
             groups.setdefault(e, []).append(b)
         index = {e: torch.tensor([b * T_ip + j for b in bs for j in range(T_ip)], device=dev) for e, bs in groups.items()}
+        Wb = {e: W.detach()[e].to(BF16).contiguous() for e in groups}  # only the experts some sample is routed to
         with tape.paused():
             for e, idx in index.items():
-                kv_ip[idx] = ops.gemm(ip_rows[idx].contiguous(), Wb[e].contiguous())
+                kv_ip[idx] = ops.gemm(ip_rows[idx].contiguous(), Wb[e])
 
         def bwd():
             dkv = tape.grad(kv_ip)

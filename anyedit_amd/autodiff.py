@@ -28,6 +28,13 @@ def _base(t):
     return t._base if t._base is not None else t
 
 
+# Frozen weights never change between steps: their transposed / rotated packed copies are built once per process, keyed by the
+# packed tensor (kept alive here, so ids stay unique).  Trainable weights are re-packed from the fp32 masters every step and are
+# NOT cached.
+_FROZEN_WT = {}
+_FROZEN_WROT = {}
+
+
 class Tape:
     def __init__(self):
         self.active = False
@@ -107,17 +114,21 @@ class Tape:
 
     # ------------------------------------------------------------------ weights for the data-gradient passes
     def transposed(self, w):
-        wt = self._wt.get(id(w))
-        if wt is None:
-            wt = w.t().contiguous()
-            self._wt[id(w)] = wt
-            self.keep.append(w)
-        return wt
+        if id(w) in self.trainable:
+            wt = self._wt.get(id(w))
+            if wt is None:
+                wt = self._wt[id(w)] = w.t().contiguous()
+            return wt
+        ent = _FROZEN_WT.get(id(w))
+        if ent is None or ent[0] is not w:
+            ent = _FROZEN_WT[id(w)] = (w, w.t().contiguous())
+        return ent[1]
 
     def rotated(self, w, cin):
         """packed conv weight [Cout, 9*CinPad] (ky,kx,cin) -> packed weight of the adjoint conv [Cin, 9*CoutPad]:
         w'[ci][ky'][kx'][co] = w[co][2-ky'][2-kx'][ci]."""
-        wr = self._wrot.get(id(w))
+        ent = _FROZEN_WROT.get(id(w))
+        wr = ent[1] if ent is not None and ent[0] is w else None
         if wr is None:
             cout = w.shape[0]
             cin_pad = w.shape[1] // 9
@@ -126,8 +137,7 @@ class Tape:
             wr = torch.zeros(cin, 3, 3, cout_pad, dtype=BF16, device=w.device)
             wr[..., :cout] = w4
             wr = wr.reshape(cin, 9 * cout_pad).contiguous()
-            self._wrot[id(w)] = wr
-            self.keep.append(w)
+            _FROZEN_WROT[id(w)] = (w, wr)
         return wr
 
     # ------------------------------------------------------------------ operators
