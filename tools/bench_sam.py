@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--parity", action="store_true", help="also run the CPU oracle (fp32, full ViT-H, ~1 min) and report rel-L2 / PSNR")
     a = ap.parse_args()
     dev = "cuda"
     torch.manual_seed(0)
@@ -66,6 +67,20 @@ def main():
                        for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])},
            "by_shape": {k: {"calls": v["calls"], "avg_us": v["avg_us"], "tflops": v["tflops"]}
                         for k, v in sorted(by_shape.items(), key=lambda kv: -kv[1]["ms"])[:12]}}
+    if a.parity:
+        # full-size parity of the HIP encoder against the oracle restatement (test infrastructure; here only as the checker)
+        from oracle import sam_ref as M
+        import math
+        torch.set_num_threads(min(os.cpu_count(), 32))
+        sd = {k: v.detach().float().cpu() for k, v in enc.state_dict().items()}
+        t0 = time.time()
+        with torch.no_grad():
+            ref = M.image_encoder(sd, "", x[:1].float().cpu(), 16, 32, 16, 14, (7, 15, 23, 31))
+        got = y[:1].float().cpu()
+        err = float((got - ref).norm() / ref.norm())
+        mse = float(((got - ref) ** 2).mean())
+        peak = float(ref.max() - ref.min())
+        out["parity"] = {"rel_l2_vs_oracle": err, "psnr_db": 10 * math.log10(peak * peak / mse), "oracle_cpu_seconds": time.time() - t0}
     print(json.dumps(out))
 
 
