@@ -65,6 +65,8 @@ SIGNATURES = {
     "ae_window_partition_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ae_sam_relpos_terms": [c_void_p, c_long, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                             c_int, c_int, c_int, c_void_p],
+    "ae_softmax_rows_f32_bf16": [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_float, c_void_p],
+    "ae_gaussian_moments_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p],
     "ae_patchify_f32_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ae_mse_f32": [c_void_p, c_void_p, c_void_p, c_long, c_void_p],
     "ae_task_gate": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],

@@ -254,6 +254,47 @@ __global__ __launch_bounds__(256) void relpos_line_kernel(const bf16_t* q, long 
     }
 }
 
+// Row softmax for the first-stage AttnBlock (diffusionmodules/model.py:188-192: single head, c = 512, N = h*w = 4096 tokens): the
+// logits are materialised by the GEMM kernel in fp32 (N x N per image: 67 MB at 512 px — outside the denoising loop, once per
+// image) and this kernel writes softmax(scale * S) as the bf16 operand of the P V GEMM.  One block per row.
+__global__ __launch_bounds__(NT) void softmax_rows_kernel(const float* S, long lds, bf16_t* P, long ldp, int cols, float scale) {
+    __shared__ float red[NT / 64];
+    const float* src = S + (long)blockIdx.x * lds;
+    bf16_t* dst = P + (long)blockIdx.x * ldp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < cols; c += NT) mx = fmaxf(mx, src[c]);
+    mx = wave_reduce_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    const float c2 = scale * 1.4426950408889634f;  // scale > 0: max of the scaled row = scale * max
+    float sum = 0.f;
+    for (int c = threadIdx.x; c < cols; c += NT) sum += __builtin_amdgcn_exp2f((src[c] - mx) * c2);
+    sum = wave_reduce_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+    for (int c = threadIdx.x; c < cols; c += NT) dst[c] = f32_to_bf16(__builtin_amdgcn_exp2f((src[c] - mx) * c2) * inv);
+}
+
+// DiagonalGaussianDistribution (distributions.py:25-37): moments [B, 2C, HW] -> mean, logvar clamped to [-30, 20], std = exp(logvar/2),
+// z = mean + std * noise (noise = NULL -> z = mean, the .mode()).
+__global__ __launch_bounds__(NT) void gaussian_kernel(const float* moments, const float* noise, float* z, float* mean_o, float* logvar_o,
+                                                      float* std_o, long per_half, long n) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const long b = i / per_half, r = i - b * per_half;
+        const float mean = moments[b * 2 * per_half + r];
+        const float logvar = fminf(fmaxf(moments[b * 2 * per_half + per_half + r], -30.0f), 20.0f);
+        const float sd = expf(0.5f * logvar);
+        z[i] = noise ? mean + sd * noise[i] : mean;
+        if (mean_o) mean_o[i] = mean;
+        if (logvar_o) logvar_o[i] = logvar;
+        if (std_o) std_o[i] = sd;
+    }
+}
+
 // PatchEmbed im2col: x [B,Cin,H,W] fp32 -> patches [B*(H/P)*(W/P), Cin*P*P] bf16, K order (c, ky, kx) = conv weight order
 __global__ void patchify_kernel(const float* x, bf16_t* y, int B, int Cin, int H, int W, int P) {
     const int gh = H / P, gw = W / P, K = Cin * P * P;
@@ -402,6 +443,22 @@ extern "C" int ae_sam_relpos_terms(const void* q, long q_sb, long q_sh, long q_s
     hipLaunchKernelGGL(relpos_kernel, grid, dim3(128), D * sizeof(float), (hipStream_t)stream, (const bf16_t*)q, q_sb, q_sh, q_sn, Rh, Rw,
                        rel_h, rel_w, B, heads, qH, qW, kH, kW, D);
     return ae_check_launch("ae_sam_relpos_terms");
+}
+
+extern "C" int ae_softmax_rows_f32_bf16(const float* S, long lds, void* P, long ldp, int rows, int cols, float scale, void* stream) {
+    AE_REQUIRE(S && P && rows > 0 && cols > 0 && lds >= cols && ldp >= cols, "ae_softmax_rows_f32_bf16: bad arguments");
+    AE_REQUIRE(scale > 0.f, "ae_softmax_rows_f32_bf16: scale must be positive");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(NT), 0, (hipStream_t)stream, S, lds, (bf16_t*)P, ldp, cols, scale);
+    return ae_check_launch("ae_softmax_rows_f32_bf16");
+}
+
+extern "C" int ae_gaussian_moments_f32(const float* moments, const float* noise, float* z, float* mean, float* logvar, float* std_out,
+                                       int B, long per_half, void* stream) {
+    AE_REQUIRE(moments && z && B > 0 && per_half > 0, "ae_gaussian_moments_f32: bad arguments");
+    const long n = (long)B * per_half;
+    hipLaunchKernelGGL(gaussian_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, moments, noise, z, mean, logvar, std_out,
+                       per_half, n);
+    return ae_check_launch("ae_gaussian_moments_f32");
 }
 
 extern "C" int ae_patchify_f32_bf16(const float* x, void* y, int B, int Cin, int H, int W, int P, void* stream) {

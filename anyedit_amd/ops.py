@@ -325,6 +325,29 @@ def sam_relpos_terms(q, q_strides, Rh, Rw, B, heads, qH, qW, D):
     return rel_h, rel_w
 
 
+def softmax_rows(S, scale):
+    """softmax(scale * S) over the last dim: fp32 [R, N] (row stride free) -> bf16 [R, N]."""
+    _chk(S, torch.float32, "softmax_rows.S", 2)
+    out = torch.empty(S.shape, dtype=BF16, device=S.device)
+    check(lib.ae_softmax_rows_f32_bf16(_p(S), S.stride(0), _p(out), out.stride(0), S.shape[0], S.shape[1], float(scale), _s()),
+          "ae_softmax_rows_f32_bf16")
+    return out
+
+
+def gaussian_moments(moments, noise=None, want_stats=False):
+    """DiagonalGaussianDistribution on moments [B, 2C, H, W] fp32: returns z (and mean, logvar, std if want_stats)."""
+    moments = moments.float().contiguous()
+    B, C2 = moments.shape[0], moments.shape[1]
+    shape = (B, C2 // 2, *moments.shape[2:])
+    z = torch.empty(shape, dtype=torch.float32, device=moments.device)
+    stats = [torch.empty_like(z) for _ in range(3)] if want_stats else [None, None, None]
+    if noise is not None:
+        noise = noise.float().contiguous()
+    check(lib.ae_gaussian_moments_f32(_p(moments), _p(noise), _p(z), _p(stats[0]), _p(stats[1]), _p(stats[2]), B, z.numel() // B, _s()),
+          "ae_gaussian_moments_f32")
+    return (z, *stats) if want_stats else z
+
+
 def patchify(x, P):
     B, Cin, H, W = x.shape
     out = torch.empty(B * (H // P) * (W // P), Cin * P * P, dtype=BF16, device=x.device)

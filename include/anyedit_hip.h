@@ -169,6 +169,15 @@ int ae_mse_f32(const float* a, const float* b, float* out, long n, void* stream)
 int ae_task_gate(const float* task_emb, const long* edit_code, const float* Wg, const float* bg, int B, int n_tasks, int Dt,
                  int E, float* probs, int* top1, float* top1_prob, void* stream);
 
+/* ---- first-stage autoencoder (SURVEY.md §8f N1; the step on either side of the denoising loop) — reuses ae_conv3x3_bf16,
+ * ae_gemm_bf16, ae_groupnorm_nhwc_bf16; two small kernels of its own:
+ * P = softmax(scale * S) row-wise, fp32 logits -> bf16 (AttnBlock, diffusionmodules/model.py:188-192).                        */
+int ae_softmax_rows_f32_bf16(const float* S, long lds, void* P, long ldp, int rows, int cols, float scale, void* stream);
+/* DiagonalGaussianDistribution (distributions.py:25-37): moments [B, 2*per_half] -> z = mean + std * noise (noise NULL: mode),
+ * optional mean / clamped logvar / std outputs.                                                                              */
+int ae_gaussian_moments_f32(const float* moments, const float* noise, float* z, float* mean, float* logvar, float* std_out, int B,
+                            long per_half, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -209,3 +209,47 @@ def test_ddim_sampler_vs_oracle_same_eps():
     # torch-CPU sqrt of the schedule scalars may differ from the correctly rounded one by 1 ulp (see test_host_logic), which
     # perturbs the trajectory at the 1e-7 level; everything else is bit-identical arithmetic
     assert float((got.cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------------------ first stage (N1)
+def test_first_stage_autoencoder_golden():
+    """AutoencoderKL encode / decode and its blocks on the HIP path vs the reference's outputs (tests/golden/vae_tiny.npz)."""
+    from anyedit_amd.ldm.models.autoencoder import AutoencoderKL
+    from anyedit_amd.ldm.modules.diffusionmodules import model as M
+    g = load_golden("vae_tiny")
+    cfg = dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 2], num_res_blocks=1,
+               attn_resolutions=[], dropout=0.0)
+    vae = AutoencoderKL(ddconfig=cfg, lossconfig=None, embed_dim=4)
+    vae.load_state_dict(sub_sd(g, "w."))
+    vae = vae.to(DEV).eval()
+    x = T(g["x"]).to(DEV)
+    post = vae.encode(x)
+    close(post.mean, g["enc.mean"], rl2=2e-2, db=34.0, what="VAE encode mean")
+    close(post.std, g["enc.std"], rl2=2e-2, db=34.0, what="VAE encode std")
+    post.randn = lambda shape, device=None: T(g["sample.noise"]).to(device)
+    close(post.sample(), g["sample.z"], rl2=2e-2, db=34.0, what="posterior sample")
+    close(vae.decode(T(g["enc.mean"]).to(DEV)), g["dec.y"], rl2=3e-2, db=40.0, what="VAE decode")  # 20 bf16 layers deep
+    h = T(g["blk.h"]).to(DEV)
+    close(vae.decoder.mid.attn_1(h), g["blk.attn"], what="AttnBlock")
+    close(vae.decoder.mid.block_1(h), g["blk.res"], what="ResnetBlock")
+    d, u = M.Downsample(64, True), M.Upsample(64, True)
+    d.load_state_dict(sub_sd(g, "down."))
+    u.load_state_dict(sub_sd(g, "up."))
+    close(d.to(DEV)(h), g["blk.down"], what="Downsample (asymmetric pad, stride 2)")
+    close(u.to(DEV)(h), g["blk.up"], what="Upsample (nearest x2 + conv)")
+
+
+def test_softmax_rows_and_gaussian_moments():
+    from anyedit_amd import ops
+    g = torch.Generator().manual_seed(3)
+    S = torch.randn(70, 333, generator=g) * 4
+    ref = torch.softmax(S * 0.125, -1)
+    got = ops.softmax_rows(S.to(DEV), 0.125).float().cpu()
+    assert rel_l2(got, ref) < 4e-3
+    mom = torch.randn(2, 8, 4, 4, generator=g) * 20
+    noise = torch.randn(2, 4, 4, 4, generator=g)
+    mean, logvar = mom.chunk(2, 1)
+    logvar = logvar.clamp(-30, 20)
+    z, m, lv, sd = ops.gaussian_moments(mom.to(DEV), noise.to(DEV), want_stats=True)
+    assert torch.equal(m.cpu(), mean) and torch.equal(lv.cpu(), logvar)
+    assert rel_l2(sd.cpu(), torch.exp(0.5 * logvar)) < 1e-6 and rel_l2(z.cpu(), mean + torch.exp(0.5 * logvar) * noise) < 1e-6

@@ -189,6 +189,25 @@ def test_conditioning_dropout_masks():
     assert im.tolist() == [1, 1, 0, 0, 0, 0, 1, 1]
 
 
+def test_vae_first_stage():
+    """N1: AutoencoderKL encode / decode and its building blocks against the reference's own outputs."""
+    from oracle import vae_ref as V
+    g = load_golden("vae_tiny")
+    sd = sub_sd(g, "w.")
+    x = T(g["x"])
+    close(V.encoder(sd, x), g["enc.h"], tol=2e-4)
+    mean, logvar, std = V.encode(sd, x)
+    close(mean, g["enc.mean"], tol=2e-4)
+    close(logvar, g["enc.logvar"], tol=2e-4)
+    close(std, g["enc.std"], tol=2e-4)
+    close(V.decode(sd, mean), g["dec.y"], tol=3e-4)
+    h = T(g["blk.h"])
+    close(V.attn_block(sd, "decoder.mid.attn_1.", h), g["blk.attn"], tol=1e-4)
+    close(V.resnet_block(sd, "decoder.mid.block_1.", h), g["blk.res"], tol=1e-4)
+    close(V.downsample(sub_sd(g, "down."), "", h), g["blk.down"], tol=1e-5)
+    close(V.upsample(sub_sd(g, "up."), "", h), g["blk.up"], tol=1e-5)
+
+
 def test_sam():
     g = load_golden("sam_tiny")
     rp = T(g["relpos.table27"])

@@ -423,6 +423,54 @@ def gen_ddim_encode():
     npz("ddim_encode", **arrs)
 
 
+TINY_VAE = dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 2], num_res_blocks=1,
+                attn_resolutions=[], dropout=0.0)
+
+
+@torch.no_grad()
+def gen_vae():
+    """AutoencoderKL (ldm/models/autoencoder.py:13-101) + Encoder/Decoder (diffusionmodules/model.py:452-653) at a tiny config with
+    the SD kl-f8 structure: ResnetBlocks, mid single-head AttnBlock, asymmetric-pad stride-2 Downsample, nearest-x2 Upsample."""
+    print("[vae]")
+    import io
+    import contextlib
+    from ldm.models.autoencoder import AutoencoderKL
+    torch.manual_seed(123)
+    with contextlib.redirect_stdout(io.StringIO()):
+        vae = AutoencoderKL(ddconfig=dict(TINY_VAE), lossconfig={"target": "torch.nn.Identity"}, embed_dim=4).eval()
+    g = G(70)
+    for p_ in vae.parameters():  # default inits are fine (no zero-init layers); make the norms non-trivial
+        if p_.dim() == 1:
+            p_.add_(0.1 * torch.randn(p_.shape, generator=g))
+    x = torch.randn(2, 3, 32, 32, generator=g)
+    arrs = {"x": x}
+    for k, v in vae.state_dict().items():
+        arrs["w." + k] = v
+    post = vae.encode(x)
+    arrs["enc.h"] = vae.encoder(x)
+    arrs["enc.mean"], arrs["enc.logvar"], arrs["enc.std"] = post.mean, post.logvar, post.std
+    z = post.mode()
+    arrs["dec.y"] = vae.decode(z)
+    noise = torch.randn(post.mean.shape, generator=g)
+    arrs["sample.noise"] = noise
+    arrs["sample.z"] = post.mean + post.std * noise   # DiagonalGaussianDistribution.sample (distributions.py:35-37) with given noise
+    # building blocks
+    from ldm.modules.diffusionmodules import model as rm
+    h = torch.randn(2, 64, 8, 8, generator=g)
+    arrs["blk.h"] = h
+    arrs["blk.attn"] = vae.decoder.mid.attn_1(h)
+    arrs["blk.res"] = vae.decoder.mid.block_1(h, None)
+    d = rm.Downsample(64, True).eval()
+    u = rm.Upsample(64, True).eval()
+    for k, v in d.state_dict().items():
+        arrs["down." + k] = v
+    for k, v in u.state_dict().items():
+        arrs["up." + k] = v
+    arrs["blk.down"] = d(h)
+    arrs["blk.up"] = u(h)
+    npz("vae_tiny", **arrs)
+
+
 @torch.no_grad()
 def gen_sam():
     print("[sam]")
@@ -496,7 +544,7 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])  # e.g. `python tools/gen_golden.py ddim_encode` regenerates one fixture
     for name, fn in (("schedule", gen_schedule), ("norms", gen_norms), ("attention", gen_attention), ("transformer", gen_transformer),
                      ("resblock", gen_resblock), ("unet", gen_unet), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode),
-                     ("sam", gen_sam), ("misc", gen_ldm_misc)):
+                     ("vae", gen_vae), ("sam", gen_sam), ("misc", gen_ldm_misc)):
         if not only or name in only:
             fn()
     print("done")
