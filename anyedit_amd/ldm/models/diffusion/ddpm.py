@@ -115,8 +115,43 @@ class LatentDiffusion(DDPM):
         super().__init__(unet_config, conditioning_key=conditioning_key, **{k: v for k, v in kwargs.items()
                                                                          if k not in ("force_null_conditioning", "use_ema")})
         self.scale_factor = scale_factor
-        self.first_stage_model = None  # VAE: SURVEY.md §8f N1
-        self.cond_stage_model = None
+        self.first_stage_model = None
+        self.cond_stage_model = None   # CLIP text tower: outside the hot path (the caller passes its hidden states)
+        if first_stage_config is not None:
+            self.instantiate_first_stage(first_stage_config)
+
+    def instantiate_first_stage(self, config):
+        """ddpm.py:615-620.  `config` is an {'target', 'params'} dict resolved inside this package (ldm.* -> anyedit_amd.ldm.*)
+        or an already built first-stage module."""
+        from anyedit_amd.ldm.util import instantiate_from_config
+        model = config if isinstance(config, nn.Module) else instantiate_from_config(config)
+        self.first_stage_model = model.eval()
+        for param in self.first_stage_model.parameters():
+            param.requires_grad = False
+
+    def get_first_stage_encoding(self, encoder_posterior):
+        """ddpm.py:655-662."""
+        from anyedit_amd.ldm.modules.distributions.distributions import DiagonalGaussianDistribution
+        if isinstance(encoder_posterior, DiagonalGaussianDistribution):
+            z = encoder_posterior.sample()
+        elif isinstance(encoder_posterior, torch.Tensor):
+            z = encoder_posterior
+        else:
+            raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")
+        return self.scale_factor * z
+
+    @torch.no_grad()
+    def decode_first_stage(self, z, predict_cids=False, force_not_quantize=False):
+        """ddpm.py:822-830."""
+        if predict_cids:
+            raise NotImplementedError("VQ first stages are not on the AnyEdit path")
+        z = 1. / self.scale_factor * z
+        return self.first_stage_model.decode(z)
+
+    @torch.no_grad()
+    def encode_first_stage(self, x):
+        """ddpm.py:832-834."""
+        return self.first_stage_model.encode(x)
 
     def apply_model(self, x_noisy, t, cond, return_ids=False):
         """ddpm.py:854-869."""

@@ -253,3 +253,25 @@ def test_softmax_rows_and_gaussian_moments():
     z, m, lv, sd = ops.gaussian_moments(mom.to(DEV), noise.to(DEV), want_stats=True)
     assert torch.equal(m.cpu(), mean) and torch.equal(lv.cpu(), logvar)
     assert rel_l2(sd.cpu(), torch.exp(0.5 * logvar)) < 1e-6 and rel_l2(z.cpu(), mean + torch.exp(0.5 * logvar) * noise) < 1e-6
+
+
+def test_latent_diffusion_first_stage_roundtrip(tiny_unet):
+    """LatentDiffusion.encode_first_stage / get_first_stage_encoding / decode_first_stage (ddpm.py:655-662, 822-834) wired to the
+    HIP AutoencoderKL through the reference's config reflection (`ldm.models.autoencoder.AutoencoderKL` resolves in-package)."""
+    from oracle import vae_ref as V
+    unet, _ = tiny_unet
+    g = load_golden("vae_tiny")
+    cfg = dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 2], num_res_blocks=1,
+               attn_resolutions=[], dropout=0.0)
+    ldm = _tiny_ldm(unet)
+    ldm.scale_factor = 0.18215
+    ldm.instantiate_first_stage({"target": "ldm.models.autoencoder.AutoencoderKL", "params": {"ddconfig": cfg, "embed_dim": 4}})
+    ldm.first_stage_model.load_state_dict(sub_sd(g, "w."))
+    ldm.first_stage_model.to(DEV)
+    x = T(g["x"]).to(DEV)
+    post = ldm.encode_first_stage(x)
+    post.randn = lambda shape, device=None: T(g["sample.noise"]).to(device)
+    z = ldm.get_first_stage_encoding(post)
+    close(z, 0.18215 * T(g["sample.z"]), rl2=2e-2, db=34.0, what="scaled first-stage encoding")
+    y = ldm.decode_first_stage(0.18215 * T(g["enc.mean"]).to(DEV))
+    close(y, g["dec.y"], rl2=3e-2, db=40.0, what="decode_first_stage")
