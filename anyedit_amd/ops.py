@@ -348,6 +348,26 @@ def gaussian_moments(moments, noise=None, want_stats=False):
     return (z, *stats) if want_stats else z
 
 
+def ms_deform_attn(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step=None):
+    """Drop-in for `_C.ms_deform_attn_forward` (GroundingDINO ms_deform_attn.py:42-60): value [bs, S, heads, d], spatial_shapes
+    [L, 2] int64, level_start_index [L] int64, sampling_locations [bs, Q, heads, L, P, 2], attention_weights [bs, Q, heads, L, P]
+    -> [bs, Q, heads*d] fp32.  `im2col_step` is accepted for signature compatibility (it only chunked the CUDA launch)."""
+    _chk(value, torch.float32, "ms_deform_attn.value", 4)
+    bs, S, heads, d = value.shape
+    _, Q, _, L, P, _ = sampling_locations.shape
+    value = value.contiguous()
+    loc = sampling_locations.float().contiguous()
+    w = attention_weights.float().contiguous()
+    shapes = spatial_shapes.to(torch.int64).contiguous()
+    starts = level_start_index.to(torch.int64).contiguous()
+    if int(shapes.prod(1).sum()) != S:
+        raise ValueError("ms_deform_attn: spatial_shapes do not add up to value.shape[1]")
+    out = torch.empty(bs, Q, heads * d, dtype=torch.float32, device=value.device)
+    check(lib.ae_ms_deform_attn_fwd_f32(_p(value), _p(shapes), _p(starts), _p(loc), _p(w), _p(out), bs, S, heads, d, Q, L, P, _s()),
+          "ae_ms_deform_attn_fwd_f32")
+    return out
+
+
 def patchify(x, P):
     B, Cin, H, W = x.shape
     out = torch.empty(B * (H // P) * (W // P), Cin * P * P, dtype=BF16, device=x.device)

@@ -178,6 +178,14 @@ int ae_softmax_rows_f32_bf16(const float* S, long lds, void* P, long ldp, int ro
 int ae_gaussian_moments_f32(const float* moments, const float* noise, float* z, float* mean, float* logvar, float* std_out, int B,
                             long per_half, void* stream);
 
+/* ---- GroundingDINO multi-scale deformable attention forward (SURVEY.md §8f N2): replaces the reference's only native op,
+ * `_C.ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)`
+ * (csrc/vision.cpp:53-56, csrc/MsDeformAttn/ms_deform_attn.h:22-41, ms_deform_im2col_cuda.cuh:237-299).
+ * value [bs, S, heads, d] fp32 (S = sum_l H_l*W_l), spatial_shapes [L,2] / level_start_index [L] int64, sampling_loc
+ * [bs, Q, heads, L, P, 2] in [0,1] (x, y), attn_weight [bs, Q, heads, L, P]; out [bs, Q, heads*d] fp32.                      */
+int ae_ms_deform_attn_fwd_f32(const float* value, const long* spatial_shapes, const long* level_start_index, const float* sampling_loc,
+                              const float* attn_weight, float* out, int bs, int S, int heads, int d, int Q, int L, int P, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -302,3 +302,42 @@ def test_mse_and_task_gate(ops):
     ref = torch.softmax(te[code] @ Wg.t() + bg, dim=-1)
     assert torch.allclose(probs.cpu(), ref, atol=1e-5)
     assert torch.equal(top1.cpu().long(), ref.argmax(-1)) and torch.allclose(top1p.cpu(), ref.max(-1).values, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------- GroundingDINO MSDeformAttn (N2)
+def test_ms_deform_attn_forward(ops):
+    """ae_ms_deform_attn_fwd_f32 (the reference's `_C.ms_deform_attn_forward`) against the reference's own PyTorch statement
+    (golden) and, on a larger seeded case with out-of-range samples, against the oracle.  fp32 gathers: tolerance 1e-5."""
+    from oracle import msda_ref as MS
+    g = load_golden("msda")
+    for tag in ("a", "b"):
+        out = ops.ms_deform_attn(T(g[f"{tag}.value"]).to(DEV), T(g[f"{tag}.shapes"]).to(DEV), T(g[f"{tag}.start"]).to(DEV),
+                                 T(g[f"{tag}.loc"]).to(DEV), T(g[f"{tag}.w"]).to(DEV), 64)
+        check_close(out, T(g[f"{tag}.out"]), rl2=1e-5, mabs=1e-5, what=f"ms_deform_attn golden {tag}")
+    gen = torch.Generator().manual_seed(5)
+    shapes = torch.tensor([(100, 134), (50, 67), (25, 34), (13, 17)], dtype=torch.long)      # an 800x1066 image's 4 feature levels
+    S = int(shapes.prod(1).sum())
+    start = torch.cat([shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]])
+    value = torch.randn(2, S, 8, 32, generator=gen)
+    loc = torch.rand(2, 900, 8, 4, 4, 2, generator=gen) * 1.2 - 0.1
+    w = torch.softmax(torch.randn(2, 900, 8, 16, generator=gen), -1).view(2, 900, 8, 4, 4)
+    ref = MS.ms_deform_attn(value, shapes, start, loc, w)
+    out = ops.ms_deform_attn(value.to(DEV), shapes.to(DEV), start.to(DEV), loc.to(DEV), w.to(DEV))
+    check_close(out, ref, rl2=1e-5, mabs=1e-5, what="ms_deform_attn 900 queries x 4 levels")
+
+
+def test_ms_deform_attn_module_golden():
+    """MultiScaleDeformableAttention mirror (state-dict compatible) vs the reference module's CPU output: 2-d and 4-d reference
+    points, query_pos, key_padding_mask."""
+    from anyedit_amd.groundingdino.ms_deform_attn import MultiScaleDeformableAttention
+    g = load_golden("msda")
+    m = MultiScaleDeformableAttention(embed_dim=64, num_heads=4, num_levels=3, num_points=4, batch_first=True)
+    m.load_state_dict(sub_sd(g, "mod.w."))
+    m = m.to(DEV).eval()
+    d = lambda k: T(g["mod." + k]).to(DEV)
+    with torch.no_grad():
+        out2 = m(d("query"), value=d("value"), query_pos=d("qpos"), key_padding_mask=d("mask"), reference_points=d("ref2"),
+                 spatial_shapes=d("shapes"), level_start_index=d("start"))
+        out4 = m(d("query"), value=d("value"), reference_points=d("ref4"), spatial_shapes=d("shapes"), level_start_index=d("start"))
+    check_close(out2, T(g["mod.out2"]), rl2=2e-5, mabs=2e-5, what="MSDeformAttn module (2-d reference points)")
+    check_close(out4, T(g["mod.out4"]), rl2=2e-5, mabs=2e-5, what="MSDeformAttn module (reference boxes)")

@@ -208,6 +208,15 @@ def test_vae_first_stage():
     close(V.upsample(sub_sd(g, "up."), "", h), g["blk.up"], tol=1e-5)
 
 
+def test_ms_deform_attn():
+    """N2: explicit-gather restatement against the reference's multi_scale_deformable_attn_pytorch."""
+    from oracle import msda_ref as MS
+    g = load_golden("msda")
+    for tag in ("a", "b"):
+        out = MS.ms_deform_attn(T(g[f"{tag}.value"]), T(g[f"{tag}.shapes"]), T(g[f"{tag}.start"]), T(g[f"{tag}.loc"]), T(g[f"{tag}.w"]))
+        close(out, g[f"{tag}.out"], tol=2e-5)
+
+
 def test_sam():
     g = load_golden("sam_tiny")
     rp = T(g["relpos.table27"])

@@ -472,6 +472,55 @@ def gen_vae():
 
 
 @torch.no_grad()
+def gen_msda():
+    """GroundingDINO's multi_scale_deformable_attn_pytorch (ms_deform_attn.py:93-133): the readable statement of the CUDA op."""
+    print("[msda]")
+    import warnings
+    path = os.path.join(REF, "GroundingDINO", "groundingdino", "models", "GroundingDINO", "ms_deform_attn.py")
+    spec = importlib.util.spec_from_file_location("ref_ms_deform_attn", path)
+    mod = importlib.util.module_from_spec(spec)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        spec.loader.exec_module(mod)
+    g = G(80)
+    arrs = {}
+    for tag, (bs, heads, d, Q, P, shapes) in {"a": (2, 4, 8, 37, 4, [(8, 8), (4, 4), (2, 3)]),
+                                              "b": (1, 8, 32, 100, 4, [(20, 27), (10, 14), (5, 7), (3, 4)])}.items():
+        S = sum(h * w for h, w in shapes)
+        value = torch.randn(bs, S, heads, d, generator=g)
+        shp = torch.tensor(shapes, dtype=torch.long)
+        start = torch.cat([shp.new_zeros(1), shp.prod(1).cumsum(0)[:-1]])
+        loc = torch.rand(bs, Q, heads, len(shapes), P, 2, generator=g) * 1.3 - 0.15      # some samples fall outside [0, 1]
+        w = torch.softmax(torch.randn(bs, Q, heads, len(shapes) * P, generator=g), -1).view(bs, Q, heads, len(shapes), P)
+        out = mod.multi_scale_deformable_attn_pytorch(value, shp, loc, w)
+        for k, v in (("value", value), ("shapes", shp), ("start", start), ("loc", loc), ("w", w), ("out", out)):
+            arrs[f"{tag}.{k}"] = v
+    # the whole module (CPU: the reference falls back to its PyTorch statement of the op)
+    torch.manual_seed(17)
+    m = mod.MultiScaleDeformableAttention(embed_dim=64, num_heads=4, num_levels=3, num_points=4, batch_first=True).eval()
+    for p_ in m.parameters():
+        p_.add_(0.05 * torch.randn(p_.shape, generator=g))
+    shapes = torch.tensor([(8, 8), (4, 4), (2, 3)], dtype=torch.long)
+    start = torch.cat([shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]])
+    S = int(shapes.prod(1).sum())
+    query = torch.randn(2, 21, 64, generator=g)
+    qpos = torch.randn(2, 21, 64, generator=g) * 0.1
+    val = torch.randn(2, S, 64, generator=g)
+    ref2 = torch.rand(2, 21, 3, 2, generator=g)
+    ref4 = torch.cat([torch.rand(2, 21, 3, 2, generator=g), torch.rand(2, 21, 3, 2, generator=g) * 0.5], -1)
+    mask = torch.zeros(2, S, dtype=torch.bool)
+    mask[1, -9:] = True
+    for k, v in m.state_dict().items():
+        arrs["mod.w." + k] = v
+    arrs.update({"mod.query": query, "mod.qpos": qpos, "mod.value": val, "mod.ref2": ref2, "mod.ref4": ref4, "mod.mask": mask,
+                 "mod.shapes": shapes, "mod.start": start})
+    arrs["mod.out2"] = m(query, value=val, query_pos=qpos, key_padding_mask=mask, reference_points=ref2, spatial_shapes=shapes,
+                         level_start_index=start)
+    arrs["mod.out4"] = m(query, value=val, reference_points=ref4, spatial_shapes=shapes, level_start_index=start)
+    npz("msda", **arrs)
+
+
+@torch.no_grad()
 def gen_sam():
     print("[sam]")
     arrs = {}
@@ -544,7 +593,7 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])  # e.g. `python tools/gen_golden.py ddim_encode` regenerates one fixture
     for name, fn in (("schedule", gen_schedule), ("norms", gen_norms), ("attention", gen_attention), ("transformer", gen_transformer),
                      ("resblock", gen_resblock), ("unet", gen_unet), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode),
-                     ("vae", gen_vae), ("sam", gen_sam), ("misc", gen_ldm_misc)):
+                     ("vae", gen_vae), ("msda", gen_msda), ("sam", gen_sam), ("misc", gen_ldm_misc)):
         if not only or name in only:
             fn()
     print("done")
