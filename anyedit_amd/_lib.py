@@ -58,6 +58,7 @@ SIGNATURES = {
     "ae_ddim_step_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_float, c_float,
                          c_float, c_float, c_float, c_float, c_float, c_void_p],
     "ae_ddim_encode_step_f32": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_float, c_float, c_void_p],
+    "ae_plms_combine_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
     "ae_mask_blend_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int, c_void_p],
     "ae_q_sample_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p],
     "ae_silu_to_bf16": [c_void_p, c_int, c_void_p, c_long, c_void_p],

@@ -119,6 +119,29 @@ __global__ void ddim_encode_step_kernel(const float* x, const float* eps, float*
     }
 }
 
+// PLMS pseudo linear multistep combination of the current and up to three previous eps predictions (plms.py:226-240), in the
+// reference's left-to-right fp32 expression order (products rounded, then summed, then one division).
+//   order 0: (e + o1) / 2  [pseudo improved Euler, o1 = eps at the next timestep]      order 1: (3 e - o1) / 2
+//   order 2: (23 e - 16 o1 + 5 o2) / 12                                                  order 3: (55 e - 59 o1 + 37 o2 - 9 o3) / 24
+__global__ void plms_combine_kernel(const float* e, const float* o1, const float* o2, const float* o3, float* out, long n, int order) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        float r;
+        if (order == 0) {
+            r = (e[i] + o1[i]) / 2.0f;
+        } else if (order == 1) {
+            const float a = 3.0f * e[i];
+            r = (a - o1[i]) / 2.0f;
+        } else if (order == 2) {
+            const float a = 23.0f * e[i], b = 16.0f * o1[i], c = 5.0f * o2[i];
+            r = ((a - b) + c) / 12.0f;
+        } else {
+            const float a = 55.0f * e[i], b = 59.0f * o1[i], c = 37.0f * o2[i], d = 9.0f * o3[i];
+            r = (((a - b) + c) - d) / 24.0f;
+        }
+        out[i] = r;
+    }
+}
+
 // out = (sa*x0 + s1*noise) * mask + (1 - mask) * img   (ddim.py:154-157 with q_sample ddpm.py:356-359);
 // mask is [B,1,H,W] broadcast over C.  order!=0 -> IP2P order: img*mask + q*(1-mask) (global_tool.py:183-184)
 __global__ void mask_blend_kernel(const float* img, const float* x0, const float* noise, const float* mask, float* out,
@@ -373,6 +396,14 @@ extern "C" int ae_ddim_encode_step_f32(const float* x, const float* eps, float* 
     AE_REQUIRE(branches == 1 || branches == 2, "ae_ddim_encode_step_f32: branches must be 1 or 2 (got %d)", branches);
     hipLaunchKernelGGL(ddim_encode_step_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, x, eps, x_next, n, branches, scale, cx, ce);
     return ae_check_launch("ae_ddim_encode_step_f32");
+}
+
+extern "C" int ae_plms_combine_f32(const float* e_t, const float* old1, const float* old2, const float* old3, float* out, long n, int order,
+                                   void* stream) {
+    AE_REQUIRE(e_t && out && n > 0 && order >= 0 && order <= 3, "ae_plms_combine_f32: bad arguments (order must be 0..3)");
+    AE_REQUIRE(old1 && (order < 2 || old2) && (order < 3 || old3), "ae_plms_combine_f32: order %d needs that many previous predictions", order);
+    hipLaunchKernelGGL(plms_combine_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, e_t, old1, old2, old3, out, n, order);
+    return ae_check_launch("ae_plms_combine_f32");
 }
 
 extern "C" int ae_mask_blend_f32(const float* img, const float* x0, const float* noise, const float* mask, float* out, int B,

@@ -242,7 +242,7 @@ def timestep_embedding(t, dim, max_period=10000.0, out_f32=False):
     return out
 
 
-def ddim_step(x, eps, coeffs, branches, s0=1.0, s1=0.0, noise=None, temperature=1.0, want_pred_x0=True):
+def ddim_step(x, eps, coeffs, branches, s0=1.0, s1=0.0, noise=None, temperature=1.0, want_pred_x0=True, want_e=False):
     """coeffs = (sqrt_one_minus_at, sqrt_at, sqrt_a_prev, dir_coef, sigma_t) as python floats holding fp32 values."""
     _chk(x, torch.float32, "ddim_step.x")
     _chk(eps, torch.float32, "ddim_step.eps")
@@ -254,8 +254,11 @@ def ddim_step(x, eps, coeffs, branches, s0=1.0, s1=0.0, noise=None, temperature=
     x_prev = torch.empty_like(x)
     pred_x0 = torch.empty_like(x) if want_pred_x0 else None
     s1m, sat, sap, dirc, sig = coeffs
-    check(lib.ae_ddim_step_f32(_p(x), _p(eps), _p(noise), _p(x_prev), _p(pred_x0), None, n, branches, s0, s1, s1m, sat, sap,
+    e_out = torch.empty_like(x) if want_e else None  # the guidance-combined eps (what PLMS keeps in its history)
+    check(lib.ae_ddim_step_f32(_p(x), _p(eps), _p(noise), _p(x_prev), _p(pred_x0), _p(e_out), n, branches, s0, s1, s1m, sat, sap,
                                dirc, sig, temperature, _s()), "ae_ddim_step_f32")
+    if want_e:
+        return x_prev, pred_x0, e_out
     return x_prev, pred_x0
 
 
@@ -267,6 +270,24 @@ def ddim_encode_step(x, eps, cx, ce, branches=1, scale=1.0):
     out = torch.empty_like(x)
     check(lib.ae_ddim_encode_step_f32(_p(x), _p(eps), _p(out), x.numel(), branches, float(scale), float(cx), float(ce), _s()),
           "ae_ddim_encode_step_f32")
+    return out
+
+
+def plms_combine(e_t, old_eps):
+    """PLMS combination of e_t with the list of previous predictions (newest last, as plms.py keeps them); for the first step pass
+    old_eps = [e_t_next] and order 0 via `plms_combine_first`."""
+    order = min(len(old_eps), 3)
+    e_t = e_t.contiguous()
+    olds = [t.contiguous() for t in old_eps[::-1][:3]] + [None, None, None]
+    out = torch.empty_like(e_t)
+    check(lib.ae_plms_combine_f32(_p(e_t), _p(olds[0]), _p(olds[1]), _p(olds[2]), _p(out), e_t.numel(), order, _s()), "ae_plms_combine_f32")
+    return out
+
+
+def plms_combine_first(e_t, e_t_next):
+    out = torch.empty_like(e_t)
+    check(lib.ae_plms_combine_f32(_p(e_t.contiguous()), _p(e_t_next.contiguous()), None, None, _p(out), e_t.numel(), 0, _s()),
+          "ae_plms_combine_f32")
     return out
 
 

@@ -142,6 +142,9 @@ int ae_timestep_embedding(const long* t_i64, const float* t_f32, void* out_bf16,
 int ae_ddim_step_f32(const float* x, const float* eps, const float* noise, float* x_prev, float* pred_x0, float* e_out, long n,
                      int branches, float s0, float s1, float sqrt_one_minus_at, float sqrt_at, float sqrt_a_prev, float dir_coef,
                      float sigma_t, float temperature, void* stream);
+/* PLMS multistep combination of eps predictions (PLMSSampler.p_sample_plms, plms.py:226-240); order 0 = (e + old1) / 2.           */
+int ae_plms_combine_f32(const float* e_t, const float* old1, const float* old2, const float* old3, float* out, long n, int order,
+                        void* stream);
 /* DDIM inversion update (DDIMSampler.encode, ddim.py:253-298): x_next = cx*x + ce*e, e = CFG combination of `branches`
  * stacked predictions ([uncond, cond]); cx, ce from the host in float64 as the reference computes them.                       */
 int ae_ddim_encode_step_f32(const float* x, const float* eps, float* x_next, long n, int branches, float scale, float cx, float ce,

@@ -170,6 +170,44 @@ def test_ddim_encode_step_bit_exact_vs_oracle_arithmetic():
     assert torch.equal(got.cpu(), ref.float())
 
 
+def test_plms_sampler_golden():
+    """PLMSSampler on the HIP path vs the reference sampler (golden from the analytic eps model: identical eps on both sides, so
+    this isolates the sampler arithmetic, the eps history, the integer bookkeeping and the RNG consumption order)."""
+    from anyedit_amd.ldm.models.diffusion.plms import PLMSSampler
+    from oracle import schedule_ref as S
+
+    class AnalyticModel:
+        parameterization = "eps"
+
+        def __init__(self, dev):
+            self.num_timesteps = 1000
+            for k, v in S.register_schedule("linear", 1000, 0.00085, 0.0120).items():
+                if isinstance(v, torch.Tensor):
+                    setattr(self, k, v.to(dev))
+            self.device = torch.device(dev)
+
+        def apply_model(self, x, t, c):
+            xc, tc, cc = x.detach().float().cpu(), t.cpu(), c.float().cpu()
+            return (torch.sin(xc * 1.7 + tc.float()[:, None, None, None] * 0.01) * 0.5 + cc[:, :, None, None] * xc).to(x.device)
+
+    g = load_golden("plms")
+    sampler = PLMSSampler(AnalyticModel(DEV))
+    sampler.randn = lambda shape, device=None: torch.randn(shape).to(device)        # replay the CPU RNG stream of the golden run
+    dev = lambda k: T(g[k]).to(DEV)
+    for tag, steps, scale, use_mask in (("s7", 7, 1.0, False), ("s10_cfg", 10, 5.0, False), ("s6_cfg_mask", 6, 3.0, True)):
+        kw = dict(mask=dev(f"{tag}.mask"), x0=dev(f"{tag}.x0")) if use_mask else {}
+        torch.manual_seed(4321)
+        samples, inter = sampler.sample(steps, 2, (4, 8, 8), dev("c"), eta=0.0, x_T=dev("x_T"), verbose=False,
+                                        unconditional_guidance_scale=scale, unconditional_conditioning=dev("uc") if scale != 1.0 else None,
+                                        log_every_t=1, **kw)
+        assert np.array_equal(sampler.ddim_timesteps, g[f"{tag}.ddim_timesteps"])
+        assert len(inter["x_inter"]) == g[f"{tag}.x_inter"].shape[0]
+        assert float((samples.cpu() - T(g[f"{tag}.samples"])).abs().max()) <= 2e-5, tag
+        assert float((torch.stack(inter["pred_x0"]).cpu() - T(g[f"{tag}.pred_x0"])).abs().max()) <= 2e-5, tag
+    with pytest.raises(ValueError):
+        sampler.make_schedule(5, ddim_eta=0.5, verbose=False)
+
+
 def test_ddim_sampler_vs_oracle_same_eps():
     """With the SAME eps fed to both, the HIP sampler arithmetic is bit-identical to the oracle's fp32 loop."""
     from anyedit_amd.ldm.models.diffusion.ddim import DDIMSampler

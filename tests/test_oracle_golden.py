@@ -217,6 +217,28 @@ def test_ms_deform_attn():
         close(out, g[f"{tag}.out"], tol=2e-5)
 
 
+def _analytic_eps(x, t, c):
+    """The deterministic stand-in network of tools/gen_golden.py::AnalyticEpsModel."""
+    return torch.sin(x * 1.7 + t.float()[:, None, None, None] * 0.01) * 0.5 + c[:, :, None, None] * x
+
+
+def test_plms_sampler():
+    """N4: PLMSSampler restatement against the reference sampler's outputs (arithmetic, eps history, integer bookkeeping, RNG order)."""
+    from oracle import plms_ref as P
+    g = load_golden("plms")
+    buffers = S.register_schedule("linear", 1000, 0.00085, 0.0120)
+    x_T, c, uc = T(g["x_T"]), T(g["c"]), T(g["uc"])
+    for tag, steps, scale, use_mask in (("s7", 7, 1.0, False), ("s10_cfg", 10, 5.0, False), ("s6_cfg_mask", 6, 3.0, True)):
+        kw = dict(mask=T(g[f"{tag}.mask"]), x0=T(g[f"{tag}.x0"])) if use_mask else {}
+        torch.manual_seed(4321)
+        img, inter, sched = P.plms_sample(_analytic_eps, buffers, steps, tuple(x_T.shape), c, x_T, scale=scale,
+                                          uc=uc if scale != 1.0 else None, log_every_t=1, **kw)
+        assert np.array_equal(sched["ddim_timesteps"], g[f"{tag}.ddim_timesteps"])
+        assert len(inter["x_inter"]) == g[f"{tag}.x_inter"].shape[0]
+        close(img, g[f"{tag}.samples"], tol=1e-5)
+        close(torch.stack(inter["pred_x0"]), g[f"{tag}.pred_x0"], tol=1e-5)
+
+
 def test_sam():
     g = load_golden("sam_tiny")
     rp = T(g["relpos.table27"])
