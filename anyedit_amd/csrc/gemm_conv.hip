@@ -64,9 +64,14 @@ constexpr int epilogue_passes(int FM, int bytes_per_frag_row, int lds_bytes) {
     return FM;
 }
 
-template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const GemmArgs p) {
-    constexpr int NT = 64 * WAVES_M * WAVES_N;
+// WAVES_K = 2: two groups of WAVES_M x WAVES_N waves split every 64-deep K tile between them (32 each) and are summed through
+// LDS once at the end.  Same thread count and staging as an 8-wave block, but each wave owns a 2x larger output tile, so the
+// block issues a third fewer LDS fragment reads per MFMA (the 128x128 tile is LDS-bound: with 15/16 of its MFMAs removed it
+// still takes 73 % of the time).
+template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false, int WAVES_K = 1>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(const GemmArgs p) {
+    static_assert(WAVES_K == 1 || WAVES_K == 2, "K groups: 1 or 2");
+    constexpr int NT = 64 * WAVES_M * WAVES_N * WAVES_K;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
     constexpr int FM = WM / 16, FN = WN / 16;            // 16x16 fragments per wave
     constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT;
@@ -77,7 +82,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
     bf16_t* sB = smem + 2 * BM * BK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int wk = wave / (WAVES_M * WAVES_N), wmn = wave % (WAVES_M * WAVES_N);  // K group, position inside the group
+    const int wm = wmn / WAVES_N, wn = wmn % WAVES_N;
     const int l15 = lane & 15, lg = lane >> 4;
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
     const int ntiles = ntm * ntn;
@@ -260,6 +266,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
         const bf16_t* cB = sB + cur * BN * BK + (wn * WN) * BK;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+            if (WAVES_K == 2 && kk != wk) continue;  // wave-uniform: this K half belongs to the other group
             bf16x8_t af[FM], bfr[FN];
             const int ch = kk * 4 + lg;
 #pragma unroll
@@ -351,8 +358,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
         // shape of this UNet: it costs the second resident block per CU, which hides more latency than the extra stage.)
     }
 
+    if (WAVES_K == 2) {
+        // sum the two K groups: group 1 parks its accumulators in LDS (the ring is free: the loop ended on a barrier), group 0 adds
+        f32x4* red = reinterpret_cast<f32x4*>(smem_raw) + (long)wmn * FM * FN * 64 + lane;
+        static_assert(WAVES_K == 1 || WAVES_M * WAVES_N * FM * FN * 64 * 16 <= 2 * (BM + BN) * BK * 2, "K-group reduction must fit the ring");
+        if (wk == 1) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) red[(i * FN + j) * 64] = acc[i][j];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const f32x4 o = red[(i * FN + j) * 64];
+                    acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
+                }
+        }
+        __syncthreads();
+    }
+    const bool writer = wk == 0;  // with K groups only group 0 holds the result; group 1 keeps the block's barriers company
+
     // ---- epilogue ---------------------------------------------------------------------------
     if (p.splitk > 1) {  // raw fp32 partials; bias / vector / residual are applied by splitk_reduce_kernel
+        if (!writer) return;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int m = m0 + wm * WM + i * 16 + l15;
@@ -381,12 +413,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
         const int n_out = geglu ? p.N / 2 : p.N;
         const bool staged = (n_out % 8 == 0) && (p.ldc % 8 == 0) && (!p.res || (p.ldr % 8 == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0));
         if (staged) {
-            float* st = reinterpret_cast<float*>(smem_raw) + wave * (WMP * WN);
+            float* st = reinterpret_cast<float*>(smem_raw) + wmn * (WMP * WN);
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) {
                 if (ps > 0) __syncthreads();
 #pragma unroll
-                for (int ii = 0; ii < FMP; ++ii) {
+                for (int ii = 0; ii < (writer ? FMP : 0); ++ii) {
                     const int i = ps * FMP + ii;
                     const int rl = ii * 16 + l15;  // row inside this pass
                     const int m = min(m0 + wm * WM + i * 16 + l15, p.M - 1);
@@ -430,7 +462,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
                 const int ow = geglu ? WN / 2 : WN;      // output columns of this wave's tile
                 const int och = ow / 8;                  // 8-column output chunks per row
                 const int nbase = geglu ? (n0 + wn * WN) / 2 : n0 + wn * WN;
-                for (int it = lane; it < WMP * och; it += 64) {
+                for (int it = lane; it < (writer ? WMP * och : 0); it += 64) {
                     const int rl = it / och, oc = it - rl * och;
                     const int m = m0 + wm * WM + ps * WMP + rl, n = nbase + oc * 8;
                     if (m >= p.M || n >= n_out) continue;
@@ -456,6 +488,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_kernel(const Gemm
         }
     }
 
+    if (!writer) return;
     // ---- direct epilogue (fallback for N % 8 != 0 or unaligned rows, e.g. the 320 -> 4 output conv) ---------------------
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -609,6 +642,13 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // one-tile-ahead pipeline.  Measured on MI355X (profiles/r01_kbench_w8.txt): dense GEMMs -15..-25 % time, the 128x64 conv
     // unchanged (+-2 %), so that one keeps 4 waves (larger wave tile, fewer LDS reads per MFMA).  AE_GEMM_W8=0 forces 4 waves.
     static const int w8 = getenv("AE_GEMM_W8") ? atoi(getenv("AE_GEMM_W8")) : 2;
+    // two K groups of 2x2 waves on the 128x128 tile: pays when the K loop is long enough to amortise the final LDS reduction
+    // (kbench, operands L2-hot: convs with >= 90 K tiles +4..7 %, GEMMs with 10-40 K tiles -5..-25 %).  Inside the UNet evaluation,
+    // where every layer's weights arrive cold, the same rule LOSES 2.5 % of the step (in-situ A/B, one box), so it stays off:
+    // AE_GEMM_WK = 0 off (default), 1 rule, 2 always.
+    static const int wk_knob = getenv("AE_GEMM_WK") ? atoi(getenv("AE_GEMM_WK")) : 0;
+    const int kt_block = ((a.K + BK - 1) / BK + a.splitk - 1) / a.splitk;
+    const bool wk_env = wk_knob == 2 || (wk_knob == 1 && conv && kt_block >= 60);
     const bool conv = AMODE == A_CONV3;
     const char* what = conv ? "ae_conv3x3_bf16" : "ae_gemm_bf16";
     // LDS-DMA loaders need whole-tile decisions: no K tail, no mixed-source tile, no upsample gather / padded channels
@@ -644,6 +684,7 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     } while (0)
         if (pick == 3) AE_LAUNCH(128, 160, 2, 2, 256);
         else if (pick == 0 && w8 == 1) AE_LAUNCH(128, 128, 2, 4, 512);
+        else if (pick == 0 && wk_env && glds) rc = launch_kernel(gemm_kernel<128, 128, AMODE, 2, 2, true, 2>, grid, 512, lds_of(128, 128, 2), stream, a, what);
         else if (pick == 0 && w8 == 2) AE_LAUNCH(128, 128, 4, 2, 512);
         else if (pick == 0) AE_LAUNCH(128, 128, 2, 2, 256);
         else if (pick == 1 && w8 && !conv) AE_LAUNCH(128, 64, 4, 2, 512);
