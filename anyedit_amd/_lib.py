@@ -42,6 +42,7 @@ SIGNATURES = {
     "ae_layernorm_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "ae_layernorm_param_grad_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "ae_add_bf16": [c_void_p, c_void_p, c_void_p, c_long, c_void_p],
+    "ae_axpy_bf16": [c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p],
     "ae_geglu_fwd_bf16": [c_void_p, c_void_p, c_long, c_int, c_void_p],
     "ae_geglu_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
     "ae_sumpool2x2_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],

@@ -24,6 +24,18 @@ __global__ __launch_bounds__(NT) void add_kernel(const bf16_t* a, const bf16_t* 
     }
 }
 
+// y = a + alpha * b (ControlNet residuals: skip + scale * control, cldm.py:336-338, 40-41)
+__global__ __launch_bounds__(NT) void axpy_kernel(const bf16_t* a, const bf16_t* b, bf16_t* y, long n8, float alpha) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n8; i += (long)gridDim.x * NT) {
+        const u32x4 va = reinterpret_cast<const u32x4*>(a)[i], vb = reinterpret_cast<const u32x4*>(b)[i];
+        const uint32_t wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(bf16lo(wa[e]) + alpha * bf16lo(wb[e]), bf16hi(wa[e]) + alpha * bf16hi(wb[e]));
+        reinterpret_cast<u32x4*>(y)[i] = (u32x4){o[0], o[1], o[2], o[3]};
+    }
+}
+
 // GEGLU (attention.py:49-57): h = [a | g] (chunk(2, dim=-1)), y = a * gelu(g), exact-erf GELU.
 __device__ __forceinline__ float gelu_grad_f(float g) {  // d/dg [g * Phi(g)] = Phi(g) + g * phi(g)
     const float cdf = 0.5f * (1.0f + erf_as_f(g * 0.70710678118654752440f));
@@ -163,6 +175,14 @@ extern "C" int ae_add_bf16(const void* a, const void* b, void* y, long n, void* 
     AE_REQUIRE(al16(a) && al16(b) && al16(y), "ae_add_bf16: 16-byte alignment");
     hipLaunchKernelGGL(add_kernel, dim3(nblocks(n / 8)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n / 8);
     return ae_check_launch("ae_add_bf16");
+}
+
+extern "C" int ae_axpy_bf16(const void* a, const void* b, float alpha, void* y, long n, void* stream) {
+    AE_REQUIRE(a && b && y && n > 0 && n % 8 == 0, "ae_axpy_bf16: n=%ld must be a positive multiple of 8", n);
+    AE_REQUIRE(al16(a) && al16(b) && al16(y), "ae_axpy_bf16: 16-byte alignment");
+    hipLaunchKernelGGL(axpy_kernel, dim3(nblocks(n / 8)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y,
+                       n / 8, alpha);
+    return ae_check_launch("ae_axpy_bf16");
 }
 
 extern "C" int ae_geglu_fwd_bf16(const void* h, void* y, long M, int F, void* stream) {

@@ -648,7 +648,7 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // AE_GEMM_WK = 0 off (default), 1 rule, 2 always.
     static const int wk_knob = getenv("AE_GEMM_WK") ? atoi(getenv("AE_GEMM_WK")) : 0;
     const int kt_block = ((a.K + BK - 1) / BK + a.splitk - 1) / a.splitk;
-    const bool wk_env = wk_knob == 2 || (wk_knob == 1 && conv && kt_block >= 60);
+    const bool wk_env = wk_knob == 2 || (wk_knob == 1 && AMODE == A_CONV3 && kt_block >= 60);
     const bool conv = AMODE == A_CONV3;
     const char* what = conv ? "ae_conv3x3_bf16" : "ae_gemm_bf16";
     // LDS-DMA loaders need whole-tile decisions: no K tail, no mixed-source tile, no upsample gather / padded channels

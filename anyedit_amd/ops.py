@@ -429,6 +429,15 @@ def add(a, b, out=None):
     return out
 
 
+def axpy(a, b, alpha=1.0, out=None):
+    """a + alpha * b (bf16, same shape)."""
+    a, b = a.contiguous(), b.contiguous()
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib.ae_axpy_bf16(_p(a), _p(b), float(alpha), _p(out), a.numel(), _s()), "ae_axpy_bf16")
+    return out
+
+
 def geglu(h):
     """h = [a | g] [M, 2F] bf16 -> a * gelu(g) [M, F] (attention.py:49-57, un-fused so that h is kept for the backward)."""
     if _TAPE is not None and _TAPE.active:

@@ -109,6 +109,8 @@ int ae_layernorm_param_grad_f32(const void* x, const void* dy, const float* row_
                                 void* stream);
 /* y = a + b (gradient accumulation where a layer's input fans out).                                                          */
 int ae_add_bf16(const void* a, const void* b, void* y, long n, void* stream);
+/* y = a + alpha * b, bf16 (ControlNet residual injection: hs.pop() + scale * control.pop(), cldm.py:40-41, 336-338).          */
+int ae_axpy_bf16(const void* a, const void* b, float alpha, void* y, long n, void* stream);
 /* GEGLU un-fused for training (attention.py:49-57): h = [a | g] [M, 2F] -> y = a * gelu(g); backward -> dh.                   */
 int ae_geglu_fwd_bf16(const void* h, void* y, long M, int F, void* stream);
 int ae_geglu_bwd_bf16(const void* h, const void* dy, void* dh, long M, int F, void* stream);

@@ -35,6 +35,8 @@ def sub_sd(arrs, prefix, device="cpu", dtype=None):
     for k, v in arrs.items():
         if k.startswith(prefix):
             t = torch.from_numpy(np.asarray(v)).to(device)
+            if t.dtype == torch.int16:  # weights stored as bf16 bit patterns (the reference ran on the bf16-rounded values)
+                t = t.view(torch.bfloat16).float()
             if dtype is not None and t.is_floating_point():
                 t = t.to(dtype)
             out[k[len(prefix):]] = t

@@ -313,3 +313,32 @@ def test_latent_diffusion_first_stage_roundtrip(tiny_unet):
     close(z, 0.18215 * T(g["sample.z"]), rl2=2e-2, db=34.0, what="scaled first-stage encoding")
     y = ldm.decode_first_stage(0.18215 * T(g["enc.mean"]).to(DEV))
     close(y, g["dec.y"], rl2=3e-2, db=40.0, what="decode_first_stage")
+
+
+# ------------------------------------------------------------------------------------------------------------ ControlNet (N4)
+def test_controlnet_and_controlled_unet_golden():
+    """ControlNet / ControlledUnetModel on the HIP path vs the reference's cldm module (golden), incl. per-residual scales and
+    only_mid_control."""
+    from anyedit_amd.cldm.cldm import ControlNet, ControlledUnetModel
+    from util_models import TINY_UNET
+    g = load_golden("cldm_tiny")
+    cfg = dict(TINY_UNET)
+    cfg["in_channels"] = 4
+    unet = ControlledUnetModel(**cfg)
+    unet.load_state_dict(sub_sd(g, "unet."))
+    cnet = ControlNet(hint_channels=3, **{k: v for k, v in cfg.items() if k != "out_channels"})
+    cnet.load_state_dict(sub_sd(g, "cnet."))
+    unet, cnet = unet.to(DEV).eval(), cnet.to(DEV).eval()
+    d = lambda k: T(g[k]).to(DEV)
+    with torch.no_grad():
+        control = cnet(d("x"), d("hint"), d("t"), d("ctx"))
+        assert len(control) == int(g["n_control"])
+        for i, c in enumerate(control):
+            close(c, g[f"control.{i}"], rl2=4e-2, db=40.0, what=f"control residual {i}")  # deepest one: whole bf16 encoder + 8-conv hint stack
+        ctx_rows = unet.context_rows(d("ctx"))
+        rows = cnet.forward_rows(d("x"), d("hint"), d("t"), ctx_rows)
+        scaled = [(c, float(s_)) for c, s_ in zip(rows, g["scales"])]
+        close(unet.forward_rows(d("x"), d("t"), ctx_rows, control=scaled), g["eps_control"], rl2=2.5e-2, db=36.0, what="controlled UNet")
+        close(unet.forward_rows(d("x"), d("t"), ctx_rows, control=rows, only_mid_control=True), g["eps_mid_only"], rl2=2.5e-2, db=36.0,
+              what="controlled UNet (mid only)")
+        close(unet(d("x"), d("t"), context=d("ctx")), g["eps_plain"], rl2=2.5e-2, db=36.0, what="controlled UNet without control")

@@ -239,6 +239,24 @@ def test_plms_sampler():
         close(torch.stack(inter["pred_x0"]), g[f"{tag}.pred_x0"], tol=1e-5)
 
 
+def test_controlnet_and_controlled_unet():
+    """N4: ControlNet + ControlledUnetModel restatement against the reference's cldm module."""
+    from oracle import cldm_ref as C
+    g = load_golden("cldm_tiny")
+    cfg = dict(TINY)
+    cfg["in_channels"] = 4
+    usd, csd = sub_sd(g, "unet."), sub_sd(g, "cnet.")
+    x, hint, t, ctx = T(g["x"]), T(g["hint"]), T(g["t"]), T(g["ctx"])
+    control = C.controlnet_forward(csd, cfg, x, hint, t, ctx)
+    assert len(control) == int(g["n_control"])
+    for i, c in enumerate(control):
+        close(c, g[f"control.{i}"], tol=2e-4)
+    scaled = [c * float(s_) for c, s_ in zip(control, g["scales"])]
+    close(C.controlled_unet_forward(usd, cfg, x, t, ctx, control=scaled), g["eps_control"], tol=3e-4)
+    close(C.controlled_unet_forward(usd, cfg, x, t, ctx, control=control, only_mid_control=True), g["eps_mid_only"], tol=3e-4)
+    close(C.controlled_unet_forward(usd, cfg, x, t, ctx, control=None), g["eps_plain"], tol=3e-4)
+
+
 def test_sam():
     g = load_golden("sam_tiny")
     rp = T(g["relpos.table27"])

@@ -536,6 +536,47 @@ def gen_plms():
 
 
 @torch.no_grad()
+def gen_cldm():
+    """ControlNet / ControlledUnetModel (AnyEdit_Collection/other_modules/cldm/cldm.py:21-304) at the tiny UNet geometry: the
+    AnyDoor-style second consumer of the UNet operators."""
+    print("[cldm]")
+    sys.path.insert(0, os.path.join(REF, "AnyEdit_Collection", "other_modules"))
+    from cldm import cldm as rc
+    cfg = dict(TINY_UNET)
+    cfg["in_channels"] = 4
+    torch.manual_seed(31)
+    unet = rc.ControlledUnetModel(**cfg).eval()
+    cn_cfg = {k: v for k, v in cfg.items() if k != "out_channels"}
+    cnet = rc.ControlNet(hint_channels=3, **cn_cfg).eval()
+    g = G(95)
+    for m in (unet, cnet):
+        for name, p_ in m.named_parameters():   # G1: zero-initialised layers would make every control residual exactly 0
+            if float(p_.abs().max()) == 0.0:
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.05)
+            p_.copy_(p_.bfloat16().float())   # weights are stored as bf16 bit patterns (halves the fixture); the reference ran on them
+    B = 2
+    x = torch.randn(B, 4, 8, 8, generator=g)
+    hint = torch.rand(B, 3, 64, 64, generator=g)
+    t = torch.tensor([981, 21], dtype=torch.long)
+    ctx = torch.randn(B, 5, 16, generator=g)
+    control = cnet(x=x, hint=hint, timesteps=t, context=ctx)
+    arrs = {"x": x, "hint": hint, "t": t, "ctx": ctx}
+    for k, v in unet.state_dict().items():
+        arrs["unet." + k] = v.bfloat16().view(torch.int16)
+    for k, v in cnet.state_dict().items():
+        arrs["cnet." + k] = v.bfloat16().view(torch.int16)
+    for i, c in enumerate(control):
+        arrs[f"control.{i}"] = c
+    arrs["n_control"] = np.asarray(len(control))
+    scales = [0.5 + 0.1 * i for i in range(len(control))]
+    arrs["scales"] = np.asarray(scales, dtype=np.float32)
+    arrs["eps_control"] = unet(x=x, timesteps=t, context=ctx, control=[c * s_ for c, s_ in zip(control, scales)], only_mid_control=False)
+    arrs["eps_mid_only"] = unet(x=x, timesteps=t, context=ctx, control=[c.clone() for c in control], only_mid_control=True)
+    arrs["eps_plain"] = unet(x=x, timesteps=t, context=ctx, control=None)
+    npz("cldm_tiny", **arrs)
+
+
+@torch.no_grad()
 def gen_msda():
     """GroundingDINO's multi_scale_deformable_attn_pytorch (ms_deform_attn.py:93-133): the readable statement of the CUDA op."""
     print("[msda]")
@@ -657,7 +698,7 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])  # e.g. `python tools/gen_golden.py ddim_encode` regenerates one fixture
     for name, fn in (("schedule", gen_schedule), ("norms", gen_norms), ("attention", gen_attention), ("transformer", gen_transformer),
                      ("resblock", gen_resblock), ("unet", gen_unet), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode),
-                     ("vae", gen_vae), ("plms", gen_plms), ("msda", gen_msda), ("sam", gen_sam), ("misc", gen_ldm_misc)):
+                     ("vae", gen_vae), ("plms", gen_plms), ("cldm", gen_cldm), ("msda", gen_msda), ("sam", gen_sam), ("misc", gen_ldm_misc)):
         if not only or name in only:
             fn()
     print("done")
