@@ -24,7 +24,7 @@ namespace {
 constexpr int BK = 64;  // 64 bf16 = 128 B per tile row = 8 chunks of 16 B
 
 enum { A_DENSE = 0, A_CONV3 = 1 };
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GEGLU = 2, EPI_SILU = 3 };
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GEGLU = 2, EPI_SILU = 3, EPI_RELU = 4 };
 
 struct GemmArgs {
     const bf16_t* A;
@@ -451,6 +451,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                                 if (av) v += av[n + r];
                                 if (p.epi == EPI_SILU) v = silu_f(v);
                                 else if (p.epi == EPI_GELU) v = gelu_erf_f(v);
+                                else if (p.epi == EPI_RELU) v = fmaxf(v, 0.f);
                                 o[r] = v;
                             }
                             const int ch = j * 4 + lg;
@@ -525,6 +526,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                 if (av) v += av[n + r];
                 if (p.epi == EPI_SILU) v = silu_f(v);
                 else if (p.epi == EPI_GELU) v = gelu_erf_f(v);
+                                else if (p.epi == EPI_RELU) v = fmaxf(v, 0.f);
                 o[r] = v;
             }
             if (p.res) {
@@ -712,7 +714,7 @@ extern "C" int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, 
     AE_REQUIRE(N % 4 == 0, "ae_gemm_bf16: N=%d must be a multiple of 4", N);
     AE_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && aligned16(A) && aligned16(W), "ae_gemm_bf16: A/W rows must be 16-byte aligned");
     AE_REQUIRE(ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0, "ae_gemm_bf16: C must be 16-byte aligned, ldc %% 4 == 0");
-    AE_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_SILU, "ae_gemm_bf16: bad epilogue %d", epilogue);
+    AE_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_RELU, "ae_gemm_bf16: bad epilogue %d", epilogue);
     if (A2) {
         AE_REQUIRE(Ksplit > 0 && Ksplit < K && Ksplit % 8 == 0 && lda2 % 8 == 0 && aligned16(A2),
                    "ae_gemm_bf16: bad two-source split (Ksplit=%d, K=%d)", Ksplit, K);

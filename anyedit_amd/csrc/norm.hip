@@ -414,6 +414,70 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, const f
     }
 }
 
+// LayerNorm over a narrow last dim (C <= 512) with an optional fused GELU: L = pow2 lanes per row, 64 / L rows per wave, so the
+// LayerNorm2d + GELU pairs of the SAM mask decoder (mask_decoder.py:53-60; C = 64 over 16384*B pixels) keep every lane busy.
+template <int L, int ACT>
+__global__ __launch_bounds__(256) void layernorm_narrow_kernel(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y,
+                                                               long M, int C, float eps) {
+    const int lane = threadIdx.x & 63, sub = lane % L;
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / L) + lane / L;
+    const bool live = row < M && sub < C / 8;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = 0.f;
+    if (live) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + row * C + sub * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f[2 * e] = bf16lo(w[e]); f[2 * e + 1] = bf16hi(w[e]); }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += f[e];
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mu = s / (float)C;
+    float q = 0.f;
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q += (f[e] - mu) * (f[e] - mu);
+    }
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    if (live) {
+        uint32_t o32[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c0 = sub * 8 + 2 * e;
+            float a = (f[2 * e] - mu) * rstd * gamma[c0] + beta[c0];
+            float c = (f[2 * e + 1] - mu) * rstd * gamma[c0 + 1] + beta[c0 + 1];
+            if (ACT == 1) { a = gelu_erf_f(a); c = gelu_erf_f(c); }
+            o32[e] = pack_bf16x2(a, c);
+        }
+        *reinterpret_cast<u32x4*>(y + row * C + sub * 8) = (u32x4){o32[0], o32[1], o32[2], o32[3]};
+    }
+}
+
+template <int ACT>
+static void launch_layernorm_narrow(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, long M, int C, float eps,
+                                    hipStream_t s) {
+    const int ncc = C / 8;
+    int L = 1;
+    while (L < ncc) L *= 2;
+    const long rows_per_block = 4L * (64 / L);
+    dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block)), block(256);
+    switch (L) {
+        case 1: hipLaunchKernelGGL((layernorm_narrow_kernel<1, ACT>), grid, block, 0, s, x, gamma, beta, y, M, C, eps); break;
+        case 2: hipLaunchKernelGGL((layernorm_narrow_kernel<2, ACT>), grid, block, 0, s, x, gamma, beta, y, M, C, eps); break;
+        case 4: hipLaunchKernelGGL((layernorm_narrow_kernel<4, ACT>), grid, block, 0, s, x, gamma, beta, y, M, C, eps); break;
+        case 8: hipLaunchKernelGGL((layernorm_narrow_kernel<8, ACT>), grid, block, 0, s, x, gamma, beta, y, M, C, eps); break;
+        case 16: hipLaunchKernelGGL((layernorm_narrow_kernel<16, ACT>), grid, block, 0, s, x, gamma, beta, y, M, C, eps); break;
+        case 32: hipLaunchKernelGGL((layernorm_narrow_kernel<32, ACT>), grid, block, 0, s, x, gamma, beta, y, M, C, eps); break;
+        default: hipLaunchKernelGGL((layernorm_narrow_kernel<64, ACT>), grid, block, 0, s, x, gamma, beta, y, M, C, eps); break;
+    }
+}
+
 }  // namespace
 
 extern "C" int ae_groupnorm_rows_per_chunk(int HW, int C) {
@@ -538,6 +602,17 @@ extern "C" int ae_groupnorm_bwd_nhwc_bf16(const void* x, const void* x2, int C1,
     if (rc) return rc;
     hipLaunchKernelGGL(gnb_apply_kernel, grid, dim3(threads), 0, s, p);
     return ae_check_launch("ae_groupnorm_bwd_nhwc_bf16(apply)");
+}
+
+extern "C" int ae_layernorm_act_bf16(const void* x, const float* gamma, const float* beta, void* y, long M, int C, float eps, int act,
+                                     void* stream) {
+    AE_REQUIRE(x && gamma && beta && y, "ae_layernorm_act_bf16: null pointer");
+    AE_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 512, "ae_layernorm_act_bf16: C=%d must be a multiple of 8 and <= 512", C);
+    AE_REQUIRE(act == 0 || act == 1, "ae_layernorm_act_bf16: act %d (0 = none, 1 = GELU)", act);
+    AE_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "ae_layernorm_act_bf16: 16-byte alignment");
+    if (act) launch_layernorm_narrow<1>((const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps, (hipStream_t)stream);
+    else launch_layernorm_narrow<0>((const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps, (hipStream_t)stream);
+    return ae_check_launch("ae_layernorm_act_bf16");
 }
 
 extern "C" int ae_layernorm_bwd_bf16(const void* x, const float* gamma, const void* dy, void* dx, float* row_stat, int M, int C,

@@ -10,7 +10,7 @@ import torch
 from ._lib import lib, check
 
 BF16 = torch.bfloat16
-EPI_NONE, EPI_GELU, EPI_GEGLU, EPI_SILU = 0, 1, 2, 3
+EPI_NONE, EPI_GELU, EPI_GEGLU, EPI_SILU, EPI_RELU = 0, 1, 2, 3, 4
 
 
 def _s():
@@ -386,6 +386,87 @@ def ms_deform_attn(value, spatial_shapes, level_start_index, sampling_locations,
     out = torch.empty(bs, Q, heads * d, dtype=torch.float32, device=value.device)
     check(lib.ae_ms_deform_attn_fwd_f32(_p(value), _p(shapes), _p(starts), _p(loc), _p(w), _p(out), bs, S, heads, d, Q, L, P, _s()),
           "ae_ms_deform_attn_fwd_f32")
+    return out
+
+
+def layernorm_act(x, gamma, beta, eps=1e-6, gelu=True, out=None):
+    """LayerNorm over a narrow last dim (C <= 512) with fused GELU: the LayerNorm2d + GELU of the SAM mask decoder on rows."""
+    _chk(x, BF16, "layernorm_act.x", 2)
+    if not x.is_contiguous():
+        raise ValueError("layernorm_act: x must be contiguous")
+    M, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.ae_layernorm_act_bf16(_p(x), _p(gamma), _p(beta), _p(out), M, C, eps, 1 if gelu else 0, _s()), "ae_layernorm_act_bf16")
+    return out
+
+
+def sam_pe_encode(coords, gauss, image_size, labels=None, table=None, offset=0.5):
+    """coords [N, 2] fp32 pixel (x, y); gauss [2, F] fp32; image_size (H, W).  -> [N, 2F] fp32 (prompt_encoder.py:73-102, 183-214)."""
+    _chk(coords, torch.float32, "sam_pe_encode.coords", 2)
+    _chk(gauss, torch.float32, "sam_pe_encode.gauss", 2)
+    N, F = coords.shape[0], gauss.shape[1]
+    if labels is not None:
+        _chk(labels, torch.int32, "sam_pe_encode.labels", 1)
+        _chk(table, torch.float32, "sam_pe_encode.table", 2)
+        if table.shape != (5, 2 * F) or labels.shape[0] != N:
+            raise ValueError("sam_pe_encode: table must be [5, 2F] and labels [N]")
+    out = torch.empty(N, 2 * F, dtype=torch.float32, device=coords.device)
+    if N == 0:
+        return out
+    check(lib.ae_sam_pe_encode_f32(_p(coords.contiguous()), _p(labels), _p(gauss.contiguous()), _p(table), _p(out), N, F, float(offset),
+                                   1.0 / image_size[1], 1.0 / image_size[0], _s()), "ae_sam_pe_encode_f32")
+    return out
+
+
+def sam_mask_downscale(masks, w1, b1, g1, e1, w2, b2, g2, e2, eps=1e-6):
+    """masks [B, 1, 4h, 4w] fp32 -> rows [B*h*w, 16] bf16 (PromptEncoder.mask_downscaling[0:6], mask_in_chans 16)."""
+    _chk(masks, torch.float32, "sam_mask_downscale.masks", 4)
+    B, one, H4, W4 = masks.shape
+    if one != 1 or H4 % 4 or W4 % 4 or tuple(w1.shape) != (4, 1, 2, 2) or tuple(w2.shape) != (16, 4, 2, 2):
+        raise ValueError("sam_mask_downscale: expects [B,1,4h,4w] masks and the mask_in_chans=16 weights")
+    out = torch.empty(B * (H4 // 4) * (W4 // 4), 16, dtype=BF16, device=masks.device)
+    check(lib.ae_sam_mask_downscale_bf16(_p(masks.contiguous()), _p(w1), _p(b1), _p(g1), _p(e1), _p(w2), _p(b2), _p(g2), _p(e2), _p(out),
+                                         B, H4 // 4, W4 // 4, eps, _s()), "ae_sam_mask_downscale_bf16")
+    return out
+
+
+def sam_mask_product(up, hyper, B, h, w):
+    """up: bf16 rows [B*h*w*16, C] in un-shuffled (b, y, x, dy1, dx1, dy2, dx2) order; hyper [B, M, C] fp32 -> [B, M, 4h, 4w] fp32."""
+    _chk(up, BF16, "sam_mask_product.up", 2)
+    _chk(hyper, torch.float32, "sam_mask_product.hyper", 3)
+    M, C = hyper.shape[1], hyper.shape[2]
+    if up.shape != (B * h * w * 16, C) or not up.is_contiguous() or not hyper.is_contiguous() or hyper.shape[0] != B:
+        raise ValueError("sam_mask_product: shape mismatch")
+    out = torch.empty(B, M, 4 * h, 4 * w, dtype=torch.float32, device=up.device)
+    check(lib.ae_sam_mask_product_f32(_p(up), _p(hyper), _p(out), B, h, w, M, C, _s()), "ae_sam_mask_product_f32")
+    return out
+
+
+def sam_postprocess_masks(low, img_size, input_size, original_size, threshold=None, want_logits=True):
+    """Sam.postprocess_masks fused (sam.py:133-162).  Returns (logits fp32 or None, bool mask or None)."""
+    _chk(low, torch.float32, "sam_postprocess_masks.low", 4)
+    B, M, Hl, Wl = low.shape
+    oh, ow = int(original_size[0]), int(original_size[1])
+    logits = torch.empty(B, M, oh, ow, dtype=torch.float32, device=low.device) if want_logits else None
+    mask = torch.empty(B, M, oh, ow, dtype=torch.uint8, device=low.device) if threshold is not None else None
+    if B * M > 0:
+        check(lib.ae_sam_postprocess_masks(_p(low.contiguous()), _p(logits), _p(mask), B * M, Hl, Wl, int(img_size), int(input_size[0]),
+                                           int(input_size[1]), oh, ow, float(threshold if threshold is not None else 0.0), _s()),
+              "ae_sam_postprocess_masks")
+    return logits, (mask.view(torch.bool) if mask is not None else None)
+
+
+def sam_preprocess(x, img_size, mean, std):
+    """Sam.preprocess (sam.py:164-174): x [B, C, h, w] uint8 or fp32 -> normalised, zero-padded [B, C, S, S] fp32."""
+    if x.dtype not in (torch.uint8, torch.float32):
+        x = x.float()
+    if not x.is_cuda:
+        raise ValueError("sam_preprocess: expected a GPU tensor (anyedit_amd has no CPU path)")
+    B, C, h, w = x.shape
+    out = torch.empty(B, C, img_size, img_size, dtype=torch.float32, device=x.device)
+    check(lib.ae_sam_preprocess_f32(_p(x.contiguous()), 1 if x.dtype == torch.uint8 else 0, _p(out), B, C, h, w, img_size, _p(mean),
+                                    _p(std), _s()), "ae_sam_preprocess_f32")
     return out
 
 

@@ -31,6 +31,7 @@ extern "C" {
 #define AE_EPI_GELU 1  /* out = gelu_erf(acc + bias) (+ residual)   (SAM MLPBlock, common.py:13-27) */
 #define AE_EPI_GEGLU 2 /* out[:, j] = a_j * gelu_erf(g_j), W rows interleaved 16 a / 16 g (attention.py:49-58) */
 #define AE_EPI_SILU 3  /* out = silu(acc + bias)                    (time_embed, openaimodel.py:526-531) */
+#define AE_EPI_RELU 4  /* out = max(acc + bias, 0) (+ residual)     (SAM decoder MLPs, mask_decoder.py:154-176, transformer.py:122) */
 
 int ae_version(void);
 const char* ae_last_error(void);
@@ -190,6 +191,32 @@ int ae_gaussian_moments_f32(const float* moments, const float* noise, float* z, 
  * [bs, Q, heads, L, P, 2] in [0,1] (x, y), attn_weight [bs, Q, heads, L, P]; out [bs, Q, heads*d] fp32.                      */
 int ae_ms_deform_attn_fwd_f32(const float* value, const long* spatial_shapes, const long* level_start_index, const float* sampling_loc,
                               const float* attn_weight, float* out, int bs, int S, int heads, int d, int Q, int L, int P, void* stream);
+
+/* ---- SAM prompt encoder / mask decoder (SURVEY.md §8f N3): the non-GEMM kernels behind SamPredictor.predict_torch
+ * (segment_anything/predictor.py:168-245).
+ * ae_layernorm_act_bf16: LayerNorm over a narrow last dim (C <= 512) with optional fused GELU (act 1) — the LayerNorm2d + GELU of
+ *   MaskDecoder.output_upscaling (mask_decoder.py:53-60) on channels-last rows.
+ * ae_sam_pe_encode_f32: PositionEmbeddingRandom (prompt_encoder.py:174-214) of N pixel coordinates (x, y): out [N, 2F] =
+ *   cat(sin, cos)(2 pi ((2c-1) @ gauss[2,F])), c = (coords + offset) * (inv_w, inv_h).  labels (int32, optional): -1 -> encoding
+ *   zeroed + table row 0 (not_a_point_embed); l >= 0 -> + table row 1+l (point_embeddings[l]) — PromptEncoder._embed_points /
+ *   _embed_boxes (:73-102).  table [5, 2F].
+ * ae_sam_mask_downscale_bf16: PromptEncoder.mask_downscaling[0:6] (:46-53) for mask_in_chans = 16: masks [B,1,4h,4w] fp32 ->
+ *   channels-last rows [B*h*w, 16] bf16 (the closing 1x1 convolution is an ae_gemm_bf16).
+ * ae_sam_mask_product_f32: masks = hyper_in @ upscaled_embedding (mask_decoder.py:141-149).  up: bf16 [B, h, w, 2,2, 2,2, C] = the
+ *   two transposed convolutions' GEMM outputs left un-shuffled; hyper [B, M, C] fp32; out [B, M, 4h, 4w] fp32.
+ * ae_sam_postprocess_masks: Sam.postprocess_masks (sam.py:133-162) fused: bilinear (Hl,Wl)->(S,S), crop [:ih,:iw], bilinear ->
+ *   (oh,ow); writes fp32 logits and/or the (logit > threshold) uint8 mask.
+ * ae_sam_preprocess_f32: Sam.preprocess (sam.py:164-174): (x - mean[c]) / std[c], zero-padded to [B, C, S, S]; x uint8 or fp32. */
+int ae_layernorm_act_bf16(const void* x, const float* gamma, const float* beta, void* y, long M, int C, float eps, int act, void* stream);
+int ae_sam_pe_encode_f32(const float* coords, const int* labels, const float* gauss, const float* table, float* out, int N, int F,
+                         float offset, float inv_w, float inv_h, void* stream);
+int ae_sam_mask_downscale_bf16(const float* masks, const float* w1, const float* b1, const float* g1, const float* e1, const float* w2,
+                               const float* b2, const float* g2, const float* e2, void* out, int B, int h, int w, float eps, void* stream);
+int ae_sam_mask_product_f32(const void* up, const float* hyper, float* out, int B, int h, int w, int M, int C, void* stream);
+int ae_sam_postprocess_masks(const float* low, float* out_f32, void* out_u8, int N, int Hl, int Wl, int S, int ih, int iw, int oh, int ow,
+                             float threshold, void* stream);
+int ae_sam_preprocess_f32(const void* x, int x_is_u8, float* y, int B, int C, int h, int w, int S, const float* mean, const float* stdv,
+                          void* stream);
 
 #ifdef __cplusplus
 }

@@ -125,3 +125,37 @@ def test_weight_packing_layouts():
         assert torch.equal(wp[32 * j:32 * j + 16], wg[16 * j:16 * j + 16])
         assert torch.equal(wp[32 * j + 16:32 * j + 32], wg[inner + 16 * j:inner + 16 * j + 16])
         assert torch.equal(bp[32 * j + 16:32 * j + 32], bg[inner + 16 * j:inner + 16 * j + 16])
+
+
+def test_sam_key_schema_and_prompt_geometry():
+    """N3: the Sam mirror has the reference's state-dict schema (golden keys of the prompt encoder / mask decoder; build_sam_vit_b's
+    93.7 M parameters), ResizeLongestSide reproduces the reference's arithmetic, SamPredictor keeps its error behaviour."""
+    import numpy as np
+    from anyedit_amd.segment_anything import SamPredictor, sam_model_registry
+    from anyedit_amd.segment_anything.modeling import MaskDecoder, PromptEncoder, TwoWayTransformer
+    from anyedit_amd.segment_anything.utils.transforms import ResizeLongestSide
+    g = load_golden("sam_decoder")
+    pe = PromptEncoder(embed_dim=64, image_embedding_size=(8, 8), input_image_size=(128, 128), mask_in_chans=16)
+    md = MaskDecoder(num_multimask_outputs=3, transformer=TwoWayTransformer(depth=2, embedding_dim=64, mlp_dim=128, num_heads=4),
+                     transformer_dim=64, iou_head_depth=3, iou_head_hidden_dim=64)
+    keys = {"prompt_encoder." + k for k in pe.state_dict()} | {"mask_decoder." + k for k in md.state_dict()}
+    assert keys == {k[2:] for k in g if k.startswith("w.")}
+    for k, v in pe.state_dict().items():
+        assert tuple(v.shape) == g["w.prompt_encoder." + k].shape, k
+    for k, v in md.state_dict().items():
+        assert tuple(v.shape) == g["w.mask_decoder." + k].shape, k
+    with torch.device("meta"):
+        sam = sam_model_registry["vit_b"]()
+    assert sum(p.numel() for p in sam.parameters()) == 93_735_472
+    assert "pixel_mean" not in sam.state_dict()                                    # non-persistent buffers (sam.py:49-50)
+    t = ResizeLongestSide(1024)
+    assert t.get_preprocess_shape(512, 768, 1024) == (683, 1024) and t.get_preprocess_shape(75, 100, 128) == (96, 128)
+    b = t.apply_boxes_torch(torch.tensor([[10.0, 20.0, 300.0, 400.0]]), (512, 768))
+    assert torch.allclose(b, torch.tensor([[10 * 1024 / 768, 20 * 683 / 512, 300 * 1024 / 768, 400 * 683 / 512]]))
+    assert np.allclose(t.apply_boxes(np.array([[10.0, 20.0, 300.0, 400.0]]), (512, 768)), b.numpy())
+    img = (np.arange(30 * 40 * 3) % 251).astype(np.uint8).reshape(30, 40, 3)
+    assert ResizeLongestSide(128).apply_image(img).shape == (96, 128, 3)
+    pred = SamPredictor.__new__(SamPredictor)
+    pred.reset_image()
+    with pytest.raises(RuntimeError, match="set_image"):
+        pred.get_image_embedding()

@@ -282,3 +282,35 @@ def test_gelu_silu_points():
     x = T(g["gelu.x"])
     close(torch.nn.functional.gelu(x), g["gelu.y"], tol=1e-7)
     close(L.silu(x), g["silu.y"], tol=1e-6)
+
+
+SAM_TINY_DEC = dict(image_embedding_size=(8, 8), input_image_size=(128, 128), img_size=128, depth=2, num_heads=4)
+
+
+def _sam_decoder_cases(g):
+    pts, lbl = T(g["point_coords"]), T(g["point_labels"])
+    return {"boxes": (None, T(g["boxes"]), None, False), "points": ((pts, lbl), None, None, True),
+            "all": ((pts, lbl), T(g["boxes"])[:2], T(g["mask_input"]), True)}
+
+
+def test_sam_prompt_encoder_and_mask_decoder():
+    """N3: prompt encoder, two-way transformer, mask decoder and mask post-processing against the reference's outputs."""
+    from oracle import sam_decoder_ref as SD
+    g = load_golden("sam_decoder")
+    sd = sub_sd(g, "w.")
+    c = SAM_TINY_DEC
+    close(SD.dense_pe(sd, c["image_embedding_size"]), g["dense_pe"], tol=1e-5)
+    emb = T(g["image_embedding"])
+    for tag, (points, boxes, masks, multi) in _sam_decoder_cases(g).items():
+        sparse, dense = SD.prompt_encoder(sd, points, boxes, masks, c["image_embedding_size"], c["input_image_size"])
+        close(sparse, g[f"{tag}.sparse"], tol=1e-5)
+        if masks is not None:
+            close(dense, g[f"{tag}.dense"], tol=1e-5)
+        low, iou = SD.mask_decoder(sd, emb, SD.dense_pe(sd, c["image_embedding_size"]), sparse, dense, multi, c["depth"], c["num_heads"])
+        close(low, g[f"{tag}.low_res"], tol=1e-4)
+        close(iou, g[f"{tag}.iou"], tol=1e-4)
+        close(SD.postprocess_masks(low, c["img_size"], (96, 128), (75, 100)), g[f"{tag}.masks"], tol=1e-4)
+    assert g["boxes.low_res"].shape == (3, 1, 32, 32) and g["points.low_res"].shape == (2, 3, 32, 32)
+    assert g["points.sparse"].shape[1] == 3 and g["all.sparse"].shape[1] == 4 and g["boxes.sparse"].shape[1] == 2  # padding point rule
+    mean, std = torch.tensor([123.675, 116.28, 103.53]), torch.tensor([58.395, 57.12, 57.375])
+    close(SD.preprocess(T(g["pre.x"]), c["img_size"], mean, std), g["pre.y"], tol=1e-6)

@@ -78,6 +78,10 @@ sys.modules["samref"] = _sam_pkg
 _load_by_path("samref.common", os.path.join(REF, "segment_anything/segment_anything/modeling/common.py"))
 rsam = _load_by_path("samref.image_encoder",
                      os.path.join(REF, "segment_anything/segment_anything/modeling/image_encoder.py"))
+rsam_tr = _load_by_path("samref.transformer", os.path.join(REF, "segment_anything/segment_anything/modeling/transformer.py"))
+rsam_pe = _load_by_path("samref.prompt_encoder", os.path.join(REF, "segment_anything/segment_anything/modeling/prompt_encoder.py"))
+rsam_md = _load_by_path("samref.mask_decoder", os.path.join(REF, "segment_anything/segment_anything/modeling/mask_decoder.py"))
+rsam_sam = _load_by_path("samref.sam", os.path.join(REF, "segment_anything/segment_anything/modeling/sam.py"))
 
 
 class CPUDDIMSampler(DDIMSampler):
@@ -682,6 +686,67 @@ def gen_sam():
     npz("sam_tiny", **arrs)
 
 
+def build_tiny_sam(seed=75):
+    """128-px SAM: 8x8 embedding of width 64, decoder depth 2 with 4 heads (head dims 16 / 8), mask_in_chans 16 (as build_sam)."""
+    torch.manual_seed(seed)
+    enc = rsam.ImageEncoderViT(img_size=128, patch_size=16, in_chans=3, embed_dim=64, depth=2, num_heads=2, mlp_ratio=4.0,
+                               out_chans=64, qkv_bias=True, norm_layer=lambda d: nn.LayerNorm(d, eps=1e-6), use_abs_pos=True,
+                               use_rel_pos=True, rel_pos_zero_init=False, window_size=4, global_attn_indexes=(1,))
+    pe = rsam_pe.PromptEncoder(embed_dim=64, image_embedding_size=(8, 8), input_image_size=(128, 128), mask_in_chans=16)
+    md = rsam_md.MaskDecoder(num_multimask_outputs=3,
+                             transformer=rsam_tr.TwoWayTransformer(depth=2, embedding_dim=64, mlp_dim=128, num_heads=4),
+                             transformer_dim=64, iou_head_depth=3, iou_head_hidden_dim=64)
+    sam = rsam_sam.Sam(image_encoder=enc, prompt_encoder=pe, mask_decoder=md, pixel_mean=[123.675, 116.28, 103.53],
+                       pixel_std=[58.395, 57.12, 57.375])
+    g = G(seed + 1)
+    for p in sam.parameters():
+        if p.abs().sum() == 0:
+            p.data = torch.randn(p.shape, generator=g) * 0.1
+    randomize_norm_affine(sam, g)
+    for m in sam.modules():
+        if isinstance(m, rsam.LayerNorm2d):
+            m.weight.data = 1.0 + 0.1 * torch.randn(m.weight.shape, generator=g)
+            m.bias.data = 0.1 * torch.randn(m.bias.shape, generator=g)
+    sam.eval()
+    return sam
+
+
+@torch.no_grad()
+def gen_sam_decoder():
+    """N3: prompt encoder + two-way-transformer mask decoder + mask post-processing (what SamPredictor.predict_torch runs after the
+    image encoder; tools/tool.py:232-237 calls it with boxes only and multimask_output=False)."""
+    print("[sam_decoder]")
+    sam = build_tiny_sam()
+    g = G(77)
+    arrs = {}
+    arrs.update({k: v for k, v in sd_np(sam, "w.").items() if not k.startswith("w.image_encoder.")})
+    emb = torch.randn(1, 64, 8, 8, generator=g)
+    arrs["image_embedding"] = emb
+    arrs["dense_pe"] = sam.prompt_encoder.get_dense_pe()
+    boxes = torch.tensor([[10.0, 12.0, 70.0, 90.0], [0.0, 0.0, 127.0, 95.0], [33.5, 40.25, 60.0, 64.0]])
+    pts = torch.tensor([[[20.0, 30.0], [100.0, 64.0]], [[64.0, 5.0], [3.0, 90.0]]])
+    lbl = torch.tensor([[1, 0], [1, 1]])
+    mask_in = torch.randn(2, 1, 32, 32, generator=g) * 4.0
+    cases = {"boxes": dict(points=None, boxes=boxes, masks=None, multimask=False),
+             "points": dict(points=(pts, lbl), boxes=None, masks=None, multimask=True),
+             "all": dict(points=(pts, lbl), boxes=boxes[:2], masks=mask_in, multimask=True)}
+    arrs["boxes"], arrs["point_coords"], arrs["point_labels"], arrs["mask_input"] = boxes, pts, lbl, mask_in
+    for tag, c in cases.items():
+        sparse, dense = sam.prompt_encoder(points=c["points"], boxes=c["boxes"], masks=c["masks"])
+        low, iou = sam.mask_decoder(image_embeddings=emb, image_pe=sam.prompt_encoder.get_dense_pe(),
+                                    sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense,
+                                    multimask_output=c["multimask"])
+        arrs[f"{tag}.sparse"], arrs[f"{tag}.low_res"], arrs[f"{tag}.iou"] = sparse, low, iou
+        if c["masks"] is not None:
+            arrs[f"{tag}.dense"] = dense
+        # image 75x100 resized to 96x128 by ResizeLongestSide(128)
+        arrs[f"{tag}.masks"] = sam.postprocess_masks(low, (96, 128), (75, 100))
+    # Sam.preprocess on a uint8-valued 96x128 image
+    img = torch.randint(0, 256, (1, 3, 96, 128), generator=g).float()
+    arrs["pre.x"], arrs["pre.y"] = img, sam.preprocess(img)
+    npz("sam_decoder", **arrs)
+
+
 @torch.no_grad()
 def gen_ldm_misc():
     """GEGLU/gelu exactness + DiffusionWrapper conditioning-key switch (ddpm.py:1332-1363)."""
@@ -698,7 +763,8 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])  # e.g. `python tools/gen_golden.py ddim_encode` regenerates one fixture
     for name, fn in (("schedule", gen_schedule), ("norms", gen_norms), ("attention", gen_attention), ("transformer", gen_transformer),
                      ("resblock", gen_resblock), ("unet", gen_unet), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode),
-                     ("vae", gen_vae), ("plms", gen_plms), ("cldm", gen_cldm), ("msda", gen_msda), ("sam", gen_sam), ("misc", gen_ldm_misc)):
+                     ("vae", gen_vae), ("plms", gen_plms), ("cldm", gen_cldm), ("msda", gen_msda), ("sam", gen_sam), ("sam_decoder", gen_sam_decoder),
+                     ("misc", gen_ldm_misc)):
         if not only or name in only:
             fn()
     print("done")
