@@ -74,7 +74,8 @@ SIGNATURES = {
     "ae_sam_pe_encode_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p],
     "ae_sam_mask_downscale_bf16": [c_void_p] * 10 + [c_int, c_int, c_int, c_float, c_void_p],
     "ae_sam_mask_product_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    "ae_sam_postprocess_masks": [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_void_p],
+    "ae_sam_postprocess_masks": [c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_float, c_int, c_void_p],
+    "ae_nms_sorted_f32": [c_void_p, c_void_p, c_int, c_float, c_void_p],
     "ae_sam_preprocess_f32": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ae_patchify_f32_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ae_mse_f32": [c_void_p, c_void_p, c_void_p, c_long, c_void_p],

@@ -173,6 +173,7 @@ struct PostArgs {
     uint8_t* out_u8;    // [N, oh, ow] or null: out > threshold
     int N, Hl, Wl, S, ih, iw, oh, ow;
     float threshold;
+    int merge;          // out_u8 [oh, ow] = OR over the N masks (tools/tool.py:239-241 mask_mode 'merge')
 };
 
 __device__ __forceinline__ float stage1_sample(const float* img, int Y, int X, const PostArgs& p, float sh, float sw) {
@@ -184,24 +185,58 @@ __device__ __forceinline__ float stage1_sample(const float* img, int Y, int X, c
     return (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * c + lx * d);
 }
 
+__device__ __forceinline__ float postprocess_pixel(const float* img, int y, int x, const PostArgs& p, float sh1, float sw1, float sh2,
+                                                   float sw2) {
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilin_src(y, sh2, p.ih, y0, y1, ly);
+    bilin_src(x, sw2, p.iw, x0, x1, lx);
+    const float a = stage1_sample(img, y0, x0, p, sh1, sw1), b = stage1_sample(img, y0, x1, p, sh1, sw1);
+    const float c = stage1_sample(img, y1, x0, p, sh1, sw1), d = stage1_sample(img, y1, x1, p, sh1, sw1);
+    return (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * c + lx * d);
+}
+
 __global__ __launch_bounds__(NT) void postprocess_kernel(const PostArgs p) {
-    const long per = (long)p.oh * p.ow, total = per * p.N;
+    const long per = (long)p.oh * p.ow, total = p.merge ? per : per * p.N;
     const float sh1 = (float)p.Hl / (float)p.S, sw1 = (float)p.Wl / (float)p.S;
     const float sh2 = (float)p.ih / (float)p.oh, sw2 = (float)p.iw / (float)p.ow;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         const int x = (int)(i % p.ow), y = (int)((i / p.ow) % p.oh);
-        const long n = i / per;
-        const float* img = p.low + n * p.Hl * p.Wl;
-        int y0, y1, x0, x1;
-        float ly, lx;
-        bilin_src(y, sh2, p.ih, y0, y1, ly);
-        bilin_src(x, sw2, p.iw, x0, x1, lx);
-        const float a = stage1_sample(img, y0, x0, p, sh1, sw1), b = stage1_sample(img, y0, x1, p, sh1, sw1);
-        const float c = stage1_sample(img, y1, x0, p, sh1, sw1), d = stage1_sample(img, y1, x1, p, sh1, sw1);
-        const float v = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * c + lx * d);
+        if (p.merge) {
+            int any = 0;
+            for (int n = 0; n < p.N; ++n) any |= postprocess_pixel(p.low + (long)n * p.Hl * p.Wl, y, x, p, sh1, sw1, sh2, sw2) > p.threshold;
+            p.out_u8[i] = (uint8_t)any;
+            continue;
+        }
+        const float v = postprocess_pixel(p.low + (i / per) * p.Hl * p.Wl, y, x, p, sh1, sw1, sh2, sw2);
         if (p.out_f32) p.out_f32[i] = v;
         if (p.out_u8) p.out_u8[i] = v > p.threshold ? 1 : 0;
     }
+}
+
+// Greedy non-maximum suppression over boxes already sorted by descending score (torchvision.ops.nms semantics, used by
+// tools/tool.py:224): box i survives unless an earlier survivor overlaps it with IoU > thr.  One block; the boxes live in LDS and the
+// N sequential rounds each clear the later boxes in parallel (detector outputs are tens of boxes, at most 900 queries).
+__global__ __launch_bounds__(NT) void nms_kernel(const float* boxes, uint8_t* keep, int N, float thr) {
+    extern __shared__ float sb[];          // [N][4] then N removed flags (as floats' bytes)
+    uint8_t* removed = reinterpret_cast<uint8_t*>(sb + 4 * (long)N);
+    for (int i = threadIdx.x; i < 4 * N; i += NT) sb[i] = boxes[i];
+    for (int i = threadIdx.x; i < N; i += NT) removed[i] = 0;
+    __syncthreads();
+    for (int i = 0; i < N; ++i) {
+        if (!removed[i]) {                  // uniform across the block (read after the barrier below)
+            const float x1 = sb[4 * i], y1 = sb[4 * i + 1], x2 = sb[4 * i + 2], y2 = sb[4 * i + 3];
+            const float ai = (x2 - x1) * (y2 - y1);
+            for (int j = i + 1 + threadIdx.x; j < N; j += NT) {
+                const float u1 = sb[4 * j], v1 = sb[4 * j + 1], u2 = sb[4 * j + 2], v2 = sb[4 * j + 3];
+                const float iw = fmaxf(fminf(x2, u2) - fmaxf(x1, u1), 0.f), ih = fmaxf(fminf(y2, v2) - fmaxf(y1, v1), 0.f);
+                const float inter = iw * ih, aj = (u2 - u1) * (v2 - v1);
+                if (inter / (ai + aj - inter) > thr) removed[j] = 1;
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < N; i += NT) keep[i] = removed[i] ? 0 : 1;
 }
 
 template <typename TIn>
@@ -262,13 +297,26 @@ extern "C" int ae_sam_mask_product_f32(const void* up, const float* hyper, float
     return ae_check_launch("ae_sam_mask_product_f32");
 }
 
+extern "C" int ae_nms_sorted_f32(const float* boxes, void* keep, int N, float iou_threshold, void* stream) {
+    AE_REQUIRE(boxes && keep && N > 0, "ae_nms_sorted_f32: bad arguments");
+    AE_REQUIRE(N <= 8192, "ae_nms_sorted_f32: %d boxes (supported: <= 8192)", N);
+    const size_t lds = (size_t)N * 16 + (size_t)((N + 3) / 4 * 4);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { ae_set_error("ae_nms_sorted_f32: hipFuncSetAttribute(%zu) failed: %s", lds, hipGetErrorString(e)); return AE_ERR_LAUNCH; }
+    }
+    hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(NT), lds, (hipStream_t)stream, boxes, (uint8_t*)keep, N, iou_threshold);
+    return ae_check_launch("ae_nms_sorted_f32");
+}
+
 extern "C" int ae_sam_postprocess_masks(const float* low, float* out_f32, void* out_u8, int N, int Hl, int Wl, int S, int ih, int iw,
-                                        int oh, int ow, float threshold, void* stream) {
+                                        int oh, int ow, float threshold, int merge, void* stream) {
     AE_REQUIRE(low && (out_f32 || out_u8), "ae_sam_postprocess_masks: null pointer");
     AE_REQUIRE(N > 0 && Hl > 0 && Wl > 0 && S > 0 && oh > 0 && ow > 0, "ae_sam_postprocess_masks: bad shape");
     AE_REQUIRE(ih > 0 && iw > 0 && ih <= S && iw <= S, "ae_sam_postprocess_masks: input_size (%d, %d) must fit the %d-pixel square", ih, iw, S);
-    PostArgs p{low, out_f32, (uint8_t*)out_u8, N, Hl, Wl, S, ih, iw, oh, ow, threshold};
-    hipLaunchKernelGGL(postprocess_kernel, dim3(blocks_for((long)N * oh * ow)), dim3(NT), 0, (hipStream_t)stream, p);
+    AE_REQUIRE(!merge || (out_u8 && !out_f32), "ae_sam_postprocess_masks: merge writes the thresholded union only");
+    PostArgs p{low, out_f32, (uint8_t*)out_u8, N, Hl, Wl, S, ih, iw, oh, ow, threshold, merge ? 1 : 0};
+    hipLaunchKernelGGL(postprocess_kernel, dim3(blocks_for((long)(merge ? 1 : N) * oh * ow)), dim3(NT), 0, (hipStream_t)stream, p);
     return ae_check_launch("ae_sam_postprocess_masks");
 }
 

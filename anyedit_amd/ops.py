@@ -443,18 +443,38 @@ def sam_mask_product(up, hyper, B, h, w):
     return out
 
 
-def sam_postprocess_masks(low, img_size, input_size, original_size, threshold=None, want_logits=True):
-    """Sam.postprocess_masks fused (sam.py:133-162).  Returns (logits fp32 or None, bool mask or None)."""
+def sam_postprocess_masks(low, img_size, input_size, original_size, threshold=None, want_logits=True, merge=False):
+    """Sam.postprocess_masks fused (sam.py:133-162).  Returns (logits fp32 or None, bool mask or None).
+    merge: the bool mask is the union over all B*M masks, shape [1, 1, oh, ow] (no logits)."""
     _chk(low, torch.float32, "sam_postprocess_masks.low", 4)
     B, M, Hl, Wl = low.shape
     oh, ow = int(original_size[0]), int(original_size[1])
+    if merge and (threshold is None or want_logits):
+        raise ValueError("sam_postprocess_masks: merge returns the thresholded union only (threshold required, want_logits=False)")
     logits = torch.empty(B, M, oh, ow, dtype=torch.float32, device=low.device) if want_logits else None
-    mask = torch.empty(B, M, oh, ow, dtype=torch.uint8, device=low.device) if threshold is not None else None
+    mask = torch.empty((1, 1, oh, ow) if merge else (B, M, oh, ow), dtype=torch.uint8, device=low.device) if threshold is not None else None
     if B * M > 0:
         check(lib.ae_sam_postprocess_masks(_p(low.contiguous()), _p(logits), _p(mask), B * M, Hl, Wl, int(img_size), int(input_size[0]),
-                                           int(input_size[1]), oh, ow, float(threshold if threshold is not None else 0.0), _s()),
-              "ae_sam_postprocess_masks")
+                                           int(input_size[1]), oh, ow, float(threshold if threshold is not None else 0.0),
+                                           1 if merge else 0, _s()), "ae_sam_postprocess_masks")
+    elif mask is not None:
+        mask.zero_()
     return logits, (mask.view(torch.bool) if mask is not None else None)
+
+
+def nms(boxes, scores, iou_threshold):
+    """torchvision.ops.nms: XYXY boxes [N, 4], scores [N] -> int64 indices of the kept boxes, by decreasing score."""
+    if not boxes.is_cuda:
+        raise ValueError("nms: expected GPU tensors (anyedit_amd has no CPU path)")
+    if boxes.dim() != 2 or boxes.shape[1] != 4 or scores.shape != boxes.shape[:1]:
+        raise ValueError(f"nms: boxes must be [N, 4] and scores [N], got {tuple(boxes.shape)} / {tuple(scores.shape)}")
+    N = boxes.shape[0]
+    if N == 0:
+        return torch.empty(0, dtype=torch.int64, device=boxes.device)
+    order = torch.sort(scores, descending=True, stable=True).indices
+    keep = torch.empty(N, dtype=torch.uint8, device=boxes.device)
+    check(lib.ae_nms_sorted_f32(_p(boxes.float()[order].contiguous()), _p(keep), N, float(iou_threshold), _s()), "ae_nms_sorted_f32")
+    return order[keep.bool()]
 
 
 def sam_preprocess(x, img_size, mean, std):

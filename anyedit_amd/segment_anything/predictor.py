@@ -69,7 +69,7 @@ class SamPredictor:
     @torch.no_grad()
     def predict_torch(self, point_coords: Optional[torch.Tensor], point_labels: Optional[torch.Tensor],
                       boxes: Optional[torch.Tensor] = None, mask_input: Optional[torch.Tensor] = None, multimask_output: bool = True,
-                      return_logits: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                      return_logits: bool = False, _merge: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """:168-245: batched torch prompts already in the resized frame -> (masks BxCxHxW bool or logits, iou BxC, low-res BxCx256x256)."""
         if not self.is_image_set:
             raise RuntimeError("An image must be set with .set_image(...) before mask prediction.")
@@ -90,10 +90,18 @@ class SamPredictor:
                                                    dense_vec=dense_vec, dense_rows=dense_rows)
         sl = slice(1, None) if multimask_output else slice(0, 1)
         low_res_masks, iou_predictions = masks_all[:, sl, :, :], iou_all[:, sl]
+        if _merge:
+            return ops.sam_postprocess_masks(low_res_masks.contiguous(), self.model.image_encoder.img_size, self.input_size,
+                                             self.original_size, threshold=self.model.mask_threshold, want_logits=False, merge=True)[1]
         logits, binary = self.model.postprocess_masks_fused(low_res_masks.contiguous(), self.input_size, self.original_size,
                                                             threshold=None if return_logits else self.model.mask_threshold,
                                                             want_logits=return_logits)
         return (logits if return_logits else binary), iou_predictions, low_res_masks
+
+    def predict_torch_merged(self, boxes: torch.Tensor) -> torch.Tensor:
+        """Union over all box prompts of the single-mask predictions, [1, 1, H, W] bool: what maskgeneration's mask_mode 'merge' does
+        with `torch.sum(masks, dim=0) > 0` (tools/tool.py:239-241), with the union taken inside the post-processing kernel."""
+        return self.predict_torch(None, None, boxes=boxes, multimask_output=False, _merge=True)
 
     def get_image_embedding(self) -> torch.Tensor:
         """:247-259."""

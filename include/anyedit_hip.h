@@ -205,7 +205,10 @@ int ae_ms_deform_attn_fwd_f32(const float* value, const long* spatial_shapes, co
  * ae_sam_mask_product_f32: masks = hyper_in @ upscaled_embedding (mask_decoder.py:141-149).  up: bf16 [B, h, w, 2,2, 2,2, C] = the
  *   two transposed convolutions' GEMM outputs left un-shuffled; hyper [B, M, C] fp32; out [B, M, 4h, 4w] fp32.
  * ae_sam_postprocess_masks: Sam.postprocess_masks (sam.py:133-162) fused: bilinear (Hl,Wl)->(S,S), crop [:ih,:iw], bilinear ->
- *   (oh,ow); writes fp32 logits and/or the (logit > threshold) uint8 mask.
+ *   (oh,ow); writes fp32 logits and/or the (logit > threshold) uint8 mask.  merge != 0: out_u8 [oh,ow] = OR over the N masks
+ *   (maskgeneration's mask_mode 'merge', tools/tool.py:239-241).
+ * ae_nms_sorted_f32: greedy IoU suppression == torchvision.ops.nms (tools/tool.py:224) over XYXY boxes already sorted by
+ *   descending score; keep[i] (uint8) = 1 for survivors.
  * ae_sam_preprocess_f32: Sam.preprocess (sam.py:164-174): (x - mean[c]) / std[c], zero-padded to [B, C, S, S]; x uint8 or fp32. */
 int ae_layernorm_act_bf16(const void* x, const float* gamma, const float* beta, void* y, long M, int C, float eps, int act, void* stream);
 int ae_sam_pe_encode_f32(const float* coords, const int* labels, const float* gauss, const float* table, float* out, int N, int F,
@@ -214,7 +217,8 @@ int ae_sam_mask_downscale_bf16(const float* masks, const float* w1, const float*
                                const float* b2, const float* g2, const float* e2, void* out, int B, int h, int w, float eps, void* stream);
 int ae_sam_mask_product_f32(const void* up, const float* hyper, float* out, int B, int h, int w, int M, int C, void* stream);
 int ae_sam_postprocess_masks(const float* low, float* out_f32, void* out_u8, int N, int Hl, int Wl, int S, int ih, int iw, int oh, int ow,
-                             float threshold, void* stream);
+                             float threshold, int merge, void* stream);
+int ae_nms_sorted_f32(const float* boxes, void* keep, int N, float iou_threshold, void* stream);
 int ae_sam_preprocess_f32(const void* x, int x_is_u8, float* y, int B, int C, int h, int w, int S, const float* mean, const float* stdv,
                           void* stream);
 

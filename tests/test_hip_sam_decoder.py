@@ -279,3 +279,66 @@ def test_sam_decoder_full_size_geometry_runs():
     assert low.shape == (5, 1, 256, 256) and iou.shape == (5, 1)
     close(low, rlow, rl2=4e-2, db=32.0, what="full-size low_res")
     close_abs(iou, riou, what="full-size iou")
+
+
+# ------------------------------------------------------------------------------------------------------------ mask tool
+@pytest.mark.parametrize("N", [1, 7, 300, 1100])
+def test_nms_vs_restatement(N):
+    from anyedit_amd import ops
+    from oracle import sam_decoder_ref as SD
+    gen = torch.Generator().manual_seed(N)
+    c = torch.rand(N, 2, generator=gen) * 400
+    wh = torch.rand(N, 2, generator=gen) * 120 + 4
+    boxes = torch.cat([c, c + wh], dim=1)
+    scores = torch.rand(N, generator=gen)
+    for thr in (0.3, 0.5):
+        got = ops.nms(boxes.to(DEV), scores.to(DEV), thr).cpu()
+        assert torch.equal(got, SD.nms(boxes, scores, thr)), (N, thr)
+    assert ops.nms(boxes[:0].to(DEV), scores[:0].to(DEV), 0.5).numel() == 0
+
+
+def test_maskgeneration_box_logic():
+    """tools/tool.py:166-269 after the detector: target filtering, NMS, SAM box prompts, mask modes and early-outs."""
+    from PIL import Image
+    from anyedit_amd.segment_anything import SamPredictor
+    from anyedit_amd.tools.tool import maskgeneration, select_target_boxes, boxes_to_pixels_xyxy
+    torch.manual_seed(31)
+    sam = tiny_sam()
+    gen = torch.Generator().manual_seed(32)
+    with torch.no_grad():
+        for p in sam.parameters():
+            if p.abs().sum() == 0:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.1)
+        sam.mask_decoder.iou_token.weight.mul_(0.2)
+    pred = SamPredictor(sam.to(DEV))
+    img = Image.fromarray(torch.randint(0, 256, (300, 400, 3), generator=gen, dtype=torch.uint8).numpy())
+    dets = (torch.tensor([[0.30, 0.40, 0.30, 0.40], [0.31, 0.41, 0.30, 0.40], [0.75, 0.70, 0.20, 0.30], [0.5, 0.5, 0.9, 0.9]]),
+            ["cat(0.81)", "cat(0.62)", "cat(0.55)", "red sofa(0.90)"])
+    det = lambda image_pil, prompt, bt, tt: (dets[0].clone(), list(dets[1]))
+
+    px = boxes_to_pixels_xyxy(dets[0], 512, 512)
+    assert torch.allclose(px[0], torch.tensor([76.8, 102.4, 230.4, 307.2]))
+    b, s = select_target_boxes(px, dets[1], "cat")
+    assert b.shape == (3, 4) and s.tolist() == pytest.approx([0.81, 0.62, 0.55])
+    assert select_target_boxes(px, dets[1], "the sofa")[0].shape == (1, 4)                # word-overlap fallback
+    assert select_target_boxes(px, dets[1], ["dog", "sofa"])[0].shape == (1, 4) and select_target_boxes(px, dets[1], "dog") is None
+
+    masks, image_pil, none, union = maskgeneration(det, pred, img, "cat", mask_mode="count", target_object="cat", device=DEV)
+    assert masks.shape == (2, 1, 512, 512) and masks.dtype == torch.bool and none is None        # NMS removed the duplicate cat
+    assert union == pytest.approx((153.6 / 512) * (204.8 / 512), rel=1e-5) and image_pil.size == (512, 512)
+    ref_masks, _, _ = pred.predict_torch(None, None, boxes=pred.transform.apply_boxes_torch(px[[0, 2]], (512, 512)).to(DEV),
+                                         multimask_output=False)
+    assert torch.equal(masks, ref_masks)
+
+    mask_pil, _, bbox_pil, _ = maskgeneration(det, pred, img, "cat", mask_mode="merge", target_object="cat", device=DEV)
+    merged = torch.from_numpy(np.array(mask_pil))
+    assert torch.equal(merged, (ref_masks.sum(dim=0) > 0)[0].cpu())
+    bb = np.array(bbox_pil)
+    assert bb[150, 100] == 255 and bb[400, 400] == 255 and bb[10, 10] == 0
+    mask_pil, _, bbox_pil, _ = maskgeneration(det, pred, img, "cat", mask_mode="max", target_object="cat", device=DEV)
+    assert torch.equal(torch.from_numpy(np.array(mask_pil)), ref_masks[0, 0].cpu()) and np.array(bbox_pil)[400, 400] == 0
+    assert maskgeneration(det, pred, img, "dog", target_object="dog", device=DEV)[0] is None
+    none_det = lambda image_pil, prompt, bt, tt: (torch.zeros(0, 4), [])
+    assert maskgeneration(none_det, pred, img, "cat", device=DEV)[0] is None
+    out = maskgeneration(det, pred, img, "cat", mask_mode="count", target_object=None, device=DEV)
+    assert out[0].shape[0] == 4                                                                   # no target -> no filtering, no NMS
