@@ -162,6 +162,41 @@ __global__ void q_sample_kernel(const float* x0, const float* noise, const float
         out[i] = sa[b] * x0[i] + s1[b] * noise[i];
     }
 }
+// DPM-Solver / DPM-Solver++ multistep step (dpm_solver.py:246-316, 352-365, 469-513, 723-777), one launch per network evaluation:
+//   e   = guided noise of the network output(s) (batch order [uncond, cond]; model_type 'v': alpha_s * out + sigma_s * x),
+//   m   = predict_x0 ? (x - sigma_s e) / alpha_s : e                              (the "model value" kept in the history),
+//   x'  = a x - b m - c D,  D = inv_r0 (m - m_prev)  (first order: m_prev == nullptr, D term dropped).
+// a, b, c, inv_r0 are the per-step scalars of the reference's update formulas, computed on the host in fp32 exactly as it does.
+// Un-fused arithmetic (contraction off) so that identical network outputs give the reference's fp32 results.
+struct DpmArgs {
+    const float* x; const float* out; const float* m_prev; float* m_cur; float* x_next;
+    long n; int branches; int v_param; int predict_x0; int update;
+    float scale, sigma_s, alpha_s, a, b, c, inv_r0;
+};
+
+__global__ void dpm_multistep_kernel(const DpmArgs p) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < p.n; i += (long)gridDim.x * NT) {
+        const float x = p.x[i];
+        float e = p.out[i];
+        if (p.v_param) e = p.alpha_s * e + p.sigma_s * x;
+        if (p.branches == 2) {
+            float ec = p.out[p.n + i];
+            if (p.v_param) ec = p.alpha_s * ec + p.sigma_s * x;
+            e = e + p.scale * (ec - e);
+        }
+        const float m = p.predict_x0 ? (x - p.sigma_s * e) / p.alpha_s : e;
+        if (p.m_cur) p.m_cur[i] = m;
+        if (p.update) {
+            float xn = p.a * x - p.b * m;
+            if (p.m_prev) {
+                const float D = p.inv_r0 * (m - p.m_prev[i]);
+                xn = xn - p.c * D;
+            }
+            p.x_next[i] = xn;
+        }
+    }
+}
+
 #pragma clang fp contract(fast)
 
 __global__ void add_bcast_kernel(const bf16_t* x, const bf16_t* p, bf16_t* y, long n, long period) {
@@ -490,6 +525,18 @@ extern "C" int ae_gaussian_moments_f32(const float* moments, const float* noise,
     hipLaunchKernelGGL(gaussian_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, moments, noise, z, mean, logvar, std_out,
                        per_half, n);
     return ae_check_launch("ae_gaussian_moments_f32");
+}
+
+extern "C" int ae_dpm_multistep_f32(const float* x, const float* model_out, const float* m_prev, float* m_cur, float* x_next, long n,
+                                    int branches, float scale, int v_param, int predict_x0, float sigma_s, float alpha_s, int update,
+                                    float a, float b, float c, float inv_r0, void* stream) {
+    AE_REQUIRE(x && model_out && n > 0, "ae_dpm_multistep_f32: null pointer / bad n");
+    AE_REQUIRE(branches == 1 || branches == 2, "ae_dpm_multistep_f32: branches must be 1 or 2 (got %d)", branches);
+    AE_REQUIRE(m_cur || update, "ae_dpm_multistep_f32: nothing to write");
+    AE_REQUIRE(!update || x_next, "ae_dpm_multistep_f32: update needs x_next");
+    DpmArgs p{x, model_out, m_prev, m_cur, x_next, n, branches, v_param, predict_x0, update, scale, sigma_s, alpha_s, a, b, c, inv_r0};
+    hipLaunchKernelGGL(dpm_multistep_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, p);
+    return ae_check_launch("ae_dpm_multistep_f32");
 }
 
 extern "C" int ae_patchify_f32_bf16(const float* x, void* y, int B, int Cin, int H, int W, int P, void* stream) {

@@ -273,6 +273,23 @@ def ddim_encode_step(x, eps, cx, ce, branches=1, scale=1.0):
     return out
 
 
+def dpm_multistep(x, model_out, branches, scale, sigma_s, alpha_s, predict_x0=True, v_param=False, m_prev=None, update=None,
+                  want_m=True):
+    """One DPM-Solver(++) multistep evaluation: returns (m, x_next).  update = (a, b, c, inv_r0) or None (history value only)."""
+    _chk(x, torch.float32, "dpm_multistep.x")
+    _chk(model_out, torch.float32, "dpm_multistep.model_out")
+    n = x.numel()
+    if model_out.numel() != branches * n or not x.is_contiguous() or not model_out.is_contiguous():
+        raise ValueError("dpm_multistep: model_out must hold `branches` contiguous copies of x's shape")
+    m = torch.empty_like(x) if want_m else None
+    xn = torch.empty_like(x) if update is not None else None
+    a, b, c, inv_r0 = update if update is not None else (0.0, 0.0, 0.0, 0.0)
+    check(lib.ae_dpm_multistep_f32(_p(x), _p(model_out), _p(m_prev), _p(m), _p(xn), n, branches, float(scale), 1 if v_param else 0,
+                                   1 if predict_x0 else 0, float(sigma_s), float(alpha_s), 1 if update is not None else 0, float(a),
+                                   float(b), float(c), float(inv_r0), _s()), "ae_dpm_multistep_f32")
+    return m, xn
+
+
 def plms_combine(e_t, old_eps):
     """PLMS combination of e_t with the list of previous predictions (newest last, as plms.py keeps them); for the first step pass
     old_eps = [e_t_next] and order 0 via `plms_combine_first`."""

@@ -192,6 +192,14 @@ int ae_gaussian_moments_f32(const float* moments, const float* noise, float* z, 
 int ae_ms_deform_attn_fwd_f32(const float* value, const long* spatial_shapes, const long* level_start_index, const float* sampling_loc,
                               const float* attn_weight, float* out, int bs, int S, int heads, int d, int Q, int L, int P, void* stream);
 
+/* DPM-Solver / DPM-Solver++ multistep step (ldm/models/diffusion/dpm_solver/dpm_solver.py:246-316 guidance, :352-365 data prediction,
+ * :469-513 first-order and :723-777 second-order multistep updates): m = predict_x0 ? (x - sigma_s e)/alpha_s : e with e the guided
+ * noise of model_out ([uncond, cond] when branches == 2; v_param: alpha_s*out + sigma_s*x); update != 0: x_next = a x - b m
+ * - c inv_r0 (m - m_prev) (m_prev NULL: first order).  a, b, c, inv_r0: the reference's per-step scalars, computed by the caller. */
+int ae_dpm_multistep_f32(const float* x, const float* model_out, const float* m_prev, float* m_cur, float* x_next, long n, int branches,
+                         float scale, int v_param, int predict_x0, float sigma_s, float alpha_s, int update, float a, float b, float c,
+                         float inv_r0, void* stream);
+
 /* ---- SAM prompt encoder / mask decoder (SURVEY.md §8f N3): the non-GEMM kernels behind SamPredictor.predict_torch
  * (segment_anything/predictor.py:168-245).
  * ae_layernorm_act_bf16: LayerNorm over a narrow last dim (C <= 512) with optional fused GELU (act 1) — the LayerNorm2d + GELU of

@@ -208,6 +208,91 @@ def test_plms_sampler_golden():
         sampler.make_schedule(5, ddim_eta=0.5, verbose=False)
 
 
+def test_dpm_solver_sampler_golden():
+    """DPMSolverSampler (DPM-Solver++ 2M, CFG) and the other multistep variants on the HIP path vs the reference solver (golden from the
+    analytic eps model: identical eps on both sides isolates the solver arithmetic, history handling and step bookkeeping)."""
+    from anyedit_amd.ldm.models.diffusion.dpm_solver import DPMSolverSampler
+    from anyedit_amd.ldm.models.diffusion.dpm_solver.dpm_solver import NoiseScheduleVP, model_wrapper, DPM_Solver
+    from oracle import schedule_ref as S
+
+    class AnalyticModel:
+        parameterization = "eps"
+
+        def __init__(self, dev):
+            self.num_timesteps = 1000
+            for k, v in S.register_schedule("linear", 1000, 0.00085, 0.0120).items():
+                if isinstance(v, torch.Tensor):
+                    setattr(self, k, v.to(dev))
+            self.device = torch.device(dev)
+            self.calls = 0
+
+        def apply_model(self, x, t, c):
+            self.calls += 1
+            xc, tc, cc = x.detach().float().cpu(), t.float().cpu(), c.float().cpu()
+            return (torch.sin(xc * 1.7 + tc[:, None, None, None] * 0.01) * 0.5 + cc[:, :, None, None] * xc).to(x.device)
+
+    def near(got, key, rel=5e-6):                                            # fp32 round-off relative to the sample magnitude
+        ref = T(g[key])
+        assert float((got.cpu() - ref).abs().max()) <= rel * max(float(ref.abs().max()), 1.0), key
+
+    g = load_golden("dpm_solver")
+    model = AnalyticModel(DEV)
+    sampler = DPMSolverSampler(model)
+    dev = lambda k: T(g[k]).to(DEV)
+    for tag, steps, scale in (("s10", 10, 1.0), ("s12_cfg", 12, 5.0), ("s20_cfg", 20, 7.5)):
+        model.calls = 0
+        samples, none = sampler.sample(steps, 2, (4, 8, 8), dev("c"), x_T=dev("x_T"), verbose=False, unconditional_guidance_scale=scale,
+                                       unconditional_conditioning=dev("uc") if scale != 1.0 else None)
+        assert none is None and model.calls == steps                      # one network evaluation per step
+        near(samples, f"{tag}.samples")
+    ns = NoiseScheduleVP('discrete', alphas_cumprod=model.alphas_cumprod)
+    tq = T(g["ns.t"])
+    assert float((ns.marginal_lambda(tq) - T(g["ns.lambda"])).abs().max()) <= 1e-5
+    assert float((ns.inverse_lambda(ns.marginal_lambda(tq)) - T(g["ns.inverse_lambda"])).abs().max()) <= 1e-6
+    mf = model_wrapper(lambda x, t, c: model.apply_model(x, t, c), ns, model_type="noise", guidance_type="classifier-free",
+                       condition=dev("c"), unconditional_condition=dev("uc"), guidance_scale=3.0)
+    for st in ("time_uniform", "logSNR", "time_quadratic"):
+        assert float((DPM_Solver(mf, ns).get_time_steps(st, 1.0, 0.001, 10, DEV) - T(g[f"ts.{st}"])).abs().max()) <= 1e-6
+    out = DPM_Solver(mf, ns, predict_x0=False).sample(dev("x_T"), steps=9, skip_type="logSNR", method="multistep", order=2)
+    near(out, "eps2m.samples")
+    out = DPM_Solver(mf, ns, predict_x0=True).sample(dev("x_T"), steps=8, skip_type="time_quadratic", method="multistep", order=2,
+                                                     solver_type="taylor", denoise_to_zero=True)
+    near(out, "taylor.samples")
+    out = DPM_Solver(mf, ns, predict_x0=True).sample(dev("x_T"), steps=6, skip_type="time_uniform", method="multistep", order=1,
+                                                     t_start=0.8, t_end=0.05)
+    near(out, "o1.samples")
+    # the wrapped model is still callable the reference's way: guided noise at a continuous time
+    x, t = dev("x_T"), torch.tensor([0.5])
+    eu = model.apply_model(x, torch.full((2,), 499.0), dev("uc"))
+    ec = model.apply_model(x, torch.full((2,), 499.0), dev("c"))
+    assert float((mf(x, t) - (eu + 3.0 * (ec - eu))).abs().max()) <= 1e-6
+    with pytest.raises(NotImplementedError):
+        DPM_Solver(mf, ns).sample(x, steps=6, method="singlestep")
+    with pytest.raises(NotImplementedError):
+        NoiseScheduleVP('linear')
+
+
+def test_dpm_solver_tiny_unet_vs_oracle(tiny_unet):
+    """DPMSolverSampler over the HIP UNet (hybrid dict conditioning, CFG 5, float timesteps) vs the oracle solver over the oracle UNet."""
+    from anyedit_amd.ldm.models.diffusion.dpm_solver import DPMSolverSampler
+    from oracle import dpm_ref as P, ldm_ref as L, schedule_ref as S
+    from util_models import TINY_UNET
+    unet, gu = tiny_unet
+    g = load_golden("ddim_tiny")
+    ldm = _tiny_ldm(unet)
+    dev = lambda k: T(g[k]).to(DEV)
+    cond = {"c_concat": [dev("img_lat")], "c_crossattn": [dev("ctx")]}
+    uncond = {"c_concat": [dev("img_lat")], "c_crossattn": [dev("null_ctx")]}
+    samples, _ = DPMSolverSampler(ldm).sample(12, 2, (4, 8, 8), cond, x_T=dev("x_T"), verbose=False, unconditional_guidance_scale=5.0,
+                                              unconditional_conditioning=uncond)
+    sd = sub_sd(gu, "w.")
+    apply_model = lambda x, t, c: L.diffusion_wrapper(sd, TINY_UNET, x, t, c["c_concat"], c["c_crossattn"], "hybrid")
+    cpu = lambda c: {k: [v.cpu() for v in vs] for k, vs in c.items()}
+    ac = S.register_schedule("linear", 1000, 0.00085, 0.0120)["alphas_cumprod"].float()
+    ref = P.multistep_sample(apply_model, ac, T(g["x_T"]), 12, cpu(cond), cpu(uncond), 5.0)
+    close(samples, ref, rl2=6e-2, db=26.0, what="DPM-Solver++ 2M, 12 steps, tiny UNet")
+
+
 def test_ddim_sampler_vs_oracle_same_eps():
     """With the SAME eps fed to both, the HIP sampler arithmetic is bit-identical to the oracle's fp32 loop."""
     from anyedit_amd.ldm.models.diffusion.ddim import DDIMSampler

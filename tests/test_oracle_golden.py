@@ -314,3 +314,30 @@ def test_sam_prompt_encoder_and_mask_decoder():
     assert g["points.sparse"].shape[1] == 3 and g["all.sparse"].shape[1] == 4 and g["boxes.sparse"].shape[1] == 2  # padding point rule
     mean, std = torch.tensor([123.675, 116.28, 103.53]), torch.tensor([58.395, 57.12, 57.375])
     close(SD.preprocess(T(g["pre.x"]), c["img_size"], mean, std), g["pre.y"], tol=1e-6)
+
+
+def _analytic_eps_float_t(x, t, c):
+    return torch.sin(x * 1.7 + t.float()[:, None, None, None] * 0.01) * 0.5 + c[:, :, None, None] * x
+
+
+def test_dpm_solver_sampler():
+    """N4: DPM-Solver++(2M) as DPMSolverSampler drives it, the noise-schedule helpers, and the other multistep variants of the solver."""
+    from oracle import dpm_ref as P
+    g = load_golden("dpm_solver")
+    ac = S.register_schedule("linear", 1000, 0.00085, 0.0120)["alphas_cumprod"].float()
+    ns = P.NoiseSchedule(ac)
+    tq = T(g["ns.t"])
+    close(ns.log_mean_coeff(tq), g["ns.log_alpha"], tol=1e-6)
+    close(ns.lam(tq), g["ns.lambda"], tol=1e-6)
+    close(ns.std(tq), g["ns.std"], tol=1e-6)
+    close(ns.inverse_lambda(ns.lam(tq)), g["ns.inverse_lambda"], tol=1e-6)
+    for st in ("time_uniform", "logSNR", "time_quadratic"):
+        close(P.time_steps(ns, st, 1.0, 0.001, 10), g[f"ts.{st}"], tol=1e-6)
+    x_T, c, uc = T(g["x_T"]), T(g["c"]), T(g["uc"])
+    for tag, steps, scale in (("s10", 10, 1.0), ("s12_cfg", 12, 5.0), ("s20_cfg", 20, 7.5)):
+        out = P.multistep_sample(_analytic_eps_float_t, ac, x_T, steps, c, uc if scale != 1.0 else None, scale)
+        close(out, g[f"{tag}.samples"], tol=2e-5)
+    close(P.multistep_sample(_analytic_eps_float_t, ac, x_T, 9, c, uc, 3.0, skip_type="logSNR", predict_x0=False), g["eps2m.samples"], tol=2e-5)
+    close(P.multistep_sample(_analytic_eps_float_t, ac, x_T, 8, c, uc, 3.0, skip_type="time_quadratic", solver_type="taylor",
+                             denoise_to_zero=True), g["taylor.samples"], tol=2e-5)
+    close(P.multistep_sample(_analytic_eps_float_t, ac, x_T, 6, c, uc, 3.0, order=1, t_start=0.8, t_end=0.05), g["o1.samples"], tol=2e-5)

@@ -540,6 +540,52 @@ def gen_plms():
 
 
 @torch.no_grad()
+def gen_dpm_solver():
+    """DPMSolverSampler (ldm/models/diffusion/dpm_solver/sampler.py) = DPM-Solver++(2M), time-uniform steps on the discrete VP schedule,
+    classifier-free guidance, on the analytic eps model; plus the noise-schedule helpers it is built from."""
+    print("[dpm_solver]")
+    import io
+    import contextlib
+    from ldm.models.diffusion.dpm_solver.sampler import DPMSolverSampler
+    from ldm.models.diffusion.dpm_solver import dpm_solver as rdpm
+
+    class CPUDPMSolverSampler(DPMSolverSampler):
+        def register_buffer(self, name, attr):
+            setattr(self, name, attr)
+
+    model = AnalyticEpsModel()
+    g = G(91)
+    B = 2
+    x_T = torch.randn(B, 4, 8, 8, generator=g)
+    c = torch.randn(B, 4, generator=g) * 0.2
+    uc = torch.randn(B, 4, generator=g) * 0.2
+    arrs = {"x_T": x_T, "c": c, "uc": uc}
+    sampler = CPUDPMSolverSampler(model)
+    ns = rdpm.NoiseScheduleVP('discrete', alphas_cumprod=sampler.alphas_cumprod)
+    tq = torch.tensor([1.0, 0.95005, 0.5, 0.3333333, 0.0513, 0.002, 0.001])
+    arrs["ns.t"], arrs["ns.log_alpha"], arrs["ns.lambda"] = tq, ns.marginal_log_mean_coeff(tq), ns.marginal_lambda(tq)
+    arrs["ns.std"], arrs["ns.inverse_lambda"] = ns.marginal_std(tq), ns.inverse_lambda(ns.marginal_lambda(tq))
+    solver = rdpm.DPM_Solver(lambda x, t: x, ns, predict_x0=True)
+    for st in ("time_uniform", "logSNR", "time_quadratic"):
+        arrs[f"ts.{st}"] = solver.get_time_steps(st, 1.0, 0.001, 10, "cpu")
+    for tag, S, scale in (("s10", 10, 1.0), ("s12_cfg", 12, 5.0), ("s20_cfg", 20, 7.5)):
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            samples, _ = sampler.sample(S, B, (4, 8, 8), c, x_T=x_T, verbose=False, unconditional_guidance_scale=scale,
+                                        unconditional_conditioning=uc if scale != 1.0 else None)
+        arrs[f"{tag}.samples"] = samples
+    # the solver outside the sampler's fixed settings: noise-prediction DPM-Solver-2 multistep, taylor variant, order 1, denoise_to_zero
+    mf = rdpm.model_wrapper(lambda x, t, cc: model.apply_model(x, t, cc), ns, model_type="noise", guidance_type="classifier-free",
+                            condition=c, unconditional_condition=uc, guidance_scale=3.0)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        arrs["eps2m.samples"] = rdpm.DPM_Solver(mf, ns, predict_x0=False).sample(x_T, steps=9, skip_type="logSNR", method="multistep", order=2)
+        arrs["taylor.samples"] = rdpm.DPM_Solver(mf, ns, predict_x0=True).sample(x_T, steps=8, skip_type="time_quadratic", method="multistep",
+                                                                               order=2, solver_type="taylor", denoise_to_zero=True)
+        arrs["o1.samples"] = rdpm.DPM_Solver(mf, ns, predict_x0=True).sample(x_T, steps=6, skip_type="time_uniform", method="multistep",
+                                                                           order=1, t_start=0.8, t_end=0.05)
+    npz("dpm_solver", **arrs)
+
+
+@torch.no_grad()
 def gen_cldm():
     """ControlNet / ControlledUnetModel (AnyEdit_Collection/other_modules/cldm/cldm.py:21-304) at the tiny UNet geometry: the
     AnyDoor-style second consumer of the UNet operators."""
@@ -763,7 +809,7 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])  # e.g. `python tools/gen_golden.py ddim_encode` regenerates one fixture
     for name, fn in (("schedule", gen_schedule), ("norms", gen_norms), ("attention", gen_attention), ("transformer", gen_transformer),
                      ("resblock", gen_resblock), ("unet", gen_unet), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode),
-                     ("vae", gen_vae), ("plms", gen_plms), ("cldm", gen_cldm), ("msda", gen_msda), ("sam", gen_sam), ("sam_decoder", gen_sam_decoder),
+                     ("vae", gen_vae), ("plms", gen_plms), ("dpm_solver", gen_dpm_solver), ("cldm", gen_cldm), ("msda", gen_msda), ("sam", gen_sam), ("sam_decoder", gen_sam_decoder),
                      ("misc", gen_ldm_misc)):
         if not only or name in only:
             fn()
