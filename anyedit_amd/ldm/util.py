@@ -18,6 +18,10 @@ def get_obj_from_str(string, reload=False):
     # reference configs name `ldm.*` targets; resolve them to this package so YAMLs work unchanged
     if module.startswith("ldm."):
         module = "anyedit_amd." + module
+    elif module.startswith("AnyEdit_Collection.other_modules.cldm."):     # anydoor.yaml:2,22,40 name the cldm classes this way
+        module = "anyedit_amd.cldm." + module[len("AnyEdit_Collection.other_modules.cldm."):]
+    elif module.startswith("cldm."):
+        module = "anyedit_amd." + module
     return getattr(importlib.import_module(module, package=None), cls)
 
 

@@ -159,3 +159,135 @@ def test_sam_key_schema_and_prompt_geometry():
     pred.reset_image()
     with pytest.raises(RuntimeError, match="set_image"):
         pred.get_image_embedding()
+
+
+SD15_UNET = dict(image_size=64, in_channels=8, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+                 channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True, transformer_depth=1, context_dim=768, legacy=False)
+
+
+def test_checkpoint_layouts_and_diffusers_key_mapping(tmp_path):
+    """N4 on-disk formats: ldm <-> diffusers key layouts (derived from the module structure), the three file forms a UNet arrives in,
+    and cldm.model's checkpoint readers."""
+    import safetensors.torch
+    from util_models import build_tiny_unet
+    from anyedit_amd import checkpoints as C
+    from anyedit_amd.cldm.model import get_state_dict, load_state_dict
+    from anyedit_amd.ldm.models.autoencoder import AutoencoderKL
+    from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    with torch.device("meta"):
+        unet = UNetModel(**SD15_UNET)
+    km = C.unet_ldm_to_diffusers_keys(unet)
+    assert len(km) == 686 and len(set(km.values())) == 686
+    known = {"input_blocks.0.0.weight": "conv_in.weight", "time_embed.0.weight": "time_embedding.linear_1.weight",
+             "input_blocks.1.0.in_layers.2.weight": "down_blocks.0.resnets.0.conv1.weight",
+             "input_blocks.2.1.transformer_blocks.0.attn2.to_k.weight": "down_blocks.0.attentions.1.transformer_blocks.0.attn2.to_k.weight",
+             "input_blocks.3.0.op.weight": "down_blocks.0.downsamplers.0.conv.weight",
+             "input_blocks.4.0.skip_connection.weight": "down_blocks.1.resnets.0.conv_shortcut.weight",
+             "input_blocks.11.0.emb_layers.1.bias": "down_blocks.3.resnets.1.time_emb_proj.bias",
+             "middle_block.1.transformer_blocks.0.ff.net.0.proj.weight": "mid_block.attentions.0.transformer_blocks.0.ff.net.0.proj.weight",
+             "middle_block.2.out_layers.3.weight": "mid_block.resnets.1.conv2.weight",
+             "output_blocks.2.1.conv.weight": "up_blocks.0.upsamplers.0.conv.weight",
+             "output_blocks.5.2.conv.weight": "up_blocks.1.upsamplers.0.conv.weight",
+             "output_blocks.3.1.proj_out.bias": "up_blocks.1.attentions.0.proj_out.bias",
+             "output_blocks.11.0.skip_connection.weight": "up_blocks.3.resnets.2.conv_shortcut.weight",
+             "out.0.weight": "conv_norm_out.weight", "out.2.bias": "conv_out.bias"}
+    for k, d in known.items():
+        assert km[k] == d, (k, km[k])
+    dd = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4], num_res_blocks=2,
+              attn_resolutions=[], dropout=0.0)
+    with torch.device("meta"):
+        vae = AutoencoderKL(ddconfig=dd, lossconfig={"target": "torch.nn.Identity"}, embed_dim=4)
+    vm = C.vae_ldm_to_diffusers_keys(vae)
+    assert len(vm) == 248 and len(set(vm.values())) == 248
+    assert vm["decoder.up.3.block.0.norm1.weight"] == "decoder.up_blocks.0.resnets.0.norm1.weight"
+    assert vm["decoder.up.1.upsample.conv.weight"] == "decoder.up_blocks.2.upsamplers.0.conv.weight"
+    assert vm["decoder.up.1.block.0.nin_shortcut.weight"] == "decoder.up_blocks.2.resnets.0.conv_shortcut.weight"
+    assert vm["encoder.mid.attn_1.q.weight"] == "encoder.mid_block.attentions.0.to_q.weight"
+    assert vm["encoder.down.2.downsample.conv.bias"] == "encoder.down_blocks.2.downsamplers.0.conv.bias"
+
+    tiny = build_tiny_unet()
+    sd = {k: v.clone() for k, v in tiny.state_dict().items()}
+    dif = C.convert_unet_to_diffusers(tiny)
+    assert set(dif) == set(C.unet_ldm_to_diffusers_keys(tiny).values())
+    k1 = next(k for k in dif if k.endswith("attentions.0.proj_in.weight"))
+    dif_lin = dict(dif)
+    dif_lin[k1] = dif[k1].reshape(dif[k1].shape[0], -1)                       # the Linear flavour of the 1x1 projection
+    back = C.convert_diffusers_unet(tiny, dif_lin)
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+    with pytest.raises(KeyError):
+        C.convert_diffusers_unet(tiny, {k: v for k, v in dif.items() if k != "conv_in.weight"})
+    with pytest.raises(ValueError):
+        C.convert_diffusers_unet(tiny, {**dif, "conv_in.weight": dif["conv_in.weight"][:, :4]})
+
+    files = {"ldm": (tmp_path / "unet_ldm.safetensors", sd), "diffusers": (tmp_path / "diffusion_pytorch_model.safetensors", dif),
+             "ldm-checkpoint": (tmp_path / "sd.ckpt", None)}
+    safetensors.torch.save_file({k: v.contiguous() for k, v in sd.items()}, str(files["ldm"][0]))
+    safetensors.torch.save_file({k: v.contiguous() for k, v in dif.items()}, str(files["diffusers"][0]))
+    full = {"model.diffusion_model." + k: v for k, v in sd.items()}
+    full["first_stage_model.encoder.conv_in.weight"] = torch.zeros(1)
+    torch.save({"state_dict": full, "global_step": 7}, str(files["ldm-checkpoint"][0]))
+    for layout, (path, _) in files.items():
+        fresh = build_tiny_unet()
+        with torch.no_grad():
+            for p in fresh.parameters():
+                p.zero_()
+        assert C.load_unet_weights(fresh, str(path)) == layout
+        assert all(torch.equal(v, sd[k]) for k, v in fresh.state_dict().items()), layout
+    assert get_state_dict({"state_dict": {"a": 1}}) == {"a": 1} and get_state_dict({"a": 1}) == {"a": 1}
+    assert set(load_state_dict(str(files["ldm-checkpoint"][0]))) == set(full)
+
+
+def test_create_model_from_reference_style_yaml(tmp_path):
+    """cldm.model.create_model on a YAML whose `target:` strings name the reference's classes (anydoor.yaml:2,22,40,56), and the
+    AnyDoor geometry (SD-2.1 widths: 64-wide heads, linear transformer projections, 1024-wide context) on the meta device."""
+    from anyedit_amd.cldm.cldm import ControlLDM, ControlNet, ControlledUnetModel
+    from anyedit_amd.cldm.model import create_model
+    tiny = "image_size: 8\n        in_channels: 4\n        model_channels: 32\n        attention_resolutions: [1, 2]\n        " \
+           "num_res_blocks: 1\n        channel_mult: [1, 2]\n        num_head_channels: 8\n        use_spatial_transformer: true\n        " \
+           "use_linear_in_transformer: true\n        transformer_depth: 1\n        context_dim: 16\n        legacy: false\n"
+    yaml_text = f"""model:
+  target: AnyEdit_Collection.other_modules.cldm.cldm.ControlLDM
+  params:
+    linear_start: 0.00085
+    linear_end: 0.0120
+    timesteps: 1000
+    image_size: 8
+    channels: 4
+    conditioning_key: crossattn
+    scale_factor: 0.18215
+    use_ema: false
+    only_mid_control: false
+    control_key: hint
+    control_stage_config:
+      target: AnyEdit_Collection.other_modules.cldm.cldm.ControlNet
+      params:
+        hint_channels: 4
+        {tiny}
+    unet_config:
+      target: AnyEdit_Collection.other_modules.cldm.cldm.ControlledUnetModel
+      params:
+        out_channels: 4
+        {tiny}
+    first_stage_config:
+      target: ldm.models.autoencoder.AutoencoderKL
+      params:
+        embed_dim: 4
+        ddconfig: {{double_z: true, z_channels: 4, resolution: 32, in_channels: 3, out_ch: 3, ch: 32, ch_mult: [1, 2], num_res_blocks: 1,
+                   attn_resolutions: [], dropout: 0.0}}
+        lossconfig:
+          target: torch.nn.Identity
+"""
+    path = tmp_path / "tiny_anydoor.yaml"
+    path.write_text(yaml_text)
+    model = create_model(str(path))
+    assert isinstance(model, ControlLDM) and isinstance(model.control_model, ControlNet)
+    assert isinstance(model.model.diffusion_model, ControlledUnetModel) and model.first_stage_model is not None
+    assert model.scale_factor == 0.18215 and float(model.betas[0]) == pytest.approx(0.00085, rel=1e-6)
+    geo = dict(image_size=32, in_channels=4, model_channels=320, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+               channel_mult=[1, 2, 4, 4], num_head_channels=64, use_spatial_transformer=True, use_linear_in_transformer=True,
+               transformer_depth=1, context_dim=1024, legacy=False)
+    with torch.device("meta"):
+        unet = ControlledUnetModel(out_channels=4, **geo)
+        cnet = ControlNet(hint_channels=4, **geo)
+    assert (sum(p.numel() for p in unet.parameters()), len(unet.state_dict())) == (865_910_724, 686)      # [probe] of the reference classes
+    assert (sum(p.numel() for p in cnet.parameters()), len(cnet.state_dict())) == (364_228_384, 340)
