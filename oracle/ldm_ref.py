@@ -143,14 +143,15 @@ def upsample(sd, p, x):
 
 # ------------------------------------------------------------------ A7 UNet
 def unet_plan(cfg):
-    """Walk of UNetModel.__init__ (openaimodel.py:542-730) for use_spatial_transformer=True, legacy=False,
-    num_head_channels=-1.  Returns (input_blocks, middle, output_blocks): lists of layer tuples."""
+    """Walk of UNetModel.__init__ (openaimodel.py:542-730) for use_spatial_transformer=True, legacy=False
+    (heads fixed by num_heads, or by num_head_channels as in the SD-2.1 / AnyDoor configs).  Returns (input_blocks, middle, output_blocks): lists of layer tuples."""
     mc = cfg["model_channels"]
     mult = list(cfg["channel_mult"])
     nrb = cfg["num_res_blocks"]
     nrb = [nrb] * len(mult) if isinstance(nrb, int) else list(nrb)
     attn_res = set(cfg["attention_resolutions"])
-    heads = cfg["num_heads"]
+    nhc = cfg.get("num_head_channels", -1)
+    hd = (lambda c: (cfg["num_heads"], c // cfg["num_heads"])) if nhc == -1 else (lambda c: (c // nhc, nhc))   # openaimodel.py:586-592
     depth = cfg.get("transformer_depth", 1)
     inp = [[("conv", cfg["in_channels"], mc)]]
     chans = [mc]
@@ -160,14 +161,14 @@ def unet_plan(cfg):
             layers = [("res", ch, m * mc)]
             ch = m * mc
             if ds in attn_res:
-                layers.append(("st", ch, heads, ch // heads, depth))
+                layers.append(("st", ch, *hd(ch), depth))
             inp.append(layers)
             chans.append(ch)
         if level != len(mult) - 1:
             inp.append([("down", ch, ch)])
             chans.append(ch)
             ds *= 2
-    mid = [("res", ch, ch), ("st", ch, heads, ch // heads, depth), ("res", ch, ch)]
+    mid = [("res", ch, ch), ("st", ch, *hd(ch), depth), ("res", ch, ch)]
     out = []
     for level, m in list(enumerate(mult))[::-1]:
         for i in range(nrb[level] + 1):
@@ -175,7 +176,7 @@ def unet_plan(cfg):
             layers = [("res", ch + ich, mc * m)]
             ch = mc * m
             if ds in attn_res:
-                layers.append(("st", ch, heads, ch // heads, depth))
+                layers.append(("st", ch, *hd(ch), depth))
             if level and i == nrb[level]:
                 layers.append(("up", ch, ch))
                 ds //= 2

@@ -293,6 +293,53 @@ def test_dpm_solver_tiny_unet_vs_oracle(tiny_unet):
     close(samples, ref, rl2=6e-2, db=26.0, what="DPM-Solver++ 2M, 12 steps, tiny UNet")
 
 
+def test_unet_sd2_options_golden():
+    """UNetModel with num_head_channels + use_linear_in_transformer (AnyDoor / SD-2.1 options) vs the reference's output."""
+    from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    g = load_golden("unet_sd2_tiny")
+    unet = UNetModel(image_size=8, in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[1, 2],
+                     channel_mult=[1, 2], num_head_channels=16, use_spatial_transformer=True, use_linear_in_transformer=True,
+                     transformer_depth=1, context_dim=24, legacy=False)
+    sd = sub_sd(g, "w.")
+    assert set(unet.state_dict().keys()) == set(sd.keys())
+    unet.load_state_dict(sd)
+    y = unet.to(DEV)(T(g["x"]).to(DEV), T(g["t"]).to(DEV), context=T(g["ctx"]).to(DEV))
+    close(y, g["y"], what="tiny UNet, head width 16, linear projections")
+
+
+def test_anydoor_geometry_runs():
+    """ControlledUnetModel + ControlNet at the AnyDoor sizes (anydoor.yaml:22-54: 320-wide, heads of 64, Linear transformer
+    projections, 1024-wide context of 257 DINOv2 tokens) at 32x32 latents: shapes, finiteness, 13 control residuals."""
+    from anyedit_amd.cldm.cldm import ControlNet, ControlledUnetModel
+    geo = dict(image_size=32, in_channels=4, model_channels=320, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+               channel_mult=[1, 2, 4, 4], num_head_channels=64, use_spatial_transformer=True, use_linear_in_transformer=True,
+               transformer_depth=1, context_dim=1024, legacy=False)
+    torch.manual_seed(0)
+    with torch.device(DEV):
+        unet = ControlledUnetModel(out_channels=4, **geo)
+        cnet = ControlNet(hint_channels=4, **geo)
+    with torch.no_grad():
+        for m in (unet, cnet):
+            for p in m.parameters():
+                if float(p.abs().max()) == 0.0:
+                    p.normal_(0, 0.02)
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 4, 32, 32, generator=gen).to(DEV)
+    hint = torch.rand(2, 4, 256, 256, generator=gen).to(DEV)
+    ctx = torch.randn(2, 257, 1024, generator=gen).to(DEV)
+    t = torch.tensor([981, 21], device=DEV)
+    with torch.no_grad():
+        control = cnet(x=x, hint=hint, timesteps=t, context=ctx)
+        eps = unet(x=x, timesteps=t, context=ctx, control=control, only_mid_control=False)
+        plain = unet(x=x, timesteps=t, context=ctx, control=None)
+    assert len(control) == 13 and control[0].shape == (2, 320, 32, 32) and control[-1].shape == (2, 1280, 4, 4)
+    assert eps.shape == (2, 4, 32, 32) and torch.isfinite(eps).all() and torch.isfinite(plain).all()
+    assert float((eps - plain).abs().max()) > 0.0
+    with torch.no_grad():
+        again = unet(x=x[:1], timesteps=t[:1], context=ctx[:1], control=[c[:1] for c in control], only_mid_control=False)
+    close(again, eps[:1].float().cpu(), rl2=1e-2, db=40.0, what="batch independence")   # split-K plans differ with M: bf16 round-off only
+
+
 def test_ddim_sampler_vs_oracle_same_eps():
     """With the SAME eps fed to both, the HIP sampler arithmetic is bit-identical to the oracle's fp32 loop."""
     from anyedit_amd.ldm.models.diffusion.ddim import DDIMSampler

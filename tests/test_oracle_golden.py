@@ -341,3 +341,15 @@ def test_dpm_solver_sampler():
     close(P.multistep_sample(_analytic_eps_float_t, ac, x_T, 8, c, uc, 3.0, skip_type="time_quadratic", solver_type="taylor",
                              denoise_to_zero=True), g["taylor.samples"], tol=2e-5)
     close(P.multistep_sample(_analytic_eps_float_t, ac, x_T, 6, c, uc, 3.0, order=1, t_start=0.8, t_end=0.05), g["o1.samples"], tol=2e-5)
+
+
+SD2_TINY = dict(image_size=8, in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[1, 2],
+                channel_mult=[1, 2], num_head_channels=16, use_spatial_transformer=True, use_linear_in_transformer=True,
+                transformer_depth=1, context_dim=24, legacy=False)
+
+
+def test_unet_sd2_options():
+    """num_head_channels + use_linear_in_transformer (the AnyDoor / SD-2.1 UNet options, anydoor.yaml:32-35)."""
+    g = load_golden("unet_sd2_tiny")
+    y = L.unet_forward(sub_sd(g, "w."), SD2_TINY, T(g["x"]), T(g["t"]), T(g["ctx"]))
+    close(y, g["y"], tol=2e-4)

@@ -309,6 +309,33 @@ def gen_unet():
     print("   params:", sum(p.numel() for p in unet.parameters()))
 
 
+SD2_TINY_UNET = dict(image_size=8, in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[1, 2],
+                     channel_mult=[1, 2], num_head_channels=16, use_spatial_transformer=True, use_linear_in_transformer=True,
+                     transformer_depth=1, context_dim=24, legacy=False, use_checkpoint=False)
+
+
+@torch.no_grad()
+def gen_unet_sd2():
+    """The SD-2.1-flavoured UNet options the AnyDoor config switches on (anydoor.yaml:32-35, 51-54): heads from a fixed head width
+    (`num_head_channels`) and Linear instead of 1x1-conv transformer projections (`use_linear_in_transformer`)."""
+    print("[unet_sd2]")
+    torch.manual_seed(52)
+    g = G(53)
+    unet = rom.UNetModel(**SD2_TINY_UNET)
+    unzero(unet, g, std=0.05)
+    randomize_norm_affine(unet, g)
+    unet.eval()
+    for p_ in unet.parameters():
+        p_.copy_(p_.bfloat16().float())       # stored as bf16 bit patterns; the reference ran on these values
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    t = torch.tensor([21, 961], dtype=torch.long)
+    ctx = torch.randn(2, 9, 24, generator=g)
+    arrs = {"x": x, "t": t, "ctx": ctx, "y": unet(x, t, context=ctx)}
+    for k, v in unet.state_dict().items():
+        arrs["w." + k] = v.bfloat16().view(torch.int16)
+    npz("unet_sd2_tiny", **arrs)
+
+
 def build_ldm(unet_params):
     ldm = OracleLDM(first_stage_config=None, cond_stage_config="__is_unconditional__",
                     force_null_conditioning=True, conditioning_key="hybrid",
@@ -808,7 +835,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     only = set(sys.argv[1:])  # e.g. `python tools/gen_golden.py ddim_encode` regenerates one fixture
     for name, fn in (("schedule", gen_schedule), ("norms", gen_norms), ("attention", gen_attention), ("transformer", gen_transformer),
-                     ("resblock", gen_resblock), ("unet", gen_unet), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode),
+                     ("resblock", gen_resblock), ("unet", gen_unet), ("unet_sd2", gen_unet_sd2), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode),
                      ("vae", gen_vae), ("plms", gen_plms), ("dpm_solver", gen_dpm_solver), ("cldm", gen_cldm), ("msda", gen_msda), ("sam", gen_sam), ("sam_decoder", gen_sam_decoder),
                      ("misc", gen_ldm_misc)):
         if not only or name in only:
