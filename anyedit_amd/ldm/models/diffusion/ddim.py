@@ -163,6 +163,35 @@ class DDIMSampler(object):
         dir_coef = np.sqrt(one - a_prev - sigma * sigma, dtype=np.float32)  # (1. - a_prev - sigma_t**2).sqrt()
         return float(s1m), float(sqrt_at), float(sqrt_a_prev), float(dir_coef), float(sigma)
 
+    def _model_eps(self, x, c, t, unconditional_guidance_scale, unconditional_conditioning):
+        """ddim.py:187-212: one network call on the [uncond, cond] batch.  Returns (eps [branches*B, ...], branches)."""
+        if unconditional_conditioning is None or unconditional_guidance_scale == 1.:
+            return self.model.apply_model(x, t, c), 1
+        x_in = torch.cat([x] * 2)
+        t_in = torch.cat([t] * 2)
+        if isinstance(c, dict):
+            assert isinstance(unconditional_conditioning, dict)
+            c_in = dict()
+            for k in c:
+                if isinstance(c[k], list):
+                    c_in[k] = [torch.cat([unconditional_conditioning[k][i], c[k][i]]) for i in range(len(c[k]))]
+                else:
+                    c_in[k] = torch.cat([unconditional_conditioning[k], c[k]])
+        elif isinstance(c, list):
+            assert isinstance(unconditional_conditioning, list)
+            c_in = [torch.cat([unconditional_conditioning[i], c[i]]) for i in range(len(c))]
+        else:
+            c_in = torch.cat([unconditional_conditioning, c])
+        return self.model.apply_model(x_in, t_in, c_in), 2  # [2B,...] = [uncond, cond]
+
+    def _encode_eps(self, x, t, c, unconditional_conditioning):
+        """ddim.py:276-280: tensor conditionings only, batch order [uncond, cond]."""
+        return self.model.apply_model(torch.cat((x, x)), torch.cat((t, t)), torch.cat((unconditional_conditioning, c)))
+
+    def _encode_timestep(self, i, use_original_steps):
+        """ddim.py:272: the inversion loop hands the LOOP INDEX to the network as the timestep (reference quirk, kept)."""
+        return i
+
     @torch.no_grad()
     def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
                       temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
@@ -175,27 +204,7 @@ class DDIMSampler(object):
             raise NotImplementedError()
         if getattr(self.model, "parameterization", "eps") != "eps":
             raise NotImplementedError("only eps-parameterisation is on the AnyEdit path")
-        if unconditional_conditioning is None or unconditional_guidance_scale == 1.:
-            eps = self.model.apply_model(x, t, c)
-            branches = 1
-        else:
-            x_in = torch.cat([x] * 2)
-            t_in = torch.cat([t] * 2)
-            if isinstance(c, dict):
-                assert isinstance(unconditional_conditioning, dict)
-                c_in = dict()
-                for k in c:
-                    if isinstance(c[k], list):
-                        c_in[k] = [torch.cat([unconditional_conditioning[k][i], c[k][i]]) for i in range(len(c[k]))]
-                    else:
-                        c_in[k] = torch.cat([unconditional_conditioning[k], c[k]])
-            elif isinstance(c, list):
-                assert isinstance(unconditional_conditioning, list)
-                c_in = [torch.cat([unconditional_conditioning[i], c[i]]) for i in range(len(c))]
-            else:
-                c_in = torch.cat([unconditional_conditioning, c])
-            eps = self.model.apply_model(x_in, t_in, c_in)  # [2B,...] = [uncond, cond]
-            branches = 2
+        eps, branches = self._model_eps(x, c, t, unconditional_guidance_scale, unconditional_conditioning)
         noise = self.randn((1, *x.shape[1:]), device=device).repeat(b, 1, 1, 1) if repeat_noise else self.randn(x.shape, device=device)
         coeffs = self._coeffs(index, use_original_steps)
         x_prev, pred_x0 = ops.ddim_step(x.float(), eps.float(), coeffs, branches, s0=float(unconditional_guidance_scale),
@@ -253,12 +262,12 @@ class DDIMSampler(object):
         intermediates, inter_steps = [], []
         cfg = unconditional_guidance_scale != 1.
         for i in range(num_steps):
-            t = torch.full((x0.shape[0],), i, device=x0.device, dtype=torch.long)
+            t = torch.full((x0.shape[0],), int(self._encode_timestep(i, use_original_steps)), device=x0.device, dtype=torch.long)
             if not cfg:
                 eps = self.model.apply_model(x_next, t, c)
             else:
                 assert unconditional_conditioning is not None
-                eps = self.model.apply_model(torch.cat((x_next, x_next)), torch.cat((t, t)), torch.cat((unconditional_conditioning, c)))
+                eps = self._encode_eps(x_next, t, c, unconditional_conditioning)
             an32, ap = np.float32(a_next[i]), a_prev[i]
             cx = np.float32(np.sqrt(np.float64(an32) / np.float64(ap)) if not use_original_steps else np.sqrt(an32 / np.float32(ap), dtype=np.float32))
             s_next = np.sqrt(an32, dtype=np.float32)                                   # alphas_next[i].sqrt()          (fp32)

@@ -96,7 +96,8 @@ def stochastic_encode(sched, x0, t, noise):
     return extract(sa, t, x0.shape) * x0 + extract(s1, t, x0.shape) * noise
 
 
-def ddim_encode(apply_model, sched, buffers, x0, c, t_enc, use_original_steps=False, return_intermediates=None, scale=1.0, uc=None):
+def ddim_encode(apply_model, sched, buffers, x0, c, t_enc, use_original_steps=False, return_intermediates=None, scale=1.0, uc=None,
+                timestep_from_schedule=False):
     """ddim.py:253-298 (DDIM inversion).  Kept quirks: the network is queried at t = LOOP INDEX i, not at ddim_timesteps[i];
     alphas_next is the fp32 schedule tensor, alphas the float64 array of previous alphas (G5 dtype mix), so the two
     coefficients are formed in float64 and rounded to fp32 when they meet the fp32 latents."""
@@ -112,7 +113,9 @@ def ddim_encode(apply_model, sched, buffers, x0, c, t_enc, use_original_steps=Fa
     x_next = x0
     intermediates, inter_steps = [], []
     for i in range(num_steps):
-        t = torch.full((x0.shape[0],), i, dtype=torch.long)
+        # cldm/ddim_hacked.py:237-254 (the AnyDoor sampler) queries the network at the schedule's timestep instead of the loop index
+        ti = i if not timestep_from_schedule else (i if use_original_steps else int(sched["ddim_timesteps"][i]))
+        t = torch.full((x0.shape[0],), ti, dtype=torch.long)
         if scale == 1.0:
             noise_pred = apply_model(x_next, t, c)
         else:

@@ -208,6 +208,50 @@ def test_plms_sampler_golden():
         sampler.make_schedule(5, ddim_eta=0.5, verbose=False)
 
 
+def test_ddim_hacked_sampler_golden():
+    """cldm.ddim_hacked.DDIMSampler (AnyDoor path) vs the reference's: two network calls per guided step, inversion at ddim_timesteps[i]."""
+    from anyedit_amd.cldm.ddim_hacked import DDIMSampler
+    from oracle import schedule_ref as S
+
+    class AnalyticModel:
+        parameterization = "eps"
+
+        def __init__(self, dev):
+            self.num_timesteps = 1000
+            for k, v in S.register_schedule("linear", 1000, 0.00085, 0.0120).items():
+                if isinstance(v, torch.Tensor):
+                    setattr(self, k, v.to(dev))
+            self.device = torch.device(dev)
+            self.calls, self.seen_t = 0, []
+
+        def apply_model(self, x, t, c):
+            self.calls += 1
+            self.seen_t.append(int(t[0]))
+            xc, tc, cc = x.detach().float().cpu(), t.float().cpu(), c.float().cpu()
+            return (torch.sin(xc * 1.7 + tc[:, None, None, None] * 0.01) * 0.5 + cc[:, :, None, None] * xc).to(x.device)
+
+    g = load_golden("ddim_hacked")
+    model = AnalyticModel(DEV)
+    sampler = DDIMSampler(model)
+    sampler.randn = lambda shape, device=None: torch.randn(shape).to(device)
+    dev = lambda k: T(g[k]).to(DEV)
+    torch.manual_seed(4322)
+    samples, inter = sampler.sample(8, 2, (4, 8, 8), dev("c"), eta=0.0, x_T=dev("x_T"), verbose=False, unconditional_guidance_scale=5.0,
+                                    unconditional_conditioning=dev("uc"), log_every_t=1)
+    assert model.calls == int(g["s8_cfg.network_calls"]) and np.array_equal(sampler.ddim_timesteps, g["ddim_timesteps"])
+    assert float((samples.cpu() - T(g["s8_cfg.samples"])).abs().max()) <= 2e-5
+    assert float((torch.stack(inter["pred_x0"]).cpu() - T(g["s8_cfg.pred_x0"])).abs().max()) <= 2e-5
+    model.seen_t = []
+    x, out = sampler.encode(dev("x_T"), dev("c"), t_enc=6, return_intermediates=2)
+    assert model.seen_t == [int(v) for v in g["ddim_timesteps"][:6]]                    # queried at the schedule's timesteps
+    assert out["intermediate_steps"] == g["enc.intermediate_steps"].tolist()
+    assert float((x.cpu() - T(g["enc.x"])).abs().max()) <= 2e-5
+    x, _ = sampler.encode(dev("x_T"), dev("c"), t_enc=6, unconditional_guidance_scale=3.0, unconditional_conditioning=dev("uc"))
+    assert float((x.cpu() - T(g["enc.x_cfg"])).abs().max()) <= 2e-5
+    x, _ = sampler.encode(dev("x_T"), dev("c"), t_enc=15, use_original_steps=True)
+    assert float((x.cpu() - T(g["enc.x_orig"])).abs().max()) <= 2e-5
+
+
 def test_dpm_solver_sampler_golden():
     """DPMSolverSampler (DPM-Solver++ 2M, CFG) and the other multistep variants on the HIP path vs the reference solver (golden from the
     analytic eps model: identical eps on both sides isolates the solver arithmetic, history handling and step bookkeeping)."""

@@ -353,3 +353,22 @@ def test_unet_sd2_options():
     g = load_golden("unet_sd2_tiny")
     y = L.unet_forward(sub_sd(g, "w."), SD2_TINY, T(g["x"]), T(g["t"]), T(g["ctx"]))
     close(y, g["y"], tol=2e-4)
+
+
+def test_ddim_hacked_sampler():
+    """N4: cldm/ddim_hacked.py — same sampling arithmetic as ldm's DDIM (two network calls instead of one batch), inversion queried at
+    ddim_timesteps[i]."""
+    g = load_golden("ddim_hacked")
+    buffers = S.register_schedule("linear", 1000, 0.00085, 0.0120)
+    x_T, c, uc = T(g["x_T"]), T(g["c"]), T(g["uc"])
+    torch.manual_seed(4322)
+    img, inter, sched = D.ddim_sample(_analytic_eps_float_t, buffers, 8, tuple(x_T.shape), c, eta=0.0, x_T=x_T, scale=5.0, uc=uc, log_every_t=1)
+    close(img, g["s8_cfg.samples"], tol=1e-5)
+    assert np.array_equal(sched["ddim_timesteps"], g["ddim_timesteps"]) and int(g["s8_cfg.network_calls"]) == 16
+    x, out = D.ddim_encode(_analytic_eps_float_t, sched, buffers, x_T, c, 6, return_intermediates=2, timestep_from_schedule=True)
+    close(x, g["enc.x"], tol=1e-5)
+    assert out["intermediate_steps"] == g["enc.intermediate_steps"].tolist()
+    x, _ = D.ddim_encode(_analytic_eps_float_t, sched, buffers, x_T, c, 6, scale=3.0, uc=uc, timestep_from_schedule=True)
+    close(x, g["enc.x_cfg"], tol=1e-5)
+    x, _ = D.ddim_encode(_analytic_eps_float_t, sched, buffers, x_T, c, 15, use_original_steps=True, timestep_from_schedule=True)
+    close(x, g["enc.x_orig"], tol=1e-5)

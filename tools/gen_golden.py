@@ -454,6 +454,51 @@ def gen_ddim_encode():
     npz("ddim_encode", **arrs)
 
 
+@torch.no_grad()
+def gen_ddim_hacked():
+    """cldm/ddim_hacked.py (the AnyDoor path's sampler, visual_reference_tool.py): guidance from two separate network calls
+    (:189-193) and an inversion that queries the network at ddim_timesteps[i] rather than at the loop index (:237-254)."""
+    print("[ddim_hacked]")
+    import io
+    import contextlib
+    sys.path.insert(0, os.path.join(REF, "AnyEdit_Collection", "other_modules"))
+    from cldm.ddim_hacked import DDIMSampler as HackedSampler
+
+    class CPUHacked(HackedSampler):
+        def register_buffer(self, name, attr):
+            setattr(self, name, attr)
+
+    class CountingModel(AnalyticEpsModel):
+        calls = 0
+
+        def apply_model(self, x, t, c):
+            CountingModel.calls += 1
+            return super().apply_model(x, t, c)
+
+    model = CountingModel()
+    g = G(92)
+    B = 2
+    x_T = torch.randn(B, 4, 8, 8, generator=g)
+    c = torch.randn(B, 4, generator=g) * 0.2
+    uc = torch.randn(B, 4, generator=g) * 0.2
+    arrs = {"x_T": x_T, "c": c, "uc": uc}
+    sampler = CPUHacked(model)
+    torch.manual_seed(4322)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        samples, inter = sampler.sample(8, B, (4, 8, 8), c, eta=0.0, x_T=x_T, verbose=False, unconditional_guidance_scale=5.0,
+                                        unconditional_conditioning=uc, log_every_t=1)
+    arrs["s8_cfg.samples"], arrs["s8_cfg.pred_x0"] = samples, torch.stack(inter["pred_x0"])
+    arrs["s8_cfg.network_calls"] = np.asarray(CountingModel.calls)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        x_enc, out = sampler.encode(x_T, c, t_enc=6, return_intermediates=2)
+        x_enc_cfg, _ = sampler.encode(x_T, c, t_enc=6, unconditional_guidance_scale=3.0, unconditional_conditioning=uc)
+        x_enc_orig, _ = sampler.encode(x_T, c, t_enc=15, use_original_steps=True)
+    arrs["enc.x"], arrs["enc.x_cfg"], arrs["enc.x_orig"] = x_enc, x_enc_cfg, x_enc_orig
+    arrs["enc.intermediate_steps"] = np.asarray(out["intermediate_steps"], dtype=np.int64)
+    arrs["ddim_timesteps"] = sampler.ddim_timesteps
+    npz("ddim_hacked", **arrs)
+
+
 TINY_VAE = dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 2], num_res_blocks=1,
                 attn_resolutions=[], dropout=0.0)
 
@@ -835,7 +880,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     only = set(sys.argv[1:])  # e.g. `python tools/gen_golden.py ddim_encode` regenerates one fixture
     for name, fn in (("schedule", gen_schedule), ("norms", gen_norms), ("attention", gen_attention), ("transformer", gen_transformer),
-                     ("resblock", gen_resblock), ("unet", gen_unet), ("unet_sd2", gen_unet_sd2), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode),
+                     ("resblock", gen_resblock), ("unet", gen_unet), ("unet_sd2", gen_unet_sd2), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode), ("ddim_hacked", gen_ddim_hacked),
                      ("vae", gen_vae), ("plms", gen_plms), ("dpm_solver", gen_dpm_solver), ("cldm", gen_cldm), ("msda", gen_msda), ("sam", gen_sam), ("sam_decoder", gen_sam_decoder),
                      ("misc", gen_ldm_misc)):
         if not only or name in only:
