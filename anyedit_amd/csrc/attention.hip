@@ -58,8 +58,10 @@ __device__ __forceinline__ int vt_pos(int key) {  // key = 16 f + 4 g + r  ->  1
 // BIAS: 0 none; 1 decomposed rel-pos bias, any key grid; 2 the same when one key tile is exactly one key ROW (kW == 64, SAM's
 // global attention on the 64x64 token grid): rel_w[q, kw] of the lane's 16 key slots lives in registers for the whole kernel
 // and rel_h[q, kh] is one value per tile — no per-element index arithmetic or gathers.
-template <int D, int QF, int NW, bool DBUF, int BIAS, bool HAS_MASK, bool SEG2 = false>
-__global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 && BIAS == 0 ? 4 : 2) : 1)) void attn_kernel(const AttnArgs p) {
+// OCC4: cap the kernel at 128 VGPRs (4 waves per SIMD = two 8-wave blocks per CU) — the rel-pos variants otherwise sit at 145-161
+// VGPRs, i.e. ONE 8-wave block per CU; the cap costs 40-160 bytes of scratch per lane.
+template <int D, int QF, int NW, bool DBUF, int BIAS, bool HAS_MASK, bool SEG2 = false, bool OCC4 = false>
+__global__ __launch_bounds__(64 * NW, (D <= 96 ? ((NW == 8 && (BIAS == 0 || OCC4)) ? 4 : 2) : 1)) void attn_kernel(const AttnArgs p) {
     constexpr bool HAS_BIAS = BIAS != 0;
     constexpr int NT = 64 * NW;
     constexpr int NC = D / 32;                 // full K=32 MFMAs per (key frag, q frag)
@@ -486,6 +488,14 @@ __global__ __launch_bounds__(64 * NW, (D <= 96 ? (NW == 8 && BIAS == 0 ? 4 : 2) 
     }
 }
 
+// tuning knob: which rel-pos (SAM) variants run under the 128-VGPR cap: 0 none, 1 the windowed (table-lookup) variant, 4 both.
+// In-situ A/B on the ViT-H encoder (one box, 2 runs each): windowed 14x14 attention 61.0 -> 49.3 us per block (two resident
+// blocks hide its short dependent load phases), global 64x64 attention 287 -> 414 us (the spills land in its long key loop): default 1.
+inline int sam_occ() {
+    static const int v = getenv("AE_ATTN_SAM_OCC") ? atoi(getenv("AE_ATTN_SAM_OCC")) : 1;
+    return v;
+}
+
 template <int D, int QF, bool DBUF, int NW = 4>
 int launch_attn(const AttnArgs& a, hipStream_t stream) {
     constexpr int QB = NW * 16 * QF;
@@ -495,6 +505,10 @@ int launch_attn(const AttnArgs& a, hipStream_t stream) {
     if (a.rel_h && a.key_mask) { ae_set_error("ae_attn_fwd_bf16: rel-pos bias together with key_mask is not supported"); return AE_ERR_UNSUPPORTED; }
     if (a.k2) {
         if constexpr (D <= 96) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, 0, false, true>), grid, block, 0, stream, a);
+    } else if (a.rel_h && NW == 8 && a.kW == KT && a.Nk % KT == 0 && sam_occ() == 4) {
+        hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, 2, false, false, NW == 8>), grid, block, 0, stream, a);
+    } else if (a.rel_h && NW == 8 && !(a.kW == KT && a.Nk % KT == 0) && sam_occ() >= 1) {
+        hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, 1, false, false, NW == 8>), grid, block, 0, stream, a);
     } else if (a.rel_h && a.kW == KT && a.Nk % KT == 0) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, 2, false>), grid, block, 0, stream, a);
     else if (a.rel_h) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, 1, false>), grid, block, 0, stream, a);
     else if (a.key_mask) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, 0, true>), grid, block, 0, stream, a);
