@@ -558,22 +558,30 @@ extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
     hipStream_t s = (hipStream_t)stream;
     static const int qf40 = env_int("AE_ATTN_QF40", 4);  // tuning knob (A/B on hardware): query fragments per wave for D=40
     static const int w8 = env_int("AE_ATTN_W8", 0);      // tuning knob: 8 waves x 1 query fragment instead of 4 x 2
+    // tuning knob: short K/V (cross-attention to 77 text + adapter tokens): 1 query fragment per wave -> half the registers, twice the
+    // resident blocks for a kernel that is a chain of dependent load phases rather than MFMA work.  In-situ A/B (2 runs each): UNet
+    // step 17.51 ms off / 17.57 ms on — neutral, stays off.
+    static const int shortk = env_int("AE_ATTN_SHORTK_QF1", 0);
+    const bool short_kv = shortk && Nk < 256 && (!k2 || Nk2 < 256) && !rel_h;
     switch (D) {
         case 8: return launch_attn<8, 2, true>(a, s);
         case 16: return launch_attn<16, 2, true>(a, s);
         case 32: return launch_attn<32, 2, true>(a, s);
         case 40:
             if (w8) return launch_attn<40, 1, true, 8>(a, s);
+            if (short_kv) return launch_attn<40, 1, true>(a, s);
             // 64 queries per wave halve the K/V staging and K-fragment reads per query (514 vs 547 us at N = 4096); only for long
             // self-attention: the two-segment variant would spill at 4 fragments, and short K/V has nothing to amortise
             return (qf40 == 4 && Nq > 1024 && Nk >= 1024 && !k2) ? launch_attn<40, 4, true>(a, s) : launch_attn<40, 2, true>(a, s);
         case 48: return launch_attn<48, 2, true>(a, s);
         case 64: return launch_attn<64, 2, true>(a, s);
         // SAM (rel-pos bias): 8 waves x 1 query fragment keeps the bias registers + softmax state under 256 VGPRs without spills
-        case 80: return (w8 || rel_h) ? launch_attn<80, 1, true, 8>(a, s) : launch_attn<80, 2, true>(a, s);
+        case 80:
+            if (short_kv) return launch_attn<80, 1, true>(a, s);
+            return (w8 || rel_h) ? launch_attn<80, 1, true, 8>(a, s) : launch_attn<80, 2, true>(a, s);
         case 96: return launch_attn<96, 2, true>(a, s);
         case 128: return launch_attn<128, 2, false>(a, s);
-        case 160: return launch_attn<160, 2, false>(a, s);
+        case 160: return short_kv ? launch_attn<160, 1, false>(a, s) : launch_attn<160, 2, false>(a, s);
         default:
             ae_set_error("ae_attn_fwd_bf16: unsupported head_dim %d (supported: 8,16,32,40,48,64,80,96,128,160)", D);
             return AE_ERR_UNSUPPORTED;

@@ -68,13 +68,22 @@ def main():
         torch.distributed.barrier()
     dt = (time.perf_counter() - t0) / args.steps
     assert torch.isfinite(loss).all()
+    by_shape = None
+    if rank == 0 and os.environ.get("AE_TRAIN_PROFILE"):
+        from anyedit_amd import ops
+        with ops.OpProfiler() as prof:
+            step(args.warmup + args.steps)
+        by_shape = {k: {"calls": v["calls"], "avg_us": round(v["avg_us"], 1), "ms": round(v["ms"], 3), "tflops": round(v["tflops"], 1)}
+                    for k, v in sorted(prof.summary(by_shape=True).items(), key=lambda kv: -kv[1]["ms"])[:40]}
+        fam = {k: {"calls": v["calls"], "ms": round(v["ms"], 3)} for k, v in sorted(prof.summary().items(), key=lambda kv: -kv[1]["ms"])}
+        by_shape = {"families": fam, "shapes": by_shape}
     if rank == 0:
         fwd_tflop = B * bench.GFLOP_PER_UNET_SAMPLE / 1e3
         print(json.dumps({"metric": "AnySD training step (adapters on frozen SD-1.5 UNet, 64x64 latents)", "ms_per_step": 1e3 * dt,
                           "pairs_per_sec": world * B / dt, "n_gpus": world, "batch_per_gpu": B, "dtype": "bf16 activations, fp32 state",
                           "forward_tflop": fwd_tflop, "approx_tflops": 3.0 * fwd_tflop / dt,
                           "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "loss": float(loss),
-                          "exchange_bytes_per_step": tr.exchange.bytes_per_step if tr.exchange else 0}))
+                          "exchange_bytes_per_step": tr.exchange.bytes_per_step if tr.exchange else 0, "profile": by_shape}))
     if world > 1:
         torch.distributed.destroy_process_group()
 
