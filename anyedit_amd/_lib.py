@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL, see docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libanyedit_hip.so")
+LIB_PATH = os.environ.get("AE_LIB_PATH") or os.path.join(_HERE, "libanyedit_hip.so")  # AE_LIB_PATH: dev knob (A/B of two builds on one box)
 
 c_void_p, c_int, c_long, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 

@@ -7,6 +7,7 @@
 typedef uint16_t bf16_t;  // raw bfloat16 bits (storage type at the C ABI)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // MFMA 16x16x32 A/B operand (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) float f32x4;       // MFMA 16x16 accumulator fragment
+typedef __attribute__((ext_vector_type(2))) float f32x2;       // packed fp32 pair (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32)
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;    // 16-byte global/LDS transaction
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
