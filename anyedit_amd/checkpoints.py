@@ -12,8 +12,6 @@ published schema — PARITY UNPINNED (tests check bijectivity, shapes and a set 
 """
 import re
 
-import torch
-
 from anyedit_amd.ldm.modules.attention import SpatialTransformer
 from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import Downsample, ResBlock, Upsample
 

@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 import torch.nn as nn
-from torch.nn.init import constant_, xavier_uniform_
+from torch.nn.init import xavier_uniform_
 
 from anyedit_amd import ops
 

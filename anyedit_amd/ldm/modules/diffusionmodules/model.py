@@ -11,7 +11,6 @@ ae_gemm_bf16.  Two things are specific to this stage:
     three GEMMs around a row-softmax kernel (fp32 logits N x N per image) rather than a head_dim-512 flash kernel; the value bias
     is added after P V (softmax rows sum to 1).
 """
-import numpy as np
 import torch
 import torch.nn as nn
 

@@ -1,7 +1,6 @@
 """Mirror of ldm/modules/diffusionmodules/util.py — schedules (host, numpy f64, bit-exact integer bookkeeping) and
 the layer factories through which every UNet layer is created (util.py:202-238), here returning HIP-backed layers.
 """
-import math
 
 import numpy as np
 import torch

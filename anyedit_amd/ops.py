@@ -3,8 +3,6 @@ checks, output allocation, stream lookup.  All arithmetic happens in the HIP ker
 
 Activations are channels-last bf16: [rows, C] with rows = B*H*W.
 """
-import math
-
 import torch
 
 from ._lib import lib, check

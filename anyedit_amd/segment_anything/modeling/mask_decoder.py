@@ -5,7 +5,7 @@ ConvTranspose2d(k=2, s=2) layers are GEMMs whose 4 * Cout output columns are the
 outputs are left in that un-shuffled order (LayerNorm2d + GELU are per-pixel, so they run on a [pixels*4, C/4] view) and the pixel
 shuffle of both layers is folded into the final `hyper_in @ upscaled_embedding` kernel's read (ae_sam_mask_product_f32).
 """
-from typing import List, Tuple, Type
+from typing import Tuple, Type
 
 import torch
 from torch import nn
