@@ -95,35 +95,38 @@ class AnySDTrainer:
         return loss, tape, leaves
 
     def _expert_kv(self, tape, ip_rows, W, experts, T_ip, name):
-        """kv_ip[b] = ip_rows[b] @ W[expert_b]^T for every sample, one GEMM per expert present; recorded as ONE tape node whose
-        backward gathers the rows per expert again (row gather / scatter is data movement, the arithmetic is ae_gemm_bf16)."""
+        """kv_ip[b] = ip_rows[b] @ W[expert_b]^T for every sample; recorded as ONE tape node.  A sample's T_ip rows are contiguous, so
+        every GEMM reads / writes row SLICES (no gather, scatter or index tensors); only the routed experts' weights are converted
+        to bf16 (once per orientation per step)."""
         B = len(experts)
         dev = ip_rows.device
         kv_ip = torch.empty(B * T_ip, W.shape[1], dtype=BF16, device=dev)
-        groups = {}
-        for b, e in enumerate(experts):
-            groups.setdefault(e, []).append(b)
-        index = {e: torch.tensor([b * T_ip + j for b in bs for j in range(T_ip)], device=dev) for e, bs in groups.items()}
-        Wb = {e: W.detach()[e].to(BF16).contiguous() for e in groups}  # only the experts some sample is routed to
+        present = sorted(set(experts))
+        rows = lambda t, b: t[b * T_ip:(b + 1) * T_ip]
+        Wb = {e: W.detach()[e].to(BF16) for e in present}                               # [2*inner, Dc], the forward orientation
         with tape.paused():
-            for e, idx in index.items():
-                kv_ip[idx] = ops.gemm(ip_rows[idx].contiguous(), Wb[e])
+            for b, e in enumerate(experts):
+                ops.gemm(rows(ip_rows, b), Wb[e], out=rows(kv_ip, b))
 
         def bwd():
             dkv = tape.grad(kv_ip)
             if dkv is None:
                 return
-            d_ip = torch.zeros_like(ip_rows)
-            dW = torch.zeros(W.shape, dtype=torch.float32, device=dev)
-            for e, idx in index.items():
-                dy, a = dkv[idx].contiguous(), ip_rows[idx].contiguous()
-                d_ip[idx] = ops.gemm(dy, Wb[e].t().contiguous())                      # dA = dY W_e
+            d_ip = torch.empty_like(ip_rows)
+            dW = torch.zeros(W.shape, dtype=torch.float32, device=dev)                  # dense: AdamW decays the un-routed experts too
+            for e in present:
+                Wt = W.detach()[e].t().to(BF16).contiguous()                            # [Dc, 2*inner]: dA = dY W_e
+                bs = [b for b in range(B) if experts[b] == e]
+                for b in bs:
+                    ops.gemm(rows(dkv, b), Wt, out=rows(d_ip, b))
+                dy = rows(dkv, bs[0]) if len(bs) == 1 else torch.cat([rows(dkv, b) for b in bs])
+                a = rows(ip_rows, bs[0]) if len(bs) == 1 else torch.cat([rows(ip_rows, b) for b in bs])
                 M, Mp = dy.shape[0], (dy.shape[0] + 7) // 8 * 8
                 dyt = torch.zeros(dy.shape[1], Mp, dtype=BF16, device=dev)
                 dyt[:, :M] = dy.t()
                 at = torch.zeros(a.shape[1], Mp, dtype=BF16, device=dev)
                 at[:, :M] = a.t()
-                dW[e] = ops.gemm(dyt, at, out_f32=True)                               # dW_e = dY^T A
+                ops.gemm(dyt, at, out_f32=True, out=dW[e])                              # dW_e = dY^T A
             tape.accumulate(ip_rows, d_ip)
             tape.add_param_grad(name, dW)
 
