@@ -105,6 +105,86 @@ def test_gemm_linearity_full_size(ops):
     assert rel_l2(y.cpu(), ref.cpu()) < 5e-4
 
 
+# ------------------------------------------------------------------------------------------------- seeded shape fuzz
+def test_fuzz_gemm_conv_attention_shapes(ops):
+    """Seeded random ragged shapes through the three MFMA kernels against fp32 torch on the same bf16-rounded inputs: every tile /
+    split-K / tail / mask path gets exercised by sizes nobody hand-picked (M, N, K not multiples of the tiles; 1-row problems;
+    keys shorter than one tile; fully masked-out tails)."""
+    from oracle import ldm_ref as L
+    rng = np.random.default_rng(2024)
+    g = torch.Generator().manual_seed(2024)
+    for i in range(24):                                                                 # GEMM
+        M, N, K = int(rng.integers(1, 700)), 4 * int(rng.integers(1, 170)), 8 * int(rng.integers(1, 110))
+        a, w = q(torch.randn(M, K, generator=g)), q(torch.randn(N, K, generator=g) / K ** 0.5)
+        bias = torch.randn(N, generator=g) if i % 2 else None
+        res = q(torch.randn(M, N, generator=g)) if i % 3 == 0 else None
+        epi = [ops.EPI_NONE, ops.EPI_GELU, ops.EPI_SILU, ops.EPI_RELU][i % 4]
+        z = a @ w.t() + (bias if bias is not None else 0.0)
+        z = {ops.EPI_NONE: z, ops.EPI_GELU: F.gelu(z), ops.EPI_SILU: F.silu(z), ops.EPI_RELU: F.relu(z)}[epi]
+        ref = z + (res if res is not None else 0.0)
+        out = ops.gemm(a.to(DEV, BF), w.to(DEV, BF), bias=None if bias is None else bias.to(DEV),
+                       residual=None if res is None else res.to(DEV, BF), epilogue=epi)
+        check_close(out, ref, rl2=5e-3, mabs=3e-2, what=f"fuzz gemm {M}x{N}x{K} epi={epi}")
+    for i in range(14):                                                                 # conv3x3
+        B, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 21)), int(rng.integers(1, 21))
+        Cin, Cout = 8 * int(rng.integers(1, 41)), 8 * int(rng.integers(1, 41))
+        stride = 2 if (i % 4 == 1 and H > 1 and W > 1) else 1
+        ups = i % 4 == 2
+        x = q(torch.randn(B, Cin, H, W, generator=g))
+        w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5))
+        bias = torch.randn(Cout, generator=g)
+        xi = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+        ref = F.conv2d(xi, w, bias, stride=stride, padding=1)
+        y, Ho, Wo = ops.conv3x3(ops.nchw_to_rows(x.to(DEV)), ops.pack_conv3x3(w.to(DEV)), bias.to(DEV), B, H, W, stride=stride, upsample2x=ups)
+        assert (Ho, Wo) == tuple(ref.shape[2:])
+        check_close(ops.rows_to_nchw(y, B, Ho, Wo), ref, rl2=5e-3, mabs=3e-2, what=f"fuzz conv B={B} {H}x{W} {Cin}->{Cout} s{stride} ups={ups}")
+    for i in range(20):                                                                 # attention (+ key mask)
+        D = [8, 16, 32, 40, 48, 64, 80, 96, 128, 160][i % 10]
+        BH, Nq, Nk = int(rng.integers(1, 5)), int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        qq, kk, vv = (q(torch.randn(BH, n, D, generator=g)) for n in (Nq, Nk, Nk))
+        mask = None
+        if i % 3 == 0:
+            mask = torch.rand(BH, Nk, generator=g) > 0.4
+            mask[:, int(rng.integers(0, Nk))] = True                                    # at least one visible key per row
+        logits = (qq @ kk.transpose(1, 2)) * D ** -0.5
+        if mask is not None:
+            logits = logits.masked_fill(~mask[:, None, :], -torch.finfo(torch.float32).max)
+        ref = torch.softmax(logits, -1) @ vv
+        out = ops.attention_bhnd(qq.to(DEV, BF), kk.to(DEV, BF), vv.to(DEV, BF),
+                                 key_mask=None if mask is None else mask.to(DEV).to(torch.uint8).contiguous())
+        check_close(out, ref, rl2=7e-3, mabs=3e-2, what=f"fuzz attention BH={BH} {Nq}x{Nk} d={D} mask={mask is not None}")
+
+
+def test_fuzz_norm_shapes(ops):
+    """Seeded random GroupNorm(+SiLU, +two-source concat) / LayerNorm / narrow LayerNorm+GELU shapes against fp32 torch."""
+    rng = np.random.default_rng(77)
+    g = torch.Generator().manual_seed(77)
+    for i in range(16):
+        B, HW, C = int(rng.integers(1, 5)), int(rng.integers(1, 400)), 32 * int(rng.integers(1, 21))
+        x = q(torch.randn(B, HW, C, generator=g) * float(rng.uniform(0.2, 3.0)) + float(rng.uniform(-1, 1)))
+        gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        eps = 1e-5 if i % 2 else 1e-6
+        silu = i % 3 != 0
+        ref = F.group_norm(x.permute(0, 2, 1), 32, gamma, beta, eps).permute(0, 2, 1)
+        ref = F.silu(ref) if silu else ref
+        rows = x.reshape(B * HW, C).to(DEV, BF)
+        C1 = 8 * int(rng.integers(1, C // 8)) if (i % 4 == 1 and C > 8) else None
+        if C1 is None:
+            out = ops.groupnorm(rows, gamma.to(DEV), beta.to(DEV), B, HW, eps, silu=silu)
+        else:
+            out = ops.groupnorm(rows[:, :C1].contiguous(), gamma.to(DEV), beta.to(DEV), B, HW, eps, silu=silu, x2=rows[:, C1:].contiguous())
+        check_close(out.reshape(B, HW, C), ref, rl2=6e-3, mabs=3e-2, what=f"fuzz groupnorm B={B} HW={HW} C={C} C1={C1} silu={silu}")
+    for i in range(12):
+        M, C = int(rng.integers(1, 900)), 8 * int(rng.integers(1, 200))
+        x = q(torch.randn(M, C, generator=g) * 1.5 + 0.3)
+        gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        check_close(ops.layernorm(x.to(DEV, BF), gamma.to(DEV), beta.to(DEV), 1e-5), F.layer_norm(x, (C,), gamma, beta, 1e-5),
+                    rl2=5e-3, mabs=3e-2, what=f"fuzz layernorm {M}x{C}")
+        if C <= 512:
+            check_close(ops.layernorm_act(x.to(DEV, BF), gamma.to(DEV), beta.to(DEV), eps=1e-6, gelu=True),
+                        F.gelu(F.layer_norm(x, (C,), gamma, beta, 1e-6)), rl2=5e-3, mabs=3e-2, what=f"fuzz layernorm_act {M}x{C}")
+
+
 # ------------------------------------------------------------------------------------------------- conv3x3
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups", [(2, 8, 8, 64, 64, 1, False), (1, 16, 16, 8, 32, 1, False),
                                                        (2, 8, 8, 96, 64, 2, False), (1, 7, 9, 64, 64, 2, False),
