@@ -112,6 +112,54 @@ def test_attention_backward(ops, BH, Nq, Nk, D):
     check_close(dq, qr.grad, rl2=1.5e-2, mabs=5e-2, what=f"dQ {BH}x{Nq}x{Nk}x{D}")
 
 
+def test_fuzz_attention_and_norm_backward_shapes(ops):
+    """Seeded random ragged shapes through the backward kernels (attention dQ/dK/dV, GroupNorm(+SiLU), LayerNorm) against autograd
+    of the fp32 oracle expressions."""
+    import numpy as np
+    from oracle import ldm_ref as L
+    rng = np.random.default_rng(31)
+    g = torch.Generator().manual_seed(31)
+    for i in range(12):
+        D = [16, 40, 48, 64, 80, 160][i % 6]
+        BH, Nq, Nk = int(rng.integers(1, 4)), int(rng.integers(1, 260)), int(rng.integers(1, 260))
+        qq, kk, vv = (q(torch.randn(BH, n, D, generator=g)) for n in (Nq, Nk, Nk))
+        do = q(torch.randn(BH, Nq, D, generator=g))
+        qr, kr, vr = (t.clone().requires_grad_(True) for t in (qq, kk, vv))
+        L.sdpa_core(qr, kr, vr, D ** -0.5).backward(do)
+        qd, kd, vd, dod = (t.to(DEV, BF).contiguous() for t in (qq, kk, vv, do))
+        lse = torch.empty(BH, 1, Nq, dtype=torch.float32, device=DEV)
+        sq, sk = (Nq * D, 0, D), (Nk * D, 0, D)
+        ops.attention(qd, kd, vd, BH, 1, Nq, Nk, D, D ** -0.5, sq, sk, sk, lse=lse)
+        dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+        ops.attention_bwd(qd, kd, vd, dod, lse, BH, 1, Nq, Nk, D, D ** -0.5, sq, sk, sk, dq, dk, dv, sq, sk, sk)
+        tag = f"fuzz attn bwd {BH}x{Nq}x{Nk}x{D}"
+        check_close(dv, vr.grad, rl2=1.2e-2, mabs=5e-2, what="dV " + tag)
+        check_close(dk, kr.grad, rl2=2e-2, mabs=6e-2, what="dK " + tag)
+        check_close(dq, qr.grad, rl2=2e-2, mabs=6e-2, what="dQ " + tag)
+    for i in range(8):
+        B, HW, C = int(rng.integers(1, 4)), int(rng.integers(2, 300)), 32 * int(rng.integers(1, 12))
+        silu = i % 2 == 0
+        x = q(torch.randn(B, HW, C, generator=g) * 1.3 + 0.2)
+        gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        dy = q(torch.randn(B, HW, C, generator=g))
+        xr = x.clone().requires_grad_(True)
+        y = F.group_norm(xr.permute(0, 2, 1), 32, gamma, beta, 1e-5).permute(0, 2, 1)
+        (F.silu(y) if silu else y).backward(dy)
+        dx = ops.groupnorm_bwd(x.reshape(B * HW, C).to(DEV, BF), gamma.to(DEV), beta.to(DEV), dy.reshape(B * HW, C).to(DEV, BF), B, HW, 1e-5, silu=silu)
+        dx = dx[0] if isinstance(dx, tuple) else dx
+        check_close(dx.reshape(B, HW, C), xr.grad, rl2=1.5e-2, mabs=6e-2, what=f"fuzz groupnorm bwd B={B} HW={HW} C={C} silu={silu}")
+    for i in range(8):
+        M, C = int(rng.integers(1, 600)), 8 * int(rng.integers(1, 160))
+        x = q(torch.randn(M, C, generator=g) * 1.5 + 0.3)
+        gamma = torch.randn(C, generator=g)
+        dy = q(torch.randn(M, C, generator=g))
+        xr = x.clone().requires_grad_(True)
+        F.layer_norm(xr, (C,), gamma, torch.zeros(C), 1e-5).backward(dy)
+        dx = ops.layernorm_bwd(x.to(DEV, BF), gamma.to(DEV), dy.to(DEV, BF), 1e-5)
+        dx = dx[0] if isinstance(dx, tuple) else dx
+        check_close(dx, xr.grad, rl2=1.5e-2, mabs=6e-2, what=f"fuzz layernorm bwd {M}x{C}")
+
+
 # ------------------------------------------------------------------------------------------------- tape: GEMM / conv adjoints
 def test_tape_gemm_and_conv_adjoints(ops):
     """Data-gradients through ops.gemm (two-source K split, residual) and ops.conv3x3 (stride 1, nearest-x2 upsample, stride 2),
