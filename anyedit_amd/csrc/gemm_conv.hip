@@ -663,6 +663,8 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // 0.37-0.43 LDS fragment reads per MFMA instead of 0.75.  Used when the tile grid fills whole rounds of 256 CUs.
     static const int t320 = getenv("AE_GEMM_T320") ? atoi(getenv("AE_GEMM_T320")) : 3;  // tuning knob, bit flags: 1 convs, 2 GEGLU GEMMs with K >= 640, 4 GEGLU K = 320, 8 other dense K >= 640.  Isolated (kbench) the
     // dense flags gain 4..20 %, inside the UNet evaluation (in-situ A/B, one box) 4 and 8 are neutral-to-negative (0.5 %): default 3
+    // (the same tile for the K = 320 dense GEMMs of the 64x64 level was A/B-ed too: N = 320 44.5 vs 34 us, N = 960 78 vs 63 us —
+    // five K iterations do not amortise the big tile's prologue / epilogue.)
     bool done = false;
     if (t320 && glds && a.splitk <= 1 && a.N % 320 == 0 && ((conv && (t320 & 1)) || (!conv && a.epi == EPI_GEGLU && a.K >= 640 && (t320 & 2)) || (!conv && a.epi == EPI_GEGLU && a.K < 640 && a.K >= 320 && (t320 & 4)) ||
                                                                      (!conv && a.epi != EPI_GEGLU && a.K >= 640 && (t320 & 8)))) {
