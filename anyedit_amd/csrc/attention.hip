@@ -572,6 +572,8 @@ extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
         case 40:
             if (w8) return launch_attn<40, 1, true, 8>(a, s);
             if (short_kv) return launch_attn<40, 1, true>(a, s);
+            // (2 fragments per wave under a 168-VGPR cap — 153 VGPRs, no spills, three resident blocks per CU — was A/B-ed against the
+            // 4-fragment variant: 18.11 vs 18.04 ms per step; the K/V reuse of 4 fragments is worth more than the third block)
             // 64 queries per wave halve the K/V staging and K-fragment reads per query (514 vs 547 us at N = 4096); only for long
             // self-attention: the two-segment variant would spill at 4 fragments, and short K/V has nothing to amortise
             return (qf40 == 4 && Nq > 1024 && Nk >= 1024 && !k2) ? launch_attn<40, 4, true>(a, s) : launch_attn<40, 2, true>(a, s);
