@@ -4,7 +4,7 @@
     (96x96 latents, 3-branch CFG, 50 DDIM steps, blend per global_tool.py:183-184) -> kl-f8 decode,
 every stage on the HIP path, random-init weights of the real geometries, synthetic image and boxes (GroundingDINO's backbone / text
 tower are outside the scope: the detector is the callable boundary of anyedit_amd.tools.tool.maskgeneration).  Reports per-stage
-latency; SAM attention runs in bf16 (fp8 deferred, DESIGN.md §9).
+latency; SAM attention runs in bf16 (fp8 deferred, DESIGN.md §10).
     python tools/run_local_edit.py [--ddim-steps 50] [--boxes 2]
 """
 import argparse
