@@ -68,8 +68,9 @@ constexpr int epilogue_passes(int FM, int bytes_per_frag_row, int lds_bytes) {
 // LDS once at the end.  Same thread count and staging as an 8-wave block, but each wave owns a 2x larger output tile, so the
 // block issues a third fewer LDS fragment reads per MFMA (the 128x128 tile is LDS-bound: with 15/16 of its MFMAs removed it
 // still takes 73 % of the time).
-template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false, int WAVES_K = 1>
+template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false, int WAVES_K = 1, int STAGES = 2>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(const GemmArgs p) {
+    static_assert(STAGES == 2 || (GLDS && WAVES_K == 1), "the deep LDS ring exists only for the LDS-DMA loader");
     static_assert(WAVES_K == 1 || WAVES_K == 2, "K groups: 1 or 2");
     constexpr int NT = 64 * WAVES_M * WAVES_N * WAVES_K;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];  // 2 * (BM + BN) * BK bf16 (dynamic: > 64 KiB for 128x160)
     bf16_t* const smem = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* sA = smem;
-    bf16_t* sB = smem + 2 * BM * BK;
+    bf16_t* sB = smem + STAGES * BM * BK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave / (WAVES_M * WAVES_N), wmn = wave % (WAVES_M * WAVES_N);  // K group, position inside the group
@@ -346,16 +347,38 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                 lds_dma16(rsW, dst, fb_off[i], k0 * 2);
             }
         };
-        dma_tile(0, 0);
-        __syncthreads();
-        for (int kt = 0; kt < KT; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < KT) dma_tile(kt + 1, cur ^ 1);  // stage cur^1 was last read before the previous barrier
-            compute_tile(cur);
+        if constexpr (STAGES == 2) {
+            dma_tile(0, 0);
             __syncthreads();
+            for (int kt = 0; kt < KT; ++kt) {
+                const int cur = kt & 1;
+                if (kt + 1 < KT) dma_tile(kt + 1, cur ^ 1);  // stage cur^1 was last read before the previous barrier
+                compute_tile(cur);
+                __syncthreads();
+            }
+        } else {
+            // Deep ring: STAGES - 1 tiles in flight.  Each wave waits (counted vmcnt: only the OLDEST tile must have landed) for its own
+            // DMA pieces, then a raw s_barrier makes every wave's pieces visible and proves all waves are done with the stage that is
+            // refilled next.  __syncthreads() is not used: its fence would drain the whole DMA queue (vmcnt(0)).
+            constexpr int PIECES = A_CH + B_CH;  // DMA instructions per tile per wave
+            constexpr int AHEAD = STAGES - 1;
+#pragma unroll
+            for (int t = 0; t < AHEAD; ++t)
+                if (t < KT) dma_tile(t, t);
+            int cur = 0, nxt = AHEAD % STAGES;
+            for (int kt = 0; kt < KT; ++kt) {
+                const int younger = min(KT - 1 - kt, AHEAD - 1);  // tiles issued after tile kt and still allowed in flight
+                if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (kt + AHEAD < KT) dma_tile(kt + AHEAD, nxt);  // refills the stage read in iteration kt - 1
+                compute_tile(cur);
+                cur = cur + 1 == STAGES ? 0 : cur + 1;
+                nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+            }
+            __builtin_amdgcn_s_barrier();  // the epilogue reuses the ring as fp32 staging
         }
-        // (A deeper ring — 3-4 LDS stages, counted vmcnt, raw s_barrier — was built and measured 5-40 % slower on every GEMM
-        // shape of this UNet: it costs the second resident block per CU, which hides more latency than the extra stage.)
     }
 
     if (WAVES_K == 2) {
@@ -406,7 +429,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
     {
         constexpr int NCH = WN / 4;  // fp32 16-byte chunks per staged row
         // staging must fit in the main-loop LDS: split the wave tile's rows into passes if it does not (128x160 tile)
-        constexpr int PASSES = epilogue_passes(FM, WAVES_M * WAVES_N * 16 * WN * 4, 2 * (BM + BN) * BK * 2);
+        constexpr int PASSES = epilogue_passes(FM, WAVES_M * WAVES_N * 16 * WN * 4, STAGES * (BM + BN) * BK * 2);
         constexpr int FMP = FM / PASSES, WMP = WM / PASSES;
         static_assert(FM % PASSES == 0, "epilogue passes must divide the fragment rows");
         const bool geglu = p.epi == EPI_GEGLU;
@@ -681,6 +704,21 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // (A 256x128 dense tile — one 8-wave block per CU, 64x64 wave tiles, 0.5 LDS fragment reads per MFMA — was built and A/B-ed in
     // situ: SAM ViT-H encoder 16.2 vs 14.25 ms, every M = 4096 / 4900 GEMM 15-25 % slower, UNet step +1 %.  Like the deeper LDS ring, it
     // trades the second resident block per CU for per-wave reuse, and the second block is worth more.  Not kept.)
+    // Three-stage LDS ring (two tiles in flight, counted vmcnt + raw s_barrier) on the 128x128 tile, for dense GEMMs whose 128x128 grid
+    // is 128..256 blocks: there is at most one block per CU anyway, so the 96 KiB ring costs no co-residency and the second tile in
+    // flight hides what the missing second block would have hidden.  In-situ A/B (UNet batch 12, same box): M = 3072 x N = 1280 at
+    // K = 5120 72.8 -> 59.5 us, K = 2560 40.7 -> 36.8, K = 1920 32.7 -> 29.0, K = 1280 25.9 -> 24.7 (K = 640: 20.7 -> 22.5, excluded);
+    // step 17.31 -> 17.22 ms.  A fourth stage adds nothing.  The same ring on grids with MORE than one block per CU loses (it evicts the
+    // second resident block: SAM M = 4096 x N = 1280 x K = 5120 with 320 blocks 90 -> 109 us), as does a 256x128 tile under it
+    // (M = 4096 x N = 5120: 93 -> 112 us).  AE_GEMM_DEEP=0 turns it off.
+    static const int deep_pref = getenv("AE_GEMM_DEEP") ? atoi(getenv("AE_GEMM_DEEP")) : 1;
+    if (!done && deep_pref && !conv && glds && a.splitk <= 1 && a.epi != EPI_GEGLU && a.N % 128 == 0 && a.K >= 1280) {
+        const long t128 = (long)((a.M + 127) / 128) * (a.N / 128);
+        if (t128 >= 128 && t128 <= 256) {
+            rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 3>, (unsigned)t128, 512, lds_of(128, 128, 3), stream, a, what);
+            done = true;
+        }
+    }
     if (!done) {
         const int BM = cand[pick][0], BN = cand[pick][1];
         const unsigned grid = (unsigned)((long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.splitk);
