@@ -734,6 +734,10 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         else if (pick == 0) AE_LAUNCH(128, 128, 2, 2, 256);
         else if (pick == 1 && w8 && !conv) AE_LAUNCH(128, 64, 4, 2, 512);
         else if (pick == 1) AE_LAUNCH(128, 64, 2, 2, 256);
+        else if (deep_pref && glds && !conv && a.splitk <= 1 && grid <= 256 && a.K >= 1280)
+            // the same ring for small 64x64 grids (8x8 level, training batches): M = 768 x N = 1280 at K = 1280 / 2560 / 5120:
+            // 23.3 -> 16.4, 37.4 -> 23.2, 67.3 -> 38.7 us; lower K thresholds and a fourth stage measured the same
+            rc = launch_kernel(gemm_kernel<64, 64, AMODE, 2, 2, true, 1, 3>, grid, 256, lds_of(64, 64, 3), stream, a, what);
         else AE_LAUNCH(64, 64, 2, 2, 256);
 #undef AE_LAUNCH
     }
