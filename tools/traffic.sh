@@ -19,9 +19,10 @@ import collections, csv, glob, json, re, sys
 R = sys.argv[1]
 
 def label(name):
-    m = re.search(r"gemm_kernel<(\d+), (\d+), (\d)", name)
-    if m:
-        return f"gemm_kernel<{m.group(1)}x{m.group(2)},{'conv3x3' if m.group(3) == '1' else 'dense'}>"
+    m = re.search(r"gemm_kernel<(\d+), (\d+), (\d)(?:, \d+, \d+, \w+, \d+, (\d+))?", name)
+    if m:  # same family names as bench.py's folded profiler labels; the three-stage-ring instantiations are their own symbols
+        ring = ",ring3" if m.group(4) == "3" else ""
+        return f"gemm_kernel<{m.group(1)}x{m.group(2)}{ring},{'conv3x3' if m.group(3) == '1' else 'dense'}>"
     m = re.search(r"attn_kernel<(\d+)", name)
     if m:
         return f"attn_kernel<D={m.group(1)}>"
