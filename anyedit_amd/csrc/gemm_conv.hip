@@ -719,8 +719,14 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     static const int deep_pref = getenv("AE_GEMM_DEEP") ? atoi(getenv("AE_GEMM_DEEP")) : 1;
     if (!done && deep_pref && !conv && glds && a.splitk <= 1 && a.epi != EPI_GEGLU && a.N % 128 == 0 && a.K >= 1280) {
         const long t128 = (long)((a.M + 127) / 128) * (a.N / 128);
+        const long t192 = (long)((a.M + 191) / 192) * (a.N / 128);
         if (t128 >= 128 && t128 <= 256) {
             rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 3>, (unsigned)t128, 512, lds_of(128, 128, 3), stream, a, what);
+            done = true;
+        } else if (t128 > 256 && t192 >= 128 && t192 <= 256 && a.K >= 2560) {
+            // a taller tile that brings the grid down to one block per CU (SAM: M = 4096 x N = 1280 x K = 5120, 320 -> 220 blocks:
+            // 89 -> 80 us; at K = 1280 it is neutral, and a 256x128 tile for M = 4900 loses: 32.5 -> 38 us)
+            rc = launch_kernel(gemm_kernel<192, 128, AMODE, 4, 2, true, 1, 3>, (unsigned)t192, 512, lds_of(192, 128, 3), stream, a, what);
             done = true;
         }
     }

@@ -701,6 +701,8 @@ def _tile_label(M, N, conv=False, K=0, geglu=False, dma_ok=True):
         return "128x160"
     if not conv and not geglu and dma_ok and N % 128 == 0 and K >= 1280 and 128 <= -(-M // 128) * (N // 128) <= 256:
         return "128x128,ring3"  # three-stage ring, one block per CU
+    if not conv and not geglu and dma_ok and N % 128 == 0 and K >= 2560 and -(-M // 128) * (N // 128) > 256 and 128 <= -(-M // 192) * (N // 128) <= 256:
+        return "192x128,ring3"
     for bm, bn in ((128, 128), (128, 64), (64, 64)):
         tm, tn = -(-M // bm), -(-N // bn)
         if tm * tn >= 256 and tn * bn / N <= 1.10:
