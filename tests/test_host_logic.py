@@ -291,3 +291,18 @@ def test_create_model_from_reference_style_yaml(tmp_path):
         cnet = ControlNet(hint_channels=4, **geo)
     assert (sum(p.numel() for p in unet.parameters()), len(unet.state_dict())) == (865_910_724, 686)      # [probe] of the reference classes
     assert (sum(p.numel() for p in cnet.parameters()), len(cnet.state_dict())) == (364_228_384, 340)
+
+
+def test_python_plan_mirror_matches_the_library():
+    """ops._conv_splitk (used only to LABEL profiler rows with the kernel that will run) must agree with the launch plan inside the
+    library; ae_conv3x3_workspace_floats is host-only and returns splitk * M * Cout (0 when unsplit), so it can be checked without a GPU."""
+    from anyedit_amd import ops
+    from anyedit_amd._lib import lib
+    for B in (1, 3, 4, 12):
+        for hw in (8, 16, 32, 64):
+            for cin, cout in ((320, 320), (640, 640), (1280, 1280), (2560, 1280), (1920, 640), (960, 320), (640, 1280), (8, 320), (320, 4)):
+                M = B * hw * hw
+                ws = lib.ae_conv3x3_workspace_floats(B, hw, hw, cin, cout, 1, 0)
+                s_lib = ws // (M * cout) if ws else 1
+                cin_pad = (cin + 63) // 64 * 64
+                assert ops._conv_splitk(M, cout, 9 * cin_pad) == s_lib, (B, hw, cin, cout, s_lib)
