@@ -1,11 +1,12 @@
-"""Mirror of AnyEdit_Collection/other_modules/cldm/model.py (:8-28): checkpoint / config loading for the ControlLDM (AnyDoor) path —
-`create_model(config_path)` + `model.load_state_dict(load_state_dict(ckpt, location))` is how visual_reference_tool.py:370-375 builds it.
+"""Checkpoint and config loading for the ControlLDM (AnyDoor) path — same three entry points, names and return values as
+AnyEdit_Collection/other_modules/cldm/model.py (:8-28); visual_reference_tool.py:370-375 calls `create_model(cfg)` followed by
+`model.load_state_dict(load_state_dict(ckpt, location))`.
 
-On-disk formats: a `.safetensors` file is a flat name -> tensor map; a `.ckpt` / `.pth` is a torch pickle that is either that map or a
-dict holding it under 'state_dict' (Lightning checkpoints).  YAML configs are read with PyYAML (the reference uses OmegaConf only as a
-YAML reader here); `target:` strings naming the reference's `ldm.*` / `cldm.*` classes resolve to this package's mirrors.
+On-disk formats handled: `.safetensors` (flat name -> tensor map) and torch pickles (`.ckpt` / `.pth` / `.bin`) holding either the
+flat map or a Lightning dict with the map under 'state_dict'.  YAML is read with PyYAML (the reference uses OmegaConf only as a YAML
+reader here); `target:` strings that name the reference's `ldm.*` / `cldm.*` classes resolve to this package's mirrors.
 """
-import os
+from pathlib import Path
 
 import torch
 
@@ -13,25 +14,30 @@ from anyedit_amd.ldm.util import instantiate_from_config
 
 
 def get_state_dict(d):
-    return d.get('state_dict', d)
+    """Unwrap a Lightning-style checkpoint: the tensors live under 'state_dict' when that key exists."""
+    return d["state_dict"] if "state_dict" in d else d
+
+
+def _read_safetensors(path, location):
+    from safetensors.torch import load_file
+    return load_file(str(path), device=location)
+
+
+def _read_pickle(path, location):
+    return torch.load(str(path), map_location=torch.device(location))
 
 
 def load_state_dict(ckpt_path, location='cpu'):
-    _, extension = os.path.splitext(ckpt_path)
-    if extension.lower() == ".safetensors":
-        import safetensors.torch
-        state_dict = safetensors.torch.load_file(ckpt_path, device=location)
-    else:
-        state_dict = get_state_dict(torch.load(ckpt_path, map_location=torch.device(location)))
-    state_dict = get_state_dict(state_dict)
+    path = Path(ckpt_path)
+    reader = _read_safetensors if path.suffix.lower() == ".safetensors" else _read_pickle
+    state_dict = get_state_dict(get_state_dict(reader(path, location)))   # the reference unwraps twice as well (model.py:18-19)
     print(f'Loaded state_dict from [{ckpt_path}]')
     return state_dict
 
 
 def create_model(config_path):
     import yaml
-    with open(config_path, "r") as f:
-        config = yaml.safe_load(f)
+    config = yaml.safe_load(Path(config_path).read_text())
     model = instantiate_from_config(config["model"]).cpu()
     print(f'Loaded model config from [{config_path}]')
     return model
