@@ -306,3 +306,26 @@ def test_python_plan_mirror_matches_the_library():
                 s_lib = ws // (M * cout) if ws else 1
                 cin_pad = (cin + 63) // 64 * 64
                 assert ops._conv_splitk(M, cout, 9 * cin_pad) == s_lib, (B, hw, cin, cout, s_lib)
+
+
+def test_mask_tool_box_logic_on_cpu():
+    """tools/tool.py:184-222 (no GPU involved): box conversion and the phrase-based target filter, including its fallbacks and the
+    list form of `target_object`."""
+    from anyedit_amd.tools.tool import boxes_to_pixels_xyxy, select_target_boxes, load_image_512
+    from PIL import Image
+    dets = torch.tensor([[0.30, 0.40, 0.30, 0.40], [0.75, 0.70, 0.20, 0.30], [0.5, 0.5, 0.9, 0.9]])
+    phrases = ["cat(0.81)", "black cat(0.55)", "red sofa(0.90)"]
+    px = boxes_to_pixels_xyxy(dets, 512, 256)
+    assert torch.allclose(px[0], torch.tensor([0.15 * 512, 0.2 * 256, 0.45 * 512, 0.6 * 256]))
+    assert torch.equal(dets, torch.tensor([[0.30, 0.40, 0.30, 0.40], [0.75, 0.70, 0.20, 0.30], [0.5, 0.5, 0.9, 0.9]]))   # input not mutated
+    b, s = select_target_boxes(px, phrases, "cat")
+    assert b.shape == (1, 4) and s.tolist() == pytest.approx([0.81])                      # exact name match wins
+    b, s = select_target_boxes(px, phrases, "black cat")
+    assert b.shape == (1, 4) and s.tolist() == pytest.approx([0.55])
+    b, s = select_target_boxes(px, phrases, "fluffy cat")                                  # no exact match -> word overlap: both cats
+    assert b.shape == (2, 4)
+    b, s = select_target_boxes(px, phrases, ["dog", "red sofa"])
+    assert b.shape == (1, 4) and s.tolist() == pytest.approx([0.90])
+    assert select_target_boxes(px, phrases, ["dog", "lamp"]) is None
+    img = load_image_512(Image.new("L", (300, 200), 128))
+    assert img.size == (512, 512) and img.mode == "RGB"
