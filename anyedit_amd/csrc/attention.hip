@@ -20,7 +20,7 @@
 //   * head_dim is padded inside the kernel (40 -> 64 for QK^T, 48 for PV); q/k/v/out are addressed through
 //     (batch, head, row) strides, so the 'b n (h d) -> (b h) n d' rearranges of the reference never happen;
 //   * softmax in fp32, exp2 domain; bf16 P (v_cvt_pk_bf16_f32); fp32 accumulation of O.
-#include "common.hpp"
+#include "attention.hpp"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -29,24 +29,6 @@ namespace {
 constexpr int KT = 64;  // keys per tile
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;  // finite "masked" logit: behaves like masked_fill(-finfo.max) (attention.py:186-187)
-
-struct AttnArgs {
-    const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o;
-    int B, H, Nq, Nk;
-    long q_sb, q_sh, q_sn, k_sb, k_sh, k_sn, v_sb, v_sh, v_sn, o_sb, o_sh, o_sn;
-    float scale;
-    const float* rel_h; const float* rel_w; int kH, kW;  // optional decomposed bias, fp32 [B*H, Nq, kH|kW]
-    const uint8_t* key_mask;                               // optional [B, Nk], 0 = masked
-    const float* out_scale;                                // optional [B]: out = (accum ? out : 0) + out_scale[b] * result
-    int accum;
-    // optional second key/value segment with its OWN softmax (decoupled adapter attention fused into the same launch):
-    // out = Attn(q,K,V) + scale2[b] * Attn(q,K2,V2)   — Q is read once, O is written once
-    const bf16_t* k2; const bf16_t* v2; int Nk2;
-    long k2_sb, k2_sh, k2_sn, v2_sb, v2_sh, v2_sn;
-    const float* scale2;
-    // optional [B, H, Nq] fp32 outputs for the backward pass: log2-domain log-sum-exp of each segment's softmax
-    float* lse; float* lse2;
-};
 
 __device__ __forceinline__ int vt_pos(int key) {  // key = 16 f + 4 g + r  ->  16 g + 4 f + r
     return ((key >> 2) & 3) * 16 + (key >> 4) * 4 + (key & 3);
@@ -558,6 +540,13 @@ extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
     a.lse = lse; a.lse2 = lse2;
     if (lse2) AE_REQUIRE(k2 != nullptr, "ae_attn_fwd_bf16: lse2 needs a second segment");
     hipStream_t s = (hipStream_t)stream;
+    // long-sequence / plain-softmax shapes (UNet self- and cross-attention at head_dim 40 / 80) go to the 32x32x16 kernel of
+    // attention_fast.hip; everything it does not cover (bias, masks, log-sum-exp outputs, other head dims) stays here.
+    static const int use_fast = env_int("AE_ATTN_FAST", 1);  // tuning knob: 0 = general kernel only (A/B)
+    if (use_fast) {
+        const int rc = ae_attn_fast_launch(a, D, s);
+        if (rc != AE_ERR_UNSUPPORTED) return rc;
+    }
     static const int qf40 = env_int("AE_ATTN_QF40", 4);  // tuning knob (A/B on hardware): query fragments per wave for D=40
     static const int w8 = env_int("AE_ATTN_W8", 0);      // tuning knob: 8 waves x 1 query fragment instead of 4 x 2
     // tuning knob: short K/V (cross-attention to 77 text + adapter tokens): 1 query fragment per wave -> half the registers, twice the

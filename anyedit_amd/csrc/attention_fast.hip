@@ -35,9 +35,21 @@ constexpr float FLOG2E = 1.4426950408889634f;
 constexpr float RESCALE_THR = 8.0f;  // log2 units
 constexpr float MASKED = -1.0e30f;
 
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, int voffset) {
+// LDS-DMA, one wave: 64 x 16 B from global (descriptor + per-lane byte offset) straight to LDS at lds_byte + lane * 16.
+// Issued through inline asm ON PURPOSE: hipcc treats the builtin form as an LDS store that may alias every later LDS read and
+// drains it (s_waitcnt vmcnt(0)) in front of the first ds_read of the SAME tile loop iteration — i.e. it waits for the prefetch of
+// tile t + 1 before computing tile t.  The asm form is invisible to that bookkeeping; dma_wait_all() below is the only wait.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, int lds_byte, int voffset) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, 0, 0, 0);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voffset), "s"(rs), "s"(lds_byte) : "memory", "m0");
+#endif
+}
+// every DMA piece this wave issued has landed, and all of the wave's LDS accesses are done; then the block-wide barrier
+__device__ __forceinline__ void dma_wait_all_and_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 #endif
 }
 
@@ -55,23 +67,31 @@ __device__ __forceinline__ bf16x8_t cat_tr(s16x4v lo, s16x4v hi) {
     return u.v;
 }
 
-template <int D, int OCC>
+#ifdef AE_ATTN_LAB
+__device__ unsigned long long g_attn_dbg[4];  // lab only: sum of per-block shader cycles, 100 MHz ticks, blocks
+#endif
+
+template <int D, int OCC, bool SEG2 = false, int ABL = 0>
 __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     static_assert(D % 8 == 0 && D <= 96, "head_dim: multiple of 8, <= 96");
-    constexpr int KS = (D + 15) / 16;   // K=16 steps of S^T = K Q^T
-    constexpr int NDF = D / 16 + 1;     // 16-row fragments of O^T; row D is the softmax denominator
-    constexpr int ROWB = 2 * D;         // bytes per K / V row in LDS
-    constexpr int CH = D / 8;           // 16-byte chunks per row = 1-KiB DMA pieces per 64-row tile
+    constexpr int KS = (D + 15) / 16;        // K=16 steps of S^T = K Q^T
+    constexpr bool QSLOT = (D % 16) != 0;    // contraction slot `D` is free: it carries the softmax offset (K side reads 1.0)
+    constexpr int NDB = D / 32 + 1;          // 32-row blocks of O^T; row D is the softmax denominator
+    constexpr int LDB = D / 32, LREG = 4 * ((D % 32) / 8);  // block / accumulator register (lanes hi = 0) of that row
+    constexpr int ROWB = 2 * D;              // bytes per K / V row in LDS
+    constexpr int CH = D / 8;                // 16-byte chunks per row = 1-KiB DMA pieces per 64-row tile
     constexpr int TILEB = FKT * ROWB;
-    constexpr int BUFB = 2 * TILEB;     // K tile then V tile
-    constexpr int CONST_OFF = 2 * BUFB; // {1,0,0,0} bf16, then zeros
-    constexpr int LDSB = CONST_OFF + 64;
+    constexpr int BUFB = 2 * TILEB;          // K tile then V tile
+    constexpr int ONES_OFF = 2 * BUFB;       // "ones tile": 64 rows of ROWB bytes, each starting with bf16 {1,0,0,0,0,0,0,0}
+    constexpr int LDSB = ONES_OFF + TILEB + 64;
     constexpr int NPIECE = 2 * CH;
     constexpr int MAXP = (NPIECE + 3) / 4;
-    constexpr int LDF = D / 16, LROW = D % 16;  // O^T fragment / row that carries the denominator
 
     __shared__ __attribute__((aligned(16))) char smem[LDSB];
 
+#ifdef AE_ATTN_LAB
+    const unsigned long long dbg_c0 = __builtin_readcyclecounter(), dbg_w0 = wall_clock64();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5, l15 = lane & 15, g = lane >> 4;
@@ -82,12 +102,12 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     const int b = bh / p.H, h = bh - b * p.H;
     const int q0 = qb * QB + wave * 32;
 
-    if (tid < 16) reinterpret_cast<uint32_t*>(smem + CONST_OFF)[tid] = tid == 0 ? 0x00003F80u : 0u;
+    if (tid < FKT) *reinterpret_cast<u32x4*>(smem + ONES_OFF + tid * ROWB) = (u32x4){0x00003F80u, 0u, 0u, 0u};
 
     // ---- Q^T operand of the 32x32x16 MFMA: lane (q = l31, hi) holds c * Q[q][16 ks + 8 hi .. +8], zero beyond head_dim
     const bf16_t* qp = p.q + (long)b * p.q_sb + (long)h * p.q_sh;
     const float c = p.scale * FLOG2E;
-    bf16x8_t qf[KS];
+    u32x4 qf[KS];
     {
         const int qrow = min(q0 + l31, p.Nq - 1);
 #pragma unroll
@@ -95,179 +115,248 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
             const int d0 = 16 * ks + 8 * hi;
             u32x4 t = *reinterpret_cast<const u32x4*>(qp + (long)qrow * p.q_sn + (d0 < D ? d0 : 0));
             if (d0 >= D) t = (u32x4){0u, 0u, 0u, 0u};
-            u32x4 w;
-            w.x = pack_bf16x2(bf16lo(t.x) * c, bf16hi(t.x) * c);
-            w.y = pack_bf16x2(bf16lo(t.y) * c, bf16hi(t.y) * c);
-            w.z = pack_bf16x2(bf16lo(t.z) * c, bf16hi(t.z) * c);
-            w.w = pack_bf16x2(bf16lo(t.w) * c, bf16hi(t.w) * c);
-            qf[ks] = as_bf16x8(w);
+            qf[ks].x = pack_bf16x2(bf16lo(t.x) * c, bf16hi(t.x) * c);
+            qf[ks].y = pack_bf16x2(bf16lo(t.y) * c, bf16hi(t.y) * c);
+            qf[ks].z = pack_bf16x2(bf16lo(t.z) * c, bf16hi(t.z) * c);
+            qf[ks].w = pack_bf16x2(bf16lo(t.w) * c, bf16hi(t.w) * c);
         }
     }
 
-    // ---- LDS-DMA plan: piece j of a tile (K pieces 0..CH-1, V pieces CH..2CH-1) is issued by wave j % 4
-    const bf16_t* kp = p.k + (long)b * p.k_sb + (long)h * p.k_sh;
-    const bf16_t* vp = p.v + (long)b * p.v_sb + (long)h * p.v_sh;
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kp), 0, (int)(((long)(p.Nk - 1) * p.k_sn + D) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vp), 0, (int)(((long)(p.Nk - 1) * p.v_sn + D) * 2), 0x00020000);
-    const int ksn2 = (int)p.k_sn * 2, vsn2 = (int)p.v_sn * 2;
-    int voff[MAXP];
-#pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-        const int j = wave + 4 * i;
-        const bool isK = j < CH;
-        const int cidx = (isK ? j : j - CH) * 64 + lane;
-        const int row = cidx / CH, cc = cidx - row * CH;
-        voff[i] = row * (isK ? ksn2 : vsn2) + cc * 16;
-    }
-    auto issue = [&](int t, int buf) {
-#pragma unroll
-        for (int i = 0; i < MAXP; ++i) {
-            const int j = wave + 4 * i;
-            if (j < NPIECE) {
-                if (j < CH) dma16(rsK, smem + buf * BUFB + j * 1024, voff[i] + t * FKT * ksn2);
-                else dma16(rsV, smem + buf * BUFB + TILEB + (j - CH) * 1024, voff[i] + t * FKT * vsn2);
-            }
-        }
-    };
+    // ---- per-lane LDS read addresses (tile-buffer offset added per tile; key-block / K-step / d-block offsets are immediates)
+    const int kaddr = l31 * ROWB + hi * 16;
+    // V^T operand by ds_read_b64_tr_b16: 16-lane group g reads a [4 keys][16 d] block, lane i of the group addresses row i >> 2,
+    // columns 4 (i & 3) .. +4, and receives column i.  Groups 0/1 -> d 0-15 / 16-31 of the lanes' hi = 0 keys, groups 2/3 -> hi = 1.
+    const int vrow = 4 * hi + (l15 >> 2);
+    const int vaddr = TILEB + vrow * ROWB + (16 * (g & 1) + 4 * (l15 & 3)) * 2;
+    const int vcol = 32 * LDB + 16 * (g & 1) + 4 * (l15 & 3);  // first of this lane's 4 columns in the last d-block
+    const bool ones_lane = vcol == D;  // supplies columns D..D+3: reads {1,0,0,0} instead
+    const bool zero_lane = vcol > D;   // padding columns: read zeros (idle multipliers) instead of the neighbouring rows
 
-    // ---- per-lane LDS read addresses
-    const int kaddr = l31 * ROWB + hi * 16;                                   // + ks * 32 + block / buffer offsets (immediates)
-    const int vkey = 16 * (g & 1) + 4 * (g >> 1) + (l15 >> 2);                // key row this lane addresses in a tr read (+8 for the second)
-    const int vaddr = vkey * ROWB + (l15 & 3) * 8;                            // + df * 32 + block / buffer offsets
-    const bool ones_lane = (16 * LDF + 4 * (l15 & 3)) == D;                   // supplies columns D..D+3 of the last fragment
-
-    f32x16 cinit;
+    f32x16 cinit;  // !QSLOT: the offset enters through the C operand
 #pragma unroll
     for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
-    float mt = 0.f;  // m~ (log2 units): S' = c q.k - m~
-    f32x4 o[2][NDF];
+    float mt = 0.f;  // m~ (log2 units, always bf16-representable): S' = c q.k - m~
+    f32x16 o[NDB];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int db = 0; db < NDB; ++db)
 #pragma unroll
-        for (int df = 0; df < NDF; ++df) o[a][df] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
 
-    const int ntiles = (p.Nk + FKT - 1) / FKT;
+    int seg_nk = p.Nk;
+    int kcur = 0, klast = 0, vcur = 0, vlast = 0;
 
-    // one 32-key block of the tile in buffer BUF
-    auto block = [&](auto buf_tag, auto blk_tag, int k0, bool first, bool tail) {
-        constexpr int BUF = decltype(buf_tag)::value, B2 = decltype(blk_tag)::value;
-        constexpr int KOFF = BUF * BUFB + B2 * 32 * ROWB;
-        constexpr int VOFF = BUF * BUFB + TILEB + B2 * 32 * ROWB;
+    // one 32-key block of the current tile
+    auto block = [&](auto blk_tag, int k0, bool first, bool tail) {
+        constexpr int B2 = decltype(blk_tag)::value;
+        constexpr int BO = B2 * 32 * ROWB;
         // ---- S'^T = K (cQ)^T - m~ : lane holds S'[key = (r&3) + 8 (r>>2) + 4 hi][q = l31]
+        if (ABL == 10 || ABL == 12) __builtin_amdgcn_s_setprio(1);
+        if (ABL == 11) __builtin_amdgcn_s_setprio(0);
         f32x16 s;
+        if (ABL == 4) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = -(float)(r + l31) - mt;
+        } else
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8_t kf = as_bf16x8(*reinterpret_cast<const u32x4*>(smem + kaddr + KOFF + ks * 32));
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? cinit : s, 0, 0, 0);
+            const int ka = (QSLOT && ks == KS - 1) ? klast + BO : kcur + BO + ks * 32;
+            const bf16x8_t kf = as_bf16x8(*reinterpret_cast<const u32x4*>(smem + ka));
+            if (ks == 0 && QSLOT) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[ks]), z, 0, 0, 0);
+            } else {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[ks]), ks == 0 ? cinit : s, 0, 0, 0);
+            }
         }
+        if (ABL == 10 || ABL == 12) __builtin_amdgcn_s_setprio(0);
+        if (ABL == 11) __builtin_amdgcn_s_setprio(1);
         if (tail) {  // keys past Nk (zero rows from the bounds-checked DMA) must not count
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (k0 + B2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= p.Nk) s[r] = MASKED;
+                if (k0 + B2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= seg_nk) s[r] = MASKED;
         }
         float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
 #pragma unroll
         for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
         mx = fmaxf(mx, s[15]);
+        if (ABL == 2) mx = s[0];
         if (__builtin_expect(first || __any(mx > RESCALE_THR), 0)) {
-            // rebase m~ (rare): rows whose block maximum is above the offset move it up to that maximum (integer steps: the
-            // factor 2^-d is exact); the first block sets it whatever its sign.  O (with its denominator row) follows.
+            // rebase m~ (rare): rows whose block maximum is above the offset move it up to that maximum, rounded up to the next
+            // bf16-representable value (the offset must survive the trip through the Q operand; 2^-(step) is exact either way);
+            // the first block sets it whatever its sign.  O (with its denominator row) follows.
             const float m2 = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float d = (first || m2 > 0.f) ? __builtin_ceilf(m2) : 0.f;
-            d = fmaxf(d, -1.0e4f);  // a fully masked first block leaves the offset finite
-            mt += d;
+            float tgt = (first || m2 > 0.f) ? mt + __builtin_ceilf(m2) : mt;
+            tgt = fmaxf(tgt, -1.0e4f);
+            uint32_t tb = __float_as_uint(tgt);
+            tb = (tgt > 0.f) ? ((tb + 0xFFFFu) & 0xFFFF0000u) : (tb & 0xFFFF0000u);  // towards +inf
+            const float mnew = __uint_as_float(tb);
+            const float d = mnew - mt;
+            mt = mnew;
+            if (QSLOT) {
+                if (hi) qf[KS - 1].x = (qf[KS - 1].x & 0xFFFF0000u) | ((tb >> 16) ^ 0x8000u);  // slot D holds -m~
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { cinit[r] = -mt; s[r] -= d; }
+                for (int r = 0; r < 16; ++r) cinit[r] = -mt;
+            }
             const float alpha = __builtin_amdgcn_exp2f(-d);
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const float aq = __shfl(alpha, a * 16 + l15, 64);
+            for (int r = 0; r < 16; ++r) s[r] -= d;
 #pragma unroll
-                for (int df = 0; df < NDF; ++df) { o[a][df][0] *= aq; o[a][df][1] *= aq; o[a][df][2] *= aq; o[a][df][3] *= aq; }
-            }
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
         }
-        // ---- P = exp2(S'), bf16, and into the B-operand layout of the 16x16x32 MFMA (both 16-query fragments)
+        // ---- P = exp2(S'), bf16: pk[4 kk .. 4 kk + 3] is the B operand of K-step kk (keys 16 kk + 4 hi + {0..3, 8..11})
         uint32_t pk[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pk[j] = pack_bf16x2(__builtin_amdgcn_exp2f(s[2 * j]), __builtin_amdgcn_exp2f(s[2 * j + 1]));
-        u32x4 w0, w1;
+        for (int j = 0; j < 8; ++j) pk[j] = (ABL == 1) ? pack_bf16x2(s[2 * j], s[2 * j + 1]) : pack_bf16x2(__builtin_amdgcn_exp2f(s[2 * j]), __builtin_amdgcn_exp2f(s[2 * j + 1]));
+        // ---- O^T += V^T P^T : lane holds O^T[d = 32 db + (r&3) + 8 (r>>2) + 4 hi][q = l31]
+        if (ABL == 10) __builtin_amdgcn_s_setprio(1);
+        if (ABL == 11) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const u32x2 sw = __builtin_amdgcn_permlane16_swap(pk[j], pk[j + 4], false, false);
-            w0[j] = sw[0];
-            w1[j] = sw[1];
-        }
-        const bf16x8_t pb0 = as_bf16x8(w0), pb1 = as_bf16x8(w1);
-        // ---- O^T += V^T P^T : lane holds O^T[d = 16 df + 4 g + r][q = 16 a + l15]
+        for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8_t pb = as_bf16x8((u32x4){pk[4 * kk], pk[4 * kk + 1], pk[4 * kk + 2], pk[4 * kk + 3]});
 #pragma unroll
-        for (int df = 0; df < NDF; ++df) {
-            int va = vaddr + VOFF + df * 32, vb2 = va + 8 * ROWB;
-            if (df == LDF) {
-                va = ones_lane ? CONST_OFF : va;
-                vb2 = ones_lane ? CONST_OFF : vb2;
+            for (int db = 0; db < NDB; ++db) {
+                const int va = (db == LDB ? vlast : vcur + db * 64) + BO + kk * 16 * ROWB;
+                if (ABL == 3) {  // no V reads, no PV MFMA (P kept alive)
+                    asm volatile("" ::"v"(pb));
+                    continue;
+                }
+                bf16x8_t vf;
+                if (ABL == 5) vf = as_bf16x8(qf[0]);  // no V reads
+                else vf = cat_tr(lds_tr16(smem + va), lds_tr16(smem + va + 8 * ROWB));
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[db], 0, 0, 0);
             }
-            const bf16x8_t vf = cat_tr(lds_tr16(smem + va), lds_tr16(smem + vb2));
-            o[0][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb0, o[0][df], 0, 0, 0);
-            o[1][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb1, o[1][df], 0, 0, 0);
         }
     };
 
-    auto tile = [&](auto buf_tag, int t) {
-        constexpr int BUF = decltype(buf_tag)::value;
-        __syncthreads();  // (drains this wave's DMA first) tile t has landed; every wave is done with tile t - 1
-        if (t + 1 < ntiles) issue(t + 1, BUF ^ 1);
-        const bool tail = (t + 1) * FKT > p.Nk;
-        block(buf_tag, std::integral_constant<int, 0>{}, t * FKT, t == 0, tail);
-        block(buf_tag, std::integral_constant<int, 1>{}, t * FKT, false, tail);
-    };
-
-    issue(0, 0);
-    for (int t = 0; t < ntiles; t += 2) {
-        tile(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < ntiles) tile(std::integral_constant<int, 1>{}, t + 1);
+    f32x16 o_first[SEG2 ? NDB : 1];  // SEG2: normalised result of the first segment while the second runs
+    const int lds0 = (int)(uintptr_t)((__attribute__((address_space(3))) char*)smem);  // LDS byte address of the tile buffers
+    constexpr int NSEG = SEG2 ? 2 : 1;
+    for (int seg = 0; seg < NSEG; ++seg) {
+        // ---- LDS-DMA plan: piece j of a tile (K pieces 0..CH-1, V pieces CH..2CH-1) is issued by wave j % 4
+        const bf16_t* kp = seg == 0 ? p.k + (long)b * p.k_sb + (long)h * p.k_sh : p.k2 + (long)b * p.k2_sb + (long)h * p.k2_sh;
+        const bf16_t* vp = seg == 0 ? p.v + (long)b * p.v_sb + (long)h * p.v_sh : p.v2 + (long)b * p.v2_sb + (long)h * p.v2_sh;
+        seg_nk = seg == 0 ? p.Nk : p.Nk2;
+        const int ksn2 = (int)(seg == 0 ? p.k_sn : p.k2_sn) * 2, vsn2 = (int)(seg == 0 ? p.v_sn : p.v2_sn) * 2;
+        // bounds-checked: rows >= Nk of a tile read as zeros
+        const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kp), 0, (seg_nk - 1) * ksn2 + D * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vp), 0, (seg_nk - 1) * vsn2 + D * 2, 0x00020000);
+        int voff[MAXP];
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int j = wave + 4 * i;
+            const bool isK = j < CH;
+            const int cidx = (isK ? j : j - CH) * 64 + lane;
+            const int row = cidx / CH, cc = cidx - row * CH;
+            voff[i] = row * (isK ? ksn2 : vsn2) + cc * 16;
+        }
+        auto issue = [&](int t) {
+            const int boff = lds0 + (t & 1) * BUFB;
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                const int j = wave + 4 * i;
+                if (j < NPIECE) {
+                    if (j < CH) dma16(rsK, boff + j * 1024, voff[i] + t * FKT * ksn2);
+                    else dma16(rsV, boff + TILEB + (j - CH) * 1024, voff[i] + t * FKT * vsn2);
+                }
+            }
+        };
+        const int ntiles = (seg_nk + FKT - 1) / FKT;
+        if (SEG2 && seg == 1) dma_wait_all_and_barrier();  // every wave is done with the first segment's last tile
+        issue(0);
+        for (int t = 0; t < ntiles; ++t) {
+            dma_wait_all_and_barrier();  // tile t has landed (every wave's pieces); every wave is done with tile t - 1
+            if (t + 1 < ntiles) issue(t + 1);
+            const int boff = (t & 1) * BUFB;
+            kcur = kaddr + boff;
+            klast = (QSLOT && hi) ? ONES_OFF + l31 * ROWB : kcur + (KS - 1) * 32;
+            vcur = vaddr + boff;
+            vlast = ones_lane ? ONES_OFF + vrow * ROWB : (zero_lane ? ONES_OFF + vrow * ROWB + 8 : vcur + LDB * 64);
+            const bool tail = (t + 1) * FKT > seg_nk;
+            block(std::integral_constant<int, 0>{}, t * FKT, t == 0, tail);
+            if (t * FKT + 32 < seg_nk) block(std::integral_constant<int, 1>{}, t * FKT, false, tail);
+        }
+        if (SEG2 && seg == 0) {  // park the first segment's normalised output, restart the online softmax
+            const float l0 = __shfl(o[LDB][LREG], l31, 64);
+            const float inv0 = 1.0f / l0;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o_first[SEG2 ? db : 0][r] = o[db][r] * inv0;
+                    o[db][r] = 0.f;
+                }
+            mt = 0.f;
+            if (QSLOT) {
+                if (hi) qf[KS - 1].x &= 0xFFFF0000u;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
+            }
+        }
     }
 
+#ifdef AE_ATTN_LAB
+    if (tid == 0 && p.kW == 777) {
+        atomicAdd(&g_attn_dbg[0], __builtin_readcyclecounter() - dbg_c0);
+        atomicAdd(&g_attn_dbg[1], wall_clock64() - dbg_w0);
+        atomicAdd(&g_attn_dbg[2], 1ull);
+    }
+#endif
     // ---- normalise and store: 4 consecutive d per lane -> 8-byte stores
     bf16_t* op = p.o + (long)b * p.o_sb + (long)h * p.o_sh;
+    const float lsum = __shfl(o[LDB][LREG], l31, 64);
+    const float inv = (SEG2 ? p.scale2[b] : (p.out_scale ? p.out_scale[b] : 1.0f)) / lsum;
+    const int qrow = q0 + l31;
+    if (qrow < p.Nq) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const float lsum = __shfl(o[a][LDF][LROW % 4], l15 + 16 * (LROW / 4), 64);
-        const float inv = (p.out_scale ? p.out_scale[b] : 1.0f) / lsum;
-        const int qrow = q0 + a * 16 + l15;
-        if (qrow >= p.Nq) continue;
+        for (int db = 0; db < NDB; ++db)
 #pragma unroll
-        for (int df = 0; df < NDF; ++df) {
-            const int d = df * 16 + g * 4;
-            if (d < D) {
-                float r0 = o[a][df][0] * inv, r1 = o[a][df][1] * inv, r2 = o[a][df][2] * inv, r3 = o[a][df][3] * inv;
-                u32x2* dst = reinterpret_cast<u32x2*>(op + (long)qrow * p.o_sn + d);
-                if (p.accum) {
-                    const u32x2 prev = *dst;
-                    r0 += bf16lo(prev.x); r1 += bf16hi(prev.x); r2 += bf16lo(prev.y); r3 += bf16hi(prev.y);
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int d = 32 * db + 8 * r4 + 4 * hi;
+                if (d < D) {
+                    float r0 = o[db][4 * r4] * inv, r1 = o[db][4 * r4 + 1] * inv, r2 = o[db][4 * r4 + 2] * inv, r3 = o[db][4 * r4 + 3] * inv;
+                    if (SEG2) {
+                        r0 += o_first[SEG2 ? db : 0][4 * r4]; r1 += o_first[SEG2 ? db : 0][4 * r4 + 1];
+                        r2 += o_first[SEG2 ? db : 0][4 * r4 + 2]; r3 += o_first[SEG2 ? db : 0][4 * r4 + 3];
+                    }
+                    u32x2* dst = reinterpret_cast<u32x2*>(op + (long)qrow * p.o_sn + d);
+                    if (p.accum) {
+                        const u32x2 prev = *dst;
+                        r0 += bf16lo(prev.x); r1 += bf16hi(prev.x); r2 += bf16lo(prev.y); r3 += bf16hi(prev.y);
+                    }
+                    *dst = (u32x2){pack_bf16x2(r0, r1), pack_bf16x2(r2, r3)};
                 }
-                *dst = (u32x2){pack_bf16x2(r0, r1), pack_bf16x2(r2, r3)};
             }
-        }
     }
 }
 
 template <int D>
 int launch_fast(const AttnArgs& a, hipStream_t stream) {
-    static const int occ = getenv("AE_ATTN_FAST_OCC") ? atoi(getenv("AE_ATTN_FAST_OCC")) : 3;
     const long blocks = (long)((a.Nq + 127) / 128) * a.B * a.H;
     dim3 grid((unsigned)blocks), block(256);
-    if (occ == 2) hipLaunchKernelGGL((attn_fast_kernel<D, 2>), grid, block, 0, stream, a);
-    else if (occ == 4) hipLaunchKernelGGL((attn_fast_kernel<D, 4>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((attn_fast_kernel<D, 3>), grid, block, 0, stream, a);
+#ifdef AE_ATTN_LAB
+    static const int abl = getenv("AE_ATTN_ABL") ? atoi(getenv("AE_ATTN_ABL")) : 0;
+#define AE_ABL(n) if (abl == n) { hipLaunchKernelGGL((attn_fast_kernel<D, 3, false, n>), grid, block, 0, stream, a); return ae_check_launch("abl"); }
+    AE_ABL(1) AE_ABL(2) AE_ABL(3) AE_ABL(4) AE_ABL(5) AE_ABL(10) AE_ABL(11) AE_ABL(12)
+#endif
+    if (a.k2) hipLaunchKernelGGL((attn_fast_kernel<D, 3, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((attn_fast_kernel<D, 3, false>), grid, block, 0, stream, a);
     return ae_check_launch("ae_attn_fwd_bf16(fast)");
 }
 
 }  // namespace
 
 int ae_attn_fast_launch(const AttnArgs& a, int D, hipStream_t stream) {
-    if (a.rel_h || a.key_mask || a.k2 || a.lse || a.lse2) return AE_ERR_UNSUPPORTED;
+    if (a.rel_h || a.key_mask || a.lse || a.lse2) return AE_ERR_UNSUPPORTED;
+    if (a.k2 && (a.accum || a.out_scale)) return AE_ERR_UNSUPPORTED;
     // 32-bit byte offsets inside one (batch, head) image of K / V
     if (((long)a.Nk * a.k_sn + D) * 2 >= (1L << 31) || ((long)a.Nk * a.v_sn + D) * 2 >= (1L << 31)) return AE_ERR_UNSUPPORTED;
+    if (a.k2 && (((long)a.Nk2 * a.k2_sn + D) * 2 >= (1L << 31) || ((long)a.Nk2 * a.v2_sn + D) * 2 >= (1L << 31))) return AE_ERR_UNSUPPORTED;
     switch (D) {
         case 40: return launch_fast<40>(a, stream);
         case 80: return launch_fast<80>(a, stream);
