@@ -53,6 +53,7 @@ SIGNATURES = {
     "ae_rowsum_f32": [c_void_p, c_void_p, c_int, c_long, c_void_p],
     "ae_scatter_add_rows_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "ae_task_gate_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "ae_task_gate_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ae_transpose_last2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ae_concat_channels_bf16": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_void_p],
     "ae_timestep_embedding": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],

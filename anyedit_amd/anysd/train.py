@@ -37,6 +37,10 @@ class AnySDTrainer:
         for i, p in enumerate(moe.adapter_modules):
             self.params[f"adapter_modules.{i}"] = p
         self.params["task_embs"] = moe.task_embs
+        # the router (our spec): trained with the adapter group — a frozen random projection would make top-1
+        # routing and the gate scale g_b arbitrary for the whole run
+        self.params["gate.weight"] = moe.gate.weight
+        self.params["gate.bias"] = moe.gate.bias
         self.state = {}
         import torch.distributed as dist
         self.exchange = None
@@ -153,6 +157,8 @@ class AnySDTrainer:
             if dgate is not None:
                 ops.scatter_add_rows(ops.task_gate_bwd(leaves["probs"], leaves["top1"], dgate, self.moe.gate.weight.detach()),
                                      leaves["code"], dtask)
+                grads["gate.weight"], grads["gate.bias"] = ops.task_gate_wgrad(leaves["probs"], leaves["top1"], dgate,
+                                                                               self.moe.task_embs.detach(), leaves["code"])
             grads["task_embs"] = dtask
             for n, p in self.params.items():  # parameters that received nothing this step (experts not routed to)
                 if n not in grads:

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(64) void task_gate_kernel(const float* task_emb, co
     }
 }
 // Backward of g_b = softmax(Wg te_b + bg)[top1_b] w.r.t. the task embedding row (argmax is a constant of the step):
-//   dlogit[e] = dg_b * g_b * ((e == top1_b) - probs[b, e]);   dte_b = Wg^T dlogit      (Wg, bg are not trained, train.py:483-485)
+//   dlogit[e] = dg_b * g_b * ((e == top1_b) - probs[b, e]);   dte_b = Wg^T dlogit;
+//   router parameters (optional outputs): dWg[e, :] = sum_b dlogit[b, e] te_b,  dbg[e] = sum_b dlogit[b, e]  (fixed summation order)
 __global__ __launch_bounds__(256) void task_gate_bwd_kernel(const float* probs, const int* top1, const float* dgate, const float* Wg,
                                                             int Dt, int E, float* dte) {
     const int b = blockIdx.x;
@@ -52,7 +53,40 @@ __global__ __launch_bounds__(256) void task_gate_bwd_kernel(const float* probs, 
         dte[(long)b * Dt + i] = acc;
     }
 }
+// one block per expert row of Wg; samples are summed in index order (deterministic)
+__global__ __launch_bounds__(256) void task_gate_wgrad_kernel(const float* probs, const int* top1, const float* dgate, const float* task_emb,
+                                                              const long* edit_code, int B, int n_tasks, int Dt, int E, float* dWg, float* dbg) {
+    const int e = blockIdx.x;
+    for (int i = threadIdx.x; i < Dt; i += 256) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const int t1 = top1[b];
+            const float dl = dgate[b] * probs[(long)b * E + t1] * ((e == t1 ? 1.0f : 0.0f) - probs[(long)b * E + e]);
+            long code = edit_code[b];
+            code = code < 0 ? 0 : (code >= n_tasks ? n_tasks - 1 : code);
+            acc += dl * task_emb[code * Dt + i];
+        }
+        dWg[(long)e * Dt + i] = acc;
+    }
+    if (threadIdx.x == 0 && dbg) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const int t1 = top1[b];
+            acc += dgate[b] * probs[(long)b * E + t1] * ((e == t1 ? 1.0f : 0.0f) - probs[(long)b * E + e]);
+        }
+        dbg[e] = acc;
+    }
+}
 }  // namespace
+
+extern "C" int ae_task_gate_wgrad(const float* probs, const int* top1, const float* dgate, const float* task_emb, const long* edit_code,
+                                  int B, int n_tasks, int Dt, int E, float* dWg, float* dbg, void* stream) {
+    AE_REQUIRE(probs && top1 && dgate && task_emb && edit_code && dWg, "ae_task_gate_wgrad: null pointer");
+    AE_REQUIRE(B > 0 && n_tasks > 0 && Dt > 0 && E > 0 && E <= 64, "ae_task_gate_wgrad: bad sizes");
+    hipLaunchKernelGGL(task_gate_wgrad_kernel, dim3(E), dim3(256), 0, (hipStream_t)stream, probs, top1, dgate, task_emb, edit_code, B, n_tasks,
+                       Dt, E, dWg, dbg);
+    return ae_check_launch("ae_task_gate_wgrad");
+}
 
 extern "C" int ae_task_gate_bwd(const float* probs, const int* top1, const float* dgate, const float* Wg, int B, int Dt, int E,
                                 float* dte, void* stream) {

@@ -5,7 +5,9 @@ Activations are channels-last bf16: [rows, C] with rows = B*H*W.
 """
 import torch
 
-from ._lib import lib, check
+import threading
+
+from ._lib import lib, check as _check
 
 BF16 = torch.bfloat16
 EPI_NONE, EPI_GELU, EPI_GEGLU, EPI_SILU, EPI_RELU = 0, 1, 2, 3, 4
@@ -17,6 +19,30 @@ def _s():
 
 def _p(t):
     return None if t is None else t.data_ptr()
+
+
+_live = threading.local()
+
+
+def _tmp(t):
+    """Keeps a converted temporary (`x.float().contiguous()` ...) alive until the launch it feeds has been enqueued.
+
+    Without this the temporary is freed as soon as `_p` has taken its address, and the NEXT temporary of the same argument
+    list gets the same block back from the caching allocator: two arguments of one kernel would alias.  `check`
+    releases the references once the launch call has returned — the allocator's stream ordering covers the rest."""
+    if t is not None:
+        lst = getattr(_live, "t", None)
+        if lst is None:
+            lst = _live.t = []
+        lst.append(t)
+    return t
+
+
+def check(rc, what=""):
+    lst = getattr(_live, "t", None)
+    if lst:
+        lst.clear()
+    _check(rc, what)
 
 
 def _chk(t, dtype, name, dims=None):
@@ -301,7 +327,7 @@ def plms_combine(e_t, old_eps):
 
 def plms_combine_first(e_t, e_t_next):
     out = torch.empty_like(e_t)
-    check(lib.ae_plms_combine_f32(_p(e_t.contiguous()), _p(e_t_next.contiguous()), None, None, _p(out), e_t.numel(), 0, _s()),
+    check(lib.ae_plms_combine_f32(_p(_tmp(e_t.contiguous())), _p(_tmp(e_t_next.contiguous())), None, None, _p(out), e_t.numel(), 0, _s()),
           "ae_plms_combine_f32")
     return out
 
@@ -309,7 +335,7 @@ def plms_combine_first(e_t, e_t_next):
 def mask_blend(img, x0, noise, mask, sqrt_ac, sqrt_one_minus_ac, ip2p_order=False):
     B, C, H, W = img.shape
     out = torch.empty_like(img)
-    check(lib.ae_mask_blend_f32(_p(img.contiguous()), _p(x0.contiguous()), _p(noise.contiguous()), _p(mask.contiguous().float()),
+    check(lib.ae_mask_blend_f32(_p(_tmp(img.contiguous())), _p(_tmp(x0.contiguous())), _p(_tmp(noise.contiguous())), _p(_tmp(mask.contiguous().float())),
                                 _p(out), B, C, H * W, sqrt_ac, sqrt_one_minus_ac, 1 if ip2p_order else 0, _s()), "ae_mask_blend_f32")
     return out
 
@@ -318,8 +344,8 @@ def q_sample(x0, noise, sqrt_ac_t, sqrt_one_minus_ac_t):
     """per-sample fp32 coefficient vectors [B] (already gathered at t)."""
     out = torch.empty_like(x0)
     B = x0.shape[0]
-    check(lib.ae_q_sample_f32(_p(x0.contiguous()), _p(noise.contiguous()), _p(sqrt_ac_t.contiguous()),
-                              _p(sqrt_one_minus_ac_t.contiguous()), _p(out), B, x0.numel() // B, _s()), "ae_q_sample_f32")
+    check(lib.ae_q_sample_f32(_p(_tmp(x0.contiguous())), _p(_tmp(noise.contiguous())), _p(_tmp(sqrt_ac_t.contiguous())),
+                              _p(_tmp(sqrt_one_minus_ac_t.contiguous())), _p(out), B, x0.numel() // B, _s()), "ae_q_sample_f32")
     return out
 
 
@@ -429,7 +455,7 @@ def sam_pe_encode(coords, gauss, image_size, labels=None, table=None, offset=0.5
     out = torch.empty(N, 2 * F, dtype=torch.float32, device=coords.device)
     if N == 0:
         return out
-    check(lib.ae_sam_pe_encode_f32(_p(coords.contiguous()), _p(labels), _p(gauss.contiguous()), _p(table), _p(out), N, F, float(offset),
+    check(lib.ae_sam_pe_encode_f32(_p(_tmp(coords.contiguous())), _p(labels), _p(_tmp(gauss.contiguous())), _p(table), _p(out), N, F, float(offset),
                                    1.0 / image_size[1], 1.0 / image_size[0], _s()), "ae_sam_pe_encode_f32")
     return out
 
@@ -441,7 +467,7 @@ def sam_mask_downscale(masks, w1, b1, g1, e1, w2, b2, g2, e2, eps=1e-6):
     if one != 1 or H4 % 4 or W4 % 4 or tuple(w1.shape) != (4, 1, 2, 2) or tuple(w2.shape) != (16, 4, 2, 2):
         raise ValueError("sam_mask_downscale: expects [B,1,4h,4w] masks and the mask_in_chans=16 weights")
     out = torch.empty(B * (H4 // 4) * (W4 // 4), 16, dtype=BF16, device=masks.device)
-    check(lib.ae_sam_mask_downscale_bf16(_p(masks.contiguous()), _p(w1), _p(b1), _p(g1), _p(e1), _p(w2), _p(b2), _p(g2), _p(e2), _p(out),
+    check(lib.ae_sam_mask_downscale_bf16(_p(_tmp(masks.contiguous())), _p(w1), _p(b1), _p(g1), _p(e1), _p(w2), _p(b2), _p(g2), _p(e2), _p(out),
                                          B, H4 // 4, W4 // 4, eps, _s()), "ae_sam_mask_downscale_bf16")
     return out
 
@@ -469,7 +495,7 @@ def sam_postprocess_masks(low, img_size, input_size, original_size, threshold=No
     logits = torch.empty(B, M, oh, ow, dtype=torch.float32, device=low.device) if want_logits else None
     mask = torch.empty((1, 1, oh, ow) if merge else (B, M, oh, ow), dtype=torch.uint8, device=low.device) if threshold is not None else None
     if B * M > 0:
-        check(lib.ae_sam_postprocess_masks(_p(low.contiguous()), _p(logits), _p(mask), B * M, Hl, Wl, int(img_size), int(input_size[0]),
+        check(lib.ae_sam_postprocess_masks(_p(_tmp(low.contiguous())), _p(logits), _p(mask), B * M, Hl, Wl, int(img_size), int(input_size[0]),
                                            int(input_size[1]), oh, ow, float(threshold if threshold is not None else 0.0),
                                            1 if merge else 0, _s()), "ae_sam_postprocess_masks")
     elif mask is not None:
@@ -488,7 +514,7 @@ def nms(boxes, scores, iou_threshold):
         return torch.empty(0, dtype=torch.int64, device=boxes.device)
     order = torch.sort(scores, descending=True, stable=True).indices
     keep = torch.empty(N, dtype=torch.uint8, device=boxes.device)
-    check(lib.ae_nms_sorted_f32(_p(boxes.float()[order].contiguous()), _p(keep), N, float(iou_threshold), _s()), "ae_nms_sorted_f32")
+    check(lib.ae_nms_sorted_f32(_p(_tmp(boxes.float()[order].contiguous())), _p(keep), N, float(iou_threshold), _s()), "ae_nms_sorted_f32")
     return order[keep.bool()]
 
 
@@ -500,7 +526,7 @@ def sam_preprocess(x, img_size, mean, std):
         raise ValueError("sam_preprocess: expected a GPU tensor (anyedit_amd has no CPU path)")
     B, C, h, w = x.shape
     out = torch.empty(B, C, img_size, img_size, dtype=torch.float32, device=x.device)
-    check(lib.ae_sam_preprocess_f32(_p(x.contiguous()), 1 if x.dtype == torch.uint8 else 0, _p(out), B, C, h, w, img_size, _p(mean),
+    check(lib.ae_sam_preprocess_f32(_p(_tmp(x.contiguous())), 1 if x.dtype == torch.uint8 else 0, _p(out), B, C, h, w, img_size, _p(mean),
                                     _p(std), _s()), "ae_sam_preprocess_f32")
     return out
 
@@ -508,13 +534,13 @@ def sam_preprocess(x, img_size, mean, std):
 def patchify(x, P):
     B, Cin, H, W = x.shape
     out = torch.empty(B * (H // P) * (W // P), Cin * P * P, dtype=BF16, device=x.device)
-    check(lib.ae_patchify_f32_bf16(_p(x.float().contiguous()), _p(out), B, Cin, H, W, P, _s()), "ae_patchify_f32_bf16")
+    check(lib.ae_patchify_f32_bf16(_p(_tmp(x.float().contiguous())), _p(out), B, Cin, H, W, P, _s()), "ae_patchify_f32_bf16")
     return out
 
 
 def mse(a, b):
     out = torch.empty(1, dtype=torch.float32, device=a.device)
-    check(lib.ae_mse_f32(_p(a.float().contiguous()), _p(b.float().contiguous()), _p(out), a.numel(), _s()), "ae_mse_f32")
+    check(lib.ae_mse_f32(_p(_tmp(a.float().contiguous())), _p(_tmp(b.float().contiguous())), _p(out), a.numel(), _s()), "ae_mse_f32")
     return out[0]
 
 
@@ -525,8 +551,8 @@ def task_gate(task_emb, edit_code, Wg, bg):
     probs = torch.empty(B, E, dtype=torch.float32, device=task_emb.device)
     top1 = torch.empty(B, dtype=torch.int32, device=task_emb.device)
     top1p = torch.empty(B, dtype=torch.float32, device=task_emb.device)
-    check(lib.ae_task_gate(_p(task_emb.float().contiguous()), _p(edit_code.long().contiguous()), _p(Wg.float().contiguous()),
-                           _p(bg.float().contiguous()) if bg is not None else None, B, n_tasks, Dt, E, _p(probs), _p(top1),
+    check(lib.ae_task_gate(_p(_tmp(task_emb.float().contiguous())), _p(_tmp(edit_code.long().contiguous())), _p(_tmp(Wg.float().contiguous())),
+                           _p(_tmp(bg.float().contiguous())) if bg is not None else None, B, n_tasks, Dt, E, _p(probs), _p(top1),
                            _p(top1p), _s()), "ae_task_gate")
     return probs, top1, top1p
 
@@ -560,13 +586,13 @@ def geglu(h):
         return _TAPE.geglu(h)
     M, F2 = h.shape
     out = torch.empty(M, F2 // 2, dtype=BF16, device=h.device)
-    check(lib.ae_geglu_fwd_bf16(_p(h.contiguous()), _p(out), M, F2 // 2, _s()), "ae_geglu_fwd_bf16")
+    check(lib.ae_geglu_fwd_bf16(_p(_tmp(h.contiguous())), _p(out), M, F2 // 2, _s()), "ae_geglu_fwd_bf16")
     return out
 
 
 def geglu_bwd(h, dy):
     dh = torch.empty_like(h)
-    check(lib.ae_geglu_bwd_bf16(_p(h.contiguous()), _p(dy.contiguous()), _p(dh), h.shape[0], h.shape[1] // 2, _s()), "ae_geglu_bwd_bf16")
+    check(lib.ae_geglu_bwd_bf16(_p(_tmp(h.contiguous())), _p(_tmp(dy.contiguous())), _p(dh), h.shape[0], h.shape[1] // 2, _s()), "ae_geglu_bwd_bf16")
     return dh
 
 
@@ -576,7 +602,7 @@ def groupnorm_bwd(x, gamma, beta, dy, B, HW, eps, silu=False, groups=32, x2=None
     dx = torch.empty_like(x)
     dx2 = torch.empty_like(x2) if x2 is not None else None
     ws = torch.empty(lib.ae_groupnorm_bwd_workspace_floats(B, HW, C, groups), dtype=torch.float32, device=x.device)
-    check(lib.ae_groupnorm_bwd_nhwc_bf16(_p(x), _p(x2), C1, _p(gamma), _p(beta), _p(dy.contiguous()), _p(dx), _p(dx2), B, HW, C, groups,
+    check(lib.ae_groupnorm_bwd_nhwc_bf16(_p(x), _p(x2), C1, _p(gamma), _p(beta), _p(_tmp(dy.contiguous())), _p(dx), _p(dx2), B, HW, C, groups,
                                          eps, 1 if silu else 0, _p(ws), _s()), "ae_groupnorm_bwd_nhwc_bf16")
     return dx, dx2
 
@@ -598,7 +624,7 @@ def layernorm_bwd(x, gamma, dy, eps=1e-5, want_param_grads=False):
 def sumpool2x2(x, B, H, W):
     """x: [B*2H*2W, C] -> [B*H*W, C] (adjoint of the nearest-x2 upsample)."""
     out = torch.empty(B * H * W, x.shape[1], dtype=BF16, device=x.device)
-    check(lib.ae_sumpool2x2_bf16(_p(x.contiguous()), _p(out), B, H, W, x.shape[1], _s()), "ae_sumpool2x2_bf16")
+    check(lib.ae_sumpool2x2_bf16(_p(_tmp(x.contiguous())), _p(out), B, H, W, x.shape[1], _s()), "ae_sumpool2x2_bf16")
     return out
 
 
@@ -636,7 +662,7 @@ def rowsum_f32(x):
 def scatter_add_rows(src, code, dst):
     """dst[code[b]] += src[b] (fp32), deterministic."""
     code = code.to(torch.int32).contiguous()
-    check(lib.ae_scatter_add_rows_f32(_p(src.contiguous()), _p(code), _p(dst), src.shape[0], src.shape[1], dst.shape[0], _s()),
+    check(lib.ae_scatter_add_rows_f32(_p(_tmp(src.contiguous())), _p(code), _p(dst), src.shape[0], src.shape[1], dst.shape[0], _s()),
           "ae_scatter_add_rows_f32")
     return dst
 
@@ -644,9 +670,22 @@ def scatter_add_rows(src, code, dst):
 def task_gate_bwd(probs, top1, dgate, Wg):
     B, E = probs.shape
     dte = torch.empty(B, Wg.shape[1], dtype=torch.float32, device=probs.device)
-    check(lib.ae_task_gate_bwd(_p(probs.contiguous()), _p(top1.contiguous()), _p(dgate.float().contiguous()), _p(Wg.float().contiguous()),
+    check(lib.ae_task_gate_bwd(_p(_tmp(probs.contiguous())), _p(_tmp(top1.contiguous())), _p(_tmp(dgate.float().contiguous())), _p(_tmp(Wg.float().contiguous())),
                                B, Wg.shape[1], E, _p(dte), _s()), "ae_task_gate_bwd")
     return dte
+
+
+def task_gate_wgrad(probs, top1, dgate, task_emb, edit_code):
+    """(dWg [E, Dt], dbg [E]) of the routed gate value (router parameters of the AnySD spec)."""
+    B, E = probs.shape
+    n_tasks, Dt = task_emb.shape
+    probs32, top1c, dg32 = probs.float().contiguous(), top1.contiguous(), dgate.float().contiguous()
+    te32, code = task_emb.float().contiguous(), edit_code.long().contiguous()
+    dW = torch.empty(E, Dt, dtype=torch.float32, device=probs.device)
+    db = torch.empty(E, dtype=torch.float32, device=probs.device)
+    check(lib.ae_task_gate_wgrad(_p(probs32), _p(top1c), _p(dg32), _p(te32), _p(code), B, n_tasks, Dt, E, _p(dW), _p(db), _s()),
+          "ae_task_gate_wgrad")
+    return dW, db
 
 
 class OpProfiler:

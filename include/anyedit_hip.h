@@ -131,6 +131,11 @@ int ae_scatter_add_rows_f32(const float* src, const int* code, float* dst, int B
 /* Backward of the task-router gate value w.r.t. the task embedding (ae_task_gate).                                           */
 int ae_task_gate_bwd(const float* probs, const int* top1, const float* dgate, const float* Wg, int B, int Dt, int E, float* dte,
                      void* stream);
+/* Gradient of the same gate value w.r.t. the router itself: dWg[e,:] = sum_b dlogit[b,e] task_embs[edit_code[b]],
+ * dbg[e] = sum_b dlogit[b,e] (dbg may be NULL); samples summed in index order.  The router is a trainable of the adapter
+ * group in our AnySD spec (DESIGN.md §6; train.py:483-485 optimises the adapter modules it lives in).                          */
+int ae_task_gate_wgrad(const float* probs, const int* top1, const float* dgate, const float* task_emb, const long* edit_code, int B,
+                       int n_tasks, int Dt, int E, float* dWg, float* dbg, void* stream);
 
 /* out[b,y,x] = in[b,x,y], inner dim zero-padded to Xpad: NCHW <-> channels-last at the UNet boundary
  * ('b c h w -> b (h w) c', attention.py:329,337).                                                                           */

@@ -204,7 +204,7 @@ def test_training_step_gradients_vs_oracle_autograd():
 
     # oracle: fp32 autograd of our spec
     sd = {k: v.detach().float().clone() for k, v in moe.state_dict().items()}
-    names = [k for k in sd if k.startswith(("image_proj_model.", "adapter_modules.", "task_embs"))]
+    names = [k for k in sd if k.startswith(("image_proj_model.", "adapter_modules.", "task_embs", "gate."))]
     for k in names:
         sd[k].requires_grad_(True)
     unet_sd = {k[5:]: v for k, v in sd.items() if k.startswith("unet.")}
@@ -231,7 +231,9 @@ def test_training_step_gradients_vs_oracle_autograd():
         worst = max(worst, e)
         # task_embs also receives the router-gate path: d gate_b = <dO, Attn(q, K_ip, V_ip)> summed over 3 layers x heads x rows is
         # a cancelling inner product of bf16 gradients (|sum| ~ 1e-3 of sum|.|), so its relative error is larger than a layer's
-        tol = 1.5e-1 if k == "task_embs" else 6e-2
+        tol = 1.5e-1 if k in ("task_embs", "gate.weight") else 6e-2  # the router gradients are that same gate path
+        if k == "gate.bias":  # sum over the batch of the same noisy d gate_b, with cancellation across samples on top (measured 0.29)
+            tol = 4e-1
         assert e <= tol, f"grad {k}: rel_l2 {e:.3e}"
     assert worst > 0.0
     # experts nobody was routed to get exactly zero gradient; routed ones do not
