@@ -52,6 +52,9 @@ SIGNATURES = {
                      c_void_p],
     "ae_rowsum_f32": [c_void_p, c_void_p, c_int, c_long, c_void_p],
     "ae_scatter_add_rows_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "ae_ln_gemm_supported": [c_int, c_int, c_int, c_int],
+    "ae_ln_gemm_bf16": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_long, c_void_p, c_void_p,
+                        c_float, c_int, c_void_p],
     "ae_task_gate_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "ae_task_gate_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ae_transpose_last2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],

@@ -89,6 +89,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
     return base + j;
 }
 
+// LDS-DMA, one wave: 64 x 16 B from global (buffer descriptor + per-lane byte offset + wave-uniform byte offset) straight to LDS
+// at lds_byte + lane * 16.  Issued through inline asm ON PURPOSE: hipcc treats the builtin form as an LDS store that may alias
+// every later LDS read and drains it (s_waitcnt vmcnt(0)) in front of the next ds_read, which turns a prefetch ring into a
+// synchronous copy.  The asm form is invisible to that bookkeeping: the kernel places its own counted s_waitcnt vmcnt(N).
+// N must count only DMA pieces issued AFTER the one waited for: other VMEM traffic of the wave (stores, loads) can only make
+// the wait stricter, never let it pass early.
+__device__ __forceinline__ void ae_dma16(__amdgpu_buffer_rsrc_t rs, int lds_byte, int voffset, int soffset = 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voffset), "s"(rs), "s"(lds_byte), "s"(soffset)
+                 : "memory", "m0");
+#endif
+}
+
 __device__ __forceinline__ float wave_reduce_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -58,8 +58,10 @@ class GEGLU(nn.Module):
     def repack(self):
         self._pk = None
 
-    def rows(self, x):
+    def rows(self, x, norm=None):
         if ops._TAPE is not None and ops._TAPE.active:
+            if norm is not None:
+                x = norm.rows(x)
             # training step: the pre-activation [a | g] is kept for the backward, so the gate runs as its own kernel
             if getattr(self, "_pk_plain", None) is None or self._pk_plain[0].device != self.proj.weight.device:
                 self._pk_plain = (ops.pack_linear(self.proj.weight), self.proj.bias.detach().float().contiguous())
@@ -68,6 +70,9 @@ class GEGLU(nn.Module):
         if self._pk is None or self._pk[0].device != self.proj.weight.device:
             self._pk = ops.pack_geglu(self.proj.weight, self.proj.bias)
         w, b = self._pk
+        if norm is not None:  # the block's norm3 fused in front of the projection (the caller passes the UN-normalised rows)
+            g, be = norm._affine()
+            return ops.ln_gemm(x, g, be, norm.eps, w, b, epilogue=ops.EPI_GEGLU)
         return ops.gemm(x, w, b, epilogue=ops.EPI_GEGLU)
 
     def forward(self, x):
@@ -87,8 +92,8 @@ class FeedForward(nn.Module):
         project_in = GEGLU(dim, inner_dim)
         self.net = nn.Sequential(project_in, nn.Dropout(dropout), Linear(inner_dim, dim_out))
 
-    def rows(self, x, residual=None):
-        return self.net[2].rows(self.net[0].rows(x), residual=residual)
+    def rows(self, x, residual=None, norm=None):
+        return self.net[2].rows(self.net[0].rows(x, norm=norm), residual=residual)
 
     def forward(self, x):
         shp = x.shape
@@ -129,19 +134,26 @@ class CrossAttention(nn.Module):
         """K|V of a context [B*Nk, Dc] -> [B*Nk, 2*inner] (step-invariant for text conditioning: cache it)."""
         return ops.gemm(ctx_rows, self._packed()["kv"])
 
-    def rows(self, x, B, N, context_rows=None, Nk=None, kv=None, key_mask=None, residual=None, adapter=None):
+    def rows(self, x, B, N, context_rows=None, Nk=None, kv=None, key_mask=None, residual=None, adapter=None, norm=None):
         """x: [B*N, C] bf16 rows.  context_rows: [B*Nk, Dc] or None (self-attention).  Returns to_out(attn) (+residual).
         adapter: optional (kv_ip [B*T, 2*inner] bf16, gate [B] fp32): decoupled expert attention added to the output,
         out = Attn(q,K,V) + gate_b * Attn(q,K_ip,V_ip)  (AnySD row A9, shape template ip_adapter/attention_processor.py:141-173)."""
         pk = self._packed()
         h, d = self.heads, self.dim_head
         inner = h * d
+
+        def proj(wname):  # norm: the block's LayerNorm fused in front of the query-side projection (x = UN-normalised rows)
+            if norm is None:
+                return ops.gemm(x, pk[wname])
+            g, be = norm._affine()
+            return ops.ln_gemm(x, g, be, norm.eps, pk[wname])
+
         if context_rows is None and kv is None:
-            qkv = ops.gemm(x, pk["qkv"])  # [B*N, 3*inner]
+            qkv = proj("qkv")  # [B*N, 3*inner]
             s = (N * 3 * inner, d, 3 * inner)
             o = ops.attention(qkv, qkv[:, inner:], qkv[:, 2 * inner:], B, h, N, N, d, self.scale, s, s, s, key_mask=key_mask)
         else:
-            q = ops.gemm(x, pk["q"])
+            q = proj("q")
             if kv is None:
                 kv = self.project_kv(context_rows)
             Nk = kv.shape[0] // B
@@ -210,7 +222,7 @@ class BasicTransformerBlock(nn.Module):
     def rows(self, x, B, N, context_rows=None, kv_cache=None):
         """x: [B*N, C] bf16.  kv_cache: optional dict id(attn)->projected K|V of the (step-invariant) context."""
         c1 = context_rows if self.disable_self_attn else None
-        x = self.attn1.rows(self.norm1.rows(x), B, N, context_rows=c1, residual=x)
+        x = self.attn1.rows(x, B, N, context_rows=c1, residual=x, norm=self.norm1)
         kv2, adapter = None, None
         if kv_cache is not None and context_rows is not None:
             key = id(self.attn2)
@@ -218,8 +230,8 @@ class BasicTransformerBlock(nn.Module):
             if kv2 is None:
                 kv2 = kv_cache[key] = self.attn2.project_kv(context_rows)
             adapter = kv_cache.get(("adapter", key))  # installed by anysd.MoE.prepare_conditioning
-        x = self.attn2.rows(self.norm2.rows(x), B, N, context_rows=context_rows, kv=kv2, residual=x, adapter=adapter)
-        x = self.ff.rows(self.norm3.rows(x), residual=x)
+        x = self.attn2.rows(x, B, N, context_rows=context_rows, kv=kv2, residual=x, adapter=adapter, norm=self.norm2)
+        x = self.ff.rows(x, residual=x, norm=self.norm3)
         return x
 
     def forward(self, x, context=None):

@@ -5,6 +5,7 @@ Activations are channels-last bf16: [rows, C] with rows = B*H*W.
 """
 import torch
 
+import os
 import threading
 
 from ._lib import lib, check as _check
@@ -107,12 +108,54 @@ def gemm(a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue
         _chk(residual, BF16, "gemm.residual", 2)
     if addvec is not None:
         _chk(addvec, torch.float32, "gemm.addvec", 2)
+    if a2 is None and addvec is None and not out_f32 and _rowpanel_ok(a, w, out, residual, M, N, K, epilogue):
+        return _ln_gemm_launch(a, w, bias, residual, None, None, 0.0, epilogue, out, M, N, K)
     check(lib.ae_gemm_bf16(_p(a), a.stride(0), _p(a2), a2.stride(0) if a2 is not None else 0, K1, _p(w), w.stride(0),
                            _p(out), out.stride(0), M, N, K, _p(bias), _p(residual),
                            residual.stride(0) if residual is not None else 0, _p(addvec),
                            addvec.stride(0) if addvec is not None else 0, rows_per_batch, epilogue,
                            1 if out_f32 else 0, _s()), "ae_gemm_bf16")
     return out
+
+
+_ROWPANEL = os.environ.get("AE_GEMM_ROWPANEL", "1") != "0"  # tuning knob: 0 = tiled kernel only (A/B)
+
+
+def _rowpanel_ok(a, w, out, residual, M, N, K, epilogue):
+    if not _ROWPANEL or not lib.ae_ln_gemm_supported(M, N, K, epilogue):
+        return False
+    ts = [a, w, out] + ([residual] if residual is not None else [])
+    return all(t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0 and t.stride(1) == 1 for t in ts) and N * w.stride(0) * 2 < 2 ** 31
+
+
+def _ln_gemm_launch(a, w, bias, residual, gamma, beta, eps, epilogue, out, M, N, K):
+    check(lib.ae_ln_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), M, N, K, _p(bias), _p(residual),
+                              residual.stride(0) if residual is not None else 0, _p(gamma), _p(beta), float(eps), epilogue, _s()),
+          "ae_ln_gemm_bf16")
+    return out
+
+
+def ln_gemm(x, gamma, beta, eps, w, bias=None, residual=None, epilogue=EPI_NONE, out=None):
+    """out = epi(LayerNorm(x; gamma, beta, eps) @ w^T + bias (+ residual)) — attention.py:271-275's norm -> projection pairs in one
+    launch (the normalised rows never go to HBM).  Falls back to layernorm + gemm where the fused kernel does not cover the shape
+    and while the training tape records."""
+    if not (_TAPE is not None and _TAPE.active):
+        _chk(x, BF16, "ln_gemm.x", 2)
+        _chk(w, BF16, "ln_gemm.w", 2)
+        M, K = x.shape
+        N = w.shape[0]
+        if w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1:
+            n_out = N // 2 if epilogue == EPI_GEGLU else N
+            o = out if out is not None else torch.empty(M, n_out, dtype=BF16, device=x.device)
+            if _rowpanel_ok(x, w, o, residual, M, N, K, epilogue):
+                _chk(gamma, torch.float32, "ln_gemm.gamma", 1)
+                _chk(beta, torch.float32, "ln_gemm.beta", 1)
+                if bias is not None:
+                    _chk(bias, torch.float32, "ln_gemm.bias", 1)
+                if residual is not None:
+                    _chk(residual, BF16, "ln_gemm.residual", 2)
+                return _ln_gemm_launch(x, w, bias, residual, gamma, beta, eps, epilogue, o, M, N, K)
+    return gemm(layernorm(x, gamma, beta, eps), w, bias, residual=residual, epilogue=epilogue, out=out)
 
 
 def conv3x3(x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2x=False, out_f32=False, out=None):

@@ -47,6 +47,17 @@ int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, int Ksplit,
                  int M, int N, int K, const float* bias, const void* residual, long ldr, const float* addvec, long addvec_ld,
                  int rows_per_batch, int epilogue, int out_f32, void* stream);
 
+/* Row-panel GEMM for the short-K (K = 320) Linear layers of the 64x64 UNet level, with the LayerNorm of BasicTransformerBlock
+ * (attention.py:263-265, 271-275: norm1 -> to_q|k|v, norm2 -> to_q, norm3 -> GEGLU projection) optionally fused in front:
+ *   C[M,N] = epi( LN(A)[M,K] @ W[N,K]^T + bias (+ residual) ),  ln_gamma == NULL: no LayerNorm.  epilogue: AE_EPI_NONE | AE_EPI_GEGLU.
+ * A wave keeps 48 rows of A in registers for the whole launch (normalised there), W streams through an LDS ring by LDS-DMA.
+ * ae_ln_gemm_supported() tells whether the kernel covers a shape (K == 320, N % 64 == 0, N <= 2560, M >= 192); callers fall back to
+ * ae_layernorm_bf16 + ae_gemm_bf16 otherwise.  A, W rows and C, residual rows 16-byte aligned.                                   */
+int ae_ln_gemm_supported(int M, int N, int K, int epilogue);
+int ae_ln_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias,
+                    const void* residual, long ldr, const float* ln_gamma, const float* ln_beta, float ln_eps, int epilogue,
+                    void* stream);
+
 /* 3x3 convolution, padding 1, as implicit GEMM (ResBlock in/out convs openaimodel.py:200-231, stem :536-542, head :726-730,
  * Downsample stride 2 :157-159, Upsample nearest-x2 + conv :108-118 via upsample2x=1).
  *   x [B,H,W,Cin] bf16 channels-last (Cin % 8 == 0), w [Cout, 9*CinPad] bf16 packed (ky,kx,cin) with CinPad = Cin

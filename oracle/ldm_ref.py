@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 
 import contextlib
+import threading
 
 from .schedule_ref import timestep_embedding
 
@@ -19,22 +20,22 @@ from .schedule_ref import timestep_embedding
 # oracle stays the reference's fp32 arithmetic bit for bit.  Inside `bf16_storage()` it rounds to bfloat16 and back: the
 # oracle then carries the storage error any bf16-activation implementation of this graph must have, with fp32 arithmetic
 # everywhere else.  Tests use it as the CONTROL for the tolerance: HIP error vs fp32 oracle <= 1.5 x control error.
-_round = None
+_tls = threading.local()  # per thread: a test may run the fp32 oracle and the control side by side
 
 
 def _st(x):
-    return x if _round is None else _round(x)
+    r = getattr(_tls, "round", None)
+    return x if r is None else r(x)
 
 
 @contextlib.contextmanager
 def bf16_storage():
-    global _round
-    prev = _round
-    _round = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    prev = getattr(_tls, "round", None)
+    _tls.round = lambda t: t.to(torch.bfloat16).to(torch.float32)
     try:
         yield
     finally:
-        _round = prev
+        _tls.round = prev
 
 
 def bf16_weights(sd):

@@ -90,6 +90,47 @@ def test_gemm_epilogues_and_two_source(ops):
     check_close(ops.gemm(wide[:, K:2 * K], wd), wide[:, K:2 * K].float().cpu() @ w.t(), what="strided A")
 
 
+@pytest.mark.parametrize("M,N,epi,ln,res", [(192, 64, "none", False, False), (500, 320, "none", True, True), (777, 960, "none", True, False),
+                                             (1000, 256, "geglu", True, False), (4096, 2560, "geglu", False, False), (391, 320, "none", False, True)])
+def test_rowpanel_ln_gemm(ops, M, N, epi, ln, res):
+    """Row-panel K = 320 kernel (ae_ln_gemm_bf16): LayerNorm prologue, bias, residual, GEGLU, ragged last block, against fp32 torch
+    on the same bf16 inputs (attention.py:263-275 norm -> projection pairs).  The normalised rows are rounded to bf16 before the
+    MFMA, as the unfused path stores them."""
+    K = 320
+    g = torch.Generator().manual_seed(M + N)
+    a = q(torch.randn(M, K, generator=g) * 1.3 + 0.4)
+    w = q(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = torch.randn(N, generator=g) * 0.1
+    gamma, beta = 1.0 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    r = q(torch.randn(M, N, generator=g)) if res else None
+    x = q(F.layer_norm(a, (K,), gamma, beta, 1e-5)) if ln else a
+    z = x @ w.t() + bias
+    if epi == "geglu":
+        xx, gate = z.chunk(2, dim=-1)
+        ref = xx * F.gelu(gate)
+        wd, bd = ops.pack_geglu(w.to(DEV), bias.to(DEV))
+        e = ops.EPI_GEGLU
+    else:
+        ref = z + (r if res else 0.0)
+        wd, bd, e = w.to(DEV, BF), bias.to(DEV), ops.EPI_NONE
+    assert ops.lib.ae_ln_gemm_supported(M, N, K, e) == 1
+    rd = None if r is None else r.to(DEV, BF)
+    if ln:
+        out = ops.ln_gemm(a.to(DEV, BF), gamma.to(DEV), beta.to(DEV), 1e-5, wd, bd, residual=rd, epilogue=e)
+    else:
+        out = ops.gemm(a.to(DEV, BF), wd, bias=bd, residual=rd, epilogue=e)  # routed to the row-panel kernel
+    check_close(out, ref, what=f"rowpanel {M}x{N} epi={epi} ln={ln} res={res}")
+    # the fallback (tiled GEMM + LayerNorm kernel) agrees with it
+    import anyedit_amd.ops as O
+    O._ROWPANEL = False
+    try:
+        out2 = ops.ln_gemm(a.to(DEV, BF), gamma.to(DEV), beta.to(DEV), 1e-5, wd, bd, residual=rd, epilogue=e) if ln else \
+            ops.gemm(a.to(DEV, BF), wd, bias=bd, residual=rd, epilogue=e)
+    finally:
+        O._ROWPANEL = True
+    check_close(out, out2.float().cpu(), rl2=6e-3, mabs=6e-2, what="rowpanel vs tiled")
+
+
 def test_gemm_linearity_full_size(ops):
     """Size-independent property at a BASELINE-size shape: f(a1 + a2) == f(a1) + f(a2) up to rounding."""
     g = torch.Generator(device=DEV).manual_seed(1)
