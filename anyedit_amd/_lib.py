@@ -52,6 +52,9 @@ SIGNATURES = {
                      c_void_p],
     "ae_rowsum_f32": [c_void_p, c_void_p, c_int, c_long, c_void_p],
     "ae_scatter_add_rows_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "ae_attn_fp8_workspace_bytes": [c_int, c_int, c_int, c_int, c_int],
+    "ae_attn_fwd_fp8": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int] + [c_long] * 12 +
+                       [c_float, c_void_p, c_void_p, c_int, c_int, c_void_p, c_long, c_void_p],
     "ae_ln_gemm_supported": [c_int, c_int, c_int, c_int],
     "ae_ln_gemm_bf16": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_long, c_void_p, c_void_p,
                         c_float, c_int, c_void_p],
@@ -88,7 +91,7 @@ SIGNATURES = {
     "ae_task_gate": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
 }
 _RESTYPES = {"ae_last_error": ctypes.c_char_p, "ae_groupnorm_workspace_floats": c_long, "ae_conv3x3_workspace_floats": c_long,
-             "ae_groupnorm_bwd_workspace_floats": c_long}
+             "ae_groupnorm_bwd_workspace_floats": c_long, "ae_attn_fp8_workspace_bytes": c_long}
 
 
 class AnyEditHipError(RuntimeError):

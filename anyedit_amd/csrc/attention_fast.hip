@@ -71,7 +71,7 @@ __device__ __forceinline__ bf16x8_t cat_tr(s16x4v lo, s16x4v hi) {
 __device__ unsigned long long g_attn_dbg[4];  // lab only: sum of per-block shader cycles, 100 MHz ticks, blocks
 #endif
 
-template <int D, int OCC, bool SEG2 = false, int ABL = 0>
+template <int D, int OCC, bool SEG2 = false, int ABL = 0, bool BIAS2 = false>
 __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     static_assert(D % 8 == 0 && D <= 96, "head_dim: multiple of 8, <= 96");
     constexpr int KS = (D + 15) / 16;        // K=16 steps of S^T = K Q^T
@@ -135,6 +135,26 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     f32x16 cinit;  // !QSLOT: the offset enters through the C operand
 #pragma unroll
     for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
+    // BIAS2: decomposed rel-pos bias whose key grid has one ROW per 64-key tile (kW == 64: SAM's global attention,
+    // image_encoder.py:325-361): rel_w[q, kw] * log2e of this lane's 2 x 16 key columns stays in registers, rel_h[q, kh] is one
+    // value per tile; both enter S' through the MFMA's C operand (one v_add per logit, no per-element index arithmetic)
+    static_assert(!BIAS2 || (!QSLOT && !SEG2), "the rel-pos variant is built for head dims that are multiples of 16, one segment");
+    f32x16 wb[BIAS2 ? 2 : 1];
+    const float* rh_row = nullptr;
+    float rh_tile = 0.f;
+    if (BIAS2) {
+        const long qc = (long)bh * p.Nq + min(q0 + l31, p.Nq - 1);
+        const float* row = p.rel_w + qc * p.kW;
+        rh_row = p.rel_h + qc * p.kH;
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(row + 32 * b2 + 8 * r4 + 4 * hi);
+                wb[BIAS2 ? b2 : 0][4 * r4] = t[0] * FLOG2E; wb[BIAS2 ? b2 : 0][4 * r4 + 1] = t[1] * FLOG2E;
+                wb[BIAS2 ? b2 : 0][4 * r4 + 2] = t[2] * FLOG2E; wb[BIAS2 ? b2 : 0][4 * r4 + 3] = t[3] * FLOG2E;
+            }
+    }
     float mt = 0.f;  // m~ (log2 units, always bf16-representable): S' = c q.k - m~
     f32x16 o[NDB];
 #pragma unroll
@@ -166,6 +186,12 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] = 0.f;
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[ks]), z, 0, 0, 0);
+            } else if (BIAS2 && ks == 0) {
+                f32x16 c0;
+                const float hb = rh_tile - mt;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c0[r] = wb[BIAS2 ? B2 : 0][r] + hb;
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[ks]), c0, 0, 0, 0);
             } else {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[ks]), ks == 0 ? cinit : s, 0, 0, 0);
             }
@@ -277,6 +303,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
             vcur = vaddr + boff;
             vlast = ones_lane ? ONES_OFF + vrow * ROWB : (zero_lane ? ONES_OFF + vrow * ROWB + 8 : vcur + LDB * 64);
             const bool tail = (t + 1) * FKT > seg_nk;
+            if (BIAS2) rh_tile = rh_row[t] * FLOG2E;
             block(std::integral_constant<int, 0>{}, t * FKT, t == 0, tail);
             if (t * FKT + 32 < seg_nk) block(std::integral_constant<int, 1>{}, t * FKT, false, tail);
         }
@@ -344,6 +371,12 @@ int launch_fast(const AttnArgs& a, hipStream_t stream) {
 #define AE_ABL(n) if (abl == n) { hipLaunchKernelGGL((attn_fast_kernel<D, 3, false, n>), grid, block, 0, stream, a); return ae_check_launch("abl"); }
     AE_ABL(1) AE_ABL(2) AE_ABL(3) AE_ABL(4) AE_ABL(5) AE_ABL(10) AE_ABL(11) AE_ABL(12)
 #endif
+    if constexpr (D % 16 == 0) {
+        if (a.rel_h) {
+            hipLaunchKernelGGL((attn_fast_kernel<D, 2, false, 0, true>), grid, block, 0, stream, a);
+            return ae_check_launch("ae_attn_fwd_bf16(fast, rel-pos)");
+        }
+    }
     if (a.k2) hipLaunchKernelGGL((attn_fast_kernel<D, 3, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((attn_fast_kernel<D, 3, false>), grid, block, 0, stream, a);
     return ae_check_launch("ae_attn_fwd_bf16(fast)");
@@ -352,7 +385,9 @@ int launch_fast(const AttnArgs& a, hipStream_t stream) {
 }  // namespace
 
 int ae_attn_fast_launch(const AttnArgs& a, int D, hipStream_t stream) {
-    if (a.rel_h || a.key_mask || a.lse || a.lse2) return AE_ERR_UNSUPPORTED;
+    if (a.key_mask || a.lse || a.lse2) return AE_ERR_UNSUPPORTED;
+    // rel-pos bias: only the one-key-row-per-tile form (kW == 64, SAM global attention) at head dims that are multiples of 16
+    if (a.rel_h && !(a.kW == FKT && a.Nk % FKT == 0 && D % 16 == 0 && !a.k2 && !a.accum && !a.out_scale)) return AE_ERR_UNSUPPORTED;
     if (a.k2 && (a.accum || a.out_scale)) return AE_ERR_UNSUPPORTED;
     // 32-bit byte offsets inside one (batch, head) image of K / V
     if (((long)a.Nk * a.k_sn + D) * 2 >= (1L << 31) || ((long)a.Nk * a.v_sn + D) * 2 >= (1L << 31)) return AE_ERR_UNSUPPORTED;

@@ -154,7 +154,7 @@ def ln_gemm(x, gamma, beta, eps, w, bias=None, residual=None, epilogue=EPI_NONE,
                     _chk(bias, torch.float32, "ln_gemm.bias", 1)
                 if residual is not None:
                     _chk(residual, BF16, "ln_gemm.residual", 2)
-                return _ln_gemm_launch(x, w, bias, residual, gamma, beta, eps, epilogue, o, M, N, K)
+                return _ln_gemm_fused(x, w, bias, residual, gamma, beta, eps, epilogue, o, M, N, K)
     return gemm(layernorm(x, gamma, beta, eps), w, bias, residual=residual, epilogue=epilogue, out=out)
 
 
@@ -237,6 +237,32 @@ def attention(q, k, v, B, H, Nq, Nk, D, scale, q_strides, k_strides, v_strides, 
     check(lib.ae_attn_fwd_bf16(_p(q), _p(k), _p(v), _p(out), B, H, Nq, Nk, D, *q_strides, *k_strides, *v_strides, *o_strides,
                                scale, _p(rel_h), _p(rel_w), kH, kW, _p(key_mask), _p(out_scale), 1 if accumulate else 0,
                                *seg_args, _p(lse), _p(lse2), _s()), "ae_attn_fwd_bf16")
+    return out
+
+
+_FP8_WS = {}
+
+
+def attention_fp8(q, k, v, B, H, Nq, Nk, D, scale, q_strides, k_strides, v_strides, out=None, rel_h=None, rel_w=None, kH=0, kW=0):
+    """fp8 (e4m3) attention forward (ae_attn_fwd_fp8): same arguments as `attention` for the no-mask / single-segment case; the
+    rel-pos bias path needs kW == 64 (SAM global attention).  Accuracy is that of e4m3 operands: rel-L2 ~5e-2 against the fp32
+    reference at unit-variance logits (tests/test_hip_ops.py)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t, BF16, "attention_fp8." + n)
+    if out is None:
+        out = torch.empty(B, Nq, H * D, dtype=BF16, device=q.device)
+    need = lib.ae_attn_fp8_workspace_bytes(B, H, Nq, Nk, D)
+    if need <= 0:
+        raise ValueError(f"attention_fp8: unsupported sizes B={B} H={H} Nq={Nq} Nk={Nk} D={D}")
+    key = (q.device, torch.cuda.current_stream(q.device).cuda_stream)
+    ws = _FP8_WS.get(key)
+    if ws is None or ws.numel() < need:  # grow-only scratch per (device, stream): the call owns it until the next call on that stream
+        ws = _FP8_WS[key] = torch.empty(need, dtype=torch.uint8, device=q.device)
+    if rel_h is not None:
+        _chk(rel_h, torch.float32, "attention_fp8.rel_h")
+        _chk(rel_w, torch.float32, "attention_fp8.rel_w")
+    check(lib.ae_attn_fwd_fp8(_p(q), _p(k), _p(v), _p(out), B, H, Nq, Nk, D, *q_strides, *k_strides, *v_strides, Nq * H * D, D, H * D,
+                              float(scale), _p(rel_h), _p(rel_w), kH, kW, _p(ws), ws.numel(), _s()), "ae_attn_fwd_fp8")
     return out
 
 
@@ -825,6 +851,8 @@ def _wrap_profiled(fn, label_fn):
 def _gemm_label(_r, a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue=EPI_NONE, out_f32=False, a2=None, **_):
     M, (N, K) = a.shape[0], w.shape
     nb = 2 * (M * K + N * K) + _r.numel() * _r.element_size() + (2 * M * N if residual is not None else 0)
+    if a2 is None and addvec is None and not out_f32 and _rowpanel_ok(a, w, _r, residual, M, N, K, epilogue):
+        return f"gemm_rowpanel_kernel<K=320{',geglu' if epilogue == EPI_GEGLU else ''}>|M={M} N={N}", 2.0 * M * N * K, nb
     return f"gemm_kernel<{_tile_label(M, N, False, K, epilogue == EPI_GEGLU, K % 64 == 0 and a2 is None)},dense>|M={M} N={N} K={K}", 2.0 * M * N * K, float(nb)
 
 
@@ -835,8 +863,16 @@ def _conv_label(_r, x, w, bias, B, H, W, addvec=None, residual=None, stride=1, u
     return f"gemm_kernel<{_tile_label(M, Cout, True, 9 * (-(-Cin // 64) * 64), False, Cin % 64 == 0)},conv3x3>|M={M} Cin={Cin} Cout={Cout} s{stride}{'u' if upsample2x else ''}", 2.0 * M * Cout * 9 * Cin, float(nb)
 
 
-def _attn_label(_r, q, k, v, B, H, Nq, Nk, D, *a, **_):
-    return f"attn_kernel<D={D}>|Nq={Nq} Nk={Nk}", 4.0 * B * H * Nq * Nk * D, 2.0 * B * H * D * (2 * Nq + 2 * Nk)
+def _attn_label(_r, q, k, v, B, H, Nq, Nk, D, *a, **kw):
+    # attention_fast.hip takes head dims 40 / 80 without mask / log-sum-exp outputs (rel-pos bias only in its kW == 64 form)
+    fast = D in (40, 80) and kw.get("key_mask") is None and kw.get("lse") is None and os.environ.get("AE_ATTN_FAST", "1") != "0" and \
+        (kw.get("rel_h") is None or (D == 80 and kw.get("kW") == 64 and Nk % 64 == 0))
+    name = "attn_fast_kernel" if fast else "attn_kernel"
+    return f"{name}<D={D}>|Nq={Nq} Nk={Nk}", 4.0 * B * H * Nq * Nk * D, 2.0 * B * H * D * (2 * Nq + 2 * Nk)
+
+
+def _attn8_label(_r, q, k, v, B, H, Nq, Nk, D, *a, **kw):
+    return f"fp8_attn_kernel<D={D}>+prepare|Nq={Nq} Nk={Nk}", 4.0 * B * H * Nq * Nk * D, 2.0 * B * H * D * (2 * Nq + 2 * Nk)
 
 
 def _gn_label(_r, x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, **_):
@@ -847,7 +883,14 @@ def _ln_label(_r, x, *a, **_):
     return f"layernorm_kernel|M={_r.shape[0]} C={_r.shape[1]}", 0.0, 2.0 * _r.numel() * 2
 
 
+def _ln_gemm_label(_r, x, w, bias, residual, gamma, beta, eps, epilogue, o, M, N, K):
+    nb = 2 * (M * K + N * K) + _r.numel() * 2 + (2 * M * N if residual is not None else 0)
+    return f"gemm_rowpanel_kernel<K=320,LN{',geglu' if epilogue == EPI_GEGLU else ''}>|M={M} N={N}", 2.0 * M * N * K, nb
+
+
+_ln_gemm_fused = _wrap_profiled(_ln_gemm_launch, _ln_gemm_label)
 gemm = _wrap_profiled(gemm, _gemm_label)
+attention_fp8 = _wrap_profiled(attention_fp8, _attn8_label)
 conv3x3 = _wrap_profiled(conv3x3, _conv_label)
 attention = _wrap_profiled(attention, _attn_label)
 groupnorm = _wrap_profiled(groupnorm, _gn_label)

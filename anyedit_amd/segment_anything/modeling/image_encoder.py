@@ -15,6 +15,7 @@ from anyedit_amd import ops
 from anyedit_amd.ldm.modules.diffusionmodules.util import Linear, Conv2d, LayerNorm
 
 BF16 = torch.bfloat16
+_ENV_FP8 = __import__("os").environ.get("AE_SAM_ATTN", "") == "fp8"
 
 
 class MLPBlock(nn.Module):
@@ -85,6 +86,7 @@ class Attention(nn.Module):
             self.rel_pos_h = nn.Parameter(torch.zeros(2 * input_size[0] - 1, head_dim))
             self.rel_pos_w = nn.Parameter(torch.zeros(2 * input_size[1] - 1, head_dim))
         self._rp = None
+        self.attn_fp8 = False
 
     def repack(self):
         self._rp = None
@@ -106,8 +108,14 @@ class Attention(nn.Module):
         if self.use_rel_pos:
             Rh, Rw = self._rel_tables(H, W)
             rel_h, rel_w = ops.sam_relpos_terms(qkv, s, Rh, Rw, B, h, H, W, d)  # from the UNSCALED q (G13)
-        o = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B, h, N, N, d, self.scale, s, s, s, rel_h=rel_h, rel_w=rel_w,
-                          kH=H if self.use_rel_pos else 0, kW=W if self.use_rel_pos else 0)
+        # fp8 (e4m3) operands for the global-attention blocks (BASELINE.json configs[4]): opt-in — set `attn_fp8 = True` on the module or
+        # AE_SAM_ATTN=fp8 in the environment; covers key grids of width 64 (ae_attn_fwd_fp8), everything else stays bf16
+        if (self.attn_fp8 or _ENV_FP8) and (not self.use_rel_pos or W == 64) and d % 8 == 0 and d <= 88:
+            o = ops.attention_fp8(qkv, qkv[:, C:], qkv[:, 2 * C:], B, h, N, N, d, self.scale, s, s, s, rel_h=rel_h, rel_w=rel_w,
+                                  kH=H if self.use_rel_pos else 0, kW=W if self.use_rel_pos else 0)
+        else:
+            o = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B, h, N, N, d, self.scale, s, s, s, rel_h=rel_h, rel_w=rel_w,
+                              kH=H if self.use_rel_pos else 0, kW=W if self.use_rel_pos else 0)
         return self.proj.rows(o.reshape(B * N, C), residual=residual)
 
     def forward(self, x):

@@ -94,6 +94,17 @@ int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, void* out, int
                      const unsigned char* key_mask, const float* out_scale, int accumulate, const void* k2, const void* v2,
                      int Nk2, long k2_sb, long k2_sh, long k2_sn, long v2_sb, long v2_sh, long v2_sn, const float* scale2,
                      float* lse, float* lse2, void* stream);
+/* fp8 (OCP e4m3) attention forward (BASELINE.json configs[4], SAM image-encoder attention image_encoder.py:224-240, rel-pos bias
+ * :325-361): Q, K, V and the probabilities are e4m3 operands of v_mfma_scale_f32_32x32x64_f8f6f4, logits / softmax / accumulation
+ * fp32.  Scales: per (batch, head) amax of q, k, v measured on the fly (k: float scale folded into q; q and v: powers of two that
+ * ride in the MFMA's E8M0 scale operand / the final normalisation).  head_dim % 8 == 0, <= 88.  rel_h / rel_w (optional): the
+ * decomposed bias for key grids with kW == 64 (global attention on 64 x 64 tokens).  `workspace`: device scratch of at least
+ * ae_attn_fp8_workspace_bytes(...) bytes, 256-byte aligned (quantised operands live there for the duration of the call).         */
+long ae_attn_fp8_workspace_bytes(int B, int H, int Nq, int Nk, int D);
+int ae_attn_fwd_fp8(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int D, long q_sb, long q_sh,
+                    long q_sn, long k_sb, long k_sh, long k_sn, long v_sb, long v_sh, long v_sn, long o_sb, long o_sh, long o_sn,
+                    float scale, const float* rel_h, const float* rel_w, int kH, int kW, void* workspace, long workspace_bytes,
+                    void* stream);
 /* lse / lse2 (optional, fp32 [B,H,Nq]): log2-domain log-sum-exp of the first / second segment's softmax, kept for
  * ae_attn_bwd_bf16.
  *

@@ -306,6 +306,34 @@ def test_attention_core(ops, BH, Nq, Nk, D):
     check_close(out, ref, rl2=6e-3, what=f"attention {BH}x{Nq}x{Nk}x{D}")
 
 
+@pytest.mark.parametrize("BH,Nq,Nk,bias", [(4, 256, 256, False), (2, 200, 190, False), (2, 384, 4096, True)])
+def test_attention_fp8(ops, BH, Nq, Nk, bias):
+    """fp8 (e4m3) attention (ae_attn_fwd_fp8, BASELINE.json configs[4]) against fp32 softmax attention on the same bf16 inputs, with
+    and without the SAM rel-pos bias (image_encoder.py:224-240, 325-361).  Tolerance = what e4m3 operands cost: a 3-bit mantissa on
+    q, k, v and on the probabilities gives rel-L2 ~5e-2 at unit-variance logits (measured 5.2e-2 / 5.3e-2 / 5.3e-2); the bf16
+    kernel's bound on the same inputs is 6e-3."""
+    from oracle import ldm_ref as L
+    D = 80
+    g = torch.Generator().manual_seed(BH * 5 + Nq)
+    qq, kk, vv = (q(torch.randn(BH, n, D, generator=g)) for n in (Nq, Nk, Nk))
+    b = None
+    rel_h = rel_w = None
+    kH, kW = 0, 0
+    if bias:
+        kW, kH = 64, Nk // 64
+        rel_h, rel_w = torch.randn(BH, Nq, kH, generator=g), torch.randn(BH, Nq, kW, generator=g)
+        b = (rel_h[:, :, :, None] + rel_w[:, :, None, :]).reshape(BH, Nq, Nk)
+    ref = L.sdpa_core(qq, kk, vv, D ** -0.5, bias=b)
+    out = ops.attention_fp8(qq.to(DEV, BF), kk.to(DEV, BF), vv.to(DEV, BF), BH, 1, Nq, Nk, D, D ** -0.5, (Nq * D, 0, D), (Nk * D, 0, D), (Nk * D, 0, D),
+                            rel_h=None if rel_h is None else rel_h.to(DEV), rel_w=None if rel_w is None else rel_w.to(DEV), kH=kH, kW=kW)
+    e = rel_l2(out.reshape(BH, Nq, D).float().cpu(), ref)
+    assert np.isfinite(e) and e <= 8e-2, f"fp8 attention rel-L2 {e:.3e}"
+    # and it is a genuinely different operator from the bf16 one (guards against a silent bf16 fallback)
+    out16 = ops.attention(qq.to(DEV, BF), kk.to(DEV, BF), vv.to(DEV, BF), BH, 1, Nq, Nk, D, D ** -0.5, (Nq * D, 0, D), (Nk * D, 0, D), (Nk * D, 0, D),
+                          rel_h=None if rel_h is None else rel_h.to(DEV), rel_w=None if rel_w is None else rel_w.to(DEV), kH=kH, kW=kW)
+    assert rel_l2(out16.reshape(BH, Nq, D).float().cpu(), ref) < 0.5 * e
+
+
 def test_attention_rescale_branch_forced(ops):
     """A spiked key late in the sequence forces the online-softmax running max to jump (rescale of O and l)."""
     from oracle import ldm_ref as L

@@ -67,6 +67,31 @@ def main():
                        for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])},
            "by_shape": {k: {"calls": v["calls"], "avg_us": v["avg_us"], "tflops": v["tflops"]}
                         for k, v in sorted(by_shape.items(), key=lambda kv: -kv[1]["ms"])[:12]}}
+    # ---- configs[4]: the same encoder with e4m3 attention operands in the global-attention blocks (ae_attn_fwd_fp8)
+    from anyedit_amd.segment_anything.modeling.image_encoder import Attention
+    with torch.no_grad():
+        for m in enc.modules():
+            if isinstance(m, Attention):
+                m.attn_fp8 = True
+        y8 = enc(x)
+        torch.cuda.synchronize()
+        t8 = []
+        for _ in range(a.iters):
+            t0 = time.perf_counter()
+            y8 = enc(x)
+            torch.cuda.synchronize()
+            t8.append(time.perf_counter() - t0)
+        t8.sort()
+        with ops.OpProfiler() as prof8:
+            enc(x)
+        for m in enc.modules():
+            if isinstance(m, Attention):
+                m.attn_fp8 = False
+    d8 = float((y8.float() - y.float()).norm() / y.float().norm())
+    out["fp8_attention"] = {"what": "global-attention blocks (4 of 32) with e4m3 q/k/v/p (ae_attn_fwd_fp8); windowed blocks stay bf16",
+                            "latency_ms_p50_eager": 1e3 * t8[len(t8) // 2], "encoder_output_rel_l2_vs_bf16_attention": d8,
+                            "attention_by_shape": {k: {"calls": v["calls"], "avg_us": v["avg_us"], "tflops": v["tflops"]}
+                                                   for k, v in prof8.summary(by_shape=True).items() if "attn" in k}}
     if a.parity:
         # full-size parity of the HIP encoder against the oracle restatement (test infrastructure; here only as the checker)
         from oracle import sam_ref as M
