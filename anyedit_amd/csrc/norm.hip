@@ -211,6 +211,134 @@ __global__ void gn_apply_kernel(const GNArgs p) {
     }
 }
 
+// ---- Single-launch GroupNorm for the small feature maps (16x16 and below): one block owns the whole slab of GP groups of one
+// sample — HW rows x (GP * C/groups) channels, at most 16 16-byte pieces per thread — and keeps it in REGISTERS: one read of the
+// activation, exact two-pass statistics (mean, then centred sum of squares), normalise + SiLU, one write.  Replaces the
+// stats / finalize / apply launches (3 passes over the data, 15-20 us for 2-15 MB) where the tensor is too small to fill the
+// chip per launch anyway.  GP = 1, 2 or 4 groups per block makes the slab's row segment a multiple of 16 bytes.
+template <int MAXCH, int GP>
+__global__ __launch_bounds__(1024) void gn_slab_kernel(const GNArgs p, int ncc, int cpg) {
+    __shared__ float red[16][GP];
+    __shared__ float bc[2][GP];
+    const int tid = threadIdx.x, T = blockDim.x, nw = T >> 6;
+    const int b = blockIdx.y, ch0 = blockIdx.x * GP * cpg;  // first channel of the pack (multiple of 8)
+    const int total = p.HW * ncc;
+    u32x4 v[MAXCH];
+    int grp[MAXCH];  // packed 3 bits per element: group (0..GP-1) of each of the 8 channels of the piece
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        const int i = tid + k * T;
+        const int ii = min(i, total - 1);
+        const int row = ii / ncc, cc = ii - row * ncc;
+        v[k] = gn_load(p, (long)b * p.HW + row, ch0 / 8 + cc);
+        int gbits = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cc * 8 + e;
+            const int gi = GP == 1 ? 0 : ((c >= cpg) + (GP > 2 ? (c >= 2 * cpg) + (c >= 3 * cpg) : 0));
+            gbits |= gi << (3 * e);
+        }
+        grp[k] = i < total ? gbits : -1;
+    }
+    auto block_sum = [&](float (&acc)[GP], int slot) {  // -> bc[slot][g] = sum over the block, fixed order (deterministic)
+#pragma unroll
+        for (int gi = 0; gi < GP; ++gi) acc[gi] = wave_reduce_sum(acc[gi]);
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int gi = 0; gi < GP; ++gi) red[tid >> 6][gi] = acc[gi];
+        }
+        __syncthreads();
+        if (tid < GP) {
+            float t = 0.f;
+            for (int w = 0; w < nw; ++w) t += red[w][tid];
+            bc[slot][tid] = t;
+        }
+        __syncthreads();
+    };
+    const float inv_n = 1.0f / ((float)cpg * (float)p.HW);
+    float acc[GP];
+#pragma unroll
+    for (int gi = 0; gi < GP; ++gi) acc[gi] = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        if (grp[k] < 0) continue;
+        const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = (e & 1) ? bf16hi(w[e >> 1]) : bf16lo(w[e >> 1]);
+            const int gi = (grp[k] >> (3 * e)) & 7;
+#pragma unroll
+            for (int q = 0; q < GP; ++q) acc[q] += (gi == q) ? x : 0.f;
+        }
+    }
+    block_sum(acc, 0);
+    float mu[GP];
+#pragma unroll
+    for (int gi = 0; gi < GP; ++gi) { mu[gi] = bc[0][gi] * inv_n; acc[gi] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        if (grp[k] < 0) continue;
+        const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = (e & 1) ? bf16hi(w[e >> 1]) : bf16lo(w[e >> 1]);
+            const int gi = (grp[k] >> (3 * e)) & 7;
+#pragma unroll
+            for (int q = 0; q < GP; ++q) {
+                const float d = x - mu[q];
+                acc[q] += (gi == q) ? d * d : 0.f;
+            }
+        }
+    }
+    block_sum(acc, 1);
+    float rs[GP];
+#pragma unroll
+    for (int gi = 0; gi < GP; ++gi) rs[gi] = rsqrtf(bc[1][gi] * inv_n + p.eps);
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) {
+        if (grp[k] < 0) continue;
+        const int i = tid + k * T;
+        const int row = i / ncc, cc = i - row * ncc;
+        const int ch = ch0 + cc * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + ch), g1 = *reinterpret_cast<const f32x4*>(p.gamma + ch + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + ch), b1 = *reinterpret_cast<const f32x4*>(p.beta + ch + 4);
+        const float gm[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+        const float bt[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = (e & 1) ? bf16hi(w[e >> 1]) : bf16lo(w[e >> 1]);
+            const int gi = (grp[k] >> (3 * e)) & 7;
+            float m = mu[0], r = rs[0];
+#pragma unroll
+            for (int q = 1; q < GP; ++q) { m = (gi == q) ? mu[q] : m; r = (gi == q) ? rs[q] : r; }
+            const float sc = gm[e] * r;
+            float y = (x - m) * sc + bt[e];
+            if (p.act == 1) y = silu_f(y);
+            o[e] = y;
+        }
+        *reinterpret_cast<u32x4*>(p.y + ((long)b * p.HW + row) * p.C + ch) =
+            (u32x4){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+    }
+}
+
+template <int GP>
+bool launch_gn_slab(const GNArgs& p, int cpg, hipStream_t s) {
+    const int ncc = GP * cpg / 8;
+    const long total = (long)p.HW * ncc;
+    int T = 256;
+    while (T < 1024 && total > (long)T * 8) T *= 2;   // aim at <= 8 pieces per thread, at most 16
+    const long per = (total + T - 1) / T;
+    if (per > 16) return false;
+    dim3 grid(p.groups / GP, p.B);
+    if (per <= 2) hipLaunchKernelGGL((gn_slab_kernel<2, GP>), grid, dim3(T), 0, s, p, ncc, cpg);
+    else if (per <= 4) hipLaunchKernelGGL((gn_slab_kernel<4, GP>), grid, dim3(T), 0, s, p, ncc, cpg);
+    else if (per <= 8) hipLaunchKernelGGL((gn_slab_kernel<8, GP>), grid, dim3(T), 0, s, p, ncc, cpg);
+    else hipLaunchKernelGGL((gn_slab_kernel<16, GP>), grid, dim3(T), 0, s, p, ncc, cpg);
+    return true;
+}
+
 // ---- GroupNorm(+SiLU) backward (training step, SURVEY.md row A11: the frozen UNet is differentiated w.r.t. its activations).
 //   z = x*scale + shift, y = act(z);  dz = dy * act'(z);  per (batch, group): m1 = mean(dz*gamma), m2 = mean(dz*gamma*xhat)
 //   dx = rstd * (dz*gamma - m1 - xhat*m2) = dz*scale + x*kA + kB,  kA = -rstd^2 m2,  kB = mu rstd^2 m2 - rstd m1
@@ -571,6 +699,18 @@ extern "C" int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, con
     if (threads < 64) threads = 64;
     dim3 grid(p.nchunk, B);
     hipStream_t s = (hipStream_t)stream;
+    // small feature maps: the whole (sample, group pack) slab fits the registers of one block -> one launch, one read, one write
+    static const int slab = getenv("AE_GN_SLAB") ? atoi(getenv("AE_GN_SLAB")) : 1;  // tuning knob: 0 = three-launch path everywhere (A/B)
+    if (slab && HW <= 256) {  // 32x32 maps measured slower this way (few, large slabs: 22-94 us against 20-35)
+        const int cpg = C / groups;
+        const int gp = (cpg % 8 == 0) ? 1 : ((2 * cpg) % 8 == 0 ? 2 : ((4 * cpg) % 8 == 0 ? 4 : 0));
+        // a pack must not straddle the two sources of a deferred concat piecewise: pieces are 8 channels and C1 % 8 == 0, so any pack works
+        bool done = false;
+        if (gp == 1 && groups % 1 == 0) done = launch_gn_slab<1>(p, cpg, s);
+        else if (gp == 2 && groups % 2 == 0) done = launch_gn_slab<2>(p, cpg, s);
+        else if (gp == 4 && groups % 4 == 0) done = launch_gn_slab<4>(p, cpg, s);
+        if (done) return ae_check_launch("ae_groupnorm_nhwc_bf16(slab)");
+    }
     hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), (size_t)(threads / ncc) * 2 * C * sizeof(float), s, p);
     int rc = ae_check_launch("ae_groupnorm_nhwc_bf16(stats)");
     if (rc) return rc;
