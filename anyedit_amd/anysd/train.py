@@ -24,7 +24,7 @@ BF16 = torch.bfloat16
 
 class AnySDTrainer:
     def __init__(self, moe, sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=1e-2, process_group=None, bucket_bytes=25 << 20):
+                 weight_decay=1e-2, process_group=None, bucket_bytes=25 << 20, always_exchange=False):
         self.moe = moe
         self.sqrt_ac = sqrt_alphas_cumprod.float()
         self.sqrt_1mac = sqrt_one_minus_alphas_cumprod.float()
@@ -44,8 +44,9 @@ class AnySDTrainer:
         self.state = {}
         import torch.distributed as dist
         self.exchange = None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
-            self.exchange = GradientExchange(list(self.params.values()), bucket_bytes, group=process_group)
+        # always_exchange: build the DDP buckets even for one rank (tests run the bucket-resident gradient path on a single GPU)
+        if always_exchange or (dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1):
+            self.exchange = GradientExchange(self.params, bucket_bytes, group=process_group)
 
     # ------------------------------------------------------------------------------------------------ forward on the tape
     def forward_loss(self, latents, image_cond, encoder_hidden_states, ref_embeds, edit_code, noise, timesteps, null_ehs=None,
@@ -117,7 +118,8 @@ class AnySDTrainer:
             if dkv is None:
                 return
             d_ip = torch.empty_like(ip_rows)
-            dW = torch.zeros(W.shape, dtype=torch.float32, device=dev)                  # dense: AdamW decays the un-routed experts too
+            # dense gradient (AdamW decays the un-routed experts too); under DDP it is written straight into its exchange bucket
+            dW = self.exchange.grad_buffer(name) if self.exchange is not None else torch.zeros(W.shape, dtype=torch.float32, device=dev)
             for e in present:
                 Wt = W.detach()[e].t().to(BF16).contiguous()                            # [Dc, 2*inner]: dA = dY W_e
                 bs = [b for b in range(B) if experts[b] == e]
@@ -133,6 +135,8 @@ class AnySDTrainer:
                 ops.gemm(dyt, at, out_f32=True, out=dW[e])                              # dW_e = dY^T A
             tape.accumulate(ip_rows, d_ip)
             tape.add_param_grad(name, dW)
+            if self.exchange is not None:  # this layer's expert weights are final: their bucket may leave while backward goes on
+                self.exchange.grad_ready(name)
 
         tape.require(kv_ip)
         tape.keep.extend([kv_ip, ip_rows])
@@ -143,6 +147,8 @@ class AnySDTrainer:
     def backward(self, tape, leaves, loss_scale=1.0):
         """Returns {parameter name: fp32 gradient}."""
         with torch.no_grad():
+            if self.exchange is not None:
+                self.exchange.begin_step()
             tape.accumulate(leaves["eps_hat"], ops.mse_grad(leaves["eps_hat"], leaves["noise"], loss_scale))
             grads = dict(tape.backward())
             B, L, Dc = leaves["B"], leaves["L"], leaves["Dc"]
@@ -164,16 +170,17 @@ class AnySDTrainer:
                 if n not in grads:
                     grads[n] = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
                 grads[n] = grads[n].reshape(p.shape).contiguous()
+            if self.exchange is not None:  # the small tensors (projection, task embeddings, router) close the last buckets
+                for n in self.params:
+                    if n in self.exchange._pending[self.exchange.bucket_of[n]]:
+                        self.exchange.grad_ready(n, grads[n])
         return grads
 
     # ------------------------------------------------------------------------------------------------ optimiser
     def optimizer_step(self, grads, grad_scale=1.0):
         with torch.no_grad():
-            if self.exchange is not None:  # DDP: one reduce-scatter + all-gather exchange of the adapter gradients per step
-                for n, p in self.params.items():
-                    p.grad = grads[n]
-                self.exchange.reduce()
-                grads = {n: p.grad for n, p in self.params.items()}
+            if self.exchange is not None:  # DDP: the buckets' reduce-scatters were issued during backward; finish + all-gather
+                grads = self.exchange.finish()
             self.step_count += 1
             for n, p in self.params.items():
                 st = self.state.get(n)

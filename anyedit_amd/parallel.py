@@ -35,43 +35,141 @@ def conditioning_dropout_masks(random_p, p):
 
 
 class GradientExchange:
-    """Bucketed mean-all-reduce of a fixed parameter list as reduce-scatter + all-gather on flat fp32 buckets."""
+    """DDP-shaped exchange of a fixed set of trainable tensors (train.py:536-538 wraps the adapter in DistributedDataParallel;
+    train.py:703 steps the optimiser on the averaged gradients): mean over ranks as reduce-scatter + all-gather on flat fp32
+    buckets, OVERLAPPED with the backward pass.
 
-    def __init__(self, params, bucket_bytes=64 << 20, group=None):
-        self.params = [p for p in params if p.requires_grad]
+    * The buckets are persistent flat fp32 buffers.  `grad_buffer(name)` hands out a view into its bucket: the backward pass
+      writes (or accumulates) the gradient THERE — no per-step flat allocation, no copy-in / copy-out.
+    * Buckets are filled in backward order (reverse registration order).  `grad_ready(name)` marks one tensor final; when the
+      last tensor of a bucket lands, that bucket's reduce-scatter is issued at once on a side stream (`async_op`), while the
+      backward of the earlier layers keeps running on the compute stream.
+    * `finish()` flushes whatever was never marked, waits for the reduce-scatters, scales by 1 / world, all-gathers, and makes
+      the compute stream wait for the side stream.  It returns {name: averaged gradient (the same views)}.
+    MI355X's xGMI is a fully connected point-to-point mesh (7 links per GPU): reduce-scatter + all-gather keeps every link busy
+    with 1/8 of a bucket at a time instead of funnelling a ring through one link pair.  `launch_log` records (event, bucket) in
+    issue order — the gloo test asserts from it that buckets left before the backward had finished.
+    """
+
+    def __init__(self, params, bucket_bytes=25 << 20, group=None):
+        if isinstance(params, dict):
+            named = list(params.items())
+        else:
+            named = [(str(i), p) for i, p in enumerate(params)]
+        named = [(n, p) for n, p in named if getattr(p, "requires_grad", True)]
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.device = dev
+        # backward order = reverse registration order
         self.buckets, cur, cur_n = [], [], 0
-        for p in self.params:
-            cur.append(p)
+        for n, p in reversed(named):
+            cur.append((n, p))
             cur_n += p.numel()
             if cur_n * 4 >= bucket_bytes:
                 self.buckets.append(cur)
                 cur, cur_n = [], 0
         if cur:
             self.buckets.append(cur)
+        self.flat, self.shard, self.views, self.bucket_of = [], [], {}, {}
+        for bi, bucket in enumerate(self.buckets):
+            n = sum(p.numel() for _, p in bucket)
+            pad = (-n) % self.world
+            flat = torch.zeros(n + pad, dtype=torch.float32, device=dev)
+            self.flat.append(flat)
+            self.shard.append(torch.empty((n + pad) // self.world, dtype=torch.float32, device=dev))
+            off = 0
+            for name, p in bucket:
+                self.views[name] = flat[off:off + p.numel()].view(p.shape)
+                self.bucket_of[name] = bi
+                off += p.numel()
         self.bytes_per_step = sum(p.numel() for p in self.params) * 4
+        self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.launch_log = []
+        self._pending, self._handles, self._launched = [], {}, set()
+        self.begin_step(zero=False)
+
+    # ------------------------------------------------------------------ per step
+    def begin_step(self, zero=True):
+        """Start a backward pass: every bucket empty (zeroed: tensors that receive no gradient this step average to zero)."""
+        if zero:
+            for f in self.flat:
+                f.zero_()
+        self._pending = [set(n for n, _ in b) for b in self.buckets]
+        self._handles, self._launched = {}, set()
+        self.launch_log = []
+
+    def grad_buffer(self, name):
+        """fp32 view of `name`'s slot in its bucket (zero at the start of the step): write the gradient here."""
+        return self.views[name]
+
+    def _launch(self, bi):
+        if bi in self._launched:
+            return
+        self._launched.add(bi)
+        self.launch_log.append(("reduce_scatter", bi))
+        if self.world == 1:
+            return
+        if self.stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.stream.wait_event(ev)
+            with torch.cuda.stream(self.stream):
+                self._handles[bi] = dist.reduce_scatter_tensor(self.shard[bi], self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._handles[bi] = dist.reduce_scatter_tensor(self.shard[bi], self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     @torch.no_grad()
+    def grad_ready(self, name, grad=None):
+        """`name`'s gradient is final.  `grad` (optional): a tensor to copy into the bucket slot (when it was not produced there)."""
+        if grad is not None and grad.data_ptr() != self.views[name].data_ptr():
+            self.views[name].copy_(grad.reshape(self.views[name].shape))
+        bi = self.bucket_of[name]
+        self._pending[bi].discard(name)
+        self.launch_log.append(("ready", name))
+        if not self._pending[bi]:
+            self._launch(bi)
+
+    @torch.no_grad()
+    def finish(self):
+        """Complete the exchange; returns {name: mean gradient} (views into the buckets, valid until the next begin_step)."""
+        for bi in range(len(self.buckets)):
+            self._launch(bi)  # whatever never reported stays as written (zeros if untouched)
+        self.launch_log.append(("finish", -1))
+        if self.world > 1:
+            ctx = torch.cuda.stream(self.stream) if self.stream is not None else _null()
+            with ctx:
+                gathers = []
+                for bi in range(len(self.buckets)):
+                    self._handles[bi].wait()
+                    self.shard[bi].div_(self.world)
+                    gathers.append(dist.all_gather_into_tensor(self.flat[bi], self.shard[bi], group=self.group, async_op=True))
+                for h in gathers:
+                    h.wait()
+            if self.stream is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return dict(self.views)
+
+    # ------------------------------------------------------------------ one-shot form (gradients already sit in p.grad)
+    @torch.no_grad()
     def reduce(self):
-        """In place: p.grad <- mean over ranks of p.grad.  Returns the handles' total payload in bytes."""
+        """In place: p.grad <- mean over ranks of p.grad, through the same buckets.  Returns the payload in bytes."""
         if self.world == 1:
             return 0
-        for bucket in self.buckets:
-            n = sum(p.numel() for p in bucket)
-            pad = (-n) % self.world
-            dev = bucket[0].grad.device
-            flat = torch.zeros(n + pad, dtype=torch.float32, device=dev)
-            off = 0
-            for p in bucket:
-                flat[off:off + p.numel()] = p.grad.reshape(-1).float()
-                off += p.numel()
-            shard = torch.empty((n + pad) // self.world, dtype=torch.float32, device=dev)
-            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=self.group)
-            shard /= self.world
-            dist.all_gather_into_tensor(flat, shard, group=self.group)
-            off = 0
-            for p in bucket:
-                p.grad.copy_(flat[off:off + p.numel()].reshape(p.grad.shape))
-                off += p.numel()
+        self.begin_step(zero=False)
+        for n, p in zip(reversed(self.names), reversed(self.params)):
+            self.grad_ready(n, p.grad.float())
+        out = self.finish()
+        for n, p in zip(self.names, self.params):
+            p.grad.copy_(out[n].reshape(p.grad.shape))
         return self.bytes_per_step
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

@@ -34,10 +34,37 @@ def _worker(rank, world, port, ret):
     for p in params:
         expect = torch.full_like(p, 1.5) + torch.arange(p.numel(), dtype=torch.float32) * 1e-3 * 1.5
         ok_grad &= bool(torch.allclose(p.grad, expect, rtol=1e-6, atol=1e-6))
+    # DDP-shaped path: gradients written into the persistent buckets in backward order, buckets leave as soon as they are full
+    named = {f"p{i}": torch.nn.Parameter(torch.randn(n)) for i, n in enumerate((5, 1000, 33, 70000))}
+    ex2 = GradientExchange(named, bucket_bytes=2048)
+    ex2.begin_step()
+    for name in reversed(list(named)):          # backward produces the LAST registered tensor first
+        buf = ex2.grad_buffer(name)
+        buf.copy_(torch.full_like(buf, float(rank + 1)) + torch.arange(buf.numel(), dtype=torch.float32) * 1e-3 * (rank + 1))
+        ex2.grad_ready(name)
+    log = list(ex2.launch_log)
+    out = ex2.finish()
+    ok_overlap = True
+    for name, pp in named.items():
+        expect = torch.full_like(pp, 1.5) + torch.arange(pp.numel(), dtype=torch.float32) * 1e-3 * 1.5
+        ok_overlap &= bool(torch.allclose(out[name], expect, rtol=1e-6, atol=1e-6))
+        ok_overlap &= out[name].data_ptr() == ex2.grad_buffer(name).data_ptr()       # no copy-out: the views ARE the result
+    first_rs = next(i for i, e in enumerate(log) if e[0] == "reduce_scatter")
+    last_ready = max(i for i, e in enumerate(log) if e[0] == "ready")
+    ok_overlap &= first_rs < last_ready                                              # a bucket left before the "backward" had finished
+    ok_overlap &= [e for e in log if e[0] == "reduce_scatter"] == [("reduce_scatter", b) for b in range(len(ex2.buckets))]  # in bucket order
+    # a second step reuses the same buffers (no reallocation) and a tensor that reports nothing averages to zero
+    ptrs = [f.data_ptr() for f in ex2.flat]
+    ex2.begin_step()
+    ex2.grad_buffer("p3").fill_(float(rank))
+    ex2.grad_ready("p3")
+    out = ex2.finish()
+    ok_overlap &= ptrs == [f.data_ptr() for f in ex2.flat]
+    ok_overlap &= bool(torch.allclose(out["p3"], torch.full_like(out["p3"], 0.5))) and float(out["p1"].abs().max()) == 0.0
     # bench.py's timing reduction
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    ret[rank] = (ok_shard, ok_slice, ok_grad, nbytes, float(t), len(ex.buckets))
+    ret[rank] = (ok_shard, ok_slice, ok_grad and ok_overlap, nbytes, float(t), len(ex.buckets))
     dist.barrier()
     dist.destroy_process_group()
 
