@@ -74,7 +74,73 @@ def synthetic_inputs(B, device, rank=0, latent=64):
     return x_T, img_lat, ehs, null, ref, code
 
 
-def cpu_baseline_and_parity(unet, device, max_seconds=40.0):
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _median_time(fn, reps=3, warm=1):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        s = time.time()
+        fn()
+        ts.append(time.time() - s)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def cpu_e2e_config1(sd):
+    """config 1 end to end on the host cores — ONE [1,4,64,64] latent, 20 DDIM steps, 8-channel UNet input,
+    cfg 7.5 / 1.5, eta 0, with k = 3 branches (IP2P / AnySD) and k = 2 (ldm-DDIM style): the oracle loop, fp32."""
+    from oracle import ddim_ref as D, ldm_ref as L, schedule_ref as S
+    g = torch.Generator().manual_seed(3)
+    x_T, img = torch.randn(1, 4, 64, 64, generator=g), torch.randn(1, 4, 64, 64, generator=g) * 0.18215
+    ctx, null = torch.randn(1, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g)
+    buffers = S.register_schedule("linear", 1000, 0.00085, 0.0120)
+    unet_fn = lambda x, t, c: L.unet_forward(sd, SD15, x, t, c)
+    out = {}
+    with torch.no_grad():
+        t0 = time.time()
+        D.ip2p_edit_loop(unet_fn, buffers, 20, x_T, img, ctx, null, 7.5, 1.5)
+        out["k3_seconds"] = time.time() - t0
+        t0 = time.time()
+        apply = lambda x, t, c: L.unet_forward(sd, SD15, torch.cat([x, img.expand(x.shape[0], -1, -1, -1)], 1), t, c)
+        D.ddim_sample(apply, buffers, 20, (1, 4, 64, 64), ctx, eta=0.0, x_T=x_T, scale=7.5, uc=null)
+        out["k2_seconds"] = time.time() - t0
+    out["k3_images_per_s"], out["k2_images_per_s"] = 1.0 / out["k3_seconds"], 1.0 / out["k2_seconds"]
+    return out
+
+
+def cpu_op_timings(sd):
+    """BASELINE.md §3 per-op legs on the host cores (oracle, fp32, median of 3 after one warm-up), seconds."""
+    from oracle import ldm_ref as L
+    g = torch.Generator().manual_seed(4)
+    emb = torch.randn(1, 1280, generator=g)
+    x64, x16 = torch.randn(1, 320, 64, 64, generator=g), torch.randn(1, 1280, 16, 16, generator=g)
+    tok = torch.randn(1, 4096, 320, generator=g)
+    ctx = torch.randn(1, 77, 768, generator=g)
+    p1 = "input_blocks.1.1.transformer_blocks.0."
+    res = {}
+    with torch.no_grad():
+        res["self_attention_L1 [1,4096,320] 8 heads d=40"] = _median_time(lambda: L.cross_attention(sd, p1 + "attn1.", tok, None, heads=8))
+        res["cross_attention_L1 Nk=77"] = _median_time(lambda: L.cross_attention(sd, p1 + "attn2.", tok, ctx, heads=8))
+        res["resblock 320@64x64"] = _median_time(lambda: L.resblock(sd, "input_blocks.1.0.", x64, emb))
+        res["resblock 1280@16x16"] = _median_time(lambda: L.resblock(sd, "input_blocks.8.0.", x16, emb))
+        res["groupnorm32 [1,320,64,64]"] = _median_time(lambda: L.group_norm32(x64, sd["input_blocks.1.0.in_layers.0.weight"], sd["input_blocks.1.0.in_layers.0.bias"]), reps=9)
+        qg, qw = torch.randn(16, 4096, 80, generator=g), torch.randn(400, 196, 80, generator=g)
+        res["sam_global_attention [16,4096,80]"] = _median_time(lambda: L.sdpa_core(qg, qg, qg, 80 ** -0.5))
+        res["sam_windowed_attention [400,196,80]"] = _median_time(lambda: L.sdpa_core(qw, qw, qw, 80 ** -0.5))
+    return res
+
+
+def cpu_baseline_and_parity(unet, device, max_seconds=40.0, e2e=False, per_op=False):
     """Oracle UNet evaluation (B=1, fp32, all host cores) on the SAME weights: CPU time + full-size parity of the HIP path."""
     from oracle import ldm_ref as L
     torch.set_num_threads(min(os.cpu_count(), 32))  # 256 threads on this shape is 30x slower than 8 (measured)
@@ -102,23 +168,29 @@ def cpu_baseline_and_parity(unet, device, max_seconds=40.0):
     psnr = 10 * math.log10(peak * peak / mse) if mse > 0 else float("inf")
     cpu = {"value": 1.0 / (150.0 * t_unet), "unit": "edited-images/sec", "cores": min(os.cpu_count(), 32), "kind": "port",
            "sample": f"oracle UNet forward B=1 [1,8,64,64], median of {len(times)} = {t_unet:.3f} s, scaled x150 evaluations/image",
-           "unet_forward_s": t_unet}
+           "unet_forward_s": t_unet, "cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(), "threads": torch.get_num_threads()}
+    if e2e:    # opt-in (--cpu-e2e): ~3-5 minutes of host time
+        cpu["config1_end_to_end_20_steps"] = cpu_e2e_config1(sd)
+    if per_op:  # opt-in (--cpu-ops)
+        cpu["per_op_seconds"] = cpu_op_timings(sd)
     parity = {"unet_full_size_rel_l2_vs_oracle": err, "psnr_db": psnr}
     return cpu, parity
 
 
 def traffic_for(kernel):
-    """HBM-side bytes per launch of `kernel` (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes over this same
-    workload: tools/traffic.sh -> profiles/r*_traffic.json).  PMC passes cannot run inside the timed process, so the figure
-    comes from the newest committed collection; None when there is none."""
+    """(HBM-side bytes per launch of `kernel`, source file): FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes over this
+    same workload (tools/traffic.sh -> profiles/r*_traffic.json).  PMC passes cannot run inside the timed process, so the figure
+    comes from the newest committed collection (its "commit" field says which code it was taken on); (None, None) when there is none."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
-        return None
-    k = json.load(open(files[-1])).get("kernels", {}).get(kernel)
+        return None, None
+    doc = json.load(open(files[-1]))
+    k = doc.get("kernels", {}).get(kernel)
+    src = os.path.basename(files[-1]) + (f" @ {doc['commit']}" if doc.get("commit") else "")
     if not k or k.get("fetch_bytes") is None or k.get("write_bytes") is None:
-        return None
-    return k["fetch_bytes"] + k["write_bytes"]
+        return None, src
+    return k["fetch_bytes"] + k["write_bytes"], src
 
 
 def main():
@@ -132,6 +204,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-e2e", action="store_true", help="BASELINE.md §3: also time config 1 (one latent, 20 DDIM steps, k = 3 and k = 2) end to end on the host cores (minutes)")
+    ap.add_argument("--cpu-ops", action="store_true", help="BASELINE.md §3: also time the per-op legs on the host cores")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -235,20 +309,21 @@ def main():
             a = {"ms": m["ms"], "flops": m["flops"], "calls": m["calls"], "avg_us": 1e3 * m["ms"] / m["calls"],
                  "tflops": m["flops"] / (m["ms"] * 1e-3) / 1e12 if m["ms"] > 0 else 0.0,
                  "gbps": m["bytes"] / (m["ms"] * 1e-3) / 1e9 if m["ms"] > 0 else 0.0}
-            traffic = traffic_for(name)   # tools/traffic.sh keys its rows by kernel symbol, i.e. by the folded name
+            traffic, traffic_src = traffic_for(name)   # tools/traffic.sh keys its rows by kernel symbol, i.e. by the folded name
             mfma = a["flops"] > 0
             result["roofline"] = {
                 "kernel": name, "bound": "mfma" if mfma else "hbm",
                 "achieved": a["tflops"] if mfma else a["gbps"], "peak": PEAK_BF16_TFLOPS if mfma else PEAK_HBM_GBPS,
                 "unit": "TFLOP/s" if mfma else "GB/s",
                 "frac": (a["tflops"] / PEAK_BF16_TFLOPS) if mfma else (a["gbps"] / PEAK_HBM_GBPS),
-                "traffic": traffic, "avg_launch_us": a["avg_us"], "launches_per_unet_step": a["calls"] // 3,
+                "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": m["bytes"] / m["calls"] if m["calls"] else None,
+                "avg_launch_us": a["avg_us"], "launches_per_unet_step": a["calls"] // 3,
                 "share_of_unet_step": a["ms"] / sum(v["ms"] for v in summ.values()),
             }
             result["kernels"] = {k: {"calls_per_step": v["calls"] // 3, "ms_per_step": v["ms"] / 3, "avg_us": v["avg_us"],
                                      "tflops": v["tflops"], "gbps": v["gbps"]} for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
         if world == 1 and not args.no_cpu_baseline:
-            cpu, parity = cpu_baseline_and_parity(unet, device)
+            cpu, parity = cpu_baseline_and_parity(unet, device, e2e=args.cpu_e2e, per_op=args.cpu_ops)
             result["cpu_baseline"] = cpu
             result["parity"] = parity
         print(json.dumps(result), flush=True)

@@ -23,6 +23,12 @@ def label(name):
     if m:  # same family names as bench.py's folded profiler labels; the three-stage-ring instantiations are their own symbols
         ring = ",ring3" if m.group(4) == "3" else ""
         return f"gemm_kernel<{m.group(1)}x{m.group(2)}{ring},{'conv3x3' if m.group(3) == '1' else 'dense'}>"
+    m = re.search(r"attn_fast_kernel<(\d+)", name)
+    if m:
+        return f"attn_fast_kernel<D={m.group(1)}>"
+    m = re.search(r"gemm_rowpanel_kernel<(\d+), (\d+), (\w+)>", name)
+    if m:  # <KS, EPI, LN>: K = 32 KS
+        return f"gemm_rowpanel_kernel<K={32 * int(m.group(1))}{',LN' if m.group(3) in ('true', '1') else ''}{',geglu' if m.group(2) == '2' else ''}>"
     m = re.search(r"attn_kernel<(\d+)", name)
     if m:
         return f"attn_kernel<D={m.group(1)}>"
@@ -41,7 +47,14 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             agg[label(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         out.setdefault(k, {})[c] = {"launches": len(v), "avg_raw": sum(v) / len(v)}
-res = {"_doc": "per-launch HBM-side bytes; raw counters are KiB; FETCH_SIZE doubled on gfx950 (128-B requests tallied at 64 B)", "kernels": {}}
+import subprocess
+try:
+    commit = subprocess.run(["git", "-C", R, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except Exception:
+    commit = None
+if not commit and __import__("os").path.exists(f"{R}/.commit_id"):
+    commit = open(f"{R}/.commit_id").read().strip()
+res = {"_doc": "per-launch HBM-side bytes; raw counters are KiB; FETCH_SIZE doubled on gfx950 (128-B requests tallied at 64 B)", "commit": commit, "kernels": {}}
 for k, d in out.items():
     f = d.get("FETCH_SIZE", {}).get("avg_raw")
     w = d.get("WRITE_SIZE", {}).get("avg_raw")
@@ -50,8 +63,9 @@ for k, d in out.items():
                          "fetch_raw_kib": f, "write_raw_kib": w}
 ln = res["kernels"].get("layernorm_kernel")
 if ln:
-    # per evaluation: (15 LN at [49152,320] + 15 at [12288,640] + 15 at [3072,1280]) + the adapter/context LNs (tiny): expected mean
-    exp = (15 * 49152 * 320 + 15 * 12288 * 640 + 15 * 3072 * 1280) * 2.0 / 45.0
+    # per evaluation: 15 LN at [12288,640] + 15 at [3072,1280] (+ 3 at [768,1280]; the level-1 LayerNorms are fused into the row-panel
+    # GEMM since round 2): expected mean
+    exp = (15 * 12288 * 640 + 15 * 3072 * 1280 + 3 * 768 * 1280) * 2.0 / 33.0
     res["calibration"] = {"kernel": "layernorm_kernel", "expected_bytes_each_way_approx": exp,
                           "fetch_over_expected": ln["fetch_bytes"] / exp if ln["fetch_bytes"] else None,
                           "write_over_expected": ln["write_bytes"] / exp if ln["write_bytes"] else None}
