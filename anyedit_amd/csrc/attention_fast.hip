@@ -310,6 +310,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
         if (SEG2 && seg == 0) {  // park the first segment's normalised output, restart the online softmax
             const float l0 = __shfl(o[LDB][LREG], l31, 64);
             const float inv0 = 1.0f / l0;
+            // log2-domain log-sum-exp of the first segment (kept for ae_attn_bwd_bf16): offset + log2(denominator)
+            if (p.lse && hi == 0 && q0 + l31 < p.Nq) p.lse[((long)b * p.H + h) * p.Nq + q0 + l31] = mt + __builtin_amdgcn_logf(l0);
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -338,6 +340,10 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     bf16_t* op = p.o + (long)b * p.o_sb + (long)h * p.o_sh;
     const float lsum = __shfl(o[LDB][LREG], l31, 64);
     const float inv = (SEG2 ? p.scale2[b] : (p.out_scale ? p.out_scale[b] : 1.0f)) / lsum;
+    {
+        float* lse_out = SEG2 ? p.lse2 : p.lse;  // v_log_f32 = log2
+        if (lse_out && hi == 0 && q0 + l31 < p.Nq) lse_out[((long)b * p.H + h) * p.Nq + q0 + l31] = mt + __builtin_amdgcn_logf(lsum);
+    }
     const int qrow = q0 + l31;
     if (qrow < p.Nq) {
 #pragma unroll
@@ -385,7 +391,7 @@ int launch_fast(const AttnArgs& a, hipStream_t stream) {
 }  // namespace
 
 int ae_attn_fast_launch(const AttnArgs& a, int D, hipStream_t stream) {
-    if (a.key_mask || a.lse || a.lse2) return AE_ERR_UNSUPPORTED;
+    if (a.key_mask) return AE_ERR_UNSUPPORTED;
     // rel-pos bias: only the one-key-row-per-tile form (kW == 64, SAM global attention) at head dims that are multiples of 16
     if (a.rel_h && !(a.kW == FKT && a.Nk % FKT == 0 && D % 16 == 0 && !a.k2 && !a.accum && !a.out_scale)) return AE_ERR_UNSUPPORTED;
     if (a.k2 && (a.accum || a.out_scale)) return AE_ERR_UNSUPPORTED;

@@ -314,6 +314,10 @@ int launch_rowpanel(const RowPanelArgs& a, int epi, hipStream_t stream) {
 
 // 1 when the row-panel kernel covers the shape (the caller otherwise uses ae_layernorm_bf16 + ae_gemm_bf16)
 extern "C" int ae_ln_gemm_supported(int M, int N, int K, int epilogue) {
+    // one 192-row block per CU: below ~3/4 of the 256 CUs the tiled kernel (more, smaller blocks) fills the chip better.  The test hook
+    // AE_ROWPANEL_ANY_M lifts the limit so that small shapes exercise the kernel.
+    static const int any_m = getenv("AE_ROWPANEL_ANY_M") ? atoi(getenv("AE_ROWPANEL_ANY_M")) : 0;
+    if (!any_m && (M + RP_BM - 1) / RP_BM < 192) return 0;
     return (K == 320 && N % (2 * RP_BN) == 0 && N <= RP_MAXN && M >= RP_BM && (epilogue == RP_EPI_NONE || epilogue == RP_EPI_GEGLU)) ? 1 : 0;
 }
 

@@ -74,8 +74,9 @@ class GradientExchange:
         if cur:
             self.buckets.append(cur)
         self.flat, self.shard, self.views, self.bucket_of = [], [], {}, {}
+        ALIGN = 64  # every tensor's slot starts on a 256-byte boundary: kernels write gradients straight into the slots
         for bi, bucket in enumerate(self.buckets):
-            n = sum(p.numel() for _, p in bucket)
+            n = sum((p.numel() + ALIGN - 1) // ALIGN * ALIGN for _, p in bucket)
             pad = (-n) % self.world
             flat = torch.zeros(n + pad, dtype=torch.float32, device=dev)
             self.flat.append(flat)
@@ -84,7 +85,7 @@ class GradientExchange:
             for name, p in bucket:
                 self.views[name] = flat[off:off + p.numel()].view(p.shape)
                 self.bucket_of[name] = bi
-                off += p.numel()
+                off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.bytes_per_step = sum(p.numel() for p in self.params) * 4
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self.launch_log = []

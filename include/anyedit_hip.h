@@ -51,7 +51,7 @@ int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, int Ksplit,
  * (attention.py:263-265, 271-275: norm1 -> to_q|k|v, norm2 -> to_q, norm3 -> GEGLU projection) optionally fused in front:
  *   C[M,N] = epi( LN(A)[M,K] @ W[N,K]^T + bias (+ residual) ),  ln_gamma == NULL: no LayerNorm.  epilogue: AE_EPI_NONE | AE_EPI_GEGLU.
  * A wave keeps 48 rows of A in registers for the whole launch (normalised there), W streams through an LDS ring by LDS-DMA.
- * ae_ln_gemm_supported() tells whether the kernel covers a shape (K == 320, N % 64 == 0, N <= 2560, M >= 192); callers fall back to
+ * ae_ln_gemm_supported() tells whether the kernel covers a shape (K == 320, N % 64 == 0, N <= 2560, M >= 192 * 192 rows: one 192-row block per CU); callers fall back to
  * ae_layernorm_bf16 + ae_gemm_bf16 otherwise.  A, W rows and C, residual rows 16-byte aligned.                                   */
 int ae_ln_gemm_supported(int M, int N, int K, int epilogue);
 int ae_ln_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias,

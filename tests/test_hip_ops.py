@@ -7,6 +7,10 @@ Tolerances (stated per the north-star "within a stated fp tolerance"):
   * bf16-in / fp32-accumulate kernels, inputs pre-rounded to bf16 on both sides: relative L2 error <= 4e-3 per operator
     (bf16 output rounding alone is ~1.1e-3) and max-abs error <= 2e-2 * max|ref|.
 """
+import os
+
+os.environ.setdefault("AE_ROWPANEL_ANY_M", "1")  # read once by the library: lets the small row-panel GEMM cases reach the kernel
+
 import numpy as np
 import pytest
 import torch
@@ -91,8 +95,8 @@ def test_gemm_epilogues_and_two_source(ops):
 
 
 @pytest.mark.parametrize("M,N,epi,ln,res", [(192, 64, "none", False, False), (500, 320, "none", True, True), (777, 960, "none", True, False),
-                                             (1000, 256, "geglu", True, False), (4096, 2560, "geglu", False, False), (391, 320, "none", False, True)])
-def test_rowpanel_ln_gemm(ops, M, N, epi, ln, res):
+                                             (1000, 256, "geglu", True, False), (4096, 2560, "geglu", False, False), (391, 320, "none", False, True), (49152, 320, "none", True, True)])
+def test_rowpanel_ln_gemm(ops, M, N, epi, ln, res, monkeypatch):
     """Row-panel K = 320 kernel (ae_ln_gemm_bf16): LayerNorm prologue, bias, residual, GEGLU, ragged last block, against fp32 torch
     on the same bf16 inputs (attention.py:263-275 norm -> projection pairs).  The normalised rows are rounded to bf16 before the
     MFMA, as the unfused path stores them."""
@@ -113,7 +117,9 @@ def test_rowpanel_ln_gemm(ops, M, N, epi, ln, res):
     else:
         ref = z + (r if res else 0.0)
         wd, bd, e = w.to(DEV, BF), bias.to(DEV), ops.EPI_NONE
-    assert ops.lib.ae_ln_gemm_supported(M, N, K, e) == 1
+    if M < 192 * 192:  # production launches want one block per CU; the small cases reach the kernel through its test hook
+        assert ops.lib.ae_ln_gemm_supported(M, N, K, e) == 0 or os.environ.get("AE_ROWPANEL_ANY_M") == "1"
+    assert os.environ.get("AE_ROWPANEL_ANY_M") == "1" and ops.lib.ae_ln_gemm_supported(M, N, K, e) == 1
     rd = None if r is None else r.to(DEV, BF)
     if ln:
         out = ops.ln_gemm(a.to(DEV, BF), gamma.to(DEV), beta.to(DEV), 1e-5, wd, bd, residual=rd, epilogue=e)
