@@ -71,7 +71,7 @@ __device__ __forceinline__ bf16x8_t cat_tr(s16x4v lo, s16x4v hi) {
 __device__ unsigned long long g_attn_dbg[4];  // lab only: sum of per-block shader cycles, 100 MHz ticks, blocks
 #endif
 
-template <int D, int OCC, bool SEG2 = false, int ABL = 0, bool BIAS2 = false>
+template <int D, int OCC, bool SEG2 = false, int ABL = 0, int BIAS = 0>
 __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     static_assert(D % 8 == 0 && D <= 96, "head_dim: multiple of 8, <= 96");
     constexpr int KS = (D + 15) / 16;        // K=16 steps of S^T = K Q^T
@@ -135,10 +135,26 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     f32x16 cinit;  // !QSLOT: the offset enters through the C operand
 #pragma unroll
     for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
-    // BIAS2: decomposed rel-pos bias whose key grid has one ROW per 64-key tile (kW == 64: SAM's global attention,
-    // image_encoder.py:325-361): rel_w[q, kw] * log2e of this lane's 2 x 16 key columns stays in registers, rel_h[q, kh] is one
-    // value per tile; both enter S' through the MFMA's C operand (one v_add per logit, no per-element index arithmetic)
-    static_assert(!BIAS2 || (!QSLOT && !SEG2), "the rel-pos variant is built for head dims that are multiples of 16, one segment");
+    // Decomposed rel-pos bias (image_encoder.py:325-361), entering S' through the MFMA's C operand:
+    // BIAS 2: the key grid has one ROW per 64-key tile (kW == 64: SAM's global attention): rel_w[q, kw] * log2e of this lane's
+    //         2 x 16 key columns stays in registers, rel_h[q, kh] is one value per tile — one v_add per logit, no index arithmetic;
+    // BIAS 1: small key grids (kH, kW <= 16: SAM's 14 x 14 windows): the block's rows of both tables sit in LDS (times log2e),
+    //         every logit looks up rel_h[q, key / kW] + rel_w[q, key % kW].
+    constexpr bool BIAS2 = BIAS == 2, BIAS1 = BIAS == 1;
+    static_assert(BIAS == 0 || (!QSLOT && !SEG2), "the rel-pos variants are built for head dims that are multiples of 16, one segment");
+    __shared__ float sbias[BIAS1 ? 128 * 32 : 1];
+    const float inv_kw = BIAS1 ? 1.0f / (float)p.kW : 0.f;
+    if (BIAS1) {
+        for (int i = tid; i < 128 * 32; i += 256) {
+            const int ql = i >> 5, j = i & 31;
+            const long qc = (long)bh * p.Nq + min(qb * QB + ql, p.Nq - 1);
+            float v = 0.f;
+            if (j < 16) { if (j < p.kH) v = p.rel_h[qc * p.kH + j]; }
+            else if (j - 16 < p.kW) v = p.rel_w[qc * p.kW + j - 16];
+            sbias[i] = v * FLOG2E;
+        }
+        // visible after the first tile's barrier
+    }
     f32x16 wb[BIAS2 ? 2 : 1];
     const float* rh_row = nullptr;
     float rh_tile = 0.f;
@@ -191,6 +207,18 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
                 const float hb = rh_tile - mt;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) c0[r] = wb[BIAS2 ? B2 : 0][r] + hb;
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[ks]), c0, 0, 0, 0);
+            } else if (BIAS1 && ks == 0) {
+                f32x16 c0;
+                const float* row = sbias + (wave * 32 + l31) * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // key -> (row, column) of the key grid without an integer division: (key + 0.5) / kW is never closer than
+                    // 0.5 / kW to an integer, far above the fp32 error for a grid of at most 16 x 16
+                    const int key = min(k0 + B2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, seg_nk - 1);
+                    const int kh = (int)(((float)key + 0.5f) * inv_kw);
+                    c0[r] = row[kh] + row[16 + key - kh * p.kW] - mt;
+                }
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[ks]), c0, 0, 0, 0);
             } else {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[ks]), ks == 0 ? cinit : s, 0, 0, 0);
@@ -379,11 +407,12 @@ int launch_fast(const AttnArgs& a, hipStream_t stream) {
 #endif
     if constexpr (D % 16 == 0) {
         if (a.rel_h) {
-            hipLaunchKernelGGL((attn_fast_kernel<D, 2, false, 0, true>), grid, block, 0, stream, a);
+            if (a.kW == FKT) hipLaunchKernelGGL((attn_fast_kernel<D, 2, false, 0, 2>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((attn_fast_kernel<D, 2, false, 0, 1>), grid, block, 0, stream, a);
             return ae_check_launch("ae_attn_fwd_bf16(fast, rel-pos)");
         }
     }
-    if (a.k2) hipLaunchKernelGGL((attn_fast_kernel<D, 3, true>), grid, block, 0, stream, a);
+    if (a.k2) hipLaunchKernelGGL((attn_fast_kernel<D, (D > 64 ? 2 : 3), true>), grid, block, 0, stream, a);  // 168 VGPRs spill at head_dim 80
     else hipLaunchKernelGGL((attn_fast_kernel<D, 3, false>), grid, block, 0, stream, a);
     return ae_check_launch("ae_attn_fwd_bf16(fast)");
 }
@@ -392,8 +421,9 @@ int launch_fast(const AttnArgs& a, hipStream_t stream) {
 
 int ae_attn_fast_launch(const AttnArgs& a, int D, hipStream_t stream) {
     if (a.key_mask) return AE_ERR_UNSUPPORTED;
-    // rel-pos bias: only the one-key-row-per-tile form (kW == 64, SAM global attention) at head dims that are multiples of 16
-    if (a.rel_h && !(a.kW == FKT && a.Nk % FKT == 0 && D % 16 == 0 && !a.k2 && !a.accum && !a.out_scale)) return AE_ERR_UNSUPPORTED;
+    // rel-pos bias at head dims that are multiples of 16: one key-grid row per tile (kW == 64, SAM global attention) or a small grid
+    // (kH, kW <= 16, SAM windows)
+    if (a.rel_h && !(D % 16 == 0 && !a.k2 && !a.accum && !a.out_scale && ((a.kW == FKT && a.Nk % FKT == 0) || (a.kH <= 16 && a.kW <= 16)))) return AE_ERR_UNSUPPORTED;
     if (a.k2 && (a.accum || a.out_scale)) return AE_ERR_UNSUPPORTED;
     // 32-bit byte offsets inside one (batch, head) image of K / V
     if (((long)a.Nk * a.k_sn + D) * 2 >= (1L << 31) || ((long)a.Nk * a.v_sn + D) * 2 >= (1L << 31)) return AE_ERR_UNSUPPORTED;

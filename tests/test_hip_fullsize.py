@@ -104,32 +104,27 @@ def test_masked_edit_5_steps_cfg_full_size_96():
             return A.moe_forward(unet_weights, SD15, weights, prefixes, x_in, t, text_embedding, ref3, code3)
         return D.ip2p_edit_loop(unet_fn, buffers, steps, x_T, img_lat, ehs, null, 7.5, 1.5, mask=mask, x0=x0, noise_for_blend=blend_noise)
 
-    # the fp32 oracle runs on a worker thread (its own OpenMP team; the storage hook is thread-local) while this thread runs the
-    # bf16-storage control: ~2 minutes of host time instead of ~4
-    import threading
-    res = {}
-
-    def worker():
-        with torch.no_grad():
-            res["ref"] = run_oracle(sd, unet_sd)
-
+    # The bf16-storage control loop doubles the host time (~5 minutes for both on 32 threads), so it runs only on request
+    # (AE_TEST_EDIT_CONTROL=1, the evidence run: profiles/r02_pytest_gpu_full.txt — HIP 3.70e-2 / 51.4 dB, control 3.77e-2 / 51.2 dB);
+    # by default the bound is 1.5 x that recorded control.
     t0 = time.time()
-    th = threading.Thread(target=worker)
-    th.start()
-    with torch.no_grad(), L.bf16_storage():
-        sdb = L.bf16_weights(sd)
-        ctl = run_oracle(sdb, {k[5:]: v for k, v in sdb.items() if k.startswith("unet.")})
-    th.join()
-    ref = res["ref"]
+    with torch.no_grad():
+        ref = run_oracle(sd, unet_sd)
+        ctl = None
+        if os.environ.get("AE_TEST_EDIT_CONTROL") == "1":
+            with L.bf16_storage():
+                sdb = L.bf16_weights(sd)
+                ctl = run_oracle(sdb, {k[5:]: v for k, v in sdb.items() if k.startswith("unet.")})
     t_oracle = time.time() - t0
     sched = DDPM(moe.unet, timesteps=1000, linear_start=0.00085, linear_end=0.0120).to(DEV)
     pipe = EditPipeline(moe, sched, use_graph=True)
     pipe.randn = lambda shape, device=None: blend_noise.to(device)
     out = pipe.edit(x_T.to(DEV), img_lat.to(DEV), ehs.to(DEV), null.to(DEV), ref_emb.to(DEV), code.to(DEV), steps=steps,
                     s_txt=7.5, s_img=1.5, mask=mask.to(DEV), x0=x0.to(DEV)).float().cpu()
-    e_hip, e_ctl = rel_l2(out, ref), rel_l2(ctl, ref)
-    print(f"\n5-step CFG edit @96x96: HIP rel-L2 {e_hip:.3e} ({psnr(out, ref):.1f} dB), bf16-storage control {e_ctl:.3e} ({psnr(ctl, ref):.1f} dB), "
-          f"oracle time {t_oracle:.1f} s")
+    e_hip = rel_l2(out, ref)
+    e_ctl = rel_l2(ctl, ref) if ctl is not None else 3.77e-2
+    print(f"\n5-step CFG edit @96x96: HIP rel-L2 {e_hip:.3e} ({psnr(out, ref):.1f} dB), bf16-storage control {e_ctl:.3e} "
+          f"({'measured' if ctl is not None else 'recorded'}), oracle time {t_oracle:.1f} s")
     # outside the mask the result is q_sample(x0) exactly as the reference blends it
     keep = (mask == 0).expand_as(out)
     assert rel_l2(out[keep], ref[keep]) <= 1e-5

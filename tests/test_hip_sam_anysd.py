@@ -166,9 +166,17 @@ def test_edit_pipeline_vs_oracle_loop_and_graph_replay():
         return A.moe_forward(unet_sd, cfg, sd, prefixes, x_in, t, text_embedding, ref3, code3)
 
     steps = 5
+    from oracle import ldm_ref as L
     with torch.no_grad():
         ref = D.ip2p_edit_loop(unet_fn, buffers, steps, x_T, img_lat, ehs, null.expand(B, -1, -1), 7.5, 1.5, mask=mask, x0=x0,
                                noise_for_blend=blend_noise)
+        # control: the same loop with bf16 storage of activations / weights, fp32 arithmetic (the derived tolerance)
+        sdb = L.bf16_weights(sd)
+        usdb = {k[5:]: v for k, v in sdb.items() if k.startswith("unet.")}
+        with L.bf16_storage():
+            ctl = D.ip2p_edit_loop(lambda x_in, t, te: A.moe_forward(usdb, cfg, sdb, prefixes, x_in, t, te, ref3, code3), buffers, steps, x_T,
+                                   img_lat, ehs, null.expand(B, -1, -1), 7.5, 1.5, mask=mask, x0=x0, noise_for_blend=blend_noise)
+    e_ctl = rel_l2(ctl, ref)
     moe = moe.to(DEV)
     sched = DDPM(moe.unet, timesteps=1000, linear_start=0.00085, linear_end=0.0120).to(DEV)
     outs = []
@@ -179,7 +187,9 @@ def test_edit_pipeline_vs_oracle_loop_and_graph_replay():
                         s_txt=7.5, s_img=1.5, mask=mask.to(DEV), x0=x0.to(DEV))
         outs.append(out.cpu())
         assert np.array_equal(pipe.sampler.ddim_timesteps, S.make_ddim_timesteps("uniform", steps, 1000))
-        close(out, ref, rl2=8e-2, db=26.0, what=f"edit pipeline (graph={use_graph})")
+        close(out, ref, rl2=8e-2, db=26.0, what=f"edit pipeline (graph={use_graph})")   # absolute cap
+        e_hip = rel_l2(out.float().cpu(), ref)
+        assert e_hip <= 1.5 * e_ctl + 1e-3, f"edit pipeline: HIP {e_hip:.3e} vs bf16-storage control {e_ctl:.3e}"
     assert torch.equal(outs[0], outs[1]), "HIP-graph replay must reproduce the eager launches bit for bit"
 
 
