@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     //         every logit looks up rel_h[q, key / kW] + rel_w[q, key % kW].
     constexpr bool BIAS2 = BIAS == 2, BIAS1 = BIAS == 1;
     static_assert(BIAS == 0 || (!QSLOT && !SEG2), "the rel-pos variants are built for head dims that are multiples of 16, one segment");
-    __shared__ float sbias[BIAS1 ? 128 * 32 : 1];
+    __shared__ float sbias[BIAS1 ? 128 * 33 : 1];  // row stride 33: lanes (= queries) reading one column hit 32 different banks
     const float inv_kw = BIAS1 ? 1.0f / (float)p.kW : 0.f;
     if (BIAS1) {
         for (int i = tid; i < 128 * 32; i += 256) {
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
             float v = 0.f;
             if (j < 16) { if (j < p.kH) v = p.rel_h[qc * p.kH + j]; }
             else if (j - 16 < p.kW) v = p.rel_w[qc * p.kW + j - 16];
-            sbias[i] = v * FLOG2E;
+            sbias[ql * 33 + j] = v * FLOG2E;
         }
         // visible after the first tile's barrier
     }
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[ks]), c0, 0, 0, 0);
             } else if (BIAS1 && ks == 0) {
                 f32x16 c0;
-                const float* row = sbias + (wave * 32 + l31) * 32;
+                const float* row = sbias + (wave * 32 + l31) * 33;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     // key -> (row, column) of the key grid without an integer division: (key + 0.5) / kW is never closer than
