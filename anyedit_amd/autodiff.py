@@ -110,7 +110,64 @@ class Tape:
         with torch.no_grad(), self.paused():
             for fn in reversed(self.nodes):
                 fn()
+        # the closures hold this tape (and through it every saved activation): dropping them here breaks the reference cycle, so a
+        # step's activations go back to the allocator when the caller drops the tape instead of waiting for a gen-2 collection
+        # (measured: +6 GB of fresh segments per step until the collector ran, with hipMalloc stalls of 100-200 ms)
+        self.nodes = []
+        self.keep = []
         return self.param_grads
+
+    # ------------------------------------------------------------------ activation checkpointing (util.py:102-143 CheckpointFunction)
+    def _child(self):
+        sub = Tape()
+        sub.trainable = self.trainable          # same trainable leaves
+        sub.req = dict(self.req)                # every tensor known to need a gradient so far (they are all alive: req holds them)
+        sub._wt, sub._wrot = self._wt, self._wrot
+        return sub
+
+    def checkpoint(self, fn):
+        """`fn()` -> tensor or tuple of tensors, closing over its inputs (ResBlock / BasicTransformerBlock bodies, the reference's
+        `checkpoint(self._forward, ...)` sites openaimodel.py:250, attention.py:268).  Forward: run it on a throw-away child tape —
+        the SAME recorded kernels as an un-checkpointed step, so values are bit-identical — and drop every intermediate.  Backward:
+        run it again on a fresh child tape, seed the outputs' gradients, back-propagate inside, and hand the gradients of
+        everything that lives outside the segment (inputs, conditioning, parameters) to this tape."""
+        tmp = self._child()
+        with tmp.recording():
+            outs = fn()
+        depends = bool(tmp.nodes)               # something inside touched a tensor that needs a gradient
+        tmp.nodes, tmp.keep, tmp.req, tmp.grads = [], [], {}, {}   # drop the intermediates now (the closures form a cycle with tmp)
+        del tmp
+        outs_t = tuple(outs) if isinstance(outs, (tuple, list)) else (outs,)
+        if not depends:
+            return outs
+        for o in outs_t:
+            self.require(o)
+        self.keep.extend(outs_t)
+
+        def bwd():
+            gs = [self.grad(o) for o in outs_t]
+            if all(g is None for g in gs):
+                return
+            sub = self._child()
+            with torch.enable_grad(), sub.recording():
+                outs2 = fn()
+            outs2_t = tuple(outs2) if isinstance(outs2, (tuple, list)) else (outs2,)
+            for o2, g in zip(outs2_t, gs):
+                if g is not None:
+                    sub.accumulate(o2, g)
+            sub.backward()
+            for name, g in sub.param_grads.items():
+                self.add_param_grad(name, g)
+            for tid, g in sub.grads.items():
+                t = self.req.get(tid)
+                if t is not None and not any(t is o for o in outs2_t):   # a tensor from outside the segment
+                    if g.dtype == torch.float32:
+                        self.accumulate_f32(t, g)   # fp32 leaves (gate values)
+                    else:
+                        self.accumulate(t, g)
+
+        self.nodes.append(bwd)
+        return outs
 
     # ------------------------------------------------------------------ weights for the data-gradient passes
     def transposed(self, w):

@@ -221,6 +221,12 @@ class BasicTransformerBlock(nn.Module):
 
     def rows(self, x, B, N, context_rows=None, kv_cache=None):
         """x: [B*N, C] bf16.  kv_cache: optional dict id(attn)->projected K|V of the (step-invariant) context."""
+        tape = ops._TAPE
+        if self.checkpoint and tape is not None and tape.active:  # attention.py:268: recompute this block in the backward pass
+            return tape.checkpoint(lambda: self._rows(x, B, N, context_rows, kv_cache))
+        return self._rows(x, B, N, context_rows, kv_cache)
+
+    def _rows(self, x, B, N, context_rows=None, kv_cache=None):
         c1 = context_rows if self.disable_self_attn else None
         x = self.attn1.rows(x, B, N, context_rows=c1, residual=x, norm=self.norm1)
         kv2, adapter = None, None

@@ -155,6 +155,12 @@ class ResBlock(TimestepBlock):
 
     def rows(self, f, emb_silu):
         """f: Feat (possibly with a pending concat); emb_silu: bf16 [B, emb_channels] = SiLU(emb)."""
+        tape = ops._TAPE
+        if self.use_checkpoint and tape is not None and tape.active:  # openaimodel.py:250: recompute this block in the backward pass
+            return Feat(tape.checkpoint(lambda: self._rows(f, emb_silu).t), f.B, f.H, f.W)
+        return self._rows(f, emb_silu)
+
+    def _rows(self, f, emb_silu):
         B, H, W = f.B, f.H, f.W
         if isinstance(emb_silu, EmbPack) and id(self) in emb_silu.offsets:
             off = emb_silu.offsets[id(self)]

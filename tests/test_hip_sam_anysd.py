@@ -268,6 +268,7 @@ def test_training_step_gradients_vs_oracle_autograd():
     trx = AnySDTrainer(moe3, sa.to(DEV), s1.to(DEV), lr=1e-3, always_exchange=True, bucket_bytes=1 << 12)
     args = (lat.to(DEV), img.to(DEV), ehs.to(DEV), ref_emb.to(DEV), code.to(DEV), noise.to(DEV), t.to(DEV))
     _, tp, lp = trp.forward_loss(*args)
+    n_plain_nodes = len(tp.nodes)
     gp = trp.backward(tp, lp)
     _, tx, lx = trx.forward_loss(*args)
     gx = trx.backward(tx, lx)
@@ -277,3 +278,27 @@ def test_training_step_gradients_vs_oracle_autograd():
         assert torch.equal(gp[k], gx[k].reshape(gp[k].shape)), k
     first_rs = next(i for i, e in enumerate(log) if e[0] == "reduce_scatter")
     assert first_rs < max(i for i, e in enumerate(log) if e[0] == "ready") and len(trx.exchange.buckets) > 2
+    # activation checkpointing (openaimodel.py:250, attention.py:268; util.py:102-143): every ResBlock / BasicTransformerBlock body is
+    # dropped after the forward and recomputed in the backward — same kernels, so the loss is bit-identical; the gradients agree to
+    # bf16 rounding only, because a segment sums its contributions to an outside tensor (skip / residual inputs) before handing
+    # them over, a different order of bf16 additions from the flat tape's
+    moe4, _ = _tiny_moe()
+    n_ck = 0
+    for m in moe4.modules():
+        if hasattr(m, "use_checkpoint"):
+            m.use_checkpoint = True
+            n_ck += 1
+        if m.__class__.__name__ == "BasicTransformerBlock":
+            m.checkpoint = True
+            n_ck += 1
+    assert n_ck >= 6
+    moe4 = moe4.to(DEV)
+    trc = AnySDTrainer(moe4, sa.to(DEV), s1.to(DEV), lr=1e-3)
+    lc, tc, lvc = trc.forward_loss(*args)
+    lp2, _, _ = trp.forward_loss(*args)
+    assert float(lc) == float(lp2)
+    assert len(tc.nodes) < n_plain_nodes            # the block bodies are single nodes now
+    gc = trc.backward(tc, lvc)
+    for k in gp:
+        # the router gradients are sums of small, cancelling per-layer terms (see the oracle comparison above), so rounding shows most there
+        assert rel_l2(gc[k].reshape(gp[k].shape), gp[k]) <= (1e-1 if k.startswith("gate.") else 3e-2), f"checkpointed gradient differs: {k}"

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--checkpoint", action="store_true", help="use_checkpoint=True: recompute every ResBlock / BasicTransformerBlock in the backward pass")
+    ap.add_argument("--per-step", action="store_true", help="synchronise after every step and report each step's time")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -38,6 +40,12 @@ def main():
     unet, moe, sched = bench.build_model(device)
     for p in list(moe.image_proj_model.parameters()) + list(moe.adapter_modules) + [moe.task_embs]:
         p.requires_grad_(True)
+    if args.checkpoint:
+        for m in moe.modules():
+            if hasattr(m, "use_checkpoint"):
+                m.use_checkpoint = True
+            if m.__class__.__name__ == "BasicTransformerBlock":
+                m.checkpoint = True
     B = args.batch
     g = torch.Generator(device="cpu").manual_seed(4 + rank)
     lat = torch.randn(B, 4, 64, 64, generator=g).to(device)
@@ -48,11 +56,17 @@ def main():
     code = (torch.arange(B) % 3).to(device)
     tr = AnySDTrainer(moe, sched.sqrt_alphas_cumprod, sched.sqrt_one_minus_alphas_cumprod, lr=1e-5)
 
-    def step(i):
+    def draw(i):
         gi = torch.Generator(device="cpu").manual_seed(100 * rank + i)
-        noise = torch.randn(B, 4, 64, 64, generator=gi).to(device)
-        t = torch.randint(0, 1000, (B,), generator=gi).to(device)
-        u = torch.rand(B, generator=gi).to(device)
+        return (torch.randn(B, 4, 64, 64, generator=gi).to(device), torch.randint(0, 1000, (B,), generator=gi).to(device),
+                torch.rand(B, generator=gi).to(device))
+
+    # per-step noise / timestep / dropout draws are made up front: the timed region holds no host->device copies
+    draws = [draw(i) for i in range(args.warmup + args.steps + 1)]
+    torch.cuda.synchronize()
+
+    def step(i):
+        noise, t, u = draws[i]
         return tr.train_step(lat, img, ehs, ref, code, noise, t, null_ehs=null.expand(B, -1, -1), dropout_u=u, dropout_p=0.05)
 
     for i in range(args.warmup):
@@ -61,8 +75,18 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     t0 = time.perf_counter()
+    per_step = []
     for i in range(args.steps):
+        ts = time.perf_counter()
         loss = step(args.warmup + i)
+        if args.per_step:
+            torch.cuda.synchronize()
+            per_step.append(round(1e3 * (time.perf_counter() - ts), 2))
+            if os.environ.get("AE_TRAIN_DIAG"):
+                import gc
+                ms = torch.cuda.memory_stats()
+                print("diag", i, per_step[-1], "reserved", ms["reserved_bytes.all.current"] >> 20, "segs", ms["segment.all.allocated"], "freed", ms["segment.all.freed"],
+                      "retries", ms["num_alloc_retries"], "gc", [g["collections"] for g in gc.get_stats()], file=sys.stderr)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -83,7 +107,9 @@ def main():
                           "pairs_per_sec": world * B / dt, "n_gpus": world, "batch_per_gpu": B, "dtype": "bf16 activations, fp32 state",
                           "forward_tflop": fwd_tflop, "approx_tflops": 3.0 * fwd_tflop / dt,
                           "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "loss": float(loss),
-                          "exchange_bytes_per_step": tr.exchange.bytes_per_step if tr.exchange else 0, "profile": by_shape}))
+                          "exchange_bytes_per_step": tr.exchange.bytes_per_step if tr.exchange else 0, "activation_checkpointing": bool(args.checkpoint),
+                          "per_step_ms": per_step or None,
+                          "profile": by_shape}))
     if world > 1:
         torch.distributed.destroy_process_group()
 
