@@ -73,7 +73,6 @@ class AnySDTrainer:
             context_rows = torch.cat([ehs.float(), te[:, None, :].float()], 1).reshape(B * (L + 1), Dc).to(BF16).contiguous()
             probs, top1, top1p = moe.route(edit_code)
             gate = top1p.float().contiguous()
-            experts = top1.long().tolist()
             tape.require(context_rows)
             tape.require(gate)
             # trainable leaves: packed bf16 copies of the fp32 masters
@@ -91,7 +90,7 @@ class AnySDTrainer:
                 for li, (blk, W) in enumerate(zip(moe._blocks, moe.adapter_modules)):
                     attn = blk.attn2
                     kv_cache[id(attn)] = attn.project_kv(context_rows)
-                    kv_ip = self._expert_kv(tape, ip_rows, W, experts, T_ip, f"adapter_modules.{li}")
+                    kv_ip = self._expert_kv(tape, ip_rows, W, top1, T_ip, f"adapter_modules.{li}")
                     kv_cache[("adapter", id(attn))] = (kv_ip, gate)
                 eps_hat = moe.unet.forward_rows(x, timesteps, context_rows, kv_cache=kv_cache)
             loss = ops.mse(eps_hat, noise.float())
@@ -99,40 +98,24 @@ class AnySDTrainer:
                   "noise": noise.float(), "L": L, "B": B, "Dc": Dc}
         return loss, tape, leaves
 
-    def _expert_kv(self, tape, ip_rows, W, experts, T_ip, name):
-        """kv_ip[b] = ip_rows[b] @ W[expert_b]^T for every sample; recorded as ONE tape node.  A sample's T_ip rows are contiguous, so
-        every GEMM reads / writes row SLICES (no gather, scatter or index tensors); only the routed experts' weights are converted
-        to bf16 (once per orientation per step)."""
-        B = len(experts)
+    def _expert_kv(self, tape, ip_rows, W, top1, T_ip, name):
+        """kv_ip[b] = ip_rows[b] @ bf16(W[expert_b])^T for every sample; recorded as ONE tape node.  Forward, data gradient and weight
+        gradient are one grouped launch each (csrc/expert_kv.hip): they read the fp32 masters directly, so a layer needs no per-expert
+        bf16 copies, transposes or zero fills (round 1 looped over samples: ~40 launches per adapter layer)."""
         dev = ip_rows.device
-        kv_ip = torch.empty(B * T_ip, W.shape[1], dtype=BF16, device=dev)
-        present = sorted(set(experts))
-        rows = lambda t, b: t[b * T_ip:(b + 1) * T_ip]
-        Wb = {e: W.detach()[e].to(BF16) for e in present}                               # [2*inner, Dc], the forward orientation
+        Wd = W.detach()
         with tape.paused():
-            for b, e in enumerate(experts):
-                ops.gemm(rows(ip_rows, b), Wb[e], out=rows(kv_ip, b))
+            kv_ip = ops.expert_kv(ip_rows, Wd, top1, T_ip)
 
         def bwd():
             dkv = tape.grad(kv_ip)
             if dkv is None:
                 return
-            d_ip = torch.empty_like(ip_rows)
+            dkv = dkv.contiguous()
+            d_ip = ops.expert_kv_dgrad(dkv, Wd, top1, T_ip)
             # dense gradient (AdamW decays the un-routed experts too); under DDP it is written straight into its exchange bucket
-            dW = self.exchange.grad_buffer(name) if self.exchange is not None else torch.zeros(W.shape, dtype=torch.float32, device=dev)
-            for e in present:
-                Wt = W.detach()[e].t().to(BF16).contiguous()                            # [Dc, 2*inner]: dA = dY W_e
-                bs = [b for b in range(B) if experts[b] == e]
-                for b in bs:
-                    ops.gemm(rows(dkv, b), Wt, out=rows(d_ip, b))
-                dy = rows(dkv, bs[0]) if len(bs) == 1 else torch.cat([rows(dkv, b) for b in bs])
-                a = rows(ip_rows, bs[0]) if len(bs) == 1 else torch.cat([rows(ip_rows, b) for b in bs])
-                M, Mp = dy.shape[0], (dy.shape[0] + 7) // 8 * 8
-                dyt = torch.zeros(dy.shape[1], Mp, dtype=BF16, device=dev)
-                dyt[:, :M] = dy.t()
-                at = torch.zeros(a.shape[1], Mp, dtype=BF16, device=dev)
-                at[:, :M] = a.t()
-                ops.gemm(dyt, at, out_f32=True, out=dW[e])                              # dW_e = dY^T A
+            dW = self.exchange.grad_buffer(name) if self.exchange is not None else None
+            dW = ops.expert_kv_wgrad(dkv, ip_rows, top1, T_ip, W.shape[0], out=dW)
             tape.accumulate(ip_rows, d_ip)
             tape.add_param_grad(name, dW)
             if self.exchange is not None:  # this layer's expert weights are final: their bucket may leave while backward goes on

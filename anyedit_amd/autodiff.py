@@ -342,10 +342,21 @@ class Tape:
             dy = self.grad(y)
             if dy is None:
                 return
-            if self.needs(a):
-                self.accumulate(a, dy[:, :ca].contiguous())
-            if self.needs(b):
-                self.accumulate(b, dy[:, ca:].contiguous())
+            na, nb = self.needs(a), self.needs(b)
+            ba, bb = _base(a), _base(b)
+            if not (na or nb) or ba is bb or a.numel() != ba.numel() or b.numel() != bb.numel() or not dy.is_contiguous():
+                if na:
+                    self.accumulate(a, dy[:, :ca].contiguous())
+                if nb:
+                    self.accumulate(b, dy[:, ca:].contiguous())
+                return
+            # one pass: each half is written to a fresh gradient buffer or added to the one its tensor already has
+            ga, gb = (self.grads.get(id(ba)) if na else None), (self.grads.get(id(bb)) if nb else None)
+            da, db = ops.split_channels(dy, ca, None if ga is None else ga.reshape(a.shape), None if gb is None else gb.reshape(b.shape), na, nb)
+            if na and ga is None:
+                self.grads[id(ba)] = da.reshape(ba.shape)
+            if nb and gb is None:
+                self.grads[id(bb)] = db.reshape(bb.shape)
 
         self._record([y], [a, b], bwd)
         return y

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libanyedit_hip.so")
-SOURCES = ["c_api.hip", "gemm_conv.hip", "gemm_rowpanel.hip", "attention.hip", "attention_fast.hip", "attention_fp8.hip", "attention_bwd.hip", "norm.hip", "elementwise.hip", "backward.hip", "gate.hip", "msda.hip",
+SOURCES = ["c_api.hip", "gemm_conv.hip", "gemm_rowpanel.hip", "attention.hip", "attention_fast.hip", "attention_fp8.hip", "attention_bwd.hip", "norm.hip", "elementwise.hip", "backward.hip", "gate.hip", "expert_kv.hip", "msda.hip",
            "sam_decoder.hip"]
 # attention: no NaN/Inf semantics are relied on (masked logits are a finite -1e30) -> lets fmaxf compile to bare v_max/v_max3
 EXTRA = {"attention.hip": ["-ffinite-math-only"], "attention_fast.hip": ["-ffinite-math-only"], "attention_fp8.hip": ["-ffinite-math-only"], "attention_bwd.hip": ["-ffinite-math-only"]}

@@ -53,6 +53,28 @@ __global__ void concat_kernel(const bf16_t* a, int Ca, const bf16_t* b, int Cb, 
     }
 }
 
+// adjoint of concat_kernel: the two channel slices of dy go to da / db in one pass (written, or added to what is there)
+__global__ void split_kernel(const bf16_t* y, int Ca, int Cb, bf16_t* a, bf16_t* b, long rows, int acc_a, int acc_b) {
+    const int C = Ca + Cb, ncc = C / 8;
+    const long total = rows * ncc;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long r = i / ncc;
+        const int ch = (int)(i % ncc) * 8;
+        const bool first = ch < Ca;
+        bf16_t* dst = first ? a + r * Ca + ch : b + r * Cb + (ch - Ca);
+        if ((first ? a : b) == nullptr) continue;
+        u32x4 v = *reinterpret_cast<const u32x4*>(y + r * C + ch);
+        if (first ? acc_a : acc_b) {
+            const u32x4 o = *reinterpret_cast<const u32x4*>(dst);
+            v.x = pack_bf16x2(bf16lo(v.x) + bf16lo(o.x), bf16hi(v.x) + bf16hi(o.x));
+            v.y = pack_bf16x2(bf16lo(v.y) + bf16lo(o.y), bf16hi(v.y) + bf16hi(o.y));
+            v.z = pack_bf16x2(bf16lo(v.z) + bf16lo(o.z), bf16hi(v.z) + bf16hi(o.z));
+            v.w = pack_bf16x2(bf16lo(v.w) + bf16lo(o.w), bf16hi(v.w) + bf16hi(o.w));
+        }
+        *reinterpret_cast<u32x4*>(dst) = v;
+    }
+}
+
 __global__ void timestep_embedding_kernel(const long* t_i64, const float* t_f32, bf16_t* out_bf16, float* out_f32, int B,
                                           int dim, float max_period) {
     const int half = dim / 2;
@@ -404,6 +426,13 @@ extern "C" int ae_concat_channels_bf16(const void* a, int Ca, const void* b, int
     hipLaunchKernelGGL(concat_kernel, dim3(grid_for(rows * ((Ca + Cb) / 8))), dim3(NT), 0, (hipStream_t)stream,
                        (const bf16_t*)a, Ca, (const bf16_t*)b, Cb, (bf16_t*)y, rows);
     return ae_check_launch("ae_concat_channels_bf16");
+}
+
+extern "C" int ae_split_channels_bf16(const void* y, int Ca, int Cb, void* a, void* b, long rows, int accumulate_a, int accumulate_b, void* stream) {
+    AE_REQUIRE(y && (a || b) && rows > 0 && Ca > 0 && Cb > 0 && Ca % 8 == 0 && Cb % 8 == 0, "ae_split_channels_bf16: bad arguments");
+    hipLaunchKernelGGL(split_kernel, dim3(grid_for(rows * ((Ca + Cb) / 8))), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)y, Ca, Cb, (bf16_t*)a,
+                       (bf16_t*)b, rows, accumulate_a, accumulate_b);
+    return ae_check_launch("ae_split_channels_bf16");
 }
 
 extern "C" int ae_timestep_embedding(const long* t_i64, const float* t_f32, void* out_bf16, float* out_f32, int B, int dim,

@@ -738,6 +738,9 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         if (glds) rc = launch_kernel(gemm_kernel<BM_, BN_, AMODE, WM_, WN_, true>, grid, THREADS, lds_of(BM_, BN_, 2), stream, a, what);   \
         else rc = launch_kernel(gemm_kernel<BM_, BN_, AMODE, WM_, WN_, false>, grid, THREADS, lds_of(BM_, BN_, 2), stream, a, what);       \
     } while (0)
+        // 64x64 grids up to three blocks per CU keep the ring too (its 48 KiB leave room for three resident blocks): training batch
+        // M = 1024 x N = 1280 x K = 1280 (320 blocks) 31.7 -> ~20 us, training step 29.0 -> 28.0 ms.  AE_GEMM_DEEP64_MAX=256 restores round 1.
+        static const int deep64_max = getenv("AE_GEMM_DEEP64_MAX") ? atoi(getenv("AE_GEMM_DEEP64_MAX")) : 768;
         static const int conv_deep_l = getenv("AE_CONV_DEEP") ? atoi(getenv("AE_CONV_DEEP")) : 1;
         if (conv && conv_deep_l && pick == 0 && glds && grid <= 256)
             rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 3>, grid, 512, lds_of(128, 128, 3), stream, a, what);
@@ -748,7 +751,7 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         else if (pick == 0) AE_LAUNCH(128, 128, 2, 2, 256);
         else if (pick == 1 && w8 && !conv) AE_LAUNCH(128, 64, 4, 2, 512);
         else if (pick == 1) AE_LAUNCH(128, 64, 2, 2, 256);
-        else if (deep_pref && glds && !conv && a.splitk <= 1 && grid <= 256 && a.K >= 1280)
+        else if (deep_pref && glds && !conv && a.splitk <= 1 && grid <= (unsigned)deep64_max && a.K >= 1280)
             // the same ring for small 64x64 grids (8x8 level, training batches): M = 768 x N = 1280 at K = 1280 / 2560 / 5120:
             // 23.3 -> 16.4, 37.4 -> 23.2, 67.3 -> 38.7 us; lower K thresholds and a fourth stage measured the same
             rc = launch_kernel(gemm_kernel<64, 64, AMODE, 2, 2, true, 1, 3>, grid, 256, lds_of(64, 64, 3), stream, a, what);

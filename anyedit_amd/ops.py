@@ -187,6 +187,19 @@ def conv3x3(x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2
 
 
 # --------------------------------------------------------------------------- norms
+_GN_COUNTERS = {}
+
+
+def _gn_counters(device, B):
+    """int32 tickets for the last-block statistics fold (zero between launches).  One buffer per (device, stream): launches on a
+    stream are ordered, so they can share it; the first use on a stream allocates (inside a graph capture that is a memset node)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    c = _GN_COUNTERS.get(key)
+    if c is None or c.numel() < B:
+        c = _GN_COUNTERS[key] = torch.zeros(max(B, 256), dtype=torch.int32, device=device)
+    return c
+
+
 def groupnorm(x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, out=None):
     """GroupNorm(+SiLU) over channels-last [B*HW, C]; x2: optional second tensor concatenated along channels."""
     if _TAPE is not None and _TAPE.active:
@@ -200,7 +213,7 @@ def groupnorm(x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, out=No
         out = torch.empty(B * HW, C, dtype=BF16, device=x.device)
     ws = torch.empty(lib.ae_groupnorm_workspace_floats(B, HW, C, groups), dtype=torch.float32, device=x.device)
     check(lib.ae_groupnorm_nhwc_bf16(_p(x), _p(x2), C1, _p(gamma), _p(beta), _p(out), B, HW, C, groups, eps,
-                                     1 if silu else 0, _p(ws), _s()), "ae_groupnorm_nhwc_bf16")
+                                     1 if silu else 0, _p(ws), _p(_gn_counters(x.device, B)), _s()), "ae_groupnorm_nhwc_bf16")
     return out
 
 
@@ -323,6 +336,17 @@ def concat_channels(a, b):
     out = torch.empty(a.shape[0], a.shape[1] + b.shape[1], dtype=BF16, device=a.device)
     check(lib.ae_concat_channels_bf16(_p(a), a.shape[1], _p(b), b.shape[1], _p(out), a.shape[0], _s()), "ae_concat_channels_bf16")
     return out
+
+
+def split_channels(dy, ca, a=None, b=None, want_a=True, want_b=True):
+    """Adjoint of `concat_channels`: (da, db) with da (+)= dy[:, :ca], db (+)= dy[:, ca:]; `a` / `b` are existing gradient
+    buffers to add into (None: a fresh buffer is written).  One launch instead of two strided copies and two adds."""
+    rows, C = dy.shape
+    cb = C - ca
+    da = a if a is not None else (torch.empty(rows, ca, dtype=BF16, device=dy.device) if want_a else None)
+    db = b if b is not None else (torch.empty(rows, cb, dtype=BF16, device=dy.device) if want_b else None)
+    check(lib.ae_split_channels_bf16(_p(dy), ca, cb, _p(da), _p(db), rows, int(a is not None), int(b is not None), _s()), "ae_split_channels_bf16")
+    return da, db
 
 
 def timestep_embedding(t, dim, max_period=10000.0, out_f32=False):
@@ -672,7 +696,7 @@ def groupnorm_bwd(x, gamma, beta, dy, B, HW, eps, silu=False, groups=32, x2=None
     dx2 = torch.empty_like(x2) if x2 is not None else None
     ws = torch.empty(lib.ae_groupnorm_bwd_workspace_floats(B, HW, C, groups), dtype=torch.float32, device=x.device)
     check(lib.ae_groupnorm_bwd_nhwc_bf16(_p(x), _p(x2), C1, _p(gamma), _p(beta), _p(_tmp(dy.contiguous())), _p(dx), _p(dx2), B, HW, C, groups,
-                                         eps, 1 if silu else 0, _p(ws), _s()), "ae_groupnorm_bwd_nhwc_bf16")
+                                         eps, 1 if silu else 0, _p(ws), _p(_gn_counters(x.device, B)), _s()), "ae_groupnorm_bwd_nhwc_bf16")
     return dx, dx2
 
 
@@ -757,6 +781,55 @@ def task_gate_wgrad(probs, top1, dgate, task_emb, edit_code):
     return dW, db
 
 
+_EXPERT_KV_WS = {}
+
+
+def _experts_i32(experts):
+    return experts.to(torch.int32).contiguous()
+
+
+def expert_kv(x, W, experts, tokens):
+    """kv[b*T+t] = x[b*T+t] @ bf16(W[experts[b]])^T for every sample in ONE launch (training forward of the AnySD adapters).
+    x [B*T, Dc] bf16, W [E, N, Dc] fp32 master, experts [B] int -> [B*T, N] bf16."""
+    E, N, Dc = W.shape
+    B = x.shape[0] // tokens
+    assert x.dtype == BF16 and x.is_contiguous() and W.dtype == torch.float32 and W.is_contiguous() and x.shape == (B * tokens, Dc)
+    ex = _tmp(_experts_i32(experts))
+    y = torch.empty(B * tokens, N, dtype=BF16, device=x.device)
+    check(lib.ae_expert_kv_fwd(_p(x), _p(W), _p(ex), _p(y), B, tokens, N, Dc, E, _s()), "ae_expert_kv_fwd")
+    return y
+
+
+def expert_kv_dgrad(dy, W, experts, tokens):
+    """dx[b*T+t] = dy[b*T+t] @ bf16(W[experts[b]]) (bf16), fixed summation order."""
+    E, N, Dc = W.shape
+    B = dy.shape[0] // tokens
+    assert dy.dtype == BF16 and dy.is_contiguous() and dy.shape == (B * tokens, N)
+    S = lib.ae_expert_kv_dgrad_slices(N)
+    key = (dy.device, torch.cuda.current_stream(dy.device).cuda_stream)
+    need = S * B * tokens * Dc
+    ws = _EXPERT_KV_WS.get(key)
+    if ws is None or ws.numel() < need:   # grow-only scratch per (device, stream): launches on a stream are ordered
+        ws = _EXPERT_KV_WS[key] = torch.empty(need, dtype=torch.float32, device=dy.device)
+    ex = _tmp(_experts_i32(experts))
+    dx = torch.empty(B * tokens, Dc, dtype=BF16, device=dy.device)
+    check(lib.ae_expert_kv_dgrad(_p(dy), _p(W), _p(ex), _p(dx), B, tokens, N, Dc, E, _p(ws), _s()), "ae_expert_kv_dgrad")
+    return dx
+
+
+def expert_kv_wgrad(dy, x, experts, tokens, n_experts, out=None):
+    """dW[e] = sum over the samples routed to e of dy[b]^T x[b] (fp32 [E, N, Dc]; zeros for experts nothing was routed to)."""
+    B = dy.shape[0] // tokens
+    N, Dc = dy.shape[1], x.shape[1]
+    assert dy.dtype == BF16 and x.dtype == BF16 and dy.is_contiguous() and x.is_contiguous()
+    if out is None:
+        out = torch.empty(n_experts, N, Dc, dtype=torch.float32, device=dy.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == n_experts * N * Dc
+    ex = _tmp(_experts_i32(experts))
+    check(lib.ae_expert_kv_wgrad(_p(dy), _p(x), _p(ex), _p(out), B, tokens, N, Dc, n_experts, _s()), "ae_expert_kv_wgrad")
+    return out
+
+
 class OpProfiler:
     """Records (kernel label, algorithmic flops, algorithmic bytes, HIP-event duration) for every GEMM / conv / attention /
     norm launch issued through this module while active.  Events are recorded on torch's current stream, which is the
@@ -815,7 +888,7 @@ def _tile_label(M, N, conv=False, K=0, geglu=False, dma_ok=True):
         tm, tn = -(-M // bm), -(-N // bn)
         if tm * tn >= 256 and tn * bn / N <= 1.10:
             return f"{bm}x{bn}"
-    if not conv and dma_ok and K >= 1280 and -(-M // 64) * -(-N // 64) <= 256:
+    if not conv and dma_ok and K >= 1280 and -(-M // 64) * -(-N // 64) <= 768:
         return "64x64,ring3"
     return "64x64"
 
@@ -895,3 +968,9 @@ conv3x3 = _wrap_profiled(conv3x3, _conv_label)
 attention = _wrap_profiled(attention, _attn_label)
 groupnorm = _wrap_profiled(groupnorm, _gn_label)
 layernorm = _wrap_profiled(layernorm, _ln_label)
+expert_kv = _wrap_profiled(expert_kv, lambda _r, x, W, experts, tokens: (
+    f"expert_kv_fwd_kernel|rows={x.shape[0]} N={W.shape[1]} Dc={W.shape[2]}", 2.0 * x.shape[0] * W.shape[1] * W.shape[2], 4.0 * (x.shape[0] // tokens) * W.shape[1] * W.shape[2]))
+expert_kv_dgrad = _wrap_profiled(expert_kv_dgrad, lambda _r, dy, W, experts, tokens: (
+    f"expert_kv_dgrad_kernel|rows={dy.shape[0]} N={W.shape[1]} Dc={W.shape[2]}", 2.0 * dy.shape[0] * W.shape[1] * W.shape[2], 4.0 * (dy.shape[0] // tokens) * W.shape[1] * W.shape[2]))
+expert_kv_wgrad = _wrap_profiled(expert_kv_wgrad, lambda _r, dy, x, experts, tokens, n_experts, out=None: (
+    f"expert_kv_wgrad_kernel|rows={dy.shape[0]} N={dy.shape[1]} Dc={x.shape[1]} E={n_experts}", 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1], 4.0 * n_experts * dy.shape[1] * x.shape[1]))

@@ -71,11 +71,15 @@ int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float
                     void* stream);
 
 /* GroupNorm32 (+SiLU) (util.py:217-219 eps 1e-5; attention.py:88-89 eps 1e-6); input may be the channel-concat [x | x2].
- * workspace: fp32, ae_groupnorm_workspace_floats(B,HW,C,groups) elements.  act: 0 none, 1 SiLU.                              */
+ * workspace: fp32, ae_groupnorm_workspace_floats(B,HW,C,groups) elements.  act: 0 none, 1 SiLU.
+ * counters: optional int32[B], ZERO on entry and zero again on exit, not shared with a launch running concurrently on another
+ * stream: the last partial-sum block of each sample then runs the statistics fold itself (two launches instead of three, same
+ * fixed summation order, bit-identical result).  NULL keeps the stand-alone finalize launch.  The tail is OFF unless AE_GN_TAIL=1:
+ * measured 3 ms per UNet step slower on MI355X (every block's device-scope release is an L2 write-back).                        */
 int ae_groupnorm_rows_per_chunk(int HW, int C);
 long ae_groupnorm_workspace_floats(int B, int HW, int C, int groups);
 int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y, int B, int HW,
-                           int C, int groups, float eps, int act, float* workspace, void* stream);
+                           int C, int groups, float eps, int act, float* workspace, int* counters, void* stream);
 
 /* nn.LayerNorm over the last dim (attention.py:263-265 eps 1e-5; SAM image_encoder.py:166-182 / common.py:30-43 eps 1e-6). */
 int ae_layernorm_bf16(const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps, void* stream);
@@ -120,11 +124,12 @@ int ae_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* do
                      long k_sh, long k_sn, long v_sb, long v_sh, long v_sn, long o_sb, long o_sh, long o_sn, long dq_sb,
                      long dq_sh, long dq_sn, long dk_sb, long dk_sh, long dk_sn, long dv_sb, long dv_sh, long dv_sn,
                      float scale, const float* out_scale, int accumulate_dq, void* stream);
-/* GroupNorm(+SiLU) backward w.r.t. the input(s) (autograd of util.py:217-219 + nn.SiLU); dx2 receives channels [C1, C).      */
+/* GroupNorm(+SiLU) backward w.r.t. the input(s) (autograd of util.py:217-219 + nn.SiLU); dx2 receives channels [C1, C).
+ * counters: as for ae_groupnorm_nhwc_bf16 (three launches instead of five).                                                    */
 long ae_groupnorm_bwd_workspace_floats(int B, int HW, int C, int groups);
 int ae_groupnorm_bwd_nhwc_bf16(const void* x, const void* x2, int C1, const float* gamma, const float* beta, const void* dy,
                                void* dx, void* dx2, int B, int HW, int C, int groups, float eps, int act, float* workspace,
-                               void* stream);
+                               int* counters, void* stream);
 /* LayerNorm backward w.r.t. the input; row_stat (optional fp32 [M,2]) receives (mean, rstd) for the parameter gradients.    */
 int ae_layernorm_bwd_bf16(const void* x, const float* gamma, const void* dy, void* dx, float* row_stat, int M, int C, float eps,
                           void* stream);
@@ -159,11 +164,26 @@ int ae_task_gate_bwd(const float* probs, const int* top1, const float* dgate, co
 int ae_task_gate_wgrad(const float* probs, const int* top1, const float* dgate, const float* task_emb, const long* edit_code, int B,
                        int n_tasks, int Dt, int E, float* dWg, float* dbg, void* stream);
 
+/* AnySD per-expert adapter K/V projection of the training step, grouped over the samples of a batch (our spec, DESIGN.md §6; the
+ * reference trains `adapter_modules` at train.py:410-424, 536-541).  x: [B*T, Dc] bf16 image-prompt rows (T <= 8 per sample),
+ * W: [E, N, Dc] fp32 masters (rounded to bf16 in registers), experts: [B] int32 routed expert per sample.
+ *   fwd    y[b*T+t, n]  = sum_k x[b*T+t, k] * W[experts[b], n, k]                              (bf16 out)
+ *   dgrad  dx[b*T+t, k] = sum_n dy[b*T+t, n] * W[experts[b], n, k]                             (bf16 out, fixed summation order;
+ *          partial: ae_expert_kv_dgrad_slices(N)*B*T*Dc floats of scratch)
+ *   wgrad  dW[e, n, k]  = sum_{b: experts[b] == e} sum_t dy[b*T+t, n] * x[b*T+t, k]            (fp32, every expert written)      */
+int ae_expert_kv_fwd(const void* x, const float* W, const int* experts, void* y, int B, int T, int N, int Dc, int E, void* stream);
+int ae_expert_kv_dgrad_slices(int N);
+int ae_expert_kv_dgrad(const void* dy, const float* W, const int* experts, void* dx, int B, int T, int N, int Dc, int E, float* partial,
+                       void* stream);
+int ae_expert_kv_wgrad(const void* dy, const void* x, const int* experts, float* dW, int B, int T, int N, int Dc, int E, void* stream);
+
 /* out[b,y,x] = in[b,x,y], inner dim zero-padded to Xpad: NCHW <-> channels-last at the UNet boundary
  * ('b c h w -> b (h w) c', attention.py:329,337).                                                                           */
 int ae_transpose_last2(const void* in, void* out, int B, int X, int Y, int Xpad, int in_bf16, int out_bf16, void* stream);
 /* th.cat([h, hs.pop()], dim=1) (openaimodel.py:780) on channels-last rows.                                                   */
 int ae_concat_channels_bf16(const void* a, int Ca, const void* b, int Cb, void* y, long rows, void* stream);
+/* Adjoint of the channel concat: a (+)= y[:, :Ca], b (+)= y[:, Ca:] in one pass; a or b may be NULL (that half is skipped).       */
+int ae_split_channels_bf16(const void* y, int Ca, int Cb, void* a, void* b, long rows, int accumulate_a, int accumulate_b, void* stream);
 /* timestep_embedding (util.py:154-174): [cos | sin], t given as int64 or fp32.                                               */
 int ae_timestep_embedding(const long* t_i64, const float* t_f32, void* out_bf16, float* out_f32, int B, int dim, float max_period,
                           void* stream);

@@ -302,3 +302,30 @@ def test_tape_adapter_attention_two_segments(ops, fused, D):
     check_close(tape.grad(kvd), kvr.grad, rl2=1.5e-2, mabs=5e-2, what="d kv (text)")
     check_close(tape.grad(kvipd), kvipr.grad, rl2=1.5e-2, mabs=5e-2, what="d kv (expert)")
     check_close(tape.grads[id(gd)], gr.grad, rl2=3e-2, mabs=5e-2, what="d gate")
+
+
+@pytest.mark.parametrize("B,T,N,Dc,E", [(4, 4, 2560, 768, 11), (3, 4, 640, 768, 5), (16, 4, 1280, 768, 11), (2, 3, 64, 256, 2)])
+def test_expert_kv_grouped_forward_dgrad_wgrad(ops, B, T, N, Dc, E):
+    """Grouped per-expert adapter K/V projection (csrc/expert_kv.hip; AnySD adapters, train.py:410-424 / DESIGN.md §6) against
+    per-sample fp32 matmuls on the bf16-rounded expert weights; the data gradient is bit-reproducible run to run."""
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    x = torch.randn(B * T, Dc, generator=g).to(DEV).to(torch.bfloat16)
+    W = (torch.randn(E, N, Dc, generator=g) * 0.05).to(DEV)
+    dy = torch.randn(B * T, N, generator=g).to(DEV).to(torch.bfloat16)
+    experts = torch.randint(0, E, (B,), generator=g).to(DEV).to(torch.int32)
+    Wb = W.to(torch.bfloat16).float()
+    xs, dys = x.float().view(B, T, Dc), dy.float().view(B, T, N)
+    y_ref = torch.stack([xs[b] @ Wb[experts[b]].t() for b in range(B)]).view(B * T, N)
+    dx_ref = torch.stack([dys[b] @ Wb[experts[b]] for b in range(B)]).view(B * T, Dc)
+    dW_ref = torch.zeros(E, N, Dc, device=DEV)
+    for b in range(B):
+        dW_ref[experts[b]] += dys[b].t() @ xs[b]
+    y = ops.expert_kv(x, W, experts, T)
+    dx = ops.expert_kv_dgrad(dy, W, experts, T)
+    dx2 = ops.expert_kv_dgrad(dy, W, experts, T)
+    dW = ops.expert_kv_wgrad(dy, x, experts, T, E)
+    assert rel_l2(y.float(), y_ref) <= 4e-3 and rel_l2(dx.float(), dx_ref) <= 4e-3      # bf16 output rounding
+    assert torch.equal(dx, dx2)
+    assert rel_l2(dW, dW_ref) <= 1e-5
+    absent = [e for e in range(E) if e not in experts.tolist()]
+    assert all(float(dW[e].abs().max()) == 0.0 for e in absent)

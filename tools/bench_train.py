@@ -80,12 +80,13 @@ def main():
         ts = time.perf_counter()
         loss = step(args.warmup + i)
         if args.per_step:
+            th = time.perf_counter()
             torch.cuda.synchronize()
-            per_step.append(round(1e3 * (time.perf_counter() - ts), 2))
+            per_step.append((round(1e3 * (th - ts), 2), round(1e3 * (time.perf_counter() - ts), 2)))   # (host enqueue time, step time)
             if os.environ.get("AE_TRAIN_DIAG"):
                 import gc
                 ms = torch.cuda.memory_stats()
-                print("diag", i, per_step[-1], "reserved", ms["reserved_bytes.all.current"] >> 20, "segs", ms["segment.all.allocated"], "freed", ms["segment.all.freed"],
+                print("diag", i, per_step[-1][1], "reserved", ms["reserved_bytes.all.current"] >> 20, "segs", ms["segment.all.allocated"], "freed", ms["segment.all.freed"],
                       "retries", ms["num_alloc_retries"], "gc", [g["collections"] for g in gc.get_stats()], file=sys.stderr)
     torch.cuda.synchronize()
     if world > 1:
