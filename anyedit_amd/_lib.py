@@ -28,7 +28,7 @@ SIGNATURES = {
     "ae_groupnorm_rows_per_chunk": [c_int, c_int],
     "ae_groupnorm_workspace_floats": [c_int, c_int, c_int, c_int],
     "ae_groupnorm_nhwc_bf16": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
-                               c_int, c_void_p, c_void_p, c_void_p],
+                               c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "ae_layernorm_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "ae_attn_fwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                          c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long,
@@ -38,7 +38,7 @@ SIGNATURES = {
     "ae_attn_bwd_bf16": [c_void_p] * 9 + [c_int] * 5 + [c_long] * 21 + [c_float, c_void_p, c_int, c_void_p],
     "ae_groupnorm_bwd_workspace_floats": [c_int, c_int, c_int, c_int],
     "ae_groupnorm_bwd_nhwc_bf16": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                   c_int, c_float, c_int, c_void_p, c_void_p, c_void_p],
+                                   c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "ae_layernorm_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "ae_layernorm_param_grad_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "ae_add_bf16": [c_void_p, c_void_p, c_void_p, c_long, c_void_p],

@@ -280,14 +280,15 @@ class Tape:
         return y, Ho, Wo
 
     def groupnorm(self, x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, out=None):
+        stat = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)   # (mean, rstd) of the forward, reused by the backward
         with self.paused():
-            y = ops.groupnorm(x, gamma, beta, B, HW, eps, silu=silu, groups=groups, x2=x2, out=out)
+            y = ops.groupnorm(x, gamma, beta, B, HW, eps, silu=silu, groups=groups, x2=x2, out=out, stat_out=stat)
 
         def bwd():
             dy = self.grad(y)
             if dy is None:
                 return
-            dx, dx2 = ops.groupnorm_bwd(x, gamma, beta, dy, B, HW, eps, silu=silu, groups=groups, x2=x2)
+            dx, dx2 = ops.groupnorm_bwd(x, gamma, beta, dy, B, HW, eps, silu=silu, groups=groups, x2=x2, stat=stat)
             if self.needs(x):
                 self.accumulate(x, dx)
             if x2 is not None and self.needs(x2):

@@ -330,6 +330,13 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const GNArgs p, int ncc, 
     float rs[GP];
 #pragma unroll
     for (int gi = 0; gi < GP; ++gi) rs[gi] = rsqrtf(bc[1][gi] * inv_n + p.eps);
+    if (p.stat && tid == 0) {  // (mean, rstd) kept for the backward pass
+#pragma unroll
+        for (int gi = 0; gi < GP; ++gi) {
+            p.stat[((long)b * p.groups + blockIdx.x * GP + gi) * 2 + 0] = mu[gi];
+            p.stat[((long)b * p.groups + blockIdx.x * GP + gi) * 2 + 1] = rs[gi];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < MAXCH; ++k) {
         if (grp[k] < 0) continue;
@@ -406,6 +413,25 @@ __device__ __forceinline__ void gnb_finalize_body(const GNArgs& p, int b, float 
     }
 }
 
+// forward coefficients of 8 channels: from the coef table written by the finalize fold, or (backward on statistics saved by the
+// forward launch: coef == nullptr) from (mean, rstd) of the channel's group — the same two operations the finalize performs
+__device__ __forceinline__ void gn_coef8(const GNArgs& p, int b, int cc, float (&sc)[8], float (&sh)[8]) {
+    if (p.coef) {
+        const float* cs = p.coef + ((long)b * 2) * p.C + cc * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = cs[e]; sh[e] = cs[p.C + e]; }
+        return;
+    }
+    const int cpg = p.C / p.groups;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = cc * 8 + e, g = ch / cpg;
+        const float mu = p.stat[((long)b * p.groups + g) * 2 + 0], rs = p.stat[((long)b * p.groups + g) * 2 + 1];
+        sc[e] = p.gamma[ch] * rs;
+        sh[e] = p.beta[ch] - mu * sc[e];
+    }
+}
+
 __global__ void gnb_partial_kernel(const GNArgs p) {
     extern __shared__ float lds[];  // [rpp][2][C]
     const int ncc = p.C / 8;
@@ -415,11 +441,11 @@ __global__ void gnb_partial_kernel(const GNArgs p) {
     const int r1 = min(r0 + p.rows_per_chunk, p.HW);
     if (rr < rpp) {
         float t1[8], t2[8], sc[8], sh[8], gm[8], bt[8];
-        const float* cs = p.coef + ((long)b * 2) * p.C + cc * 8;
+        gn_coef8(p, b, cc, sc, sh);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             t1[e] = t2[e] = 0.f;
-            sc[e] = cs[e]; sh[e] = cs[p.C + e]; gm[e] = p.gamma[cc * 8 + e]; bt[e] = p.beta[cc * 8 + e];
+            gm[e] = p.gamma[cc * 8 + e]; bt[e] = p.beta[cc * 8 + e];
         }
         for (int r = r0 + rr; r < r1; r += rpp) {
             const long row = (long)b * p.HW + r;
@@ -474,10 +500,10 @@ __global__ void gnb_apply_kernel(const GNArgs p) {
     if (rr >= rpp) return;
     const int b = blockIdx.y;
     float sc[8], sh[8], ka[8], kb[8];
-    const float* cs = p.coef + ((long)b * 2) * p.C + cc * 8;
+    gn_coef8(p, b, cc, sc, sh);
     const float* c2 = p.coef2 + ((long)b * 2) * p.C + cc * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = cs[e]; sh[e] = cs[p.C + e]; ka[e] = c2[e]; kb[e] = c2[p.C + e]; }
+    for (int e = 0; e < 8; ++e) { ka[e] = c2[e]; kb[e] = c2[p.C + e]; }
     const int r0 = blockIdx.x * p.rows_per_chunk;
     const int r1 = min(r0 + p.rows_per_chunk, p.HW);
     const int ch = cc * 8;
@@ -712,7 +738,8 @@ extern "C" long ae_groupnorm_workspace_floats(int B, int HW, int C, int groups) 
 }
 
 extern "C" int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y,
-                                      int B, int HW, int C, int groups, float eps, int act, float* workspace, int* counters, void* stream) {
+                                      int B, int HW, int C, int groups, float eps, int act, float* workspace, int* counters, float* stat_out,
+                                      void* stream) {
     AE_REQUIRE(x && gamma && beta && y && workspace, "ae_groupnorm_nhwc_bf16: null pointer");
     AE_REQUIRE(B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, "ae_groupnorm_nhwc_bf16: bad shape C=%d groups=%d", C, groups);
     AE_REQUIRE(C % 8 == 0 && C <= 8192, "ae_groupnorm_nhwc_bf16: C=%d must be a multiple of 8 and <= 8192", C);
@@ -730,6 +757,7 @@ extern "C" int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, con
     p.nchunk = (HW + p.rows_per_chunk - 1) / p.rows_per_chunk;
     p.part = workspace;
     p.coef = workspace + (((long)B * p.nchunk * groups * 2 + 3) / 4) * 4;
+    p.stat = stat_out;
     // tuning knob: 1 lets the last partial-sum block of a sample run the finalize fold (one launch fewer).  Measured in situ (UNet batch 12,
     // two runs each way on one box): 18.6 ms per UNet step with the tail against 15.4 ms without — the device-scope release every block
     // needs before it takes its ticket is an L2 write-back on this multi-XCD part (buffer_wbl2), ~50 us per GroupNorm, far more than the
@@ -761,7 +789,8 @@ extern "C" int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, con
     // tuning knob: 1 folds the finalize into every apply block.  In-situ A/B (one box, 2 runs each, UNet batch 12): 17.77 ms per UNet
     // step fused vs 17.60 ms with the separate 1-block-per-sample finalize launch — inside the captured graph a tiny dependent launch
     // costs less than the per-block re-fold it replaces.  Default off.
-    static const int fuse = getenv("AE_GN_FUSE") ? atoi(getenv("AE_GN_FUSE")) : 0;
+    static const int fuse_env = getenv("AE_GN_FUSE") ? atoi(getenv("AE_GN_FUSE")) : 0;
+    const int fuse = fuse_env && !stat_out;  // the fused apply does not write the statistics
     if (p.counters) {  // the last stats block of every sample has already written the per-channel coefficients
         hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(threads), 0, s, p);
         return ae_check_launch("ae_groupnorm_nhwc_bf16(apply)");
@@ -802,7 +831,7 @@ extern "C" long ae_groupnorm_bwd_workspace_floats(int B, int HW, int C, int grou
 
 extern "C" int ae_groupnorm_bwd_nhwc_bf16(const void* x, const void* x2, int C1, const float* gamma, const float* beta, const void* dy,
                                           void* dx, void* dx2, int B, int HW, int C, int groups, float eps, int act,
-                                          float* workspace, int* counters, void* stream) {
+                                          float* workspace, int* counters, const float* stat_in, void* stream) {
     AE_REQUIRE(x && gamma && beta && dy && dx && workspace, "ae_groupnorm_bwd_nhwc_bf16: null pointer");
     AE_REQUIRE(B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, "ae_groupnorm_bwd_nhwc_bf16: bad shape C=%d groups=%d", C, groups);
     AE_REQUIRE(C % 8 == 0 && C <= 8192 && groups <= 64 && B <= 65535, "ae_groupnorm_bwd_nhwc_bf16: unsupported size");
@@ -834,13 +863,19 @@ extern "C" int ae_groupnorm_bwd_nhwc_bf16(const void* x, const void* x2, int C1,
     dim3 grid(p.nchunk, B);
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)(threads / ncc) * 2 * C * sizeof(float);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), lds, s, p);
-    int rc = ae_check_launch("ae_groupnorm_bwd_nhwc_bf16(stats)");
-    if (rc) return rc;
-    if (!p.counters) {
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(1024), 0, s, p);
-        rc = ae_check_launch("ae_groupnorm_bwd_nhwc_bf16(finalize)");
+    int rc = 0;
+    if (stat_in) {  // (mean, rstd) saved by the forward launch: no second statistics pass over x, coefficients rebuilt per thread
+        p.stat = const_cast<float*>(stat_in);
+        p.coef = nullptr;
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), lds, s, p);
+        rc = ae_check_launch("ae_groupnorm_bwd_nhwc_bf16(stats)");
         if (rc) return rc;
+        if (!p.counters) {
+            hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(1024), 0, s, p);
+            rc = ae_check_launch("ae_groupnorm_bwd_nhwc_bf16(finalize)");
+            if (rc) return rc;
+        }
     }
     hipLaunchKernelGGL(gnb_partial_kernel, grid, dim3(threads), lds, s, p);
     rc = ae_check_launch("ae_groupnorm_bwd_nhwc_bf16(partial)");

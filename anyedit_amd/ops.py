@@ -200,8 +200,9 @@ def _gn_counters(device, B):
     return c
 
 
-def groupnorm(x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, out=None):
-    """GroupNorm(+SiLU) over channels-last [B*HW, C]; x2: optional second tensor concatenated along channels."""
+def groupnorm(x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, out=None, stat_out=None):
+    """GroupNorm(+SiLU) over channels-last [B*HW, C]; x2: optional second tensor concatenated along channels.
+    stat_out: optional fp32 [B, groups, 2] that receives (mean, rstd) for `groupnorm_bwd`."""
     if _TAPE is not None and _TAPE.active:
         return _TAPE.groupnorm(x, gamma, beta, B, HW, eps, silu=silu, groups=groups, x2=x2, out=out)
     _chk(x, BF16, "groupnorm.x", 2)
@@ -213,7 +214,7 @@ def groupnorm(x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, out=No
         out = torch.empty(B * HW, C, dtype=BF16, device=x.device)
     ws = torch.empty(lib.ae_groupnorm_workspace_floats(B, HW, C, groups), dtype=torch.float32, device=x.device)
     check(lib.ae_groupnorm_nhwc_bf16(_p(x), _p(x2), C1, _p(gamma), _p(beta), _p(out), B, HW, C, groups, eps,
-                                     1 if silu else 0, _p(ws), _p(_gn_counters(x.device, B)), _s()), "ae_groupnorm_nhwc_bf16")
+                                     1 if silu else 0, _p(ws), _p(_gn_counters(x.device, B)), _p(stat_out), _s()), "ae_groupnorm_nhwc_bf16")
     return out
 
 
@@ -689,14 +690,14 @@ def geglu_bwd(h, dy):
     return dh
 
 
-def groupnorm_bwd(x, gamma, beta, dy, B, HW, eps, silu=False, groups=32, x2=None):
+def groupnorm_bwd(x, gamma, beta, dy, B, HW, eps, silu=False, groups=32, x2=None, stat=None):
     C1 = x.shape[1]
     C = C1 + (x2.shape[1] if x2 is not None else 0)
     dx = torch.empty_like(x)
     dx2 = torch.empty_like(x2) if x2 is not None else None
     ws = torch.empty(lib.ae_groupnorm_bwd_workspace_floats(B, HW, C, groups), dtype=torch.float32, device=x.device)
     check(lib.ae_groupnorm_bwd_nhwc_bf16(_p(x), _p(x2), C1, _p(gamma), _p(beta), _p(_tmp(dy.contiguous())), _p(dx), _p(dx2), B, HW, C, groups,
-                                         eps, 1 if silu else 0, _p(ws), _p(_gn_counters(x.device, B)), _s()), "ae_groupnorm_bwd_nhwc_bf16")
+                                         eps, 1 if silu else 0, _p(ws), _p(_gn_counters(x.device, B)), _p(stat), _s()), "ae_groupnorm_bwd_nhwc_bf16")
     return dx, dx2
 
 
@@ -887,6 +888,8 @@ def _tile_label(M, N, conv=False, K=0, geglu=False, dma_ok=True):
     for bm, bn in ((128, 128), (128, 64), (64, 64)):
         tm, tn = -(-M // bm), -(-N // bn)
         if tm * tn >= 256 and tn * bn / N <= 1.10:
+            if bm == 64 and not conv and dma_ok and K >= 1280 and tm * tn <= 768:
+                return "64x64,ring3"
             return f"{bm}x{bn}"
     if not conv and dma_ok and K >= 1280 and -(-M // 64) * -(-N // 64) <= 768:
         return "64x64,ring3"

@@ -75,11 +75,12 @@ int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float
  * counters: optional int32[B], ZERO on entry and zero again on exit, not shared with a launch running concurrently on another
  * stream: the last partial-sum block of each sample then runs the statistics fold itself (two launches instead of three, same
  * fixed summation order, bit-identical result).  NULL keeps the stand-alone finalize launch.  The tail is OFF unless AE_GN_TAIL=1:
- * measured 3 ms per UNet step slower on MI355X (every block's device-scope release is an L2 write-back).                        */
+ * measured 3 ms per UNet step slower on MI355X (every block's device-scope release is an L2 write-back).
+ * stat_out: optional fp32 [B][groups][2] (mean, rstd) kept for ae_groupnorm_bwd_nhwc_bf16.                                      */
 int ae_groupnorm_rows_per_chunk(int HW, int C);
 long ae_groupnorm_workspace_floats(int B, int HW, int C, int groups);
 int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y, int B, int HW,
-                           int C, int groups, float eps, int act, float* workspace, int* counters, void* stream);
+                           int C, int groups, float eps, int act, float* workspace, int* counters, float* stat_out, void* stream);
 
 /* nn.LayerNorm over the last dim (attention.py:263-265 eps 1e-5; SAM image_encoder.py:166-182 / common.py:30-43 eps 1e-6). */
 int ae_layernorm_bf16(const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps, void* stream);
@@ -125,11 +126,12 @@ int ae_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* do
                      long dq_sh, long dq_sn, long dk_sb, long dk_sh, long dk_sn, long dv_sb, long dv_sh, long dv_sn,
                      float scale, const float* out_scale, int accumulate_dq, void* stream);
 /* GroupNorm(+SiLU) backward w.r.t. the input(s) (autograd of util.py:217-219 + nn.SiLU); dx2 receives channels [C1, C).
- * counters: as for ae_groupnorm_nhwc_bf16 (three launches instead of five).                                                    */
+ * counters: as for ae_groupnorm_nhwc_bf16.  stat_in: optional (mean, rstd) saved by the forward launch — the statistics pass over
+ * x is skipped (three launches instead of five) and the gradient uses exactly the statistics the forward normalised with.      */
 long ae_groupnorm_bwd_workspace_floats(int B, int HW, int C, int groups);
 int ae_groupnorm_bwd_nhwc_bf16(const void* x, const void* x2, int C1, const float* gamma, const float* beta, const void* dy,
                                void* dx, void* dx2, int B, int HW, int C, int groups, float eps, int act, float* workspace,
-                               int* counters, void* stream);
+                               int* counters, const float* stat_in, void* stream);
 /* LayerNorm backward w.r.t. the input; row_stat (optional fp32 [M,2]) receives (mean, rstd) for the parameter gradients.    */
 int ae_layernorm_bwd_bf16(const void* x, const float* gamma, const void* dy, void* dx, float* row_stat, int M, int C, float eps,
                           void* stream);

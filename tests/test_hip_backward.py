@@ -57,6 +57,16 @@ def test_groupnorm_backward(ops, B, HW, C, C1, silu, eps):
         x1, x2 = rows[:, :C1].contiguous(), rows[:, C1:].contiguous()
         dx1, dx2 = ops.groupnorm_bwd(x1, w.to(DEV), b.to(DEV), dy.reshape(B * HW, C).to(DEV, BF), B, HW, eps, silu=silu, x2=x2)
         check_close(torch.cat([dx1, dx2], 1).reshape(B, HW, C), xr.grad, what="groupnorm (concat) dx")
+    # the training tape keeps the forward's (mean, rstd) and hands them to the backward: no second statistics pass over x
+    x1, x2 = (rows, None) if C1 is None else (rows[:, :C1].contiguous(), rows[:, C1:].contiguous())
+    stat = torch.empty(B, 32, 2, dtype=torch.float32, device=DEV)
+    yf = ops.groupnorm(x1, w.to(DEV), b.to(DEV), B, HW, eps, silu=silu, x2=x2, stat_out=stat)
+    check_close(yf.reshape(B, HW, C), y.detach(), what="groupnorm forward (with saved statistics)")
+    xg = x.reshape(B, HW, 32, C // 32).permute(0, 2, 1, 3).reshape(B, 32, -1)
+    assert rel_l2(stat[..., 0].cpu(), xg.mean(-1)) <= 1e-4 and rel_l2(stat[..., 1].cpu(), (xg.var(-1, unbiased=False) + eps).rsqrt()) <= 1e-4
+    dxs, dxs2 = ops.groupnorm_bwd(x1, w.to(DEV), b.to(DEV), dy.reshape(B * HW, C).to(DEV, BF), B, HW, eps, silu=silu, x2=x2, stat=stat)
+    got = dxs if C1 is None else torch.cat([dxs, dxs2], 1)
+    check_close(got.reshape(B, HW, C), xr.grad, what="groupnorm dx from saved statistics")
 
 
 @pytest.mark.parametrize("M,C", [(16, 768), (4096, 320), (777, 1280), (10, 64)])
