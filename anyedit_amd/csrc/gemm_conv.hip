@@ -614,6 +614,21 @@ Plan make_plan(int M, int N, int K, bool can_split) {
     const int t = pick_tile(M, N);
     const int kt = (K + BK - 1) / BK;
     static const int force_s = getenv("AE_GEMM_SPLITK") ? atoi(getenv("AE_GEMM_SPLITK")) : 0;  // dev knob
+    // 16x16-level convs (UNet batch 12: M = 3072 = 64 tiles of 192x320) cut K four ways under the 192x320 tile (120 FLOP per LDS-DMA byte,
+    // against 65 for the 128x128 tile the other split plans use): kbench 1280->1280 104.6 -> 97.5 us, 2560->1280 186 -> 162 us (1.12 PFLOP/s
+    // incl. the reduce); in situ 15.35 -> 15.10 ms per UNet step (two runs each way).  Extending the rule to the 32x32 level's 128-tile
+    // grids (split 2) gains on the K = 17280 convs in isolation (272 -> 241 us) and is neutral-to-negative inside the UNet: knob value 1
+    // (3: only for >= 180 K tiles).  0 = round-1 plans.  tile id 4.
+    static const int t320_split = getenv("AE_CONV_T320_SPLITK") ? atoi(getenv("AE_CONV_T320_SPLITK")) : 2;
+    if (t320_split && can_split && N % 320 == 0 && M % 192 == 0 && force_s <= 0) {
+        const long t192 = (long)(M / 192) * (N / 320);
+        if (t192 >= 32 && t192 <= (t320_split == 2 ? 64 : (t320_split == 3 && kt < 180 ? 64 : 128))) {
+            int s = (int)(256 / t192);
+            if (s > 8) s = 8;
+            while (s > 1 && kt / s < 16) --s;
+            if (s >= 2) return {4, s};
+        }
+    }
     if (!can_split || kt < 32 || t == 0 || t == 3) return {t, 1};
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const double waste128 = (double)(((N + 127) / 128) * 128) / (double)N;
@@ -694,7 +709,12 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // (the same tile for the K = 320 dense GEMMs of the 64x64 level was A/B-ed too: N = 320 44.5 vs 34 us, N = 960 78 vs 63 us —
     // five K iterations do not amortise the big tile's prologue / epilogue.)
     bool done = false;
-    if (t320 && glds && a.splitk <= 1 && a.N % 320 == 0 && ((conv && (t320 & 1)) || (!conv && a.epi == EPI_GEGLU && a.K >= 640 && (t320 & 2)) || (!conv && a.epi == EPI_GEGLU && a.K < 640 && a.K >= 320 && (t320 & 4)) ||
+    if (conv && a.splitk > 1 && glds && make_plan(a.M, a.N, a.K, true).tile == 4) {  // split-K under the 192x320 tile (make_plan)
+        const long t = (long)(a.M / 192) * (a.N / 320) * a.splitk;
+        rc = launch_kernel(gemm_kernel<192, 320, AMODE, 2, 4, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
+        done = true;
+    }
+    if (!done && t320 && glds && a.splitk <= 1 && a.N % 320 == 0 && ((conv && (t320 & 1)) || (!conv && a.epi == EPI_GEGLU && a.K >= 640 && (t320 & 2)) || (!conv && a.epi == EPI_GEGLU && a.K < 640 && a.K >= 320 && (t320 & 4)) ||
                                                                      (!conv && a.epi != EPI_GEGLU && a.K >= 640 && (t320 & 8)))) {
         const long t = (long)((a.M + 191) / 192) * (a.N / 320);
         const double fill = (double)t / (double)(((t + 255) / 256) * 256) * ((double)a.M / (double)(((a.M + 191) / 192) * 192));

@@ -872,6 +872,8 @@ _PROF = None
 
 def _tile_label(M, N, conv=False, K=0, geglu=False, dma_ok=True):
     """Mirror of the tile choice in csrc/gemm_conv.hip::launch / make_plan (for labelling only)."""
+    if conv and dma_ok and _conv_t320_split(M, N, K):
+        return "192x320,splitK"
     if dma_ok and N % 320 == 0 and (conv or (geglu and K >= 640)):
         tm = -(-M // 192)
         t = tm * (N // 320)
@@ -896,8 +898,21 @@ def _tile_label(M, N, conv=False, K=0, geglu=False, dma_ok=True):
     return "64x64"
 
 
+def _conv_t320_split(M, N, K):
+    """split count of the 192x320 split-K plan (16x16-level convs), 0 when it does not apply (make_plan, tile id 4)."""
+    kt = -(-K // 64)
+    if N % 320 == 0 and M % 192 == 0 and 32 <= (M // 192) * (N // 320) <= 64:
+        s_ = min(256 // ((M // 192) * (N // 320)), 8)
+        while s_ > 1 and kt // s_ < 16:
+            s_ -= 1
+        return s_ if s_ >= 2 else 0
+    return 0
+
+
 def _conv_splitk(M, N, K):
     kt = -(-K // 64)
+    if _conv_t320_split(M, N, K):
+        return _conv_t320_split(M, N, K)
     t128 = -(-M // 128) * -(-N // 128)
     picked_big = any(-(-M // bm) * -(-N // bn) >= 256 and -(-N // bn) * bn / N <= 1.10 for bm, bn in ((128, 128),))
     is160 = N % 160 == 0 and N % 128 != 0 and -(-M // 128) * (N // 160) >= 256

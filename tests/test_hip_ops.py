@@ -236,7 +236,9 @@ def test_fuzz_norm_shapes(ops):
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups", [(2, 8, 8, 64, 64, 1, False), (1, 16, 16, 8, 32, 1, False),
                                                        (2, 8, 8, 96, 64, 2, False), (1, 7, 9, 64, 64, 2, False),
                                                        (2, 8, 8, 64, 64, 1, True), (1, 32, 32, 320, 4, 1, False),
-                                                       (1, 64, 64, 320, 320, 1, False), (3, 5, 6, 128, 72, 1, False)])
+                                                       (1, 64, 64, 320, 320, 1, False), (3, 5, 6, 128, 72, 1, False),
+                                                       # UNet-batch-12 16x16 level: M = 3072, the split-K plan under the 192x320 tile
+                                                       (12, 16, 16, 256, 1280, 1, False), (12, 16, 16, 320, 640, 1, False)])
 def test_conv3x3(ops, B, H, W, Cin, Cout, stride, ups):
     g = torch.Generator().manual_seed(B + H * 3 + Cin + Cout + stride)
     x = q(torch.randn(B, Cin, H, W, generator=g))
