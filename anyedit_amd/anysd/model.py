@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from anyedit_amd import ops
+from anyedit_amd.cldm.model import trusted_torch_load
 from anyedit_amd.ldm.modules.attention import BasicTransformerBlock
 
 BF16 = torch.bfloat16
@@ -69,7 +70,7 @@ class MoE(nn.Module):
             [nn.Parameter(torch.randn(expert_num, 2 * b.attn2.heads * b.attn2.dim_head, context_dim) * context_dim ** -0.5)
              for b in self._blocks])
         if ckpt_path is not None:
-            self.load_state_dict(torch.load(ckpt_path, map_location="cpu"), strict=False)
+            self.load_state_dict(trusted_torch_load(ckpt_path, "cpu"), strict=False)
 
     def save_pretrained(self, path):
         sd = {k: v for k, v in self.state_dict().items() if not k.startswith("unet.")}

@@ -23,8 +23,24 @@ def _read_safetensors(path, location):
     return load_file(str(path), device=location)
 
 
+def trusted_torch_load(path, location="cpu"):
+    """torch.load for reference checkpoints.  torch >= 2.6 unpickles with weights_only=True by default, which rejects Lightning
+    `.ckpt` files (callbacks, hyper_parameters, OmegaConf nodes next to the tensors) that the reference loads on its older torch.
+    The safe loader is tried first; only when it refuses AND the caller opted in (ANYEDIT_TRUST_CHECKPOINTS=1 — unpickling executes
+    code from the file) is the full unpickler used."""
+    import os
+    import pickle
+    try:
+        return torch.load(str(path), map_location=torch.device(location), weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError) as e:
+        if os.environ.get("ANYEDIT_TRUST_CHECKPOINTS") != "1":
+            raise RuntimeError(f"{path}: not loadable with weights_only=True ({str(e).splitlines()[0]}). Checkpoints that carry non-tensor objects "
+                               "(Lightning .ckpt) need the full unpickler: set ANYEDIT_TRUST_CHECKPOINTS=1 if you trust this file.") from e
+        return torch.load(str(path), map_location=torch.device(location), weights_only=False)
+
+
 def _read_pickle(path, location):
-    return torch.load(str(path), map_location=torch.device(location))
+    return trusted_torch_load(path, location)
 
 
 def load_state_dict(ckpt_path, location='cpu'):

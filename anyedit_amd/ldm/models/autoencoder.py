@@ -35,7 +35,8 @@ class AutoencoderKL(nn.Module):
 
     def init_from_ckpt(self, path, ignore_keys=list()):
         """autoencoder.py:52-61."""
-        sd = torch.load(path, map_location="cpu")["state_dict"]
+        from anyedit_amd.cldm.model import trusted_torch_load
+        sd = trusted_torch_load(path, "cpu")["state_dict"]
         for k in list(sd.keys()):
             if any(k.startswith(ik) for ik in ignore_keys):
                 del sd[k]
@@ -50,7 +51,9 @@ class AutoencoderKL(nn.Module):
         return r
 
     def _cache(self):
-        if self._pk.get("dev") != self.device:
+        own = (self.quant_conv.weight, self.quant_conv.bias, self.post_quant_conv.weight, self.post_quant_conv.bias)
+        if self.__dict__.get("_pk_tok") != ops.weights_token(*own) or self._pk.get("dev") != self.device:
+            self.__dict__["_pk_tok"] = ops.weights_token(*own)
             self._pk = {"dev": self.device}
         return self._pk
 

@@ -125,7 +125,7 @@ class DDIMSampler(object):
                 noise = self.randn(x0.shape, device=device)
                 sa = float(_f32(self.model.sqrt_alphas_cumprod[int(step)]))
                 s1 = float(_f32(self.model.sqrt_one_minus_alphas_cumprod[int(step)]))
-                img = ops.mask_blend(img, x0, noise, mask.expand(b, 1, *mask.shape[2:]), sa, s1)
+                img = ops.mask_blend(img, x0, noise, mask, sa, s1)   # any mask that broadcasts against img ([B,1,H,W] or [B,C,H,W])
             if ucg_schedule is not None:
                 assert len(ucg_schedule) == len(time_range)
                 unconditional_guidance_scale = ucg_schedule[i]

@@ -62,7 +62,7 @@ class PLMSSampler(DDIMSampler):
                 noise = self.randn(x0.shape, device=device)                         # q_sample's draw (plms.py:151)
                 sa = float(_f32(self.model.sqrt_alphas_cumprod[int(step)]))
                 s1 = float(_f32(self.model.sqrt_one_minus_alphas_cumprod[int(step)]))
-                img = ops.mask_blend(img, x0, noise, mask.expand(b, 1, *mask.shape[2:]), sa, s1)
+                img = ops.mask_blend(img, x0, noise, mask, sa, s1)
             img, pred_x0, e_t = self.p_sample_plms(img, cond, ts, index=index, use_original_steps=ddim_use_original_steps,
                                                    quantize_denoised=quantize_denoised, temperature=temperature,
                                                    noise_dropout=noise_dropout, score_corrector=score_corrector,

@@ -25,11 +25,9 @@ class _GN6(nn.GroupNorm):
     """Normalize(): GroupNorm(32, C, eps=1e-6, affine) (attention.py:88-89)."""
 
     def _affine(self):
-        pk = getattr(self, "_pk", None)
-        if pk is None or pk[0].device != self.weight.device:
-            pk = (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous())
-            self._pk = pk
-        return pk
+        if ops.cache_stale(self, "_pk", self.weight, self.bias):
+            self._pk = (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous())
+        return self._pk
 
     def repack(self):
         self._pk = None
@@ -63,11 +61,11 @@ class GEGLU(nn.Module):
             if norm is not None:
                 x = norm.rows(x)
             # training step: the pre-activation [a | g] is kept for the backward, so the gate runs as its own kernel
-            if getattr(self, "_pk_plain", None) is None or self._pk_plain[0].device != self.proj.weight.device:
+            if ops.cache_stale(self, "_pk_plain", self.proj.weight, self.proj.bias):
                 self._pk_plain = (ops.pack_linear(self.proj.weight), self.proj.bias.detach().float().contiguous())
             w, b = self._pk_plain
             return ops.geglu(ops.gemm(x, w, b))
-        if self._pk is None or self._pk[0].device != self.proj.weight.device:
+        if ops.cache_stale(self, "_pk", self.proj.weight, self.proj.bias):
             self._pk = ops.pack_geglu(self.proj.weight, self.proj.bias)
         w, b = self._pk
         if norm is not None:  # the block's norm3 fused in front of the projection (the caller passes the UN-normalised rows)
@@ -122,7 +120,7 @@ class CrossAttention(nn.Module):
         self._pk = None
 
     def _packed(self):
-        if self._pk is None or self._pk["dev"] != self.to_q.weight.device:
+        if ops.cache_stale(self, "_pk", self.to_q.weight, self.to_k.weight, self.to_v.weight):
             wq, wk, wv = (ops.pack_linear(m.weight) for m in (self.to_q, self.to_k, self.to_v))
             pk = {"dev": self.to_q.weight.device, "q": wq, "kv": torch.cat([wk, wv], 0).contiguous()}
             if wq.shape[1] == wk.shape[1]:

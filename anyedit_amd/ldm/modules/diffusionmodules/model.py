@@ -37,11 +37,9 @@ class _Rows:
     """Per-module cache of packed weights (bf16, channel counts padded to multiples of 8 so every row stays 16-byte aligned)."""
 
     def _cache(self):
-        c = getattr(self, "_pk", None)
-        dev = next(self.parameters()).device
-        if c is None or c.get("dev") != dev:
-            c = self._pk = {"dev": dev}
-        return c
+        if ops.cache_stale(self, "_pk", *self.parameters()):   # off the denoising loop: a walk over the block's own parameters is fine
+            self._pk = {"dev": next(self.parameters()).device}
+        return self._pk
 
     def repack(self):
         self._pk = None

@@ -308,9 +308,11 @@ class UNetModel(nn.Module):
 
     def _emb_pack(self, emb_silu):
         """All ResBlock.emb_layers Linears as ONE GEMM: W = cat over blocks [sum(Cout), 4*mc]; each block reads its column slice."""
+        blocks = self.__dict__.get("_emb_blocks")
+        if blocks is None:
+            blocks = self.__dict__["_emb_blocks"] = [m for m in self.modules() if isinstance(m, ResBlock)]
         pk = getattr(self, "_emb_pk", None)
-        if pk is None or pk[0].device != emb_silu.device:
-            blocks = [m for m in self.modules() if isinstance(m, ResBlock)]
+        if ops.cache_stale(self, "_emb_pk", *[p for b in blocks for p in (b.emb_layers[1].weight, b.emb_layers[1].bias)]):
             w = torch.cat([ops.pack_linear(b.emb_layers[1].weight) for b in blocks], 0).contiguous()
             bias = torch.cat([b.emb_layers[1].bias.detach().float() for b in blocks], 0).contiguous()
             offsets, off = {}, 0

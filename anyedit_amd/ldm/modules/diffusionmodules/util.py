@@ -96,12 +96,11 @@ class _Packed:
         self._pk = None
 
     def _packed(self):
-        pk = getattr(self, "_pk", None)
-        if pk is None or pk["device"] != self.weight.device:
+        if ops.cache_stale(self, "_pk", self.weight, getattr(self, "bias", None)):
             pk = self._pack()
             pk["device"] = self.weight.device
             self._pk = pk
-        return pk
+        return self._pk
 
 
 class Linear(nn.Linear, _Packed):
@@ -153,11 +152,9 @@ class GroupNorm32(nn.GroupNorm):
     """util.py:217-219: statistics in fp32.  `rows` runs the fused GroupNorm(+SiLU) HIP kernel on channels-last rows."""
 
     def _affine(self):
-        pk = getattr(self, "_pk", None)
-        if pk is None or pk[0].device != self.weight.device:
-            pk = (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous())
-            self._pk = pk
-        return pk
+        if ops.cache_stale(self, "_pk", self.weight, self.bias):
+            self._pk = (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous())
+        return self._pk
 
     def repack(self):
         self._pk = None
@@ -174,11 +171,9 @@ class GroupNorm32(nn.GroupNorm):
 
 class LayerNorm(nn.LayerNorm):
     def _affine(self):
-        pk = getattr(self, "_pk", None)
-        if pk is None or pk[0].device != self.weight.device:
-            pk = (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous())
-            self._pk = pk
-        return pk
+        if ops.cache_stale(self, "_pk", self.weight, self.bias):
+            self._pk = (self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous())
+        return self._pk
 
     def repack(self):
         self._pk = None

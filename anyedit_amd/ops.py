@@ -46,6 +46,29 @@ def check(rc, what=""):
     _check(rc, what)
 
 
+def weights_token(*tensors):
+    """Identity + in-place version of every tensor a packed-weight cache was built from: (storage address, autograd version counter).
+    `load_state_dict` (on the module or on ANY parent), optimizer steps and `.to(device)` all change it, so a cache keyed on the token
+    can never serve stale packed weights (only the outermost load_state_dict used to invalidate)."""
+    return tuple((t.data_ptr(), _version_of(t)) for t in tensors if t is not None)
+
+
+def _version_of(t):
+    try:
+        return t._version
+    except RuntimeError:      # inference tensors carry no version counter: identity only
+        return -1
+
+
+def cache_stale(mod, attr, *tensors):
+    """True when `mod.<attr>` is missing or was built from other values of `tensors`; records the new token (the caller rebuilds now)."""
+    tok = weights_token(*tensors)
+    if getattr(mod, attr, None) is None or mod.__dict__.get(attr + "_tok") != tok:
+        mod.__dict__[attr + "_tok"] = tok
+        return True
+    return False
+
+
 def _chk(t, dtype, name, dims=None):
     if not t.is_cuda:
         raise ValueError(f"{name}: expected a GPU tensor (anyedit_amd has no CPU path)")
@@ -426,11 +449,25 @@ def plms_combine_first(e_t, e_t_next):
     return out
 
 
+def mask_blend_shape(mask, B, C, H, W):
+    """How a mask broadcastable against [B, C, H, W] (the reference's `img_orig * mask + (1 - mask) * img`, ddim.py:154-157) is handed to
+    the kernel, which reads one mask plane per sample: -> (mask expanded, samples, channels) with a per-channel mask ([B or 1, C, H, W])
+    run as B*C single-channel samples."""
+    while mask.dim() < 4:
+        mask = mask.unsqueeze(0)
+    if mask.shape[1] == 1:
+        return mask.expand(B, 1, H, W), B, C
+    if mask.shape[1] == C:
+        return mask.expand(B, C, H, W).reshape(B * C, 1, H, W), B * C, 1
+    raise ValueError(f"mask_blend: mask of shape {tuple(mask.shape)} does not broadcast against [{B}, {C}, {H}, {W}]")
+
+
 def mask_blend(img, x0, noise, mask, sqrt_ac, sqrt_one_minus_ac, ip2p_order=False):
     B, C, H, W = img.shape
     out = torch.empty_like(img)
-    check(lib.ae_mask_blend_f32(_p(_tmp(img.contiguous())), _p(_tmp(x0.contiguous())), _p(_tmp(noise.contiguous())), _p(_tmp(mask.contiguous().float())),
-                                _p(out), B, C, H * W, sqrt_ac, sqrt_one_minus_ac, 1 if ip2p_order else 0, _s()), "ae_mask_blend_f32")
+    m, Bk, Ck = mask_blend_shape(mask, B, C, H, W)
+    check(lib.ae_mask_blend_f32(_p(_tmp(img.contiguous())), _p(_tmp(x0.contiguous())), _p(_tmp(noise.contiguous())), _p(_tmp(m.contiguous().float())),
+                                _p(out), Bk, Ck, H * W, sqrt_ac, sqrt_one_minus_ac, 1 if ip2p_order else 0, _s()), "ae_mask_blend_f32")
     return out
 
 

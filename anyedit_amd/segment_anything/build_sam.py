@@ -44,6 +44,6 @@ def _build_sam(encoder_embed_dim, encoder_depth, encoder_num_heads, encoder_glob
         pixel_mean=[123.675, 116.28, 103.53], pixel_std=[58.395, 57.12, 57.375])
     sam.eval()
     if checkpoint is not None:
-        with open(checkpoint, "rb") as f:
-            sam.load_state_dict(torch.load(f, map_location="cpu"))
+        from anyedit_amd.cldm.model import trusted_torch_load
+        sam.load_state_dict(trusted_torch_load(checkpoint, "cpu"))
     return sam

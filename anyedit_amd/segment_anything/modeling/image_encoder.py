@@ -173,7 +173,7 @@ class PatchEmbed(nn.Module):
     def rows(self, x):
         B, Cin, H, W = x.shape
         P = self.proj.kernel_size[0]
-        if self._pk is None or self._pk[0].device != self.proj.weight.device:
+        if ops.cache_stale(self, "_pk", self.proj.weight, self.proj.bias):
             self._pk = (ops.pack_linear(self.proj.weight), self.proj.bias.detach().float().contiguous())
         return ops.gemm(ops.patchify(x, P), self._pk[0], self._pk[1]), H // P, W // P
 

@@ -88,7 +88,7 @@ class PromptEncoder(nn.Module):
 
     def _packed(self):
         dev = self.no_mask_embed.weight.device
-        if self._pk is None or self._pk["device"] != dev:
+        if ops.cache_stale(self, "_pk", *self.parameters()):
             f = lambda t: t.detach().float().contiguous()
             md = self.mask_downscaling
             self._pk = {

@@ -94,7 +94,7 @@ class TwoWayAttentionBlock(nn.Module):
     def _image_side_projection(self):
         """`keys + key_pe` feeds k_proj of (2) and q_proj of (4): one GEMM over the concatenated weights."""
         t2i, i2t = self.cross_attn_token_to_image, self.cross_attn_image_to_token
-        if self._kq is None or self._kq[0].device != t2i.k_proj.weight.device:
+        if ops.cache_stale(self, "_kq", t2i.k_proj.weight, t2i.k_proj.bias, i2t.q_proj.weight, i2t.q_proj.bias):
             w = torch.cat([t2i.k_proj.weight.detach(), i2t.q_proj.weight.detach()], dim=0)
             b = torch.cat([t2i.k_proj.bias.detach(), i2t.q_proj.bias.detach()], dim=0)
             self._kq = (ops.pack_linear(w), b.float().contiguous())

@@ -512,6 +512,11 @@ def test_q_sample_and_mask_blend_bit_exact(ops):
     assert torch.equal(got.cpu(), ref)
     ref2 = img * mask + qs * (1. - mask)
     assert torch.equal(ops.mask_blend(img.to(DEV), x0.to(DEV), noise.to(DEV), mask.to(DEV), float(sa), float(s1), ip2p_order=True).cpu(), ref2)
+    # masks the reference's broadcasting accepts as well: per-channel [B, C, H, W] (latent masks) and a shared [1, 1, H, W] plane
+    mc = (torch.rand(2, 4, 8, 8, generator=g) > 0.5).float()
+    assert torch.equal(ops.mask_blend(img.to(DEV), x0.to(DEV), noise.to(DEV), mc.to(DEV), float(sa), float(s1)).cpu(), qs * mc + (1. - mc) * img)
+    m1 = mask[:1]
+    assert torch.equal(ops.mask_blend(img.to(DEV), x0.to(DEV), noise.to(DEV), m1.to(DEV), float(sa), float(s1)).cpu(), qs * m1 + (1. - m1) * img)
     sav, s1v = torch.tensor([0.73, 0.2]), torch.tensor([0.68, 0.97])
     ref3 = sav[:, None, None, None] * x0 + s1v[:, None, None, None] * noise
     assert torch.equal(ops.q_sample(x0.to(DEV), noise.to(DEV), sav.to(DEV), s1v.to(DEV)).cpu(), ref3)

@@ -329,3 +329,63 @@ def test_mask_tool_box_logic_on_cpu():
     assert select_target_boxes(px, phrases, ["dog", "lamp"]) is None
     img = load_image_512(Image.new("L", (300, 200), 128))
     assert img.size == (512, 512) and img.mode == "RGB"
+
+
+def test_packed_weight_caches_follow_the_parameters(tmp_path):
+    """packed bf16 weight caches must not survive a load_state_dict on a PARENT module, an in-place parameter update or a
+    device move.  The caches are keyed on (storage address, version counter) of the tensors they were built from."""
+    import torch.nn as nn
+    from anyedit_amd.ldm.modules.diffusionmodules.util import Linear, GroupNorm32
+    from anyedit_amd.ldm.modules.attention import CrossAttention
+
+    class Parent(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin, self.attn, self.gn = Linear(16, 8), CrossAttention(16, heads=2, dim_head=8), GroupNorm32(4, 16)
+
+    torch.manual_seed(0)
+    p = Parent()
+    w0, q0 = p.lin._packed()["w"].clone(), p.attn._packed()["q"].clone()
+    assert p.lin._packed() is p.lin._packed()                      # a second call serves the cache
+    sd = {k: torch.randn_like(v) for k, v in p.state_dict().items()}
+    p.load_state_dict(sd)                                           # the parent's load never calls a child's load_state_dict override
+    assert torch.equal(p.lin._packed()["w"].float(), sd["lin.weight"].to(torch.bfloat16).float()) and not torch.equal(p.lin._packed()["w"], w0)
+    assert torch.equal(p.attn._packed()["q"].float(), sd["attn.to_q.weight"].to(torch.bfloat16).float()) and not torch.equal(p.attn._packed()["q"], q0)
+    assert torch.equal(p.gn._affine()[0], sd["gn.weight"])
+    with torch.no_grad():
+        p.lin.weight.mul_(2.0)                                      # optimiser-style in-place update
+    assert torch.equal(p.lin._packed()["w"].float(), (sd["lin.weight"] * 2.0).to(torch.bfloat16).float())
+
+
+def test_checkpoint_loader_weights_only_then_trusted_fallback(tmp_path, monkeypatch):
+    """torch >= 2.6 unpickles with weights_only=True; a Lightning-style .ckpt with non-tensor objects needs an explicit opt-in."""
+    import argparse
+    from anyedit_amd.cldm.model import load_state_dict, trusted_torch_load
+    plain = tmp_path / "plain.ckpt"
+    torch.save({"state_dict": {"a.weight": torch.ones(2, 2)}}, plain)
+    assert torch.equal(load_state_dict(str(plain))["a.weight"], torch.ones(2, 2))
+    lightning = tmp_path / "lightning.ckpt"
+    torch.save({"state_dict": {"a.weight": torch.ones(2, 2)}, "hyper_parameters": argparse.Namespace(lr=1e-4), "callbacks": {object: 1}}, lightning)
+    monkeypatch.delenv("ANYEDIT_TRUST_CHECKPOINTS", raising=False)
+    with pytest.raises(RuntimeError, match="ANYEDIT_TRUST_CHECKPOINTS"):
+        trusted_torch_load(lightning)
+    monkeypatch.setenv("ANYEDIT_TRUST_CHECKPOINTS", "1")
+    assert torch.equal(load_state_dict(str(lightning))["a.weight"], torch.ones(2, 2))
+
+
+def test_mask_blend_accepts_every_mask_that_broadcasts():
+    """the reference's `img_orig * mask + (1 - mask) * img` (ddim.py:154-157) takes any broadcastable mask; the kernel reads
+    one plane per sample, so a per-channel mask runs as B*C single-channel samples."""
+    from anyedit_amd import ops
+    B, C, H, W = 2, 4, 3, 5
+    m, Bk, Ck = ops.mask_blend_shape(torch.rand(B, 1, H, W), B, C, H, W)
+    assert (tuple(m.shape), Bk, Ck) == ((B, 1, H, W), B, C)
+    m, Bk, Ck = ops.mask_blend_shape(torch.rand(1, 1, H, W), B, C, H, W)
+    assert (tuple(m.shape), Bk, Ck) == ((B, 1, H, W), B, C)
+    mc = torch.rand(B, C, H, W)
+    m, Bk, Ck = ops.mask_blend_shape(mc, B, C, H, W)
+    assert (tuple(m.shape), Bk, Ck) == ((B * C, 1, H, W), B * C, 1) and torch.equal(m.reshape(B, C, H, W), mc)
+    m, Bk, Ck = ops.mask_blend_shape(torch.rand(H, W), B, C, H, W)
+    assert (tuple(m.shape), Bk, Ck) == ((B, 1, H, W), B, C)
+    with pytest.raises(ValueError):
+        ops.mask_blend_shape(torch.rand(B, 3, H, W), B, C, H, W)
