@@ -389,3 +389,34 @@ def test_mask_blend_accepts_every_mask_that_broadcasts():
     assert (tuple(m.shape), Bk, Ck) == ((B, 1, H, W), B, C)
     with pytest.raises(ValueError):
         ops.mask_blend_shape(torch.rand(B, 3, H, W), B, C, H, W)
+
+
+def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
+    """Error behaviour of the drop-in boundary: every entry point validates its arguments on the host first and returns AE_ERR_ARG (-1)
+    with a message behind ae_last_error() — no launch is attempted, so this runs without a GPU.  (Empty inputs, misaligned rows,
+    unsupported sizes: the cases the reference would surface as Python exceptions from torch.)"""
+    import ctypes
+    from anyedit_amd._lib import lib
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.addressof(buf)
+    p16 = (p + 15) // 16 * 16
+
+    def expect(rc, fragment):
+        assert rc == -1, rc
+        msg = lib.ae_last_error().decode()
+        assert fragment in msg, msg
+
+    expect(lib.ae_gemm_bf16(None, 64, None, 0, 0, p16, 64, p16, 64, 8, 8, 64, None, None, 0, None, 0, 0, 0, 0, None), "null pointer")
+    expect(lib.ae_gemm_bf16(p16, 64, None, 0, 0, p16, 64, p16, 64, 0, 8, 64, None, None, 0, None, 0, 0, 0, 0, None), "must be positive")       # empty M
+    expect(lib.ae_gemm_bf16(p16, 64, None, 0, 0, p16, 64, p16, 64, 8, 8, 60, None, None, 0, None, 0, 0, 0, 0, None), "multiple of 8")           # ragged K
+    expect(lib.ae_gemm_bf16(p16 + 2, 64, None, 0, 0, p16, 64, p16, 64, 8, 8, 64, None, None, 0, None, 0, 0, 0, 0, None), "16-byte aligned")    # misaligned A
+    expect(lib.ae_gemm_bf16(p16, 64, None, 0, 0, p16, 64, p16, 64, 8, 8, 64, None, None, 0, None, 0, 0, 9, 0, None), "bad epilogue")
+    expect(lib.ae_conv3x3_bf16(p16, p16, None, None, 0, None, p16, 0, 8, 8, 64, 64, 1, 0, 0, None, None), "bad shape")                           # empty batch
+    expect(lib.ae_conv3x3_bf16(p16, p16, None, None, 0, None, p16, 1, 8, 8, 60, 64, 1, 0, 0, None, None), "multiple of 8")
+    expect(lib.ae_conv3x3_bf16(p16, p16, None, None, 0, None, p16, 1, 8, 8, 64, 64, 3, 0, 0, None, None), "stride must be 1 or 2")
+    expect(lib.ae_groupnorm_nhwc_bf16(p16, None, 0, p16, p16, p16, 1, 64, 60, 32, 1e-5, 0, p16, None, None, None), "bad shape")                  # C % groups
+    expect(lib.ae_groupnorm_nhwc_bf16(p16, None, 0, p16, p16, p16, 1, 64, 64, 32, 1e-5, 7, p16, None, None, None), "act must be")
+    expect(lib.ae_layernorm_bf16(p16, p16, p16, p16, 4, 60, 1e-5, None), "multiple of 8")
+    expect(lib.ae_expert_kv_fwd(p16, p16, p16, p16, 2, 9, 64, 64, 2, None), "unsupported shape")                                                 # more than 8 tokens per sample
+    expect(lib.ae_split_channels_bf16(p16, 12, 8, p16, p16, 4, 0, 0, None), "bad arguments")
+    assert lib.ae_ln_gemm_supported(49152, 320, 320, 0) == 1 and lib.ae_ln_gemm_supported(49152, 320, 640, 0) == 0
