@@ -36,12 +36,28 @@ struct BwdArgs {
     int accum_dq;  // dq += (second segment sharing the same queries)
 };
 
+typedef __attribute__((ext_vector_type(4))) short s16x4v;
+// ds_read_b64_tr_b16: inside a 16-lane group lane i addresses row (i >> 2), columns 4 (i & 3) .. +3 of a [4 rows][16 columns] block of
+// 16-bit elements and receives COLUMN i (its 4 rows, ascending) — a transposing fragment read straight from a row-major image.
+__device__ __forceinline__ s16x4v lds_tr16(const bf16_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)p);
+#else
+    return s16x4v{};
+#endif
+}
+__device__ __forceinline__ bf16x8_t cat_tr(s16x4v lo, s16x4v hi) {
+    union { struct { s16x4v a, b; } s; bf16x8_t v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+}
+
 __device__ __forceinline__ int perm_pos(int r) {  // streamed row 16 f + 4 g + e  ->  slot 16 g + 4 f + e (accumulator order)
     return ((r >> 2) & 3) * 16 + (r >> 4) * 4 + (r & 3);
 }
 
 template <int D, int QF, int MODE>
-__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdArgs p) {
+__global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const BwdArgs p) {
     constexpr int NW = 4, NT = 256;
     constexpr int NC = D / 32;
     constexpr bool TAIL16 = (D % 32) != 0;
@@ -51,16 +67,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdArgs p) {
     constexpr int NDF = DV / 16;
     constexpr int DCH = D / 8;
     constexpr int ROW = DQK + 8;   // row-major images (streamed rows x head dim), +16 B pad
-    constexpr int TROW = ST + 8;   // transposed images (head dim x streamed slots)
-    constexpr int NTR = MODE == MODE_DQ ? 1 : 2;
     constexpr int FB = NW * 16 * QF;  // fixed-side rows per block
 
+    // Two stages of the streamed tile, row-major only: X (K in DQ mode, Q in DKV mode) and Y (V / dO), 64 rows x (DQK + 8) each.  The
+    // second product's transposed A operand (Z^T[d][streamed slot]) is read from the SAME images with ds_read_b64_tr_b16 — round 1
+    // kept separate transposed images, written with 4-byte LDS stores after a register permute.
+    constexpr int IMG = ST * ROW;                  // elements per image
+    constexpr int STAGE = 2 * IMG;                 // X then Y
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16_t* const sX = reinterpret_cast<bf16_t*>(smem_raw);          // K (DQ) / Q (DKV), row-major
-    bf16_t* const sY = sX + ST * ROW;                                 // V (DQ) / dO (DKV), row-major
-    bf16_t* const sT0 = sY + ST * ROW;                                // K^T (DQ) / Q^T (DKV)
-    bf16_t* const sT1 = sT0 + DV * TROW;                              // dO^T (DKV only)
-    float* const sStat = reinterpret_cast<float*>(sT0 + NTR * DV * TROW);  // DKV: L2[64], delta[64] of the query tile
+    bf16_t* const sImg = reinterpret_cast<bf16_t*>(smem_raw);
+    float* const sStat = reinterpret_cast<float*>(sImg + 2 * STAGE);  // DKV: [stage][L2[64], delta[64]] of the query tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -81,17 +97,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdArgs p) {
     const bf16_t* xs_p = MODE == MODE_DQ ? kp : qp;   const long xs_sn = MODE == MODE_DQ ? p.k_sn : p.q_sn;
     const bf16_t* ys_p = MODE == MODE_DQ ? vp : dop;  const long ys_sn = MODE == MODE_DQ ? p.v_sn : p.o_sn;
 
-    // zero the pad columns of the row-major images and the pad rows of the transposed ones once
+    // zero the pad columns of the four row-major images once (the staging below only writes columns < D)
+    static_assert(DQK >= DV, "the transposing reads of the second product cover DV columns of a DQK-column image");
     if (DQK > D) {
-        for (int i = tid; i < 2 * ST * (DQK - D); i += NT) {
+        for (int i = tid; i < 4 * ST * (DQK - D); i += NT) {
             const int img = i / (ST * (DQK - D)), r = i % (ST * (DQK - D));
-            (img ? sY : sX)[(r / (DQK - D)) * ROW + D + r % (DQK - D)] = 0;
-        }
-    }
-    if (DV > D) {
-        for (int i = tid; i < NTR * (DV - D) * TROW; i += NT) {
-            const int img = i / ((DV - D) * TROW), r = i % ((DV - D) * TROW);
-            (img ? sT1 : sT0)[D * TROW + r] = 0;
+            sImg[img * IMG + (r / (DQK - D)) * ROW + D + r % (DQK - D)] = 0;
         }
     }
 
@@ -129,43 +140,61 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdArgs p) {
         for (int df = 0; df < NDF; ++df) acc0[a][df] = acc1[a][df] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int ntiles = (nstream + ST - 1) / ST;
-    for (int t = 0; t < ntiles; ++t) {
+    // Software pipeline: the global loads of tile t + 1 are issued into registers before tile t is multiplied out of LDS and written
+    // to the other stage after it — one barrier per tile, load latency under the MFMAs.
+    constexpr int ITEMS = (ST / 2) * DCH;              // (pair of streamed rows) x (16-byte chunk)
+    constexpr int NIT = (ITEMS + NT - 1) / NT;
+    u32x4 px[NIT][4];                                  // x(row 2pr), x(row 2pr+1), y(row 2pr), y(row 2pr+1)
+    float pst[2] = {0.f, 0.f};
+    auto load_tile = [&](int t) {
         const int t0 = t * ST;
-        __syncthreads();  // everyone is done with the previous tile's images
-        // ---- stage the streamed tile: pairs of rows -> row-major images + transposed images (slots permuted) -------------
-        for (int i = tid; i < (ST / 2) * DCH; i += NT) {
-            const int pr = i / DCH, c = i - pr * DCH;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * NT;
+            const int pr = min(i, ITEMS - 1) / DCH, c = min(i, ITEMS - 1) - pr * DCH;
             const int r0 = t0 + 2 * pr, r1 = r0 + 1;
             const u32x4 z4 = {0u, 0u, 0u, 0u};
-            const u32x4 x0 = r0 < nstream ? *reinterpret_cast<const u32x4*>(xs_p + (long)r0 * xs_sn + c * 8) : z4;
-            const u32x4 x1 = r1 < nstream ? *reinterpret_cast<const u32x4*>(xs_p + (long)r1 * xs_sn + c * 8) : z4;
-            const u32x4 y0 = r0 < nstream ? *reinterpret_cast<const u32x4*>(ys_p + (long)r0 * ys_sn + c * 8) : z4;
-            const u32x4 y1 = r1 < nstream ? *reinterpret_cast<const u32x4*>(ys_p + (long)r1 * ys_sn + c * 8) : z4;
-            *reinterpret_cast<u32x4*>(sX + (2 * pr) * ROW + c * 8) = x0;
-            *reinterpret_cast<u32x4*>(sX + (2 * pr + 1) * ROW + c * 8) = x1;
-            *reinterpret_cast<u32x4*>(sY + (2 * pr) * ROW + c * 8) = y0;
-            *reinterpret_cast<u32x4*>(sY + (2 * pr + 1) * ROW + c * 8) = y1;
-            const int pos = perm_pos(2 * pr);  // even; row 2pr+1 lands at pos+1
-            const uint32_t a0[4] = {x0.x, x0.y, x0.z, x0.w}, a1[4] = {x1.x, x1.y, x1.z, x1.w};
-            const uint32_t b0[4] = {y0.x, y0.y, y0.z, y0.w}, b1[4] = {y1.x, y1.y, y1.z, y1.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                // transposed image of X_s (K^T in DQ mode, Q^T in DKV mode)
-                *reinterpret_cast<uint32_t*>(sT0 + (c * 8 + 2 * e) * TROW + pos) = __builtin_amdgcn_perm(a1[e], a0[e], 0x05040100u);
-                *reinterpret_cast<uint32_t*>(sT0 + (c * 8 + 2 * e + 1) * TROW + pos) = __builtin_amdgcn_perm(a1[e], a0[e], 0x07060302u);
-                if (MODE == MODE_DKV) {  // dO^T
-                    *reinterpret_cast<uint32_t*>(sT1 + (c * 8 + 2 * e) * TROW + pos) = __builtin_amdgcn_perm(b1[e], b0[e], 0x05040100u);
-                    *reinterpret_cast<uint32_t*>(sT1 + (c * 8 + 2 * e + 1) * TROW + pos) = __builtin_amdgcn_perm(b1[e], b0[e], 0x07060302u);
-                }
-            }
+            px[it][0] = r0 < nstream ? *reinterpret_cast<const u32x4*>(xs_p + (long)r0 * xs_sn + c * 8) : z4;
+            px[it][1] = r1 < nstream ? *reinterpret_cast<const u32x4*>(xs_p + (long)r1 * xs_sn + c * 8) : z4;
+            px[it][2] = r0 < nstream ? *reinterpret_cast<const u32x4*>(ys_p + (long)r0 * ys_sn + c * 8) : z4;
+            px[it][3] = r1 < nstream ? *reinterpret_cast<const u32x4*>(ys_p + (long)r1 * ys_sn + c * 8) : z4;
         }
         if (MODE == MODE_DKV && tid < ST) {
             const int qrow = t0 + tid;
             const long si = ((long)b * p.H + h) * p.Nq + min(qrow, p.Nq - 1);
-            sStat[tid] = qrow < p.Nq ? p.lse[si] : 1.0e30f;  // padding queries: P = 2^(s - 1e30) = 0
-            sStat[ST + tid] = qrow < p.Nq ? p.delta[si] : 0.f;
+            pst[0] = qrow < p.Nq ? p.lse[si] : 1.0e30f;  // padding queries: P = 2^(s - 1e30) = 0
+            pst[1] = qrow < p.Nq ? p.delta[si] : 0.f;
         }
-        __syncthreads();
+    };
+    auto store_tile = [&](int stage) {
+        bf16_t* const dX = sImg + stage * STAGE;
+        bf16_t* const dY = dX + IMG;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * NT;
+            if (i >= ITEMS) break;
+            const int pr = i / DCH, c = i - pr * DCH;
+            *reinterpret_cast<u32x4*>(dX + (2 * pr) * ROW + c * 8) = px[it][0];
+            *reinterpret_cast<u32x4*>(dX + (2 * pr + 1) * ROW + c * 8) = px[it][1];
+            *reinterpret_cast<u32x4*>(dY + (2 * pr) * ROW + c * 8) = px[it][2];
+            *reinterpret_cast<u32x4*>(dY + (2 * pr + 1) * ROW + c * 8) = px[it][3];
+        }
+        if (MODE == MODE_DKV && tid < ST) {
+            sStat[stage * 2 * ST + tid] = pst[0];
+            sStat[stage * 2 * ST + ST + tid] = pst[1];
+        }
+    };
+    load_tile(0);
+    __syncthreads();  // pad columns zeroed
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int t0 = t * ST;
+        const int cur = t & 1;
+        const bf16_t* const sX = sImg + cur * STAGE;
+        const bf16_t* const sY = sX + IMG;
+        const float* const sSt = sStat + cur * 2 * ST;
+        if (t + 1 < ntiles) load_tile(t + 1);
 
         // ---- S_T = X_s X_f^T and dP_T = Y_s Y_f^T : lane holds [streamed row 16 f + 4 lg + r][fixed row l15] -----------------
         f32x4 s[QF][4], dp[QF][4];
@@ -210,8 +239,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdArgs p) {
             for (int f = 0; f < 4; ++f) {
                 f32x4 lrow = {0.f, 0.f, 0.f, 0.f}, drow = {0.f, 0.f, 0.f, 0.f};
                 if (MODE == MODE_DKV) {
-                    lrow = *reinterpret_cast<const f32x4*>(sStat + f * 16 + lg * 4);
-                    drow = *reinterpret_cast<const f32x4*>(sStat + ST + f * 16 + lg * 4);
+                    lrow = *reinterpret_cast<const f32x4*>(sSt + f * 16 + lg * 4);
+                    drow = *reinterpret_cast<const f32x4*>(sSt + ST + f * 16 + lg * 4);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -243,13 +272,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdArgs p) {
         }
 
         // ---- acc^T[d][fixed] += Z^T[d][streamed] R[streamed][fixed] -------------------------------------------------------------
+        // contraction slot (group lg, e) of half j = streamed row 16 (2j + e / 4) + 4 lg + e % 4 (the accumulator order of rb): two
+        // transposing reads of 4 consecutive rows each deliver this lane's 8 values of head-dim column 16 df + l15
+        const int trow = l15 >> 2, tcol = 4 * (l15 & 3);
 #pragma unroll
         for (int df = 0; df < NDF; ++df) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const bf16x8_t z0 = as_bf16x8(*reinterpret_cast<const u32x4*>(sT0 + (df * 16 + l15) * TROW + lg * 16 + j * 8));
+                const int a0 = (32 * j + 4 * lg + trow) * ROW + df * 16 + tcol;
+                const bf16x8_t z0 = cat_tr(lds_tr16(sX + a0), lds_tr16(sX + a0 + 16 * ROW));
                 bf16x8_t z1 = z0;  // DQ: both products use K^T ; DKV: dV uses dO^T
-                if (MODE == MODE_DKV) z1 = as_bf16x8(*reinterpret_cast<const u32x4*>(sT1 + (df * 16 + l15) * TROW + lg * 16 + j * 8));
+                if (MODE == MODE_DKV) z1 = cat_tr(lds_tr16(sY + a0), lds_tr16(sY + a0 + 16 * ROW));
 #pragma unroll
                 for (int a = 0; a < QF; ++a) {
                     acc0[a][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z0, rb0[a][j], acc0[a][df], 0, 0, 0);
@@ -257,6 +290,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const BwdArgs p) {
                 }
             }
         }
+        if (t + 1 < ntiles) store_tile(cur ^ 1);  // the other stage was last read before the previous barrier
+        __syncthreads();
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------------------
@@ -305,8 +340,7 @@ int launch_bwd(const BwdArgs& a, hipStream_t stream) {
     constexpr int NC = D / 32;
     constexpr int DQK = NC * 32 + ((D % 32) ? 16 : 0);
     constexpr int DV = (D + 15) / 16 * 16;
-    constexpr int NTR = MODE == MODE_DQ ? 1 : 2;
-    constexpr size_t lds = (size_t)(2 * ST * (DQK + 8) + NTR * DV * (ST + 8)) * sizeof(bf16_t) + 2 * ST * sizeof(float);
+    constexpr size_t lds = (size_t)(4 * ST * (DQK + 8)) * sizeof(bf16_t) + 4 * ST * sizeof(float);  // two stages of (X, Y) + (L2, delta)
     constexpr int FB = 4 * 16 * QF;
     const int nfixed = MODE == MODE_DQ ? a.Nq : a.Nk;
     const long blocks = (long)((nfixed + FB - 1) / FB) * a.B * a.H;
