@@ -35,7 +35,7 @@ SIGNATURES = {
                          c_float, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
                          c_void_p, c_void_p, c_int, c_long, c_long, c_long, c_long, c_long, c_long, c_void_p, c_void_p, c_void_p,
                          c_void_p],
-    "ae_attn_bwd_bf16": [c_void_p] * 9 + [c_int] * 5 + [c_long] * 21 + [c_float, c_void_p, c_int, c_void_p],
+    "ae_attn_bwd_bf16": [c_void_p] * 10 + [c_int] * 5 + [c_long] * 21 + [c_float, c_void_p, c_int, c_void_p],
     "ae_groupnorm_bwd_workspace_floats": [c_int, c_int, c_int, c_int],
     "ae_groupnorm_bwd_nhwc_bf16": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p],

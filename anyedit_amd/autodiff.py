@@ -46,6 +46,7 @@ class Tape:
         self._wt = {}            # id(packed weight) -> transposed packed weight
         self._wrot = {}          # id(packed conv weight) -> rotated packed weight
         self.keep = []           # keeps every recorded tensor alive (ids stay unique)
+        self.mutated = set()     # ids of attention outputs a later call accumulated into in place (they no longer hold ONE segment's output)
 
     # ------------------------------------------------------------------ bookkeeping
     @contextlib.contextmanager
@@ -382,6 +383,8 @@ class Tape:
         if accumulate and out is None:
             raise RuntimeError("autodiff: accumulate=True needs the tensor to accumulate into")
         dev = q.device
+        if accumulate:
+            self.mutated.add(id(out))
         lse = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
         lse2 = torch.empty(B, H, Nq, dtype=torch.float32, device=dev) if seg2 is not None else None
         with self.paused():
@@ -420,7 +423,8 @@ class Tape:
                 if covered < b.numel():
                     gb.zero_()
             delta = ops.attention_bwd(q, k, v, dy, lse, B, H, Nq, Nk, D, scale, q_strides, k_strides, v_strides, dq, dk if need_kv else None,
-                                      dv if need_kv else None, q_strides, k_strides, v_strides, out_scale=out_scale)
+                                      dv if need_kv else None, q_strides, k_strides, v_strides, out_scale=out_scale,
+                                      out=y if (seg2 is None and out_scale is None and not accumulate and y.is_contiguous() and id(y) not in self.mutated) else None)
             if out_scale is not None and self.needs(out_scale):
                 self.accumulate_f32(out_scale, ops.rowsum_f32(delta.reshape(B, -1)))
             if seg2 is not None:

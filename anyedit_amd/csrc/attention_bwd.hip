@@ -56,8 +56,32 @@ __device__ __forceinline__ int perm_pos(int r) {  // streamed row 16 f + 4 g + e
     return ((r >> 2) & 3) * 16 + (r >> 4) * 4 + (r & 3);
 }
 
-template <int D, int QF, int MODE>
+// delta[b,h,q] = sum_d dO[b,q,h,d] O[b,q,h,d] (= rowsum(P o dP) of a single-segment attention whose output is O): one thread per
+// (b, q, h), adjacent threads read adjacent head slices of a token row.
+template <int D>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* dO, const bf16_t* O, float* delta, int B, int H, int Nq, long o_sb, long o_sh,
+                                                         long o_sn) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * Nq * H) return;
+    const int h = (int)(i % H);
+    const long bq = i / H;
+    const int q = (int)(bq % Nq), b = (int)(bq / Nq);
+    const long off = (long)b * o_sb + (long)q * o_sn + (long)h * o_sh;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < D / 8; ++c) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(dO + off + c * 8), o = *reinterpret_cast<const u32x4*>(O + off + c * 8);
+        acc += bf16lo(a.x) * bf16lo(o.x) + bf16hi(a.x) * bf16hi(o.x) + bf16lo(a.y) * bf16lo(o.y) + bf16hi(a.y) * bf16hi(o.y) +
+               bf16lo(a.z) * bf16lo(o.z) + bf16hi(a.z) * bf16hi(o.z) + bf16lo(a.w) * bf16lo(o.w) + bf16hi(a.w) * bf16hi(o.w);
+    }
+    delta[((long)b * H + h) * Nq + q] = acc;
+}
+
+// PRE (MODE_DQ only): delta is already in p.delta (attn_delta_kernel), so dS = P o (dP - delta) is formed directly and the pass keeps
+// ONE accumulator set (dQ = g scale sum_k dS K) instead of two (T1, T2) — a quarter of the pass's MFMAs and 40 registers less.
+template <int D, int QF, int MODE, bool PRE = false>
 __global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const BwdArgs p) {
+    static_assert(!PRE || MODE == MODE_DQ, "PRE is a variant of the dQ pass");
     constexpr int NW = 4, NT = 256;
     constexpr int NC = D / 32;
     constexpr bool TAIL16 = (D % 32) != 0;
@@ -130,7 +154,7 @@ __global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const 
     float l2f[QF], dlt[QF];  // MODE_DQ: per-lane L2 of its query row, running delta
 #pragma unroll
     for (int a = 0; a < QF; ++a) {
-        dlt[a] = 0.f;
+        dlt[a] = PRE ? p.delta[((long)b * p.H + h) * p.Nq + min(f0 + a * 16 + l15, p.Nq - 1)] : 0.f;
         l2f[a] = MODE == MODE_DQ ? p.lse[((long)b * p.H + h) * p.Nq + min(f0 + a * 16 + l15, p.Nq - 1)] : 0.f;
     }
     f32x4 acc0[QF][NDF], acc1[QF][NDF];  // DQ: T1, T2 ; DKV: dK^T, dV^T   (lane: [d = 16 df + 4 lg + r][fixed row l15])
@@ -248,10 +272,15 @@ __global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const 
                     if (MODE == MODE_DQ) {
                         pv = __builtin_amdgcn_exp2f(fmaf(s[a][f][r], c2, -l2f[a]));
                         if (t0 + f * 16 + lg * 4 + r >= p.Nk) pv = 0.f;  // padding keys
-                        const float w = pv * dp[a][f][r];
-                        dlt[a] += w;
-                        r0v[f][r] = w;
-                        r1v[f][r] = pv;
+                        if (PRE) {
+                            r0v[f][r] = pv * (dp[a][f][r] - dlt[a]);
+                            r1v[f][r] = 0.f;
+                        } else {
+                            const float w = pv * dp[a][f][r];
+                            dlt[a] += w;
+                            r0v[f][r] = w;
+                            r1v[f][r] = pv;
+                        }
                     } else {
                         pv = __builtin_amdgcn_exp2f(fmaf(s[a][f][r], c2, -lrow[r]));
                         r0v[f][r] = pv * (dp[a][f][r] - drow[r]);
@@ -264,10 +293,12 @@ __global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const 
                 u32x4 w0, w1;
                 w0.x = pack_bf16x2(r0v[2 * j][0], r0v[2 * j][1]); w0.y = pack_bf16x2(r0v[2 * j][2], r0v[2 * j][3]);
                 w0.z = pack_bf16x2(r0v[2 * j + 1][0], r0v[2 * j + 1][1]); w0.w = pack_bf16x2(r0v[2 * j + 1][2], r0v[2 * j + 1][3]);
-                w1.x = pack_bf16x2(r1v[2 * j][0], r1v[2 * j][1]); w1.y = pack_bf16x2(r1v[2 * j][2], r1v[2 * j][3]);
-                w1.z = pack_bf16x2(r1v[2 * j + 1][0], r1v[2 * j + 1][1]); w1.w = pack_bf16x2(r1v[2 * j + 1][2], r1v[2 * j + 1][3]);
                 rb0[a][j] = as_bf16x8(w0);
-                rb1[a][j] = as_bf16x8(w1);
+                if (!PRE) {
+                    w1.x = pack_bf16x2(r1v[2 * j][0], r1v[2 * j][1]); w1.y = pack_bf16x2(r1v[2 * j][2], r1v[2 * j][3]);
+                    w1.z = pack_bf16x2(r1v[2 * j + 1][0], r1v[2 * j + 1][1]); w1.w = pack_bf16x2(r1v[2 * j + 1][2], r1v[2 * j + 1][3]);
+                    rb1[a][j] = as_bf16x8(w1);
+                }
             }
         }
 
@@ -286,7 +317,7 @@ __global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const 
 #pragma unroll
                 for (int a = 0; a < QF; ++a) {
                     acc0[a][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z0, rb0[a][j], acc0[a][df], 0, 0, 0);
-                    acc1[a][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z1, rb1[a][j], acc1[a][df], 0, 0, 0);
+                    if (!PRE) acc1[a][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z1, rb1[a][j], acc1[a][df], 0, 0, 0);
                 }
             }
         }
@@ -299,10 +330,13 @@ __global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const 
     for (int a = 0; a < QF; ++a) {
         const int row = f0 + a * 16 + l15;
         if (MODE == MODE_DQ) {
-            float dsum = dlt[a];
-            dsum += __shfl_xor(dsum, 16, 64);
-            dsum += __shfl_xor(dsum, 32, 64);
-            if (row < p.Nq && lg == 0) p.delta[((long)b * p.H + h) * p.Nq + row] = dsum;
+            float dsum = 0.f;
+            if (!PRE) {
+                dsum = dlt[a];
+                dsum += __shfl_xor(dsum, 16, 64);
+                dsum += __shfl_xor(dsum, 32, 64);
+                if (row < p.Nq && lg == 0) p.delta[((long)b * p.H + h) * p.Nq + row] = dsum;
+            }
             if (row >= p.Nq) continue;
             bf16_t* dst = p.dq + (long)b * p.dq_sb + (long)h * p.dq_sh + (long)row * p.dq_sn;
             const float gs = g * p.scale;
@@ -312,7 +346,7 @@ __global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const 
                 if (d >= D) continue;
                 float o[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = gs * (acc0[a][df][r] - dsum * acc1[a][df][r]);
+                for (int r = 0; r < 4; ++r) o[r] = PRE ? gs * acc0[a][df][r] : gs * (acc0[a][df][r] - dsum * acc1[a][df][r]);
                 if (p.accum_dq) {
                     const u32x2 old = *reinterpret_cast<const u32x2*>(dst + d);
                     o[0] += bf16lo(old.x); o[1] += bf16hi(old.x); o[2] += bf16lo(old.y); o[3] += bf16hi(old.y);
@@ -335,7 +369,7 @@ __global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const 
     }
 }
 
-template <int D, int QF, int MODE>
+template <int D, int QF, int MODE, bool PRE = false>
 int launch_bwd(const BwdArgs& a, hipStream_t stream) {
     constexpr int NC = D / 32;
     constexpr int DQK = NC * 32 + ((D % 32) ? 16 : 0);
@@ -347,20 +381,30 @@ int launch_bwd(const BwdArgs& a, hipStream_t stream) {
     if (lds > 64 * 1024) {
         static bool done = false;
         if (!done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<D, QF, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<D, QF, MODE, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
                 ae_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", lds);
                 return AE_ERR_LAUNCH;
             }
             done = true;
         }
     }
-    hipLaunchKernelGGL((attn_bwd_kernel<D, QF, MODE>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((attn_bwd_kernel<D, QF, MODE, PRE>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
     return ae_check_launch(MODE == MODE_DQ ? "ae_attn_bwd_bf16(dQ)" : "ae_attn_bwd_bf16(dK,dV)");
 }
 
 template <int D, int QF>
-int launch_both(const BwdArgs& a, hipStream_t stream) {
-    int rc = launch_bwd<D, QF, MODE_DQ>(a, stream);
+int launch_both(const BwdArgs& a, const bf16_t* out, hipStream_t stream) {
+    int rc;
+    if (out) {  // single-segment attention whose own output is known: delta = rowsum(dO o O) up front, one accumulator set in the dQ pass
+        const long n = (long)a.B * a.Nq * a.H;
+        hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a.dO, out, a.delta, a.B, a.H, a.Nq, a.o_sb, a.o_sh,
+                           a.o_sn);
+        rc = ae_check_launch("ae_attn_bwd_bf16(delta)");
+        if (rc) return rc;
+        rc = launch_bwd<D, QF, MODE_DQ, true>(a, stream);
+    } else {
+        rc = launch_bwd<D, QF, MODE_DQ>(a, stream);
+    }
     if (rc) return rc;
     if (!a.dk) return 0;  // caller only needs dQ (frozen key/value side)
     return launch_bwd<D, QF, MODE_DKV>(a, stream);
@@ -371,7 +415,7 @@ int launch_both(const BwdArgs& a, hipStream_t stream) {
 // Gradients of ae_attn_fwd_bf16 for one key/value segment.  `lse` is the forward's log2-domain log-sum-exp for THIS segment;
 // `delta` ([B,H,Nq] fp32) is an output (rowsum(P o dP) with the UN-scaled dO: summed over heads and rows it is the gradient of
 // the segment's out_scale).  dk / dv may both be NULL when only dQ is needed.  dq is overwritten, or accumulated if accumulate_dq.
-extern "C" int ae_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dout, const float* lse, float* delta,
+extern "C" int ae_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dout, const void* out, const float* lse, float* delta,
                                 void* dq, void* dk, void* dv, int B, int H, int Nq, int Nk, int D,
                                 long q_sb, long q_sh, long q_sn, long k_sb, long k_sh, long k_sn, long v_sb, long v_sh, long v_sn,
                                 long o_sb, long o_sh, long o_sn, long dq_sb, long dq_sh, long dq_sn, long dk_sb, long dk_sh, long dk_sn,
@@ -397,17 +441,20 @@ extern "C" int ae_attn_bwd_bf16(const void* q, const void* k, const void* v, con
     a.dv_sb = dv_sb; a.dv_sh = dv_sh; a.dv_sn = dv_sn;
     a.scale = scale; a.accum_dq = accumulate_dq;
     hipStream_t s = (hipStream_t)stream;
+    // `out` (optional): THIS segment's own forward output, same layout as dout.  Only usable when nothing else was folded into it.
+    AE_REQUIRE(!out || (((uintptr_t)out & 15) == 0), "ae_attn_bwd_bf16: out must be 16-byte aligned");
+    const bf16_t* o_own = (out && !out_scale && !accumulate_dq) ? (const bf16_t*)out : nullptr;
     switch (D) {
-        case 8: return launch_both<8, 2>(a, s);
-        case 16: return launch_both<16, 2>(a, s);
-        case 32: return launch_both<32, 2>(a, s);
-        case 40: return launch_both<40, 2>(a, s);
-        case 48: return launch_both<48, 2>(a, s);
-        case 64: return launch_both<64, 2>(a, s);
-        case 80: return launch_both<80, 2>(a, s);
-        case 96: return launch_both<96, 1>(a, s);
-        case 128: return launch_both<128, 1>(a, s);
-        case 160: return launch_both<160, 1>(a, s);
+        case 8: return launch_both<8, 2>(a, o_own, s);
+        case 16: return launch_both<16, 2>(a, o_own, s);
+        case 32: return launch_both<32, 2>(a, o_own, s);
+        case 40: return launch_both<40, 2>(a, o_own, s);
+        case 48: return launch_both<48, 2>(a, o_own, s);
+        case 64: return launch_both<64, 2>(a, o_own, s);
+        case 80: return launch_both<80, 2>(a, o_own, s);
+        case 96: return launch_both<96, 1>(a, o_own, s);
+        case 128: return launch_both<128, 1>(a, o_own, s);
+        case 160: return launch_both<160, 1>(a, o_own, s);
         default:
             ae_set_error("ae_attn_bwd_bf16: unsupported head_dim %d (supported: 8,16,32,40,48,64,80,96,128,160)", D);
             return AE_ERR_UNSUPPORTED;

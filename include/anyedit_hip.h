@@ -119,8 +119,10 @@ int ae_attn_fwd_fp8(const void* q, const void* k, const void* v, void* out, int 
  * stride-2 Downsample conv, openaimodel.py:157-159).
  *
  * Attention backward for one key/value segment (autograd of attention.py:171-193): delta [B,H,Nq] fp32 is an OUTPUT
- * (rowsum(P o dP) with the un-scaled dout; its sum over heads and rows is d/d out_scale[b]).  dk, dv may both be NULL.       */
-int ae_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dout, const float* lse, float* delta, void* dq,
+ * (rowsum(P o dP) with the un-scaled dout; its sum over heads and rows is d/d out_scale[b]).  dk, dv may both be NULL.
+ * out (optional, layout of dout): the forward output of THIS segment alone (no second segment, no out_scale folded in): delta is
+ * then rowsum(dout o out), computed up front, and the dQ pass keeps one accumulator set instead of two.                        */
+int ae_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dout, const void* out, const float* lse, float* delta, void* dq,
                      void* dk, void* dv, int B, int H, int Nq, int Nk, int D, long q_sb, long q_sh, long q_sn, long k_sb,
                      long k_sh, long k_sn, long v_sb, long v_sh, long v_sn, long o_sb, long o_sh, long o_sn, long dq_sb,
                      long dq_sh, long dq_sn, long dk_sb, long dk_sh, long dk_sn, long dv_sb, long dv_sh, long dv_sn,

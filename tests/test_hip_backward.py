@@ -120,6 +120,13 @@ def test_attention_backward(ops, BH, Nq, Nk, D):
     check_close(dv, vr.grad, rl2=1e-2, what=f"dV {BH}x{Nq}x{Nk}x{D}")
     check_close(dk, kr.grad, rl2=1.5e-2, mabs=5e-2, what=f"dK {BH}x{Nq}x{Nk}x{D}")
     check_close(dq, qr.grad, rl2=1.5e-2, mabs=5e-2, what=f"dQ {BH}x{Nq}x{Nk}x{D}")
+    # with the segment's own forward output at hand, delta = rowsum(dO o O) is taken up front and the dQ pass keeps one accumulator set
+    dq2, dk2, dv2 = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    delta2 = ops.attention_bwd(qd, kd, vd, dod, lse, BH, 1, Nq, Nk, D, D ** -0.5, sq, sk, sk, dq2, dk2, dv2, sq, sk, sk, out=out)
+    check_close(delta2.reshape(BH, Nq), (do * ref_o).sum(-1), rl2=2e-2, mabs=5e-2, what="delta (from the output)")
+    check_close(dv2, vr.grad, rl2=1e-2, what=f"dV' {BH}x{Nq}x{Nk}x{D}")
+    check_close(dk2, kr.grad, rl2=1.5e-2, mabs=5e-2, what=f"dK' {BH}x{Nq}x{Nk}x{D}")
+    check_close(dq2, qr.grad, rl2=1.5e-2, mabs=5e-2, what=f"dQ' {BH}x{Nq}x{Nk}x{D}")
 
 
 def test_fuzz_attention_and_norm_backward_shapes(ops):
