@@ -213,9 +213,14 @@ def conv3x3(x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2
 _GN_COUNTERS = {}
 
 
+_GN_TAIL = os.environ.get("AE_GN_TAIL") == "1"   # the last-block finalize is a measured loss on MI355X: opt-in only
+
+
 def _gn_counters(device, B):
-    """int32 tickets for the last-block statistics fold (zero between launches).  One buffer per (device, stream): launches on a
-    stream are ordered, so they can share it; the first use on a stream allocates (inside a graph capture that is a memset node)."""
+    """int32 tickets for the last-block statistics fold (zero between launches), or None while that variant is off.  One buffer per
+    (device, stream): launches on a stream are ordered, so they can share it."""
+    if not _GN_TAIL:
+        return None
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     c = _GN_COUNTERS.get(key)
     if c is None or c.numel() < B:
