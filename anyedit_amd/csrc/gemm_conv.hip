@@ -709,6 +709,9 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // (the same tile for the K = 320 dense GEMMs of the 64x64 level was A/B-ed too: N = 320 44.5 vs 34 us, N = 960 78 vs 63 us —
     // five K iterations do not amortise the big tile's prologue / epilogue.)
     bool done = false;
+    // (192x320 with FOUR waves of 96x160 — 0.27 LDS fragment reads per MFMA instead of 0.37, 240 accumulator registers per lane — was
+    // instantiated and measured: hipcc places the accumulators in AGPRs and brackets the MFMAs with v_accvgpr moves, 166-206 TFLOP/s
+    // against 911-1123 for the 8-wave form.  Bigger wave tiles need hand-scheduled AGPR code; not kept.)
     if (conv && a.splitk > 1 && glds && make_plan(a.M, a.N, a.K, true).tile == 4) {  // split-K under the 192x320 tile (make_plan)
         const long t = (long)(a.M / 192) * (a.N / 320) * a.splitk;
         rc = launch_kernel(gemm_kernel<192, 320, AMODE, 2, 4, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
@@ -762,6 +765,8 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         // M = 1024 x N = 1280 x K = 1280 (320 blocks) 31.7 -> ~20 us, training step 29.0 -> 28.0 ms.  AE_GEMM_DEEP64_MAX=256 restores round 1.
         static const int deep64_max = getenv("AE_GEMM_DEEP64_MAX") ? atoi(getenv("AE_GEMM_DEEP64_MAX")) : 768;
         static const int conv_deep_l = getenv("AE_CONV_DEEP") ? atoi(getenv("AE_CONV_DEEP")) : 1;
+        // (a FOURTH stage — three tiles in flight, 128 KiB — measured the same on the 8x8-level convs: 41.9 vs 40.4 us; these launches are
+        // not latency-bound by ring depth but by LDS bandwidth: 0.75 ds_read_b128 per MFMA x 8 cycles each against 16-cycle MFMAs)
         if (conv && conv_deep_l && pick == 0 && glds && grid <= 256)
             rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 3>, grid, 512, lds_of(128, 128, 3), stream, a, what);
         else if (pick == 3) AE_LAUNCH(128, 160, 2, 2, 256);
