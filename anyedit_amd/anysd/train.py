@@ -24,7 +24,7 @@ BF16 = torch.bfloat16
 
 class AnySDTrainer:
     def __init__(self, moe, sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=1e-2, process_group=None, bucket_bytes=25 << 20, always_exchange=False):
+                 weight_decay=1e-2, process_group=None, bucket_bytes=25 << 20, always_exchange=False, force_collectives=False):
         self.moe = moe
         self.sqrt_ac = sqrt_alphas_cumprod.float()
         self.sqrt_1mac = sqrt_one_minus_alphas_cumprod.float()
@@ -46,7 +46,7 @@ class AnySDTrainer:
         self.exchange = None
         # always_exchange: build the DDP buckets even for one rank (tests run the bucket-resident gradient path on a single GPU)
         if always_exchange or (dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1):
-            self.exchange = GradientExchange(self.params, bucket_bytes, group=process_group)
+            self.exchange = GradientExchange(self.params, bucket_bytes, group=process_group, force_collectives=force_collectives)
 
     # ------------------------------------------------------------------------------------------------ forward on the tape
     def forward_loss(self, latents, image_cond, encoder_hidden_states, ref_embeds, edit_code, noise, timesteps, null_ehs=None,

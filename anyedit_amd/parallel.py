@@ -51,7 +51,7 @@ class GradientExchange:
     issue order — the gloo test asserts from it that buckets left before the backward had finished.
     """
 
-    def __init__(self, params, bucket_bytes=25 << 20, group=None):
+    def __init__(self, params, bucket_bytes=25 << 20, group=None, force_collectives=False):
         if isinstance(params, dict):
             named = list(params.items())
         else:
@@ -61,6 +61,9 @@ class GradientExchange:
         self.params = [p for _, p in named]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # force_collectives: issue the reduce-scatter / all-gather even for ONE rank (tests drive the RCCL call sequence, streams and
+        # handles on a single GPU; with one rank the collectives are identities)
+        self.collect = self.world > 1 or (force_collectives and dist.is_initialized())
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.device = dev
         # backward order = reverse registration order
@@ -111,7 +114,7 @@ class GradientExchange:
             return
         self._launched.add(bi)
         self.launch_log.append(("reduce_scatter", bi))
-        if self.world == 1:
+        if not self.collect:
             return
         if self.stream is not None:
             ev = torch.cuda.Event()
@@ -139,7 +142,7 @@ class GradientExchange:
         for bi in range(len(self.buckets)):
             self._launch(bi)  # whatever never reported stays as written (zeros if untouched)
         self.launch_log.append(("finish", -1))
-        if self.world > 1:
+        if self.collect:
             ctx = torch.cuda.stream(self.stream) if self.stream is not None else _null()
             with ctx:
                 gathers = []
@@ -157,7 +160,7 @@ class GradientExchange:
     @torch.no_grad()
     def reduce(self):
         """In place: p.grad <- mean over ranks of p.grad, through the same buckets.  Returns the payload in bytes."""
-        if self.world == 1:
+        if not self.collect:
             return 0
         self.begin_step(zero=False)
         for n, p in zip(reversed(self.names), reversed(self.params)):

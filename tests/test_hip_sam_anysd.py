@@ -278,6 +278,31 @@ def test_training_step_gradients_vs_oracle_autograd():
         assert torch.equal(gp[k], gx[k].reshape(gp[k].shape)), k
     first_rs = next(i for i, e in enumerate(log) if e[0] == "reduce_scatter")
     assert first_rs < max(i for i, e in enumerate(log) if e[0] == "ready") and len(trx.exchange.buckets) > 2
+    # the same step with the collectives really issued through RCCL ("nccl" backend, ONE rank: reduce-scatter / all-gather are identities):
+    # drives the call sequence, the side stream, the async handles and the 256-byte-aligned bucket slots on the GPU stack the 8-GPU job uses
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        import os
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        try:
+            moe5, _ = _tiny_moe()
+            moe5 = moe5.to(DEV)
+            trr = AnySDTrainer(moe5, sa.to(DEV), s1.to(DEV), lr=1e-3, always_exchange=True, bucket_bytes=1 << 12, force_collectives=True)
+            assert trr.exchange.collect and trr.exchange.world == 1
+            for _ in range(2):                                  # twice: persistent buckets and handles are reused across steps
+                _, tr_, lr_ = trr.forward_loss(*args)
+                trr.backward(tr_, lr_)
+                gr = {k: v.clone() for k, v in trr.exchange.finish().items()}
+                for k in gp:
+                    assert torch.equal(gp[k], gr[k].reshape(gp[k].shape)), f"RCCL single-rank exchange changed {k}"
+            torch.cuda.synchronize()
+        finally:
+            dist.destroy_process_group()
     # activation checkpointing (openaimodel.py:250, attention.py:268; util.py:102-143): every ResBlock / BasicTransformerBlock body is
     # dropped after the forward and recomputed in the backward — same kernels, so the loss is bit-identical; the gradients agree to
     # bf16 rounding only, because a segment sums its contributions to an outside tensor (skip / residual inputs) before handing
