@@ -217,7 +217,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run the process group is set up even for ONE rank, so that a 1-GPU box exercises the same init / barrier /
+    # max-over-ranks / teardown calls the N-GPU job makes (python bench.py without the launcher stays collective-free)
+    dist_on = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
@@ -234,7 +237,7 @@ def main():
         return pipe.edit(x_T, img_lat, ehs, null, ref, code, steps=args.ddim_steps, s_txt=7.5, s_img=1.5, eta=0.0)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -246,7 +249,7 @@ def main():
         out = one_step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -327,7 +330,7 @@ def main():
             result["cpu_baseline"] = cpu
             result["parity"] = parity
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
