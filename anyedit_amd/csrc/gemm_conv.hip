@@ -57,6 +57,17 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, bf16_t* lds
 #endif
 }
 
+#ifdef AE_GEMM_LAB
+// lab only (tools/ubench/conv_lab.hip): shader-cycle buckets of waves 0 and 4 (one SIMD's two waves) of one block in the middle of the grid:
+// [0] prologue, [1] DMA issue, [2] LDS reads + MFMAs, [3] barrier + DMA drain, [4] epilogue tail, [5] K tiles, [6] epilogue staging (bias /
+// activation + fp32 tile into LDS), [7] epilogue output (barrier, LDS reads, residual, global stores).  The stamps serialise the scalar
+// pipe: the split between [1] and [2] is pessimistic (un-instrumented, the DMA issue overlaps the first MFMAs); totals per phase are sound.
+__device__ unsigned long long g_gemm_dbg[16];
+#define GL_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (lab_me) g_gemm_dbg[lab_base + (i)] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define GL_T(i)
+#endif
+
 // smallest divisor of FM (16-row fragments per wave) whose share of the fp32 tile fits the main-loop LDS
 constexpr int epilogue_passes(int FM, int bytes_per_frag_row, int lds_bytes) {
     for (int ps = 1; ps <= FM; ++ps)
@@ -83,6 +94,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
     bf16_t* sB = smem + STAGES * BM * BK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef AE_GEMM_LAB
+    unsigned long long tlast = __builtin_readcyclecounter();
+    const bool lab_me = blockIdx.x == gridDim.x / 2 && lane == 0 && (wave == 0 || wave == 4);
+    const int lab_base = wave == 0 ? 0 : 8;
+#endif
     const int wk = wave / (WAVES_M * WAVES_N), wmn = wave % (WAVES_M * WAVES_N);  // K group, position inside the group
     const int wm = wmn / WAVES_N, wn = wmn % WAVES_N;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -350,11 +366,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
         if constexpr (STAGES == 2) {
             dma_tile(0, 0);
             __syncthreads();
+            GL_T(0);
             for (int kt = 0; kt < KT; ++kt) {
                 const int cur = kt & 1;
                 if (kt + 1 < KT) dma_tile(kt + 1, cur ^ 1);  // stage cur^1 was last read before the previous barrier
+                GL_T(1);
                 compute_tile(cur);
+                GL_T(2);
                 __syncthreads();
+                GL_T(3);
+#ifdef AE_GEMM_LAB
+                if (lab_me) g_gemm_dbg[lab_base + 5] += 1;
+#endif
             }
         } else {
             // Deep ring: STAGES - 1 tiles in flight.  Each wave waits (counted vmcnt: only the OLDEST tile must have landed) for its own
@@ -437,6 +460,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
         const bool staged = (n_out % 8 == 0) && (p.ldc % 8 == 0) && (!p.res || (p.ldr % 8 == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0));
         if (staged) {
             float* st = reinterpret_cast<float*>(smem_raw) + wmn * (WMP * WN);
+            // Bias (and, per row fragment, the time-embedding vector) of this lane's 4 columns per fragment: ONE 16-byte load each, issued
+            // together ahead of the arithmetic.  Round 1 loaded every value as a scalar right before its use — hipcc waits (vmcnt(0)) after
+            // each: 120 dependent L2 round trips per wave on the 192x320 tile, 39 k of the kernel's ~190 k cycles (tools/ubench/conv_lab.hip).
+            const bool bias_v4 = (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
+            const bool av_v4 = (reinterpret_cast<uintptr_t>(p.addvec) & 15) == 0 && (p.ldav & 3) == 0;
+            int ncol[FN];
+            f32x4 bz[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                if (geglu) ncol[j] = min(n0 + wn * WN + (j & ~1) * 16 + lg * 4, p.N - 20) + (j & 1) * 16;   // 'a' rows, gate rows at +16
+                else ncol[j] = min(n0 + wn * WN + j * 16 + lg * 4, p.N - 4);
+                bz[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (p.bias) {
+                    if (bias_v4) bz[j] = *reinterpret_cast<const f32x4*>(p.bias + ncol[j]);
+                    else bz[j] = (f32x4){p.bias[ncol[j]], p.bias[ncol[j] + 1], p.bias[ncol[j] + 2], p.bias[ncol[j] + 3]};
+                }
+            }
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) {
                 if (ps > 0) __syncthreads();
@@ -446,16 +486,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                     const int rl = ii * 16 + l15;  // row inside this pass
                     const int m = min(m0 + wm * WM + i * 16 + l15, p.M - 1);
                     const float* av = p.addvec ? p.addvec + (long)(m / p.rows_per_batch) * p.ldav : nullptr;
+                    f32x4 az[FN];  // the row's time-embedding values (zero without addvec); summation order as before: (acc + bias) + vector
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        az[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (av) {
+                            if (av_v4) az[j] = *reinterpret_cast<const f32x4*>(av + ncol[j]);
+                            else az[j] = (f32x4){av[ncol[j]], av[ncol[j] + 1], av[ncol[j] + 2], av[ncol[j] + 3]};
+                        }
+                    }
                     if (geglu) {
                         if constexpr (FN % 2 == 0) {
 #pragma unroll
                             for (int j = 0; j < FN; j += 2) {
-                                const int na = min(n0 + wn * WN + j * 16 + lg * 4, p.N - 20);
                                 f32x4 o;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
-                                    const float a = acc[i][j][r] + (p.bias ? p.bias[na + r] : 0.f);
-                                    const float g = acc[i][j + 1][r] + (p.bias ? p.bias[na + 16 + r] : 0.f);
+                                    const float a = acc[i][j][r] + bz[j][r];
+                                    const float g = acc[i][j + 1][r] + bz[j + 1][r];
                                     o[r] = a * gelu_erf_f(g);
                                 }
                                 const int ch = (j / 2) * 4 + lg;
@@ -465,13 +513,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                     } else {
 #pragma unroll
                         for (int j = 0; j < FN; ++j) {
-                            const int n = min(n0 + wn * WN + j * 16 + lg * 4, p.N - 4);
                             f32x4 o;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                float v = acc[i][j][r];
-                                if (p.bias) v += p.bias[n + r];
-                                if (av) v += av[n + r];
+                                float v = acc[i][j][r] + bz[j][r];
+                                if (av) v += az[j][r];
                                 if (p.epi == EPI_SILU) v = silu_f(v);
                                 else if (p.epi == EPI_GELU) v = gelu_erf_f(v);
                                 else if (p.epi == EPI_RELU) v = fmaxf(v, 0.f);
@@ -482,6 +528,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                         }
                     }
                 }
+                GL_T(6);
                 __syncthreads();
                 const int ow = geglu ? WN / 2 : WN;      // output columns of this wave's tile
                 const int och = ow / 8;                  // 8-column output chunks per row
@@ -507,7 +554,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                             (u32x4){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
                     }
                 }
+                GL_T(7);
             }
+            GL_T(4);
             return;
         }
     }
