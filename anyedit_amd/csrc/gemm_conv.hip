@@ -429,6 +429,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
     const bool writer = wk == 0;  // with K groups only group 0 holds the result; group 1 keeps the block's barriers company
 
     // ---- epilogue ---------------------------------------------------------------------------
+#ifdef AE_GEMM_LAB_NOEPI
+    if (p.M > 0) {  // lab ablation: what the kernel costs WITHOUT its epilogue (one store keeps the accumulators alive)
+        if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(p.C)[0] = acc[FM - 1][FN - 1][3];
+        return;
+    }
+#endif
     if (p.splitk > 1) {  // raw fp32 partials; bias / vector / residual are applied by splitk_reduce_kernel
         if (!writer) return;
 #pragma unroll

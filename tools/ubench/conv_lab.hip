@@ -2,6 +2,7 @@
 // conv shapes at batch 12 and prints where one SIMD's two waves of a mid-grid block spend their cycles per K tile:
 // DMA issue / LDS reads + MFMAs / barrier + DMA drain, plus prologue and epilogue.  Parity is covered by tests/test_hip_ops.py.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DAE_GEMM_LAB -I anyedit_amd/csrc -o tools/ubench/build/conv_lab tools/ubench/conv_lab.hip
+//   without -DAE_GEMM_LAB: plain timing of the shipped kernels; with -DAE_GEMM_LAB_NOEPI: the same kernels without their epilogue (ablation)
 #include "../../anyedit_amd/csrc/gemm_conv.hip"
 #include <cstdio>
 #include <cstring>
@@ -30,18 +31,22 @@ static void run(int B, int H, int Cin, int Cout, const char* tag) {
     auto launch = [&]() { return ae_conv3x3_bf16(dx, dw, dbias, nullptr, 0, nullptr, dy, B, H, H, Cin, Cout, 1, 0, 0, ws, nullptr); };
     for (int i = 0; i < 3; ++i) if (launch() != AE_OK) { printf("launch failed\n"); exit(1); }
     CK(hipDeviceSynchronize());
-    unsigned long long zero[16] = {0}, dbg[16];
+    unsigned long long zero[16] = {0}, dbg[16] = {0};
+#ifdef AE_GEMM_LAB
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), zero, sizeof(zero)));
+#endif
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int iters = 10;
     CK(hipEventRecord(e0));
     for (int i = 0; i < iters; ++i) launch();
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+#ifdef AE_GEMM_LAB
     CK(hipMemcpyFromSymbol(dbg, HIP_SYMBOL(g_gemm_dbg), sizeof(dbg)));
+#endif
     const double us = 1e3 * ms / iters, fl = 2.0 * B * H * H * (double)Cout * 9 * Cin;
     printf("%-28s %8.1f us %7.1f TFLOP/s  split-K workspace %ld floats\n", tag, us, fl / us / 1e6, wsf);
-    for (int w = 0; w < 2; ++w) {
+    for (int w = 0; w < 2 && dbg[5]; ++w) {   // buckets only in the -DAE_GEMM_LAB build
         const unsigned long long* d = dbg + 8 * w;
         const double kt = d[5] ? (double)d[5] : 1.0;
         printf("    wave %d: per K tile: DMA issue %6.0f  LDS+MFMA %6.0f  barrier+drain %6.0f cycles   (K tiles/launch %.0f)\n             per launch: prologue %.0f, epilogue staging %.0f + output %.0f + tail %.0f cycles\n",
