@@ -624,24 +624,37 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
 // out[m][n] = sum_s partial[s][m][n] + bias[n] + addvec[m / rows_per_batch][n] (+ residual), fixed summation order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const long total = (long)p.M * p.N / 4;
+    const long MN = (long)p.M * p.N;
+    // every operand of an output quad is fetched as ONE vector load and all of them are issued before the first is used (the scalar
+    // per-value form made hipcc wait after each load: 15 dependent round trips per quad in a kernel that is nothing but latency)
+    const bool bias_v4 = (reinterpret_cast<uintptr_t>(p.bias) & 15) == 0;
+    const bool av_v4 = (reinterpret_cast<uintptr_t>(p.addvec) & 15) == 0 && (p.ldav & 3) == 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long e = i * 4;
         const int m = (int)(e / p.N), n = (int)(e % p.N);
-        f32x4 v = *reinterpret_cast<const f32x4*>(p.partial + e);
-        for (int s2 = 1; s2 < p.splitk; ++s2) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(p.partial + (long)s2 * p.M * p.N + e);
-            v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+        f32x4 w[8];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) w[s2] = s2 < p.splitk ? *reinterpret_cast<const f32x4*>(p.partial + (long)s2 * MN + e) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 bz = {0.f, 0.f, 0.f, 0.f}, az = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bz = bias_v4 ? *reinterpret_cast<const f32x4*>(p.bias + n) : (f32x4){p.bias[n], p.bias[n + 1], p.bias[n + 2], p.bias[n + 3]};
+        if (p.addvec) {
+            const float* av = p.addvec + (long)(m / p.rows_per_batch) * p.ldav + n;
+            az = av_v4 ? *reinterpret_cast<const f32x4*>(av) : (f32x4){av[0], av[1], av[2], av[3]};
+        }
+        u32x2 rr = {0u, 0u};
+        if (p.res) rr = *reinterpret_cast<const u32x2*>(p.res + (long)m * p.ldr + n);
+        f32x4 v = w[0];
+#pragma unroll
+        for (int s2 = 1; s2 < 8; ++s2) {  // fixed summation order; splits beyond splitk contribute exact zeros
+            if (s2 < p.splitk) { v[0] += w[s2][0]; v[1] += w[s2][1]; v[2] += w[s2][2]; v[3] += w[s2][3]; }
         }
         float o[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (p.bias) o[r] += p.bias[n + r];
-            if (p.addvec) o[r] += p.addvec[(long)(m / p.rows_per_batch) * p.ldav + n + r];
+            if (p.bias) o[r] += bz[r];
+            if (p.addvec) o[r] += az[r];
         }
-        if (p.res) {
-            const u32x2 rr = *reinterpret_cast<const u32x2*>(p.res + (long)m * p.ldr + n);
-            o[0] += bf16lo(rr.x); o[1] += bf16hi(rr.x); o[2] += bf16lo(rr.y); o[3] += bf16hi(rr.y);
-        }
+        if (p.res) { o[0] += bf16lo(rr.x); o[1] += bf16hi(rr.x); o[2] += bf16lo(rr.y); o[3] += bf16hi(rr.y); }
         if (p.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = (f32x4){o[0], o[1], o[2], o[3]};
         else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) = (u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
     }
