@@ -18,6 +18,7 @@
 //   * XCD-aware bijective tile remap so tiles sharing an A panel run on the same XCD's L2.
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -486,53 +487,71 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) {
                 if (ps > 0) __syncthreads();
+                // The staging loop is instantiated once per epilogue kind: inside it nothing depends on a runtime flag.  (Round 1 tested p.epi and
+                // the addvec pointer per VALUE: four scalar branches around every one of the 120 values a wave stages on the 192x320 tile.)
+                auto stage = [&](auto EPI_TAG, auto AV_TAG) {
+                    constexpr int epi = decltype(EPI_TAG)::value;
+                    constexpr bool has_av = decltype(AV_TAG)::value;
 #pragma unroll
-                for (int ii = 0; ii < (writer ? FMP : 0); ++ii) {
-                    const int i = ps * FMP + ii;
-                    const int rl = ii * 16 + l15;  // row inside this pass
-                    const int m = min(m0 + wm * WM + i * 16 + l15, p.M - 1);
-                    const float* av = p.addvec ? p.addvec + (long)(m / p.rows_per_batch) * p.ldav : nullptr;
-                    f32x4 az[FN];  // the row's time-embedding values (zero without addvec); summation order as before: (acc + bias) + vector
+                    for (int ii = 0; ii < FMP; ++ii) {
+                        const int i = ps * FMP + ii;
+                        const int rl = ii * 16 + l15;  // row inside this pass
+                        f32x4 az[FN];  // the row's time-embedding values; summation order as before: (acc + bias) + vector
+                        if constexpr (has_av) {
+                            const int m = min(m0 + wm * WM + i * 16 + l15, p.M - 1);
+                            const float* av = p.addvec + (long)(m / p.rows_per_batch) * p.ldav;
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        az[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        if (av) {
-                            if (av_v4) az[j] = *reinterpret_cast<const f32x4*>(av + ncol[j]);
-                            else az[j] = (f32x4){av[ncol[j]], av[ncol[j] + 1], av[ncol[j] + 2], av[ncol[j] + 3]};
+                            for (int j = 0; j < FN; ++j) {
+                                if (av_v4) az[j] = *reinterpret_cast<const f32x4*>(av + ncol[j]);
+                                else az[j] = (f32x4){av[ncol[j]], av[ncol[j] + 1], av[ncol[j] + 2], av[ncol[j] + 3]};
+                            }
                         }
-                    }
-                    if (geglu) {
-                        if constexpr (FN % 2 == 0) {
+                        if constexpr (epi == EPI_GEGLU) {
+                            if constexpr (FN % 2 == 0) {
 #pragma unroll
-                            for (int j = 0; j < FN; j += 2) {
+                                for (int j = 0; j < FN; j += 2) {
+                                    f32x4 o;
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const float a = acc[i][j][r] + bz[j][r];
+                                        const float g = acc[i][j + 1][r] + bz[j + 1][r];
+                                        o[r] = a * gelu_erf_f(g);
+                                    }
+                                    const int ch = (j / 2) * 4 + lg;
+                                    *reinterpret_cast<f32x4*>(st + rl * WN + (((ch + rl) % NCH) << 2)) = o;
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < FN; ++j) {
                                 f32x4 o;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
-                                    const float a = acc[i][j][r] + bz[j][r];
-                                    const float g = acc[i][j + 1][r] + bz[j + 1][r];
-                                    o[r] = a * gelu_erf_f(g);
+                                    float v = acc[i][j][r] + bz[j][r];
+                                    if constexpr (has_av) v += az[j][r];
+                                    if constexpr (epi == EPI_SILU) v = silu_f(v);
+                                    else if constexpr (epi == EPI_GELU) v = gelu_erf_f(v);
+                                    else if constexpr (epi == EPI_RELU) v = fmaxf(v, 0.f);
+                                    o[r] = v;
                                 }
-                                const int ch = (j / 2) * 4 + lg;
+                                const int ch = j * 4 + lg;
                                 *reinterpret_cast<f32x4*>(st + rl * WN + (((ch + rl) % NCH) << 2)) = o;
                             }
                         }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < FN; ++j) {
-                            f32x4 o;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                float v = acc[i][j][r] + bz[j][r];
-                                if (av) v += az[j][r];
-                                if (p.epi == EPI_SILU) v = silu_f(v);
-                                else if (p.epi == EPI_GELU) v = gelu_erf_f(v);
-                                else if (p.epi == EPI_RELU) v = fmaxf(v, 0.f);
-                                o[r] = v;
-                            }
-                            const int ch = j * 4 + lg;
-                            *reinterpret_cast<f32x4*>(st + rl * WN + (((ch + rl) % NCH) << 2)) = o;
-                        }
                     }
+                };
+                if (writer) {
+                    using T = std::true_type;
+                    using F = std::false_type;
+                    if (geglu) stage(std::integral_constant<int, EPI_GEGLU>{}, F{});
+                    else if (p.epi == EPI_NONE && p.addvec) stage(std::integral_constant<int, EPI_NONE>{}, T{});
+                    else if (p.epi == EPI_NONE) stage(std::integral_constant<int, EPI_NONE>{}, F{});
+                    else if (p.epi == EPI_SILU && p.addvec) stage(std::integral_constant<int, EPI_SILU>{}, T{});
+                    else if (p.epi == EPI_SILU) stage(std::integral_constant<int, EPI_SILU>{}, F{});
+                    else if (p.epi == EPI_GELU && p.addvec) stage(std::integral_constant<int, EPI_GELU>{}, T{});
+                    else if (p.epi == EPI_GELU) stage(std::integral_constant<int, EPI_GELU>{}, F{});
+                    else if (p.addvec) stage(std::integral_constant<int, EPI_RELU>{}, T{});
+                    else stage(std::integral_constant<int, EPI_RELU>{}, F{});
                 }
                 GL_T(6);
                 __syncthreads();
