@@ -12,8 +12,11 @@
 //             dV = g sum_q P^T dO,  dK = g scale sum_q dS^T Q.
 // `g` = optional per-batch output scale (the adapter gate: out = Attn(q,K,V) + g_b Attn(q,K_ip,V_ip)); delta is kept UN-scaled.
 // Same MFMA conventions as the forward: the streamed side is the row (A) operand read from LDS, the fixed side the column (B)
-// operand held in registers, so every lane owns one fixed-side row; the second product takes its A operand from a transposed LDS
-// image (key/query slots permuted to the accumulator order) and its B operand straight from the accumulator registers.
+// operand held in registers, so every lane owns one fixed-side row; the second product takes its A operand — the transposed
+// streamed tile, contraction slots in accumulator order — by ds_read_b64_tr_b16 from the same row-major image and its B operand
+// straight from the accumulator registers.  The streamed tiles are double-buffered (next tile's global loads in registers under the
+// MFMAs, one barrier per tile); with the segment's own forward output at hand, delta = rowsum(dO o O) comes from a small pre-pass
+// and MODE_DQ keeps one accumulator set (PRE).
 #include "common.hpp"
 #include <stdlib.h>
 
@@ -50,10 +53,6 @@ __device__ __forceinline__ bf16x8_t cat_tr(s16x4v lo, s16x4v hi) {
     union { struct { s16x4v a, b; } s; bf16x8_t v; } u;
     u.s.a = lo; u.s.b = hi;
     return u.v;
-}
-
-__device__ __forceinline__ int perm_pos(int r) {  // streamed row 16 f + 4 g + e  ->  slot 16 g + 4 f + e (accumulator order)
-    return ((r >> 2) & 3) * 16 + (r >> 4) * 4 + (r & 3);
 }
 
 // delta[b,h,q] = sum_d dO[b,q,h,d] O[b,q,h,d] (= rowsum(P o dP) of a single-segment attention whose output is O): one thread per
