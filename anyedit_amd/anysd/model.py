@@ -94,18 +94,15 @@ class MoE(nn.Module):
         ip_rows = self.image_proj_model.rows(ref_embeds)                                  # [B*T, Dc]
         T_ip = self.image_proj_model.tokens
         kv_cache = {}
-        experts = top1.long().tolist()  # once per edit: tiny host sync, outside the step loop
         for blk, W in zip(self._blocks, self.adapter_modules):
             attn = blk.attn2
             kv_cache[id(attn)] = attn.project_kv(context_rows)
-            Wb = W.detach().to(BF16)
-            kv_ip = torch.empty(B * T_ip, Wb.shape[1], dtype=BF16, device=dev)
-            for e in sorted(set(experts)):                                               # one GEMM per expert present
-                idx = [b for b in range(B) if experts[b] == e]
-                rows = torch.cat([ip_rows[b * T_ip:(b + 1) * T_ip] for b in idx], 0).contiguous()
-                y = ops.gemm(rows, Wb[e].contiguous())
-                for j, b in enumerate(idx):
-                    kv_ip[b * T_ip:(b + 1) * T_ip] = y[j * T_ip:(j + 1) * T_ip]
+            # every sample's routed expert in ONE grouped launch reading the fp32 masters (csrc/expert_kv.hip; weights rounded to bf16 in
+            # registers = the packed weights' values): no host sync on the routing, no per-expert slices and copies
+            Wm = W.detach()
+            if Wm.dtype != torch.float32 or not Wm.is_contiguous():
+                Wm = Wm.float().contiguous()
+            kv_ip = ops.expert_kv(ip_rows, Wm, top1, T_ip)
             kv_cache[("adapter", id(attn))] = (kv_ip, gate.float().contiguous())
         return context_rows, kv_cache
 

@@ -330,6 +330,10 @@ extern "C" int ae_ln_gemm_bf16(const void* A, long lda, const void* W, long ldw,
     AE_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && (!residual || ldr % 8 == 0), "ae_ln_gemm_bf16: row strides must keep 16-byte alignment");
     AE_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)residual & 15) == 0, "ae_ln_gemm_bf16: pointer alignment");
     AE_REQUIRE((long)N * ldw * 2 < (1L << 31), "ae_ln_gemm_bf16: W too large for 32-bit offsets");
+    {   // A, C and the residual are addressed with 32-bit byte offsets too (descriptor extent, per-block base, row * ld): refuse instead of wrapping
+        const long ldmax = lda > ldc ? (lda > ldr ? lda : ldr) : (ldc > ldr ? ldc : ldr);
+        AE_REQUIRE(((long)M + RP_BM) * ldmax * 2 < (1L << 31), "ae_ln_gemm_bf16: M * row stride reaches 2 GiB (32-bit offsets): use ae_gemm_bf16 for this shape");
+    }
     AE_REQUIRE(!(epilogue == RP_EPI_GEGLU && residual), "ae_ln_gemm_bf16: GEGLU has no residual");
     RowPanelArgs a{};
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.bias = bias; a.res = (const bf16_t*)residual;

@@ -232,8 +232,15 @@ class BasicTransformerBlock(nn.Module):
             key = id(self.attn2)
             kv2 = kv_cache.get(key)
             if kv2 is None:
-                kv2 = kv_cache[key] = self.attn2.project_kv(context_rows)
+                kv2 = self.attn2.project_kv(context_rows)
+                if not (ops._TAPE is not None and ops._TAPE.active):
+                    # Cached for the following DDIM steps.  NOT while a training tape records: this body may be a checkpoint segment
+                    # that runs twice (throw-away forward, recompute in the backward), and a tensor created on the throw-away tape
+                    # must not be what the recompute finds (its gradient would be dropped silently — ADVICE r2).
+                    kv_cache[key] = kv2
             adapter = kv_cache.get(("adapter", key))  # installed by anysd.MoE.prepare_conditioning
+            if callable(adapter):  # training: the expert K|V projection is recorded here, next to the attention that consumes it
+                adapter = adapter()
         x = self.attn2.rows(x, B, N, context_rows=context_rows, kv=kv2, residual=x, adapter=adapter, norm=self.norm2)
         x = self.ff.rows(x, residual=x, norm=self.norm3)
         return x

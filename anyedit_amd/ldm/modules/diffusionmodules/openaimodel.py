@@ -171,12 +171,15 @@ class ResBlock(TimestepBlock):
         h = self.in_layers[0].rows(f.t, B, H * W, silu=True, x2=f.t2)
         h, _, _ = self.in_layers[2].rows(h, B, H, W, addvec=emb_out)
         h = self.out_layers[0].rows(h, B, H * W, silu=True)
+        # This body may run twice as a checkpoint segment (throw-away forward + recompute): it must not change `f` — a concat
+        # materialised into f.t on the throw-away tape would be unknown to the recompute's tape and its gradient dropped.
+        whole = (lambda: f.t if f.t2 is None else ops.concat_channels(f.t, f.t2))
         if isinstance(self.skip_connection, nn.Identity):
-            res = f.materialize()
+            res = whole()
         elif self.skip_connection.kernel_size[0] == 1:
             res, _, _ = self.skip_connection.rows(f.t, B, H, W, a2=f.t2)
         else:
-            res, _, _ = self.skip_connection.rows(f.materialize(), B, H, W)
+            res, _, _ = self.skip_connection.rows(whole(), B, H, W)
         y, _, _ = self.out_layers[3].rows(h, B, H, W, residual=res)
         return Feat(y, B, H, W)
 

@@ -48,8 +48,10 @@ def check(rc, what=""):
 
 def weights_token(*tensors):
     """Identity + in-place version of every tensor a packed-weight cache was built from: (storage address, autograd version counter).
-    `load_state_dict` (on the module or on ANY parent), optimizer steps and `.to(device)` all change it, so a cache keyed on the token
-    can never serve stale packed weights (only the outermost load_state_dict used to invalidate)."""
+    `load_state_dict` (on the module or on ANY parent), torch optimizer steps and `.to(device)` all change it, so a cache keyed on the
+    token can never serve stale packed weights (only the outermost load_state_dict used to invalidate).  Kernels that
+    update parameters through raw pointers do NOT move the counter by themselves: `AnySDTrainer.optimizer_step` bumps it after
+    `adamw_step` (torch.autograd.graph.increment_version), and any other raw-pointer writer must do the same."""
     return tuple((t.data_ptr(), _version_of(t)) for t in tensors if t is not None)
 
 
@@ -148,7 +150,11 @@ def _rowpanel_ok(a, w, out, residual, M, N, K, epilogue):
     if not _ROWPANEL or not lib.ae_ln_gemm_supported(M, N, K, epilogue):
         return False
     ts = [a, w, out] + ([residual] if residual is not None else [])
-    return all(t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0 and t.stride(1) == 1 for t in ts) and N * w.stride(0) * 2 < 2 ** 31
+    # the row-panel kernel addresses A, C and the residual with 32-bit byte offsets (buffer descriptors, per-block base offsets): shapes
+    # whose rows x stride reach 2 GiB fall back to the tiled kernel instead of wrapping
+    ld_max = max(t.stride(0) for t in ts if t is not w)
+    return all(t.data_ptr() % 16 == 0 and t.stride(0) % 8 == 0 and t.stride(1) == 1 for t in ts) and N * w.stride(0) * 2 < 2 ** 31 \
+        and (M + 192) * ld_max * 2 < 2 ** 31
 
 
 def _ln_gemm_launch(a, w, bias, residual, gamma, beta, eps, epilogue, out, M, N, K):

@@ -249,8 +249,13 @@ def main():
         out = one_step()
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
     if dist_on:
+        # every rank's own wall time (the scaling run's first question is "which rank was slow"), then the MAX over ranks as the job's time
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        allt = torch.zeros(world, device=device, dtype=torch.float64)
+        torch.distributed.all_gather_into_tensor(allt, tt)
+        per_rank = [float(v) for v in allt.tolist()]
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(out).all(), "non-finite latents"
@@ -269,6 +274,8 @@ def main():
                                    f"{n_unet_steps} DDIM steps, batch={B}/GPU, 3-branch CFG (UNet batch {3 * B})",
                        "images_per_gpu": B, "ddim_steps": n_unet_steps, "cfg_branches": 3, "hip_graph": not args.no_graph,
                        "parallelism": f"dp{world} (image-sharded, no data-path collective)"},
+            "per_rank_ms_per_step": {"min": 1e3 * min(per_rank) / args.steps, "max": 1e3 * max(per_rank) / args.steps,
+                                     "all": [round(1e3 * v / args.steps, 3) for v in per_rank]},
             "unet_step_ms": ms_per_step / n_unet_steps,
             "unet_tflops": 3 * B * (GFLOP_PER_UNET_SAMPLE if args.latent == 64 else 2148.3 if args.latent == 96 else float("nan")) * n_unet_steps / (ms_per_step * 1e-3) / 1e3,
         }

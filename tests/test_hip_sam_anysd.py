@@ -212,42 +212,40 @@ def test_training_step_gradients_vs_oracle_autograd():
     acp = torch.linspace(0.9999, 0.005, 1000)
     sa, s1 = acp.sqrt(), (1 - acp).sqrt()
 
-    # oracle: fp32 autograd of our spec
+    # oracle: fp32 autograd of our spec, and the bf16-storage CONTROL of the same graph (forward and backward storage rounded to bf16,
+    # exact arithmetic): the tolerance of every gradient below is derived from it, as the forward tests do
+    from util_models import oracle_training_grads, grad_tolerance
     sd = {k: v.detach().float().clone() for k, v in moe.state_dict().items()}
-    names = [k for k in sd if k.startswith(("image_proj_model.", "adapter_modules.", "task_embs", "gate."))]
-    for k in names:
-        sd[k].requires_grad_(True)
-    unet_sd = {k[5:]: v for k, v in sd.items() if k.startswith("unet.")}
     prefixes = [n + ".attn2." for n, m in moe.unet.named_modules() if m.__class__.__name__ == "BasicTransformerBlock"]
-    noisy = D.q_sample({"sqrt_alphas_cumprod": sa, "sqrt_one_minus_alphas_cumprod": s1}, lat, t, noise)
-    x = torch.cat([noisy, img], 1)
-    eps_ref = A.moe_forward(unet_sd, cfg, sd, prefixes, x, t, ehs, ref_emb, code)
-    loss_ref = D.eps_mse(eps_ref, noise)
-    loss_ref.backward()
+    batch = (lat, img, noise, t, ehs, ref_emb, code, sa, s1)
+    loss_ref_v, g_ref = oracle_training_grads(sd, cfg, prefixes, batch, control=False)
+    loss_ctl_v, g_ctl = oracle_training_grads(sd, cfg, prefixes, batch, control=True)
+    names = list(g_ref)
 
     moe = moe.to(DEV)
     tr = AnySDTrainer(moe, sa.to(DEV), s1.to(DEV), lr=1e-3)
     loss, tape, leaves = tr.forward_loss(lat.to(DEV), img.to(DEV), ehs.to(DEV), ref_emb.to(DEV), code.to(DEV), noise.to(DEV), t.to(DEV))
-    assert abs(float(loss) - float(loss_ref.detach())) <= 2e-2 * abs(float(loss_ref.detach())), (float(loss), float(loss_ref.detach()))
+    assert abs(float(loss) - loss_ref_v) <= 1.5 * abs(loss_ctl_v - loss_ref_v) + 2e-3 * abs(loss_ref_v), (float(loss), loss_ref_v, loss_ctl_v)
     grads = tr.backward(tape, leaves)
     assert set(grads) == set(names)
     worst = 0.0
+    print()
     for k in names:
-        gr = sd[k].grad
+        gr = g_ref[k]
         if gr is None or float(gr.abs().max()) == 0.0:
             assert float(grads[k].abs().max()) == 0.0, f"{k}: expected an all-zero gradient"
             continue
-        e = rel_l2(grads[k].cpu(), gr)
+        e, e_ctl = rel_l2(grads[k].cpu(), gr), rel_l2(g_ctl[k], gr)
         worst = max(worst, e)
-        # task_embs also receives the router-gate path: d gate_b = <dO, Attn(q, K_ip, V_ip)> summed over 3 layers x heads x rows is
-        # a cancelling inner product of bf16 gradients (|sum| ~ 1e-3 of sum|.|), so its relative error is larger than a layer's
-        tol = 1.5e-1 if k in ("task_embs", "gate.weight") else 6e-2  # the router gradients are that same gate path
-        if k == "gate.bias":  # sum over the batch of the same noisy d gate_b, with cancellation across samples on top (measured 0.29)
-            tol = 4e-1
-        assert e <= tol, f"grad {k}: rel_l2 {e:.3e}"
+        # err(HIP) <= 1.5 x err(control) (2.5 x for gradients with a handful of non-zero entries: util_models.grad_tolerance).  The
+        # router-gate path (task_embs, gate.*) is a cancelling inner product of bf16 gradients, so ITS control error is large too
+        # (gate.bias: 0.2 for the exact-arithmetic control) — the bound follows the control instead of a hand-picked constant.
+        tol = grad_tolerance(k, gr, e_ctl)
+        print(f"  grad {k:34s} HIP {e:.3e}  control {e_ctl:.3e}  bound {tol:.3e}")
+        assert e <= tol, f"grad {k}: HIP rel_l2 {e:.3e} vs bf16-storage control {e_ctl:.3e}"
     assert worst > 0.0
     # experts nobody was routed to get exactly zero gradient; routed ones do not
-    _, top1, _ = A.task_gate(sd["task_embs"].detach(), code, sd["gate.weight"], sd["gate.bias"])
+    _, top1, _ = A.task_gate(sd["task_embs"], code, sd["gate.weight"], sd["gate.bias"])
     g0 = grads["adapter_modules.0"].cpu()
     for e in range(g0.shape[0]):
         assert (float(g0[e].abs().max()) > 0) == (e in set(top1.tolist()))
@@ -278,6 +276,55 @@ def test_training_step_gradients_vs_oracle_autograd():
         assert torch.equal(gp[k], gx[k].reshape(gp[k].shape)), k
     first_rs = next(i for i, e in enumerate(log) if e[0] == "reduce_scatter")
     assert first_rs < max(i for i, e in enumerate(log) if e[0] == "ready") and len(trx.exchange.buckets) > 2
+    # gradient accumulation (train.py --gradient_accumulation_steps): two micro-batches before ONE optimizer step sum their
+    # gradients — identically in the plain path and in the bucket path, where the first micro-batch runs under no-sync (nothing is sent)
+    # and the buckets leave during the LAST backward; the optimizer then steps on the sum, not on the last micro-batch
+    def fresh(**kw):
+        m, _ = _tiny_moe()
+        return AnySDTrainer(m.to(DEV), sa.to(DEV), s1.to(DEV), lr=1e-3, **kw)
+
+    args_b = (lat.flip(0).to(DEV), img.to(DEV), ehs.flip(0).to(DEV), ref_emb.to(DEV), code.to(DEV), noise.flip(0).to(DEV), t.to(DEV))
+    trq = fresh()
+    _, tb, lb = trq.forward_loss(*args_b)
+    gb_alone = {k: v.clone() for k, v in trq.backward(tb, lb).items()}
+    for trainer in (fresh(), fresh(always_exchange=True, bucket_bytes=1 << 12)):
+        _, t1, l1 = trainer.forward_loss(*args)
+        trainer.backward(t1, l1, sync=False)
+        if trainer.exchange is not None:
+            assert not [e for e in trainer.exchange.launch_log if e[0] == "reduce_scatter"], "no-sync micro-batch: nothing may be sent"
+        _, t2, l2 = trainer.forward_loss(*args_b)
+        acc = trainer.backward(t2, l2, sync=True)
+        if trainer.exchange is not None:
+            sent = [e for e in trainer.exchange.launch_log if e[0] == "reduce_scatter"]
+            assert len(sent) == len(trainer.exchange.buckets), "every bucket leaves exactly once, during the last micro-batch"
+            acc = trainer.reduce_gradients()
+        for k in gp:
+            assert torch.equal(acc[k].reshape(gp[k].shape), gp[k] + gb_alone[k]), f"accumulated gradient of {k} is not the sum of the micro-batches"
+        before = {k: trainer.params[k].detach().clone() for k in ("task_embs", "adapter_modules.0")}
+        v0 = trainer.params["task_embs"]._version
+        trainer.optimizer_step(acc)
+        assert trainer._micro == 0 and all(not torch.equal(before[k], trainer.params[k].detach()) for k in before)
+        assert trainer.params["task_embs"]._version > v0, "optimizer steps must bump the parameter version (packed-weight caches key on it)"
+    try4 = fresh(always_exchange=True, bucket_bytes=1 << 12)
+    _, t3, l3 = try4.forward_loss(*args)
+    g3 = try4.backward(t3, l3)
+    with pytest.raises(ValueError):          # DDP: a dict of other tensors would be un-averaged local values
+        try4.optimizer_step({k: v.clone() for k, v in g3.items()})
+    try4.zero_grad()
+    # backward/communication overlap: with the expert projections recorded next to their blocks, the first bucket leaves while tape
+    # nodes of EARLIER blocks are still to run — i.e. before the backward pass has reached every adapter layer
+    _, t4, l4 = try4.forward_loss(*args)
+    replayed, at_launch = [], []
+    t4.nodes = [(lambda f=f, i=i: (replayed.append(i), f())[1]) for i, f in enumerate(t4.nodes)]   # count tape nodes as they replay
+    n_nodes = len(t4.nodes)
+    launch = try4.exchange._launch
+    try4.exchange._launch = lambda bi: (at_launch.append(len(replayed)), launch(bi))[1]
+    try4.backward(t4, l4)
+    try4.exchange._launch = launch
+    assert len(at_launch) == len(try4.exchange.buckets) and len(replayed) == n_nodes
+    assert at_launch[0] < n_nodes // 3, f"first reduce-scatter after {at_launch[0]} of {n_nodes} tape nodes: it must leave early in the backward pass"
+    assert sum(1 for a in at_launch if a < n_nodes - 8) >= len(try4.moe.adapter_modules) - 1, "adapter buckets must leave while the UNet backward is running"
+    try4.zero_grad()
     # the same step with the collectives really issued through RCCL ("nccl" backend, ONE rank: reduce-scatter / all-gather are identities):
     # drives the call sequence, the side stream, the async handles and the 256-byte-aligned bucket slots on the GPU stack the 8-GPU job uses
     import torch.distributed as dist
@@ -297,7 +344,8 @@ def test_training_step_gradients_vs_oracle_autograd():
             for _ in range(2):                                  # twice: persistent buckets and handles are reused across steps
                 _, tr_, lr_ = trr.forward_loss(*args)
                 trr.backward(tr_, lr_)
-                gr = {k: v.clone() for k, v in trr.exchange.finish().items()}
+                gr = {k: v.clone() for k, v in trr.reduce_gradients().items()}
+                trr.zero_grad()
                 for k in gp:
                     assert torch.equal(gp[k], gr[k].reshape(gp[k].shape)), f"RCCL single-rank exchange changed {k}"
             torch.cuda.synchronize()

@@ -1,5 +1,7 @@
 """Test helpers: rebuild the golden-fixture models with anyedit_amd classes (same seeds / same RNG order as
 tools/gen_golden.py, which ran the reference constructors)."""
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -43,3 +45,35 @@ def build_tiny_unet(seed=50):
     unzero(unet, g, std=0.05)
     randomize_norm_affine(unet, g)
     return unet.eval()
+
+
+# ------------------------------------------------------------------ training-step oracle + bf16-storage control (row A11)
+def oracle_training_grads(moe_sd, cfg, prefixes, batch, control):
+    """torch.autograd of the oracle's AnySD training step (oracle/anysd_ref.py + ddim_ref.eps_mse).  control=True: every stored
+    activation AND every stored activation-gradient rounded to bf16 (`ldm_ref.bf16_storage`: the casts round in both directions
+    under autograd), trainable / frozen weights rounded to bf16 as `ops.pack_*` stores them, fp32 arithmetic and fp32 parameter
+    gradients — the storage format of the HIP training path with exact arithmetic."""
+    from oracle import anysd_ref as A, ddim_ref as D, ldm_ref as L
+    lat, img, noise, t, ehs, ref_emb, code, sa, s1 = batch
+    sd = {k: v.detach().float().clone() for k, v in moe_sd.items()}
+    if control:
+        sd = L.bf16_weights(sd)
+    names = [k for k in sd if k.startswith(("image_proj_model.", "adapter_modules.", "task_embs", "gate."))]
+    for k in names:
+        sd[k].requires_grad_(True)
+    unet_sd = {k[5:]: v for k, v in sd.items() if k.startswith("unet.")}
+    noisy = D.q_sample({"sqrt_alphas_cumprod": sa, "sqrt_one_minus_alphas_cumprod": s1}, lat, t, noise)
+    x = torch.cat([noisy, img], 1)
+    with (L.bf16_storage() if control else contextlib.nullcontext()):
+        eps = A.moe_forward(unet_sd, cfg, sd, prefixes, x, t, ehs, ref_emb, code)
+        loss = D.eps_mse(eps, noise)
+        loss.backward()
+    return float(loss.detach()), {k: sd[k].grad for k in names}
+
+
+def grad_tolerance(name, g_ref, e_ctl):
+    """Derived bound for one trainable's gradient: 1.5 x the bf16-storage control's own error.  A gradient with only a handful of
+    non-zero entries (the router bias: one entry per routed expert) is a NOISE NORM estimated from that handful of samples — two
+    independent realisations of it (HIP, control) differ by a chi-like factor, so those get 2.5 x."""
+    nz = int((g_ref != 0).sum())
+    return (2.5 if nz < 64 else 1.5) * e_ctl + 1e-3
