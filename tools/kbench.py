@@ -63,12 +63,17 @@ def main():
                            (49152, 320, 1280, "ff2 L1"), (12288, 1920, 640, "qkv L2"), (12288, 5120, 640, "ff1 L2 (geglu)"),
                            (12288, 640, 2560, "ff2 L2"), (3072, 3840, 1280, "qkv L3"), (3072, 10240, 1280, "ff1 L3 (geglu)"),
                            (3072, 1280, 5120, "ff2 L3"), (936, 640, 768, "ctx kv L1"), (12, 1280, 1280, "time_embed"),
-                           (49152, 320, 960, "skip1x1 960->320")):
+                           (49152, 320, 960, "skip1x1 960->320"),
+                           # the latency-bound linear layers of the 32x32 / 16x16 / 8x8 levels
+                           (12288, 640, 640, "proj L2"), (12288, 640, 1280, "skip1x1 L2"), (3072, 1280, 1280, "proj L3"),
+                           (3072, 1280, 2560, "skip1x1 L3"), (768, 1280, 1280, "proj L4"), (768, 3840, 1280, "qkv L4"),
+                           (768, 1280, 5120, "ff2 L4")):
         a, w = rnd(M, K), rnd(N, K)
         bias = torch.randn(N, device=DEV)
         epi = ops.EPI_GEGLU if "geglu" in tag else ops.EPI_NONE
-        case(f"gemm {tag} M={M} N={N} K={K}", lambda a=a, w=w, bias=bias, epi=epi: ops.gemm(a, w, bias, epilogue=epi),
-             2.0 * M * N * K, 2.0 * (M * K + N * K + M * (N // 2 if epi else N)))
+        res = rnd(M, N) if tag.startswith(("proj", "ff2")) else None   # to_out / proj_out / ff2 add the residual stream in their epilogue
+        case(f"gemm {tag} M={M} N={N} K={K}", lambda a=a, w=w, bias=bias, epi=epi, res=res: ops.gemm(a, w, bias, residual=res, epilogue=epi),
+             2.0 * M * N * K, 2.0 * (M * K + N * K + M * (N // 2 if epi else N) + (M * N if res is not None else 0)))
     # ---- conv3x3
     for (H, Cin, Cout, stride, ups, tag) in ((64, 320, 320, 1, False, "res L1"), (64, 960, 320, 1, False, "res dec L1"),
                                              (32, 640, 640, 1, False, "res L2"), (32, 1920, 640, 1, False, "res dec L2"),
