@@ -21,14 +21,14 @@ SIGNATURES = {
     "ae_device_arch": [ctypes.c_char_p, c_int],
     "ae_device_info": [ctypes.POINTER(c_int), ctypes.POINTER(c_long), ctypes.POINTER(c_int)],
     "ae_gemm_bf16": [c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int,
-                     c_void_p, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p],
+                     c_void_p, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p],
     "ae_conv3x3_workspace_floats": [c_int, c_int, c_int, c_int, c_int, c_int, c_int],
     "ae_conv3x3_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                        c_int, c_int, c_int, c_void_p, c_void_p],
+                        c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ae_groupnorm_rows_per_chunk": [c_int, c_int],
     "ae_groupnorm_workspace_floats": [c_int, c_int, c_int, c_int],
     "ae_groupnorm_nhwc_bf16": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
-                               c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+                               c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "ae_layernorm_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "ae_attn_fwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                          c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long, c_long,
@@ -57,7 +57,7 @@ SIGNATURES = {
                        [c_float, c_void_p, c_void_p, c_int, c_int, c_void_p, c_long, c_void_p],
     "ae_ln_gemm_supported": [c_int, c_int, c_int, c_int],
     "ae_ln_gemm_bf16": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_long, c_void_p, c_void_p,
-                        c_float, c_int, c_void_p],
+                        c_float, c_int, c_void_p, c_void_p],
     "ae_task_gate_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "ae_task_gate_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ae_expert_kv_fwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],

@@ -31,6 +31,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) short s16x4v;
 
 constexpr int FKT = 64;  // keys per LDS tile
+#ifndef AE_ATTN_V_DEFAULT
+#define AE_ATTN_V_DEFAULT 0   // default variant of the plain long-sequence kernel (see launch_fast); decided by measurement
+#endif
 constexpr float FLOG2E = 1.4426950408889634f;
 constexpr float RESCALE_THR = 8.0f;  // log2 units
 constexpr float MASKED = -1.0e30f;
@@ -71,9 +74,19 @@ __device__ __forceinline__ bf16x8_t cat_tr(s16x4v lo, s16x4v hi) {
 __device__ unsigned long long g_attn_dbg[4];  // lab only: sum of per-block shader cycles, 100 MHz ticks, blocks
 #endif
 
-template <int D, int OCC, bool SEG2 = false, int ABL = 0, int BIAS = 0>
+// QG: 32-query column groups per wave (1 or 2).  QG = 2: a wave owns 64 queries; every K / V fragment it reads from LDS feeds two
+// MFMAs (half the LDS reads, DMA bytes and barriers per FLOP), and the two groups' softmax chains are independent work the
+// scheduler can lay beside each other's MFMAs.
+// VSPLIT: the V tile is kept in LDS as one [64 keys][64 B] image per 32-wide d-block plus a narrow image for the remainder
+// (head_dim 40: [64][64 B] + [64][16 B]) instead of rows of 2 D bytes: the four key rows a ds_read_b64_tr_b16 lane group touches are
+// then 256 contiguous bytes — every bank once (rows of 80 / 160 bytes put rows 0 and 3 on the same banks: 22 % of the LDS
+// instruction cycles were bank conflicts, profiles/r02_pmc_attn_fast_d40_b.txt).  The re-arrangement costs nothing: it is the
+// per-lane SOURCE offset of the LDS-DMA pieces.
+template <int D, int OCC, bool SEG2 = false, int ABL = 0, int BIAS = 0, int QG = 1, bool VSPLIT = false>
 __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     static_assert(D % 8 == 0 && D <= 96, "head_dim: multiple of 8, <= 96");
+    static_assert(QG == 1 || QG == 2, "one or two 32-query groups per wave");
+    static_assert(BIAS == 0 || QG == 1, "the rel-pos variants keep one query group per wave");
     constexpr int KS = (D + 15) / 16;        // K=16 steps of S^T = K Q^T
     constexpr bool QSLOT = (D % 16) != 0;    // contraction slot `D` is free: it carries the softmax offset (K side reads 1.0)
     constexpr int NDB = D / 32 + 1;          // 32-row blocks of O^T; row D is the softmax denominator
@@ -83,7 +96,11 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     constexpr int TILEB = FKT * ROWB;
     constexpr int BUFB = 2 * TILEB;          // K tile then V tile
     constexpr int ONES_OFF = 2 * BUFB;       // "ones tile": 64 rows of ROWB bytes, each starting with bf16 {1,0,0,0,0,0,0,0}
-    constexpr int LDSB = ONES_OFF + TILEB + 64;
+    constexpr int NFULL = D / 32, REM = D % 32;          // VSPLIT: full 32-wide d-blocks, remainder columns
+    constexpr int RS = REM * 2 > 16 ? REM * 2 : 16;      // VSPLIT: row bytes of the remainder image (and of its ones tile)
+    constexpr int RC = REM / 8;                          // 16-byte chunks per row of the remainder image
+    constexpr int VONES_OFF = ONES_OFF + TILEB + 64;     // VSPLIT: ones tile with the remainder image's row stride
+    constexpr int LDSB = VSPLIT ? VONES_OFF + 64 * RS : ONES_OFF + TILEB + 64;
     constexpr int NPIECE = 2 * CH;
     constexpr int MAXP = (NPIECE + 3) / 4;
 
@@ -95,30 +112,32 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5, l15 = lane & 15, g = lane >> 4;
-    constexpr int QB = 128;
+    constexpr int QB = 128 * QG;
     const int nqb = (p.Nq + QB - 1) / QB;
     const int vb = xcd_remap(blockIdx.x, nqb * p.B * p.H);
     const int bh = vb / nqb, qb = vb - bh * nqb;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = qb * QB + wave * 32;
+    const int q0 = qb * QB + wave * 32 * QG;   // group gq of the wave holds queries q0 + 32 gq .. + 31
 
     if (tid < FKT) *reinterpret_cast<u32x4*>(smem + ONES_OFF + tid * ROWB) = (u32x4){0x00003F80u, 0u, 0u, 0u};
+    if (VSPLIT && tid < FKT) *reinterpret_cast<u32x4*>(smem + VONES_OFF + tid * RS) = (u32x4){0x00003F80u, 0u, 0u, 0u};
 
     // ---- Q^T operand of the 32x32x16 MFMA: lane (q = l31, hi) holds c * Q[q][16 ks + 8 hi .. +8], zero beyond head_dim
     const bf16_t* qp = p.q + (long)b * p.q_sb + (long)h * p.q_sh;
     const float c = p.scale * FLOG2E;
-    u32x4 qf[KS];
-    {
-        const int qrow = min(q0 + l31, p.Nq - 1);
+    u32x4 qf[QG][KS];
+#pragma unroll
+    for (int gq = 0; gq < QG; ++gq) {
+        const int qrow = min(q0 + 32 * gq + l31, p.Nq - 1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int d0 = 16 * ks + 8 * hi;
             u32x4 t = *reinterpret_cast<const u32x4*>(qp + (long)qrow * p.q_sn + (d0 < D ? d0 : 0));
             if (d0 >= D) t = (u32x4){0u, 0u, 0u, 0u};
-            qf[ks].x = pack_bf16x2(bf16lo(t.x) * c, bf16hi(t.x) * c);
-            qf[ks].y = pack_bf16x2(bf16lo(t.y) * c, bf16hi(t.y) * c);
-            qf[ks].z = pack_bf16x2(bf16lo(t.z) * c, bf16hi(t.z) * c);
-            qf[ks].w = pack_bf16x2(bf16lo(t.w) * c, bf16hi(t.w) * c);
+            qf[gq][ks].x = pack_bf16x2(bf16lo(t.x) * c, bf16hi(t.x) * c);
+            qf[gq][ks].y = pack_bf16x2(bf16lo(t.y) * c, bf16hi(t.y) * c);
+            qf[gq][ks].z = pack_bf16x2(bf16lo(t.z) * c, bf16hi(t.z) * c);
+            qf[gq][ks].w = pack_bf16x2(bf16lo(t.w) * c, bf16hi(t.w) * c);
         }
     }
 
@@ -127,14 +146,16 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     // V^T operand by ds_read_b64_tr_b16: 16-lane group g reads a [4 keys][16 d] block, lane i of the group addresses row i >> 2,
     // columns 4 (i & 3) .. +4, and receives column i.  Groups 0/1 -> d 0-15 / 16-31 of the lanes' hi = 0 keys, groups 2/3 -> hi = 1.
     const int vrow = 4 * hi + (l15 >> 2);
-    const int vaddr = TILEB + vrow * ROWB + (16 * (g & 1) + 4 * (l15 & 3)) * 2;
+    const int vaddr = VSPLIT ? TILEB + vrow * 64 + (16 * (g & 1) + 4 * (l15 & 3)) * 2 : TILEB + vrow * ROWB + (16 * (g & 1) + 4 * (l15 & 3)) * 2;
     const int vcol = 32 * LDB + 16 * (g & 1) + 4 * (l15 & 3);  // first of this lane's 4 columns in the last d-block
     const bool ones_lane = vcol == D;  // supplies columns D..D+3: reads {1,0,0,0} instead
     const bool zero_lane = vcol > D;   // padding columns: read zeros (idle multipliers) instead of the neighbouring rows
 
-    f32x16 cinit;  // !QSLOT: the offset enters through the C operand
+    f32x16 cinit[QG];  // !QSLOT: the offset enters through the C operand
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
+    for (int gq = 0; gq < QG; ++gq)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cinit[gq][r] = 0.f;
     // Decomposed rel-pos bias (image_encoder.py:325-361), entering S' through the MFMA's C operand:
     // BIAS 2: the key grid has one ROW per 64-key tile (kW == 64: SAM's global attention): rel_w[q, kw] * log2e of this lane's
     //         2 x 16 key columns stays in registers, rel_h[q, kh] is one value per tile — one v_add per logit, no index arithmetic;
@@ -171,12 +192,16 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
                 wb[BIAS2 ? b2 : 0][4 * r4 + 2] = t[2] * FLOG2E; wb[BIAS2 ? b2 : 0][4 * r4 + 3] = t[3] * FLOG2E;
             }
     }
-    float mt = 0.f;  // m~ (log2 units, always bf16-representable): S' = c q.k - m~
-    f32x16 o[NDB];
+    float mt[QG];  // m~ (log2 units, always bf16-representable): S' = c q.k - m~
+    f32x16 o[QG][NDB];
 #pragma unroll
-    for (int db = 0; db < NDB; ++db)
+    for (int gq = 0; gq < QG; ++gq) {
+        mt[gq] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[gq][db][r] = 0.f;
+    }
 
     int seg_nk = p.Nk;
     int kcur = 0, klast = 0, vcur = 0, vlast = 0;
@@ -185,109 +210,137 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     auto block = [&](auto blk_tag, int k0, bool first, bool tail) {
         constexpr int B2 = decltype(blk_tag)::value;
         constexpr int BO = B2 * 32 * ROWB;
-        // ---- S'^T = K (cQ)^T - m~ : lane holds S'[key = (r&3) + 8 (r>>2) + 4 hi][q = l31]
+        // ---- S'^T = K (cQ)^T - m~ : lane holds S'[key = (r&3) + 8 (r>>2) + 4 hi][q = l31] of every query group
         if (ABL == 10 || ABL == 12) __builtin_amdgcn_s_setprio(1);
         if (ABL == 11) __builtin_amdgcn_s_setprio(0);
-        f32x16 s;
+        f32x16 s[QG];
         if (ABL == 4) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = -(float)(r + l31) - mt;
+            for (int gq = 0; gq < QG; ++gq)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[gq][r] = -(float)(r + l31) - mt[gq];
         } else
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int ka = (QSLOT && ks == KS - 1) ? klast + BO : kcur + BO + ks * 32;
-            const bf16x8_t kf = as_bf16x8(*reinterpret_cast<const u32x4*>(smem + ka));
-            if (ks == 0 && QSLOT) {
-                f32x16 z;
+            const bf16x8_t kf = as_bf16x8(*reinterpret_cast<const u32x4*>(smem + ka));   // one K fragment feeds every query group
 #pragma unroll
-                for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[ks]), z, 0, 0, 0);
-            } else if (BIAS2 && ks == 0) {
-                f32x16 c0;
-                const float hb = rh_tile - mt;
+            for (int gq = 0; gq < QG; ++gq) {
+                if (ks == 0 && QSLOT) {
+                    f32x16 z;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) c0[r] = wb[BIAS2 ? B2 : 0][r] + hb;
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[ks]), c0, 0, 0, 0);
-            } else if (BIAS1 && ks == 0) {
-                f32x16 c0;
-                const float* row = sbias + (wave * 32 + l31) * 33;
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    s[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[gq][ks]), z, 0, 0, 0);
+                } else if (BIAS2 && ks == 0) {
+                    f32x16 c0;
+                    const float hb = rh_tile - mt[gq];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    // key -> (row, column) of the key grid without an integer division: (key + 0.5) / kW is never closer than
-                    // 0.5 / kW to an integer, far above the fp32 error for a grid of at most 16 x 16
-                    const int key = min(k0 + B2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, seg_nk - 1);
-                    const int kh = (int)(((float)key + 0.5f) * inv_kw);
-                    c0[r] = row[kh] + row[16 + key - kh * p.kW] - mt;
+                    for (int r = 0; r < 16; ++r) c0[r] = wb[BIAS2 ? B2 : 0][r] + hb;
+                    s[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[gq][ks]), c0, 0, 0, 0);
+                } else if (BIAS1 && ks == 0) {
+                    f32x16 c0;
+                    const float* row = sbias + (wave * 32 + l31) * 33;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        // key -> (row, column) of the key grid without an integer division: (key + 0.5) / kW is never closer than
+                        // 0.5 / kW to an integer, far above the fp32 error for a grid of at most 16 x 16
+                        const int key = min(k0 + B2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, seg_nk - 1);
+                        const int kh = (int)(((float)key + 0.5f) * inv_kw);
+                        c0[r] = row[kh] + row[16 + key - kh * p.kW] - mt[gq];
+                    }
+                    s[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[gq][ks]), c0, 0, 0, 0);
+                } else {
+                    s[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[gq][ks]), ks == 0 ? cinit[gq] : s[gq], 0, 0, 0);
                 }
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[ks]), c0, 0, 0, 0);
-            } else {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[ks]), ks == 0 ? cinit : s, 0, 0, 0);
             }
         }
         if (ABL == 10 || ABL == 12) __builtin_amdgcn_s_setprio(0);
         if (ABL == 11) __builtin_amdgcn_s_setprio(1);
-        if (tail) {  // keys past Nk (zero rows from the bounds-checked DMA) must not count
+        uint32_t pk[QG][8];
+        float mx[QG];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (k0 + B2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= seg_nk) s[r] = MASKED;
-        }
-        float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
+        for (int gq = 0; gq < QG; ++gq) {
+            if (tail) {  // keys past Nk (zero rows from the bounds-checked DMA) must not count
 #pragma unroll
-        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
-        mx = fmaxf(mx, s[15]);
-        if (ABL == 2) mx = s[0];
-        if (__builtin_expect(first || __any(mx > RESCALE_THR), 0)) {
-            // rebase m~ (rare): rows whose block maximum is above the offset move it up to that maximum, rounded up to the next
-            // bf16-representable value (the offset must survive the trip through the Q operand; 2^-(step) is exact either way);
-            // the first block sets it whatever its sign.  O (with its denominator row) follows.
-            const float m2 = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float tgt = (first || m2 > 0.f) ? mt + __builtin_ceilf(m2) : mt;
-            tgt = fmaxf(tgt, -1.0e4f);
-            uint32_t tb = __float_as_uint(tgt);
-            tb = (tgt > 0.f) ? ((tb + 0xFFFFu) & 0xFFFF0000u) : (tb & 0xFFFF0000u);  // towards +inf
-            const float mnew = __uint_as_float(tb);
-            const float d = mnew - mt;
-            mt = mnew;
-            if (QSLOT) {
-                if (hi) qf[KS - 1].x = (qf[KS - 1].x & 0xFFFF0000u) | ((tb >> 16) ^ 0x8000u);  // slot D holds -m~
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) cinit[r] = -mt;
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + B2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= seg_nk) s[gq][r] = MASKED;
             }
-            const float alpha = __builtin_amdgcn_exp2f(-d);
+            mx[gq] = fmaxf(fmaxf(s[gq][0], s[gq][1]), s[gq][2]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] -= d;
+            for (int r = 3; r < 15; r += 2) mx[gq] = fmaxf(fmaxf(mx[gq], s[gq][r]), s[gq][r + 1]);
+            mx[gq] = fmaxf(mx[gq], s[gq][15]);
+            if (ABL == 2) mx[gq] = s[gq][0];
+        }
+        // ONE rarely taken wave-uniform branch for all query groups: the common path stays a single straight-line block in which the
+        // groups' exp2 / convert work and the other group's MFMAs are independent instructions
+        if (__builtin_expect(first || __any((QG == 2 ? fmaxf(mx[0], mx[QG - 1]) : mx[0]) > RESCALE_THR), 0)) {
 #pragma unroll
-            for (int db = 0; db < NDB; ++db)
+            for (int gq = 0; gq < QG; ++gq) {
+                // rebase m~ (rare): rows whose block maximum is above the offset move it up to that maximum, rounded up to the next
+                // bf16-representable value (the offset must survive the trip through the Q operand; 2^-(step) is exact either way);
+                // the first block sets it whatever its sign.  O (with its denominator row) follows.  A group that did not trigger
+                // keeps its offset unless its own maximum is positive (then it moves by an exact integer step too: harmless).
+                const float m2 = fmaxf(mx[gq], __shfl_xor(mx[gq], 32, 64));
+                float tgt = (first || m2 > 0.f) ? mt[gq] + __builtin_ceilf(m2) : mt[gq];
+                tgt = fmaxf(tgt, -1.0e4f);
+                uint32_t tb = __float_as_uint(tgt);
+                tb = (tgt > 0.f) ? ((tb + 0xFFFFu) & 0xFFFF0000u) : (tb & 0xFFFF0000u);  // towards +inf
+                const float mnew = __uint_as_float(tb);
+                const float d = mnew - mt[gq];
+                mt[gq] = mnew;
+                if (QSLOT) {
+                    if (hi) qf[gq][KS - 1].x = (qf[gq][KS - 1].x & 0xFFFF0000u) | ((tb >> 16) ^ 0x8000u);  // slot D holds -m~
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) cinit[gq][r] = -mt[gq];
+                }
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[gq][r] -= d;
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[gq][db][r] *= alpha;
+            }
         }
         // ---- P = exp2(S'), bf16: pk[4 kk .. 4 kk + 3] is the B operand of K-step kk (keys 16 kk + 4 hi + {0..3, 8..11})
-        uint32_t pk[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pk[j] = (ABL == 1) ? pack_bf16x2(s[2 * j], s[2 * j + 1]) : pack_bf16x2(__builtin_amdgcn_exp2f(s[2 * j]), __builtin_amdgcn_exp2f(s[2 * j + 1]));
-        // ---- O^T += V^T P^T : lane holds O^T[d = 32 db + (r&3) + 8 (r>>2) + 4 hi][q = l31]
+        for (int gq = 0; gq < QG; ++gq)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pk[gq][j] = (ABL == 1) ? pack_bf16x2(s[gq][2 * j], s[gq][2 * j + 1]) : pack_bf16x2(__builtin_amdgcn_exp2f(s[gq][2 * j]), __builtin_amdgcn_exp2f(s[gq][2 * j + 1]));
+        // ---- O^T += V^T P^T : lane holds O^T[d = 32 db + (r&3) + 8 (r>>2) + 4 hi][q = l31]; one V fragment feeds every query group
         if (ABL == 10) __builtin_amdgcn_s_setprio(1);
         if (ABL == 11) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const bf16x8_t pb = as_bf16x8((u32x4){pk[4 * kk], pk[4 * kk + 1], pk[4 * kk + 2], pk[4 * kk + 3]});
 #pragma unroll
             for (int db = 0; db < NDB; ++db) {
-                const int va = (db == LDB ? vlast : vcur + db * 64) + BO + kk * 16 * ROWB;
+                int va, vstep;
+                if (VSPLIT) {
+                    va = (db == LDB) ? vlast + B2 * 32 * RS + kk * 16 * RS : vcur + db * 4096 + B2 * 32 * 64 + kk * 16 * 64;
+                    vstep = (db == LDB) ? 8 * RS : 8 * 64;
+                } else {
+                    va = (db == LDB ? vlast : vcur + db * 64) + BO + kk * 16 * ROWB;
+                    vstep = 8 * ROWB;
+                }
                 if (ABL == 3) {  // no V reads, no PV MFMA (P kept alive)
-                    asm volatile("" ::"v"(pb));
+#pragma unroll
+                    for (int gq = 0; gq < QG; ++gq) asm volatile("" ::"v"(pk[gq][4 * kk]), "v"(pk[gq][4 * kk + 3]));
                     continue;
                 }
                 bf16x8_t vf;
-                if (ABL == 5) vf = as_bf16x8(qf[0]);  // no V reads
-                else vf = cat_tr(lds_tr16(smem + va), lds_tr16(smem + va + 8 * ROWB));
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[db], 0, 0, 0);
+                if (ABL == 5) vf = as_bf16x8(qf[0][0]);  // no V reads
+                else vf = cat_tr(lds_tr16(smem + va), lds_tr16(smem + va + vstep));
+#pragma unroll
+                for (int gq = 0; gq < QG; ++gq) {
+                    const bf16x8_t pb = as_bf16x8((u32x4){pk[gq][4 * kk], pk[gq][4 * kk + 1], pk[gq][4 * kk + 2], pk[gq][4 * kk + 3]});
+                    o[gq][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[gq][db], 0, 0, 0);
+                }
             }
         }
     };
 
-    f32x16 o_first[SEG2 ? NDB : 1];  // SEG2: normalised result of the first segment while the second runs
+    f32x16 o_first[SEG2 ? QG : 1][SEG2 ? NDB : 1];  // SEG2: normalised result of the first segment while the second runs
     const int lds0 = (int)(uintptr_t)((__attribute__((address_space(3))) char*)smem);  // LDS byte address of the tile buffers
     constexpr int NSEG = SEG2 ? 2 : 1;
     for (int seg = 0; seg < NSEG; ++seg) {
@@ -305,7 +358,11 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
             const int j = wave + 4 * i;
             const bool isK = j < CH;
             const int cidx = (isK ? j : j - CH) * 64 + lane;
-            const int row = cidx / CH, cc = cidx - row * CH;
+            int row = cidx / CH, cc = cidx - row * CH;
+            if (VSPLIT && !isK) {  // chunk cidx of the V image: d-block images [64][4 chunks] first, then the remainder image [64][RC]
+                if (cidx < NFULL * 256) { row = (cidx & 255) >> 2; cc = (cidx >> 8) * 4 + (cidx & 3); }
+                else { const int c2 = cidx - NFULL * 256; row = c2 / (RC > 0 ? RC : 1); cc = NFULL * 4 + (c2 - row * (RC > 0 ? RC : 1)); }
+            }
             voff[i] = row * (isK ? ksn2 : vsn2) + cc * 16;
         }
         auto issue = [&](int t) {
@@ -329,30 +386,37 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
             kcur = kaddr + boff;
             klast = (QSLOT && hi) ? ONES_OFF + l31 * ROWB : kcur + (KS - 1) * 32;
             vcur = vaddr + boff;
-            vlast = ones_lane ? ONES_OFF + vrow * ROWB : (zero_lane ? ONES_OFF + vrow * ROWB + 8 : vcur + LDB * 64);
+            if (VSPLIT)
+                vlast = ones_lane ? VONES_OFF + vrow * RS : (zero_lane ? VONES_OFF + vrow * RS + 8 : TILEB + boff + NFULL * 4096 + vrow * RS + (16 * (g & 1) + 4 * (l15 & 3)) * 2);
+            else
+                vlast = ones_lane ? ONES_OFF + vrow * ROWB : (zero_lane ? ONES_OFF + vrow * ROWB + 8 : vcur + LDB * 64);
             const bool tail = (t + 1) * FKT > seg_nk;
             if (BIAS2) rh_tile = rh_row[t] * FLOG2E;
             block(std::integral_constant<int, 0>{}, t * FKT, t == 0, tail);
             if (t * FKT + 32 < seg_nk) block(std::integral_constant<int, 1>{}, t * FKT, false, tail);
         }
         if (SEG2 && seg == 0) {  // park the first segment's normalised output, restart the online softmax
-            const float l0 = __shfl(o[LDB][LREG], l31, 64);
-            const float inv0 = 1.0f / l0;
-            // log2-domain log-sum-exp of the first segment (kept for ae_attn_bwd_bf16): offset + log2(denominator)
-            if (p.lse && hi == 0 && q0 + l31 < p.Nq) p.lse[((long)b * p.H + h) * p.Nq + q0 + l31] = mt + __builtin_amdgcn_logf(l0);
 #pragma unroll
-            for (int db = 0; db < NDB; ++db)
+            for (int gq = 0; gq < QG; ++gq) {
+                const float l0 = __shfl(o[gq][LDB][LREG], l31, 64);
+                const float inv0 = 1.0f / l0;
+                const int qr = q0 + 32 * gq + l31;
+                // log2-domain log-sum-exp of the first segment (kept for ae_attn_bwd_bf16): offset + log2(denominator)
+                if (p.lse && hi == 0 && qr < p.Nq) p.lse[((long)b * p.H + h) * p.Nq + qr] = mt[gq] + __builtin_amdgcn_logf(l0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    o_first[SEG2 ? db : 0][r] = o[db][r] * inv0;
-                    o[db][r] = 0.f;
+                for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        o_first[SEG2 ? gq : 0][SEG2 ? db : 0][r] = o[gq][db][r] * inv0;
+                        o[gq][db][r] = 0.f;
+                    }
+                mt[gq] = 0.f;
+                if (QSLOT) {
+                    if (hi) qf[gq][KS - 1].x &= 0xFFFF0000u;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cinit[gq][r] = 0.f;
                 }
-            mt = 0.f;
-            if (QSLOT) {
-                if (hi) qf[KS - 1].x &= 0xFFFF0000u;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
             }
         }
     }
@@ -366,33 +430,36 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
 #endif
     // ---- normalise and store: 4 consecutive d per lane -> 8-byte stores
     bf16_t* op = p.o + (long)b * p.o_sb + (long)h * p.o_sh;
-    const float lsum = __shfl(o[LDB][LREG], l31, 64);
-    const float inv = (SEG2 ? p.scale2[b] : (p.out_scale ? p.out_scale[b] : 1.0f)) / lsum;
-    {
-        float* lse_out = SEG2 ? p.lse2 : p.lse;  // v_log_f32 = log2
-        if (lse_out && hi == 0 && q0 + l31 < p.Nq) lse_out[((long)b * p.H + h) * p.Nq + q0 + l31] = mt + __builtin_amdgcn_logf(lsum);
-    }
-    const int qrow = q0 + l31;
-    if (qrow < p.Nq) {
 #pragma unroll
-        for (int db = 0; db < NDB; ++db)
+    for (int gq = 0; gq < QG; ++gq) {
+        const float lsum = __shfl(o[gq][LDB][LREG], l31, 64);
+        const float inv = (SEG2 ? p.scale2[b] : (p.out_scale ? p.out_scale[b] : 1.0f)) / lsum;
+        const int qrow = q0 + 32 * gq + l31;
+        {
+            float* lse_out = SEG2 ? p.lse2 : p.lse;  // v_log_f32 = log2
+            if (lse_out && hi == 0 && qrow < p.Nq) lse_out[((long)b * p.H + h) * p.Nq + qrow] = mt[gq] + __builtin_amdgcn_logf(lsum);
+        }
+        if (qrow < p.Nq) {
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int d = 32 * db + 8 * r4 + 4 * hi;
-                if (d < D) {
-                    float r0 = o[db][4 * r4] * inv, r1 = o[db][4 * r4 + 1] * inv, r2 = o[db][4 * r4 + 2] * inv, r3 = o[db][4 * r4 + 3] * inv;
-                    if (SEG2) {
-                        r0 += o_first[SEG2 ? db : 0][4 * r4]; r1 += o_first[SEG2 ? db : 0][4 * r4 + 1];
-                        r2 += o_first[SEG2 ? db : 0][4 * r4 + 2]; r3 += o_first[SEG2 ? db : 0][4 * r4 + 3];
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int d = 32 * db + 8 * r4 + 4 * hi;
+                    if (d < D) {
+                        float r0 = o[gq][db][4 * r4] * inv, r1 = o[gq][db][4 * r4 + 1] * inv, r2 = o[gq][db][4 * r4 + 2] * inv, r3 = o[gq][db][4 * r4 + 3] * inv;
+                        if (SEG2) {
+                            r0 += o_first[SEG2 ? gq : 0][SEG2 ? db : 0][4 * r4]; r1 += o_first[SEG2 ? gq : 0][SEG2 ? db : 0][4 * r4 + 1];
+                            r2 += o_first[SEG2 ? gq : 0][SEG2 ? db : 0][4 * r4 + 2]; r3 += o_first[SEG2 ? gq : 0][SEG2 ? db : 0][4 * r4 + 3];
+                        }
+                        u32x2* dst = reinterpret_cast<u32x2*>(op + (long)qrow * p.o_sn + d);
+                        if (p.accum) {
+                            const u32x2 prev = *dst;
+                            r0 += bf16lo(prev.x); r1 += bf16hi(prev.x); r2 += bf16lo(prev.y); r3 += bf16hi(prev.y);
+                        }
+                        *dst = (u32x2){pack_bf16x2(r0, r1), pack_bf16x2(r2, r3)};
                     }
-                    u32x2* dst = reinterpret_cast<u32x2*>(op + (long)qrow * p.o_sn + d);
-                    if (p.accum) {
-                        const u32x2 prev = *dst;
-                        r0 += bf16lo(prev.x); r1 += bf16hi(prev.x); r2 += bf16lo(prev.y); r3 += bf16hi(prev.y);
-                    }
-                    *dst = (u32x2){pack_bf16x2(r0, r1), pack_bf16x2(r2, r3)};
                 }
-            }
+        }
     }
 }
 
@@ -412,7 +479,20 @@ int launch_fast(const AttnArgs& a, hipStream_t stream) {
             return ae_check_launch("ae_attn_fwd_bf16(fast, rel-pos)");
         }
     }
-    if (a.k2) hipLaunchKernelGGL((attn_fast_kernel<D, (D > 64 ? 2 : 3), true>), grid, block, 0, stream, a);  // 168 VGPRs spill at head_dim 80
+    if (a.k2) {
+        hipLaunchKernelGGL((attn_fast_kernel<D, (D > 64 ? 2 : 3), true>), grid, block, 0, stream, a);  // 168 VGPRs spill at head_dim 80
+        return ae_check_launch("ae_attn_fwd_bf16(fast)");
+    }
+    // Variants of the plain long-sequence kernel (tuning knob AE_ATTN_V, bit flags): 1 = conflict-free V image (VSPLIT), 2 = two query
+    // groups per wave (QG = 2: 64 queries per wave, 256 per block) for sequences long enough to fill the chip with the larger blocks.
+    static const int var_env = getenv("AE_ATTN_V") ? atoi(getenv("AE_ATTN_V")) : AE_ATTN_V_DEFAULT;
+    const bool qg2 = (var_env & 2) && (long)((a.Nq + 255) / 256) * a.B * a.H >= 1024;
+    const bool vs = (var_env & 1) != 0;
+    if (qg2) {
+        dim3 grid2((unsigned)((long)((a.Nq + 255) / 256) * a.B * a.H));
+        if (vs) hipLaunchKernelGGL((attn_fast_kernel<D, 2, false, 0, 0, 2, true>), grid2, block, 0, stream, a);
+        else hipLaunchKernelGGL((attn_fast_kernel<D, 2, false, 0, 0, 2, false>), grid2, block, 0, stream, a);
+    } else if (vs) hipLaunchKernelGGL((attn_fast_kernel<D, 3, false, 0, 0, 1, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((attn_fast_kernel<D, 3, false>), grid, block, 0, stream, a);
     return ae_check_launch("ae_attn_fwd_bf16(fast)");
 }

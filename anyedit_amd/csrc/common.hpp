@@ -19,6 +19,9 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 // error plumbing (c_api.hip)
 void ae_set_error(const char* fmt, ...);
 int ae_check_launch(const char* what);
+// per-channel (sum, sum of squares) of a bf16 [M, N] tensor over each 32-row slab -> out [ceil(M/32)][N][2] fp32 (gemm_conv.hip): the
+// statistics a producing kernel hands to the GroupNorm that consumes its output; N % 8 == 0, rows 16-byte aligned
+int ae_launch_colstats(const uint16_t* x, long ld, int M, int N, float* out, hipStream_t stream);
 
 #define AE_REQUIRE(cond, ...)                 \
     do {                                      \

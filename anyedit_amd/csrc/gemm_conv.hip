@@ -42,6 +42,8 @@ struct GemmArgs {
     unsigned a_bytes, a2_bytes, w_bytes;  // buffer extents (bytes) for the bounds-checked fast loaders
     int splitk;      // > 1: K is cut into `splitk` ranges, each block writes raw fp32 partials (small-M, huge-K convs)
     float* partial;  // [splitk][M][N] fp32
+    float* colstats; // optional [ceil(M/32)][N][2] fp32: per-channel (sum, sum of squares) of the bf16-rounded OUTPUT over each 32-row slab, written
+                     // by the epilogue (CS instantiations) so that the GroupNorm that consumes this tensor needs no statistics pass
     int m_fast;      // tile order inside an XCD's run: 1 = M tiles fastest (tiles sharing a WEIGHT panel are neighbours: small-M layers whose
                      // weights outweigh the activations), 0 = N tiles fastest (tiles sharing an ACTIVATION panel are neighbours)
 };
@@ -80,7 +82,10 @@ constexpr int epilogue_passes(int FM, int bytes_per_frag_row, int lds_bytes) {
 // LDS once at the end.  Same thread count and staging as an 8-wave block, but each wave owns a 2x larger output tile, so the
 // block issues a third fewer LDS fragment reads per MFMA (the 128x128 tile is LDS-bound: with 15/16 of its MFMAs removed it
 // still takes 73 % of the time).
-template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false, int WAVES_K = 1, int STAGES = 2>
+// CS = true: the epilogue also emits the per-channel statistics of its output (GemmArgs::colstats).  The wave tile is then staged in
+// 32-row passes (one statistics slab per pass) and the output loop gives every lane a FIXED 8-column chunk, so a lane can carry the
+// column sums of its rows in registers; the R = 64 / (WN / 8) row-lanes of a chunk are folded through the wave's own staging slice.
+template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false, int WAVES_K = 1, int STAGES = 2, bool CS = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(const GemmArgs p) {
     static_assert(STAGES == 2 || (GLDS && WAVES_K == 1), "the deep LDS ring exists only for the LDS-DMA loader");
     static_assert(WAVES_K == 1 || WAVES_K == 2, "K groups: 1 or 2");
@@ -459,7 +464,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
     {
         constexpr int NCH = WN / 4;  // fp32 16-byte chunks per staged row
         // staging must fit in the main-loop LDS: split the wave tile's rows into passes if it does not (128x160 tile)
-        constexpr int PASSES = epilogue_passes(FM, WAVES_M * WAVES_N * 16 * WN * 4, STAGES * (BM + BN) * BK * 2);
+        static_assert(!CS || (WAVES_K == 1 && FM % 2 == 0 && WN % 16 == 0 && WAVES_M * WAVES_N * 32 * WN * 4 <= STAGES * (BM + BN) * BK * 2),
+                      "column statistics need 32-row staging passes that fit the main-loop LDS");
+        constexpr int PASSES = CS ? FM / 2 : epilogue_passes(FM, WAVES_M * WAVES_N * 16 * WN * 4, STAGES * (BM + BN) * BK * 2);
         constexpr int FMP = FM / PASSES, WMP = WM / PASSES;
         static_assert(FM % PASSES == 0, "epilogue passes must divide the fragment rows");
         const bool geglu = p.epi == EPI_GEGLU;
@@ -558,6 +565,65 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                 const int ow = geglu ? WN / 2 : WN;      // output columns of this wave's tile
                 const int och = ow / 8;                  // 8-column output chunks per row
                 const int nbase = geglu ? (n0 + wn * WN) / 2 : n0 + wn * WN;
+                if constexpr (CS) {
+                    // ---- output + per-channel statistics of this 32-row slab (bf16 output, no GEGLU: checked by the launcher)
+                    constexpr int OCH = WN / 8, R = 64 / OCH;       // lanes = R rows x OCH column chunks (R * OCH <= 64)
+                    const int oc = lane % OCH, rr = lane / OCH;
+                    const int n = nbase + oc * 8;
+                    float cs[8], cq[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;
+#pragma unroll
+                    for (int r0 = 0; r0 < 32; r0 += R) {
+                        const int rl = r0 + rr;
+                        const int m = m0 + wm * WM + ps * 32 + rl;
+                        if (rr < R && rl < 32 && m < p.M && n < n_out) {
+                            const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + rl * WN + (((2 * oc + rl) % NCH) << 2));
+                            const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + rl * WN + (((2 * oc + 1 + rl) % NCH) << 2));
+                            float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                            if (p.res) {
+                                const u32x4 rr4 = *reinterpret_cast<const u32x4*>(p.res + (long)m * p.ldr + n);
+                                o[0] += bf16lo(rr4.x); o[1] += bf16hi(rr4.x); o[2] += bf16lo(rr4.y); o[3] += bf16hi(rr4.y);
+                                o[4] += bf16lo(rr4.z); o[5] += bf16hi(rr4.z); o[6] += bf16lo(rr4.w); o[7] += bf16hi(rr4.w);
+                            }
+                            const u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) = pk;
+                            // statistics of the STORED (bf16-rounded) values: what the consuming GroupNorm reads
+                            const uint32_t w4[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float a = bf16lo(w4[e]), c = bf16hi(w4[e]);
+                                cs[2 * e] += a; cq[2 * e] += a * a;
+                                cs[2 * e + 1] += c; cq[2 * e + 1] += c * c;
+                            }
+                        }
+                    }
+                    // fold the R row-lanes of every column chunk through this wave's own staging slice: the wave's LDS operations retire
+                    // in order, so the writes below cannot overtake the loop's reads and the reads after them see the writes
+                    asm volatile("" ::: "memory");
+                    if (rr < R) {
+                        float* d0 = st + (rr * 2) * WN + oc * 8;
+                        *reinterpret_cast<f32x4*>(d0) = (f32x4){cs[0], cs[1], cs[2], cs[3]};
+                        *reinterpret_cast<f32x4*>(d0 + 4) = (f32x4){cs[4], cs[5], cs[6], cs[7]};
+                        *reinterpret_cast<f32x4*>(d0 + WN) = (f32x4){cq[0], cq[1], cq[2], cq[3]};
+                        *reinterpret_cast<f32x4*>(d0 + WN + 4) = (f32x4){cq[4], cq[5], cq[6], cq[7]};
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const int mslab = m0 + wm * WM + ps * 32;   // multiple of 32: BM, WM are
+                    for (int c2 = lane; c2 < WN / 2; c2 += 64) {
+                        const int nc = nbase + 2 * c2;
+                        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const f32x2 a = *reinterpret_cast<const f32x2*>(st + (r * 2) * WN + 2 * c2);
+                            const f32x2 c = *reinterpret_cast<const f32x2*>(st + (r * 2 + 1) * WN + 2 * c2);
+                            s0 += a[0]; s1 += a[1]; q0 += c[0]; q1 += c[1];
+                        }
+                        if (mslab < p.M && nc < n_out)
+                            *reinterpret_cast<f32x4*>(p.colstats + ((long)(mslab >> 5) * n_out + nc) * 2) = (f32x4){s0, q0, s1, q1};
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                } else
                 for (int it = lane; it < (writer ? WMP * och : 0); it += 64) {
                     const int rl = it / och, oc = it - rl * och;
                     const int m = m0 + wm * WM + ps * WMP + rl, n = nbase + oc * 8;
@@ -679,6 +745,45 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     }
 }
 
+// Stand-alone producer of the same per-channel statistics ([ceil(M/32)][N][2]: sum, sum of squares over each 32-row slab) for outputs
+// whose kernel has no CS epilogue (split-K reduce, row-panel GEMM, small tiles): one read of the bf16 tensor.  Block = 256 threads =
+// 32 column chunks (8 channels each) x 8 row lanes, 4 rows per thread in flight; grid = (slabs, ceil(N / 256)).
+__global__ __launch_bounds__(256) void colstats_kernel(const bf16_t* x, long ld, int M, int N, float* out) {
+    __shared__ float red[8][2][256];
+    const int cc = threadIdx.x & 31, rr = threadIdx.x >> 5;
+    const int n = blockIdx.y * 256 + cc * 8;
+    const int r0 = blockIdx.x * 32;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    if (n < N) {
+        u32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const u32x4*>(x + (long)min(r0 + rr + 8 * j, M - 1) * ld + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float keep = (r0 + rr + 8 * j < M) ? 1.f : 0.f;
+            const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = bf16lo(w[e]) * keep, c = bf16hi(w[e]) * keep;
+                s[2 * e] += a; q[2 * e] += a * a;
+                s[2 * e + 1] += c; q[2 * e + 1] += c * c;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[rr][0][cc * 8 + e] = s[e]; red[rr][1][cc * 8 + e] = q[e]; }
+    __syncthreads();
+    const int col = threadIdx.x;  // one column per thread, fixed summation order over the 8 row lanes
+    if (blockIdx.y * 256 + col < N) {
+        float a = 0.f, c = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { a += red[r][0][col]; c += red[r][1][col]; }
+        *reinterpret_cast<f32x2*>(out + ((long)blockIdx.x * N + blockIdx.y * 256 + col) * 2) = (f32x2){a, c};
+    }
+}
+
 // tile choice: the largest tile that still fills the 256 CUs and does not waste >10% of N
 int pick_tile(int M, int N) {
     const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
@@ -796,6 +901,11 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // (the same tile for the K = 320 dense GEMMs of the 64x64 level was A/B-ed too: N = 320 44.5 vs 34 us, N = 960 78 vs 63 us —
     // five K iterations do not amortise the big tile's prologue / epilogue.)
     bool done = false;
+    // Column statistics for the consuming GroupNorm (GemmArgs::colstats): emitted by the epilogue where a CS instantiation exists (the
+    // un-split 192x320 conv tile of the 64x64 level, the 8-wave 128x128 tile of the 32x32 level), by the stand-alone kernel otherwise.
+    const bool cs_epi_ok = a.colstats && a.epi != EPI_GEGLU && !a.out_f32 && a.splitk <= 1 && a.N % 8 == 0 && a.ldc % 8 == 0 &&
+                           (!a.res || (a.ldr % 8 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0));
+    bool cs_done = false;
     // (192x320 with FOUR waves of 96x160 — 0.27 LDS fragment reads per MFMA instead of 0.37, 240 accumulator registers per lane — was
     // instantiated and measured: hipcc places the accumulators in AGPRs and brackets the MFMAs with v_accvgpr moves, 166-206 TFLOP/s
     // against 911-1123 for the 8-wave form.  Bigger wave tiles need hand-scheduled AGPR code; not kept.)
@@ -812,7 +922,10 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         // 32x32 level (M = 12288) measured 9-13 % slower than the 128x128 tile there and was dropped.
         if (fill >= 0.85) {
             if (a.epi == EPI_GEGLU) rc = launch_kernel(gemm_kernel<192, 320, AMODE, 4, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
-            else rc = launch_kernel(gemm_kernel<192, 320, AMODE, 2, 4, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
+            else if (cs_epi_ok && AMODE == A_CONV3) {
+                if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
+                cs_done = true;
+            } else rc = launch_kernel(gemm_kernel<192, 320, AMODE, 2, 4, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
             done = true;
         }
     }
@@ -859,7 +972,10 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         else if (pick == 3) AE_LAUNCH(128, 160, 2, 2, 256);
         else if (pick == 0 && w8 == 1) AE_LAUNCH(128, 128, 2, 4, 512);
         else if (pick == 0 && wk_env && glds) rc = launch_kernel(gemm_kernel<128, 128, AMODE, 2, 2, true, 2>, grid, 512, lds_of(128, 128, 2), stream, a, what);
-        else if (pick == 0 && w8 == 2) AE_LAUNCH(128, 128, 4, 2, 512);
+        else if (pick == 0 && w8 == 2 && cs_epi_ok && glds) {
+            rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, true>, grid, 512, lds_of(128, 128, 2), stream, a, what);
+            cs_done = true;
+        } else if (pick == 0 && w8 == 2) AE_LAUNCH(128, 128, 4, 2, 512);
         else if (pick == 0) AE_LAUNCH(128, 128, 2, 2, 256);
         else if (pick == 1 && w8 && !conv) AE_LAUNCH(128, 64, 4, 2, 512);
         else if (pick == 1) AE_LAUNCH(128, 64, 2, 2, 256);
@@ -870,21 +986,32 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         else AE_LAUNCH(64, 64, 2, 2, 256);
 #undef AE_LAUNCH
     }
-    if (rc || a.splitk <= 1) return rc;
-    long nb = ((long)a.M * a.N / 4 + 255) / 256;
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a);
-    return ae_check_launch("ae_conv3x3_bf16(split-K reduce)");
+    if (rc) return rc;
+    if (a.splitk > 1) {
+        long nb = ((long)a.M * a.N / 4 + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a);
+        rc = ae_check_launch("ae_conv3x3_bf16(split-K reduce)");
+        if (rc) return rc;
+    }
+    if (a.colstats && !cs_done) return ae_launch_colstats(reinterpret_cast<const bf16_t*>(a.C), a.ldc, a.M, a.epi == EPI_GEGLU ? a.N / 2 : a.N, a.colstats, stream);
+    return rc;
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
+int ae_launch_colstats(const bf16_t* x, long ld, int M, int N, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(colstats_kernel, dim3((unsigned)((M + 31) / 32), (unsigned)((N + 255) / 256)), dim3(256), 0, stream, x, ld, M, N, out);
+    return ae_check_launch("column statistics");
+}
+
 extern "C" int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, int Ksplit, const void* W, long ldw,
                             void* C, long ldc, int M, int N, int K, const float* bias, const void* residual, long ldr,
-                            const float* addvec, long addvec_ld, int rows_per_batch, int epilogue, int out_f32, void* stream) {
+                            const float* addvec, long addvec_ld, int rows_per_batch, int epilogue, int out_f32, float* colstats, void* stream) {
     AE_REQUIRE(A && W && C, "ae_gemm_bf16: null pointer");
+    if (colstats) AE_REQUIRE(!out_f32 && N % 8 == 0 && ldc % 8 == 0 && (reinterpret_cast<uintptr_t>(colstats) & 15) == 0, "ae_gemm_bf16: column statistics need a bf16 output with N %% 8 == 0 and 16-byte rows");
     AE_REQUIRE(M > 0 && N > 0 && K > 0, "ae_gemm_bf16: M,N,K must be positive (got %d,%d,%d)", M, N, K);
     AE_REQUIRE(K % 8 == 0, "ae_gemm_bf16: K=%d must be a multiple of 8", K);
     AE_REQUIRE(N % 4 == 0, "ae_gemm_bf16: N=%d must be a multiple of 4", N);
@@ -906,7 +1033,7 @@ extern "C" int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, 
     a.M = M; a.N = N; a.K = K; a.Ksplit = A2 ? Ksplit : K;
     a.lda = lda; a.lda2 = lda2; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.ldav = addvec_ld > 0 ? addvec_ld : N;
     a.epi = epilogue; a.out_f32 = out_f32; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
-    a.splitk = 1; a.partial = nullptr;
+    a.splitk = 1; a.partial = nullptr; a.colstats = colstats;
     a.a_bytes = (unsigned)((((long)M - 1) * lda + (A2 ? Ksplit : K)) * 2);
     a.a2_bytes = A2 ? (unsigned)((((long)M - 1) * lda2 + (K - Ksplit)) * 2) : 0u;
     a.w_bytes = (unsigned)((((long)N - 1) * ldw + K) * 2);
@@ -926,8 +1053,9 @@ extern "C" long ae_conv3x3_workspace_floats(int B, int H, int W, int Cin, int Co
 
 extern "C" int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float* addvec, long addvec_ld,
                                const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int stride, int upsample2x,
-                               int out_f32, float* workspace, void* stream) {
+                               int out_f32, float* workspace, float* colstats, void* stream) {
     AE_REQUIRE(x && w && y, "ae_conv3x3_bf16: null pointer");
+    if (colstats) AE_REQUIRE(!out_f32 && Cout % 8 == 0 && (reinterpret_cast<uintptr_t>(colstats) & 15) == 0, "ae_conv3x3_bf16: column statistics need a bf16 output with Cout %% 8 == 0");
     AE_REQUIRE(B > 0 && H > 0 && W > 0, "ae_conv3x3_bf16: bad shape B=%d H=%d W=%d", B, H, W);
     AE_REQUIRE(Cin % 8 == 0, "ae_conv3x3_bf16: Cin=%d must be a multiple of 8", Cin);
     AE_REQUIRE(Cout % 4 == 0, "ae_conv3x3_bf16: Cout=%d must be a multiple of 4", Cout);
@@ -949,5 +1077,6 @@ extern "C" int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, 
     AE_REQUIRE((long)B * H * W * Cin * 2 < (1L << 31) && (long)Cout * 9 * CinPad * 2 < (1L << 31), "ae_conv3x3_bf16: operands must be smaller than 2 GiB");
     a.splitk = workspace ? make_plan(a.M, a.N, a.K, true).splitk : 1;  // without a workspace the kernel runs unsplit
     a.partial = workspace;
+    a.colstats = colstats;
     return launch<A_CONV3>(a, (hipStream_t)stream);
 }

@@ -323,7 +323,7 @@ extern "C" int ae_ln_gemm_supported(int M, int N, int K, int epilogue) {
 
 extern "C" int ae_ln_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias,
                                const void* residual, long ldr, const float* ln_gamma, const float* ln_beta, float ln_eps, int epilogue,
-                               void* stream) {
+                               float* colstats, void* stream) {
     AE_REQUIRE(A && W && C, "ae_ln_gemm_bf16: null pointer");
     AE_REQUIRE(ae_ln_gemm_supported(M, N, K, epilogue), "ae_ln_gemm_bf16: unsupported shape M=%d N=%d K=%d epilogue=%d (K must be 320, N %% 64 == 0)", M, N, K, epilogue);
     AE_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), "ae_ln_gemm_bf16: gamma and beta go together");
@@ -338,5 +338,10 @@ extern "C" int ae_ln_gemm_bf16(const void* A, long lda, const void* W, long ldw,
     RowPanelArgs a{};
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.bias = bias; a.res = (const bf16_t*)residual;
     a.ln_g = ln_gamma; a.ln_b = ln_beta; a.ln_eps = ln_eps; a.M = M; a.N = N; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
-    return launch_rowpanel<10>(a, epilogue, (hipStream_t)stream);
+    const int rc = launch_rowpanel<10>(a, epilogue, (hipStream_t)stream);
+    if (rc || !colstats) return rc;
+    // per-channel statistics of the output for the GroupNorm that consumes it (proj_out of the 64x64 level): this kernel's epilogue keeps
+    // a lane on ONE row across all columns, so the column sums come from the stand-alone pass over the (L2-resident) output
+    AE_REQUIRE(((uintptr_t)colstats & 15) == 0, "ae_ln_gemm_bf16: colstats alignment");
+    return ae_launch_colstats((const bf16_t*)C, ldc, M, epilogue == RP_EPI_GEGLU ? N / 2 : N, colstats, (hipStream_t)stream);
 }

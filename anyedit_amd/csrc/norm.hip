@@ -31,6 +31,8 @@ struct GNArgs {
     float* part2;  // [B][nchunk][groups][2]  partial (sum dz*gamma, sum dz*(z - beta))
     float* coef2;  // [B][2][C]               per-channel kA, kB of dx = dz*scale + x*kA + kB
     int* counters; // optional [B], zero on entry and on exit: the LAST partial-sum block of a sample runs the finalize fold itself
+    const float* cs1; const float* cs2;  // optional per-channel (sum, sumsq) over 32-row slabs of x / x2, written by their PRODUCERS
+                                         // ([B*HW/32][C1][2], [B*HW/32][C-C1][2]): replaces the statistics pass over the activation
 };
 
 // Fold of the per-chunk partials of sample b by the calling block (any block size): 16 slices x 64 group lanes, slice i takes chunks
@@ -162,6 +164,45 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const GNArgs p) {
     __shared__ float red[2][16][64];
     __shared__ float mean[64], rstd[64];
     gn_finalize_body(p, blockIdx.x, red, mean, rstd);
+}
+
+// (2') finalize from the producers' per-channel slab statistics (ae_gemm_bf16 / ae_conv3x3_bf16 / ae_ln_gemm_bf16 `colstats`): one
+// block per (group, sample) sums the group's channels over the sample's HW / 32 slabs in a fixed order (thread-strided partials,
+// shuffle tree, four waves in wave order -> deterministic) and writes the per-channel scale / shift of that group.  The activation
+// itself is not read: the statistics pass of GroupNorm (one full read of the tensor, 31 launches per UNet evaluation) is gone.
+__global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const GNArgs p) {
+    __shared__ float red[2][4];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cpg = p.C / p.groups, nslab = p.HW / 32, C2 = p.C - p.C1;
+    float a = 0.f, c = 0.f;
+    for (int idx = threadIdx.x; idx < nslab * cpg; idx += 256) {
+        const int i = idx / cpg, ch = g * cpg + (idx - i * cpg);
+        const long slab = (long)b * nslab + i;
+        const f32x2 v = ch < p.C1 ? *reinterpret_cast<const f32x2*>(p.cs1 + (slab * p.C1 + ch) * 2)
+                                  : *reinterpret_cast<const f32x2*>(p.cs2 + (slab * C2 + (ch - p.C1)) * 2);
+        a += v[0];
+        c += v[1];
+    }
+    a = wave_reduce_sum(a);
+    c = wave_reduce_sum(c);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = c; }
+    __syncthreads();
+    const float sa = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    const float sq = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    const float n = (float)cpg * (float)p.HW;
+    const float mu = sa / n;
+    const float var = fmaxf(sq / n - mu * mu, 0.f);
+    const float rs = rsqrtf(var + p.eps);
+    if (threadIdx.x == 0 && p.stat) {
+        p.stat[((long)b * p.groups + g) * 2 + 0] = mu;
+        p.stat[((long)b * p.groups + g) * 2 + 1] = rs;
+    }
+    for (int j = threadIdx.x; j < cpg; j += 256) {
+        const int ch = g * cpg + j;
+        const float sc = p.gamma[ch] * rs;
+        p.coef[((long)b * 2 + 0) * p.C + ch] = sc;
+        p.coef[((long)b * 2 + 1) * p.C + ch] = p.beta[ch] - mu * sc;
+    }
 }
 
 // (3) apply: pure streaming.  Same thread layout as (1): a thread keeps its 8 scales + 8 shifts in registers.
@@ -739,7 +780,7 @@ extern "C" long ae_groupnorm_workspace_floats(int B, int HW, int C, int groups) 
 
 extern "C" int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y,
                                       int B, int HW, int C, int groups, float eps, int act, float* workspace, int* counters, float* stat_out,
-                                      void* stream) {
+                                      const float* colstats, const float* colstats2, void* stream) {
     AE_REQUIRE(x && gamma && beta && y && workspace, "ae_groupnorm_nhwc_bf16: null pointer");
     AE_REQUIRE(B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, "ae_groupnorm_nhwc_bf16: bad shape C=%d groups=%d", C, groups);
     AE_REQUIRE(C % 8 == 0 && C <= 8192, "ae_groupnorm_nhwc_bf16: C=%d must be a multiple of 8 and <= 8192", C);
@@ -771,6 +812,17 @@ extern "C" int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, con
     if (threads < 64) threads = 64;
     dim3 grid(p.nchunk, B);
     hipStream_t s = (hipStream_t)stream;
+    if (colstats) {  // the producers of x (and x2) already delivered the per-channel slab statistics: finalize from them, then apply
+        AE_REQUIRE(HW % 32 == 0, "ae_groupnorm_nhwc_bf16: producer statistics are kept per 32-row slab: HW=%d must be a multiple of 32", HW);
+        AE_REQUIRE((x2 == nullptr) == (colstats2 == nullptr), "ae_groupnorm_nhwc_bf16: statistics are needed for both sources of a concat input");
+        AE_REQUIRE(((uintptr_t)colstats & 7) == 0 && ((uintptr_t)colstats2 & 7) == 0, "ae_groupnorm_nhwc_bf16: colstats alignment");
+        p.cs1 = colstats; p.cs2 = colstats2;
+        hipLaunchKernelGGL(gn_finalize_cs_kernel, dim3(groups, B), dim3(256), 0, s, p);
+        int rc0 = ae_check_launch("ae_groupnorm_nhwc_bf16(finalize from producer statistics)");
+        if (rc0) return rc0;
+        hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(threads), 0, s, p);
+        return ae_check_launch("ae_groupnorm_nhwc_bf16(apply)");
+    }
     // small feature maps: the whole (sample, group pack) slab fits the registers of one block -> one launch, one read, one write
     static const int slab = getenv("AE_GN_SLAB") ? atoi(getenv("AE_GN_SLAB")) : 1;  // tuning knob: 0 = three-launch path everywhere (A/B)
     if (slab && HW <= 256) {  // 32x32 maps measured slower this way (few, large slabs: 22-94 us against 20-35)

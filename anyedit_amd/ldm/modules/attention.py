@@ -32,9 +32,9 @@ class _GN6(nn.GroupNorm):
     def repack(self):
         self._pk = None
 
-    def rows(self, x, B, HW):
+    def rows(self, x, B, HW, colstats=None):
         g, b = self._affine()
-        return ops.groupnorm(x, g, b, B, HW, self.eps, silu=False, groups=self.num_groups)
+        return ops.groupnorm(x, g, b, B, HW, self.eps, silu=False, groups=self.num_groups, colstats=colstats)
 
     def forward(self, x):
         B, C, H, W = x.shape
@@ -281,19 +281,21 @@ class SpatialTransformer(nn.Module):
             self.proj_out = zero_module(Linear(in_channels, inner_dim))
         self.use_linear = use_linear
 
-    def rows(self, x, B, H, W, context_rows=None, kv_cache=None):
+    def rows(self, x, B, H, W, context_rows=None, kv_cache=None, colstats=None, out_colstats=None):
+        """colstats: per-channel slab statistics of x from its producer (the norm then skips its statistics pass); out_colstats: buffer
+        that receives the statistics of the result (proj_out's epilogue), for the GroupNorm of the block that follows."""
         if isinstance(context_rows, (list, tuple)):
             ctxs = list(context_rows)
         else:
             ctxs = [context_rows] * len(self.transformer_blocks)
         N = H * W
-        h = self.norm.rows(x, B, N)
+        h = self.norm.rows(x, B, N, colstats=colstats)
         pin = self.proj_in._packed()
         h = ops.gemm(h, pin["w"], pin["b"])
         for i, blk in enumerate(self.transformer_blocks):
             h = blk.rows(h, B, N, context_rows=ctxs[i], kv_cache=kv_cache)
         pout = self.proj_out._packed()
-        return ops.gemm(h, pout["w"], pout["b"], residual=x)
+        return ops.gemm(h, pout["w"], pout["b"], residual=x, colstats=out_colstats)
 
     def forward(self, x, context=None):
         B, C, H, W = x.shape

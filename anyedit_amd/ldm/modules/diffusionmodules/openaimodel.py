@@ -28,17 +28,25 @@ class TimestepBlock(nn.Module):
 
 
 class Feat:
-    """Channels-last activation handle: rows [B*H*W, C] bf16 (+ optional second source = pending channel-concat)."""
-    __slots__ = ("t", "B", "H", "W", "t2")
+    """Channels-last activation handle: rows [B*H*W, C] bf16 (+ optional second source = pending channel-concat).
+    st / st2: per-channel slab statistics of t / t2 written by the kernels that produced them (`ops.colstats_buffer`), or None: the
+    GroupNorm that consumes the tensor then needs no statistics pass (SURVEY.md §7 hard part (iii))."""
+    __slots__ = ("t", "B", "H", "W", "t2", "st", "st2")
 
-    def __init__(self, t, B, H, W, t2=None):
-        self.t, self.B, self.H, self.W, self.t2 = t, B, H, W, t2
+    def __init__(self, t, B, H, W, t2=None, st=None, st2=None):
+        self.t, self.B, self.H, self.W, self.t2, self.st, self.st2 = t, B, H, W, t2, st, st2
 
     def materialize(self):
         if self.t2 is not None:
             self.t = ops.concat_channels(self.t, self.t2)
             self.t2 = None
+            self.st = self.st2 = None
         return self.t
+
+
+def _stats_for(B, H, W, C, device):
+    """A statistics buffer for a [B*H*W, C] output whose consumer is a GroupNorm taking producer statistics, else None."""
+    return ops.colstats_buffer(B * H * W, C, device) if ops.want_colstats(H * W) else None
 
 
 class EmbPack:
@@ -57,7 +65,11 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
             if isinstance(layer, TimestepBlock):
                 f = layer.rows(f, emb_silu)
             elif isinstance(layer, SpatialTransformer):
-                f = Feat(layer.rows(f.materialize(), f.B, f.H, f.W, context_rows=context_rows, kv_cache=kv_cache), f.B, f.H, f.W)
+                x_st = f.st if f.t2 is None else None
+                x = f.materialize()
+                st = _stats_for(f.B, f.H, f.W, x.shape[1], x.device)
+                f = Feat(layer.rows(x, f.B, f.H, f.W, context_rows=context_rows, kv_cache=kv_cache, colstats=x_st, out_colstats=st),
+                         f.B, f.H, f.W, st=st)
             else:
                 f = layer.rows(f)
         return f
@@ -87,8 +99,10 @@ class Upsample(nn.Module):
         self.conv = conv_nd(dims, self.channels, self.out_channels, 3, padding=padding)
 
     def rows(self, f):
-        y, Ho, Wo = self.conv.rows(f.materialize(), f.B, f.H, f.W, upsample2x=True)
-        return Feat(y, f.B, Ho, Wo)
+        Ho, Wo = self.conv.out_hw(f.H, f.W, upsample2x=True)
+        st = _stats_for(f.B, Ho, Wo, self.out_channels, f.t.device)
+        y, Ho, Wo = self.conv.rows(f.materialize(), f.B, f.H, f.W, upsample2x=True, colstats=st)
+        return Feat(y, f.B, Ho, Wo, st=st)
 
     def forward(self, x):
         assert x.shape[1] == self.channels
@@ -111,8 +125,10 @@ class Downsample(nn.Module):
         self.op = conv_nd(dims, self.channels, self.out_channels, 3, stride=2, padding=padding)
 
     def rows(self, f):
-        y, Ho, Wo = self.op.rows(f.materialize(), f.B, f.H, f.W)
-        return Feat(y, f.B, Ho, Wo)
+        Ho, Wo = self.op.out_hw(f.H, f.W)
+        st = _stats_for(f.B, Ho, Wo, self.out_channels, f.t.device)
+        y, Ho, Wo = self.op.rows(f.materialize(), f.B, f.H, f.W, colstats=st)
+        return Feat(y, f.B, Ho, Wo, st=st)
 
     def forward(self, x):
         assert x.shape[1] == self.channels
@@ -168,9 +184,11 @@ class ResBlock(TimestepBlock):
         else:
             silu = emb_silu.silu if isinstance(emb_silu, EmbPack) else emb_silu
             emb_out = self.emb_layers[1].rows(silu, out_f32=True)  # [B, Cout] fp32
-        h = self.in_layers[0].rows(f.t, B, H * W, silu=True, x2=f.t2)
-        h, _, _ = self.in_layers[2].rows(h, B, H, W, addvec=emb_out)
-        h = self.out_layers[0].rows(h, B, H * W, silu=True)
+        dev = f.t.device
+        h = self.in_layers[0].rows(f.t, B, H * W, silu=True, x2=f.t2, colstats=f.st, colstats2=f.st2)
+        st1 = _stats_for(B, H, W, self.out_channels, dev)       # conv1's epilogue delivers the statistics out_layers[0] needs
+        h, _, _ = self.in_layers[2].rows(h, B, H, W, addvec=emb_out, colstats=st1)
+        h = self.out_layers[0].rows(h, B, H * W, silu=True, colstats=st1)
         # This body may run twice as a checkpoint segment (throw-away forward + recompute): it must not change `f` — a concat
         # materialised into f.t on the throw-away tape would be unknown to the recompute's tape and its gradient dropped.
         whole = (lambda: f.t if f.t2 is None else ops.concat_channels(f.t, f.t2))
@@ -180,8 +198,9 @@ class ResBlock(TimestepBlock):
             res, _, _ = self.skip_connection.rows(f.t, B, H, W, a2=f.t2)
         else:
             res, _, _ = self.skip_connection.rows(whole(), B, H, W)
-        y, _, _ = self.out_layers[3].rows(h, B, H, W, residual=res)
-        return Feat(y, B, H, W)
+        st = _stats_for(B, H, W, self.out_channels, dev)        # ... and conv2's those of the block's output (next norm / decoder concat)
+        y, _, _ = self.out_layers[3].rows(h, B, H, W, residual=res, colstats=st)
+        return Feat(y, B, H, W, st=st)
 
     def forward(self, x, emb):
         B, C, H, W = x.shape
@@ -351,15 +370,18 @@ class UNetModel(nn.Module):
             if isinstance(module[0], TimestepBlock) or isinstance(module[0], (Downsample, Upsample)) or len(module) > 1:
                 f = module.rows(f, emb_silu, context_rows, kv_cache)
             else:  # stem conv
-                y, _, _ = module[0].rows(f.t, B, H, W)
-                f = Feat(y, B, H, W)
+                st = _stats_for(B, H, W, module[0].out_channels, f.t.device)
+                y, _, _ = module[0].rows(f.t, B, H, W, colstats=st)
+                f = Feat(y, B, H, W, st=st)
             hs.append(f)
         f = self.middle_block.rows(f, emb_silu, context_rows, kv_cache)
         for module in self.output_blocks:
             skip = hs.pop()
-            f = Feat(f.materialize(), f.B, f.H, f.W, t2=skip.materialize())  # th.cat([h, hs.pop()], 1), deferred
+            st_a = f.st if f.t2 is None else None
+            st_b = skip.st if skip.t2 is None else None
+            f = Feat(f.materialize(), f.B, f.H, f.W, t2=skip.materialize(), st=st_a, st2=st_b)  # th.cat([h, hs.pop()], 1), deferred
             f = module.rows(f, emb_silu, context_rows, kv_cache)
-        h = self.out[0].rows(f.materialize(), f.B, f.H * f.W, silu=True)
+        h = self.out[0].rows(f.materialize(), f.B, f.H * f.W, silu=True, colstats=f.st if f.t2 is None else None)
         y, _, _ = self.out[2].rows(h, f.B, f.H, f.W, out_f32=True)
         return ops.rows_to_nchw(y, f.B, f.H, f.W, out_dtype=torch.float32)
 

@@ -131,13 +131,20 @@ class Conv2d(nn.Conv2d, _Packed):
             return {"w": ops.pack_conv3x3(self.weight), "b": b}
         raise NotImplementedError(f"anyedit_amd Conv2d: unsupported configuration k={k} stride={self.stride} padding={self.padding}")
 
-    def rows(self, x, B, H, W, addvec=None, residual=None, upsample2x=False, out_f32=False, a2=None):
-        """x: channels-last rows [B*H*W, Cin] -> (rows [B*Ho*Wo, Cout], Ho, Wo)."""
+    def rows(self, x, B, H, W, addvec=None, residual=None, upsample2x=False, out_f32=False, a2=None, colstats=None):
+        """x: channels-last rows [B*H*W, Cin] -> (rows [B*Ho*Wo, Cout], Ho, Wo).  colstats: `ops.colstats_buffer` for the output."""
         pk = self._packed()
         if self.kernel_size[0] == 1:
-            return ops.gemm(x, pk["w"], pk["b"], residual=residual, out_f32=out_f32, a2=a2), H, W
+            return ops.gemm(x, pk["w"], pk["b"], residual=residual, out_f32=out_f32, a2=a2, colstats=colstats), H, W
         return ops.conv3x3(x, pk["w"], pk["b"], B, H, W, addvec=addvec, residual=residual, stride=self.stride[0],
-                           upsample2x=upsample2x, out_f32=out_f32)
+                           upsample2x=upsample2x, out_f32=out_f32, colstats=colstats)
+
+    def out_hw(self, H, W, upsample2x=False):
+        """Output extent of `rows` for an H x W input."""
+        if self.kernel_size[0] == 1:
+            return H, W
+        Hv, Wv = (2 * H, 2 * W) if upsample2x else (H, W)
+        return (Hv - 1) // self.stride[0] + 1, (Wv - 1) // self.stride[0] + 1
 
     def forward(self, x):
         B, C, H, W = x.shape
@@ -159,9 +166,9 @@ class GroupNorm32(nn.GroupNorm):
     def repack(self):
         self._pk = None
 
-    def rows(self, x, B, HW, silu=False, x2=None):
+    def rows(self, x, B, HW, silu=False, x2=None, colstats=None, colstats2=None):
         g, b = self._affine()
-        return ops.groupnorm(x, g, b, B, HW, self.eps, silu=silu, groups=self.num_groups, x2=x2)
+        return ops.groupnorm(x, g, b, B, HW, self.eps, silu=silu, groups=self.num_groups, x2=x2, colstats=colstats, colstats2=colstats2)
 
     def forward(self, x):
         B, C, H, W = x.shape

@@ -106,8 +106,26 @@ def pack_geglu(w, b):
 
 
 # --------------------------------------------------------------------------- GEMM / conv
-def gemm(a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue=EPI_NONE, out_f32=False, a2=None, out=None):
-    """out[M,N] = epi(cat([a, a2], 1) @ w^T).  a: [M,K1] bf16 (row stride free), w: [N,K] bf16."""
+def colstats_buffer(M, N, device):
+    """fp32 [ceil(M/32), N, 2]: per-channel (sum, sum of squares) over each 32-row slab of a bf16 [M, N] activation — filled by the kernel
+    that PRODUCES the activation (`colstats=` of gemm / ln_gemm / conv3x3) and consumed by `groupnorm(..., colstats=...)`, which then
+    skips its own statistics pass (the GroupNorm inputs of the 64x64 / 32x32 UNet levels: SURVEY.md §7 hard part (iii))."""
+    return torch.empty((M + 31) // 32, N, 2, dtype=torch.float32, device=device)
+
+
+_GN_COLSTATS = os.environ.get("AE_GN_COLSTATS", "1") != "0"  # tuning knob: 0 = GroupNorm computes its own statistics everywhere (A/B)
+
+
+def want_colstats(HW):
+    """True where a GroupNorm over HW positions per sample takes its statistics from the producer: maps above the single-launch slab
+    kernel's range (HW > 256) whose samples are whole 32-row slabs; never while the training tape records (its GroupNorm keeps
+    (mean, rstd) for the backward pass through the plain path)."""
+    return _GN_COLSTATS and HW > 256 and HW % 32 == 0 and not (_TAPE is not None and _TAPE.active)
+
+
+def gemm(a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue=EPI_NONE, out_f32=False, a2=None, out=None, colstats=None):
+    """out[M,N] = epi(cat([a, a2], 1) @ w^T).  a: [M,K1] bf16 (row stride free), w: [N,K] bf16.
+    colstats: optional `colstats_buffer(M, N)` that receives the per-channel slab statistics of the output."""
     if _TAPE is not None and _TAPE.active:
         return _TAPE.gemm(a, w, bias=bias, residual=residual, addvec=addvec, rows_per_batch=rows_per_batch, epilogue=epilogue, out_f32=out_f32, a2=a2, out=out)
     _chk(a, BF16, "gemm.a", 2)
@@ -133,13 +151,17 @@ def gemm(a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue
         _chk(residual, BF16, "gemm.residual", 2)
     if addvec is not None:
         _chk(addvec, torch.float32, "gemm.addvec", 2)
+    if colstats is not None:
+        _chk(colstats, torch.float32, "gemm.colstats", 3)
+        if tuple(colstats.shape) != ((M + 31) // 32, n_out, 2) or not colstats.is_contiguous():
+            raise ValueError(f"gemm: colstats must be a contiguous [{(M + 31) // 32}, {n_out}, 2] fp32 buffer")
     if a2 is None and addvec is None and not out_f32 and _rowpanel_ok(a, w, out, residual, M, N, K, epilogue):
-        return _ln_gemm_launch(a, w, bias, residual, None, None, 0.0, epilogue, out, M, N, K)
+        return _ln_gemm_launch(a, w, bias, residual, None, None, 0.0, epilogue, out, M, N, K, colstats)
     check(lib.ae_gemm_bf16(_p(a), a.stride(0), _p(a2), a2.stride(0) if a2 is not None else 0, K1, _p(w), w.stride(0),
                            _p(out), out.stride(0), M, N, K, _p(bias), _p(residual),
                            residual.stride(0) if residual is not None else 0, _p(addvec),
                            addvec.stride(0) if addvec is not None else 0, rows_per_batch, epilogue,
-                           1 if out_f32 else 0, _s()), "ae_gemm_bf16")
+                           1 if out_f32 else 0, _p(colstats), _s()), "ae_gemm_bf16")
     return out
 
 
@@ -157,14 +179,15 @@ def _rowpanel_ok(a, w, out, residual, M, N, K, epilogue):
         and (M + 192) * ld_max * 2 < 2 ** 31
 
 
-def _ln_gemm_launch(a, w, bias, residual, gamma, beta, eps, epilogue, out, M, N, K):
+def _ln_gemm_launch(a, w, bias, residual, gamma, beta, eps, epilogue, out, M, N, K, colstats=None):
     check(lib.ae_ln_gemm_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), M, N, K, _p(bias), _p(residual),
-                              residual.stride(0) if residual is not None else 0, _p(gamma), _p(beta), float(eps), epilogue, _s()),
+                              residual.stride(0) if residual is not None else 0, _p(gamma), _p(beta), float(eps), epilogue,
+                              _p(colstats), _s()),
           "ae_ln_gemm_bf16")
     return out
 
 
-def ln_gemm(x, gamma, beta, eps, w, bias=None, residual=None, epilogue=EPI_NONE, out=None):
+def ln_gemm(x, gamma, beta, eps, w, bias=None, residual=None, epilogue=EPI_NONE, out=None, colstats=None):
     """out = epi(LayerNorm(x; gamma, beta, eps) @ w^T + bias (+ residual)) — attention.py:271-275's norm -> projection pairs in one
     launch (the normalised rows never go to HBM).  Falls back to layernorm + gemm where the fused kernel does not cover the shape
     and while the training tape records."""
@@ -183,12 +206,13 @@ def ln_gemm(x, gamma, beta, eps, w, bias=None, residual=None, epilogue=EPI_NONE,
                     _chk(bias, torch.float32, "ln_gemm.bias", 1)
                 if residual is not None:
                     _chk(residual, BF16, "ln_gemm.residual", 2)
-                return _ln_gemm_fused(x, w, bias, residual, gamma, beta, eps, epilogue, o, M, N, K)
-    return gemm(layernorm(x, gamma, beta, eps), w, bias, residual=residual, epilogue=epilogue, out=out)
+                return _ln_gemm_fused(x, w, bias, residual, gamma, beta, eps, epilogue, o, M, N, K, colstats)
+    return gemm(layernorm(x, gamma, beta, eps), w, bias, residual=residual, epilogue=epilogue, out=out, colstats=colstats)
 
 
-def conv3x3(x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2x=False, out_f32=False, out=None):
-    """x: [B*H*W, Cin] bf16 channels-last, w: packed [Cout, 9*Cin].  Returns ([B*Ho*Wo, Cout], Ho, Wo)."""
+def conv3x3(x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2x=False, out_f32=False, out=None, colstats=None):
+    """x: [B*H*W, Cin] bf16 channels-last, w: packed [Cout, 9*Cin].  Returns ([B*Ho*Wo, Cout], Ho, Wo).
+    colstats: optional `colstats_buffer(B*Ho*Wo, Cout)` that receives the per-channel slab statistics of the output."""
     if _TAPE is not None and _TAPE.active:
         return _TAPE.conv3x3(x, w, bias, B, H, W, addvec=addvec, residual=residual, stride=stride, upsample2x=upsample2x, out_f32=out_f32, out=out)
     _chk(x, BF16, "conv3x3.x", 2)
@@ -209,8 +233,12 @@ def conv3x3(x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2
             raise ValueError("conv3x3: residual shape mismatch")
     nws = lib.ae_conv3x3_workspace_floats(B, H, W, Cin, Cout, stride, int(upsample2x))
     ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws > 0 else None  # split-K partials (small-M layers)
+    if colstats is not None:
+        _chk(colstats, torch.float32, "conv3x3.colstats", 3)
+        if tuple(colstats.shape) != ((B * Ho * Wo + 31) // 32, Cout, 2) or not colstats.is_contiguous():
+            raise ValueError(f"conv3x3: colstats must be a contiguous [{(B * Ho * Wo + 31) // 32}, {Cout}, 2] fp32 buffer")
     check(lib.ae_conv3x3_bf16(_p(x), _p(w), _p(bias), _p(addvec), addvec.stride(0) if addvec is not None else 0, _p(residual),
-                              _p(out), B, H, W, Cin, Cout, stride, int(upsample2x), 1 if out_f32 else 0, _p(ws), _s()),
+                              _p(out), B, H, W, Cin, Cout, stride, int(upsample2x), 1 if out_f32 else 0, _p(ws), _p(colstats), _s()),
           "ae_conv3x3_bf16")
     return out, Ho, Wo
 
@@ -234,9 +262,11 @@ def _gn_counters(device, B):
     return c
 
 
-def groupnorm(x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, out=None, stat_out=None):
+def groupnorm(x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, out=None, stat_out=None, colstats=None, colstats2=None):
     """GroupNorm(+SiLU) over channels-last [B*HW, C]; x2: optional second tensor concatenated along channels.
-    stat_out: optional fp32 [B, groups, 2] that receives (mean, rstd) for `groupnorm_bwd`."""
+    stat_out: optional fp32 [B, groups, 2] that receives (mean, rstd) for `groupnorm_bwd`.
+    colstats / colstats2: per-channel slab statistics of x / x2 from the kernels that produced them (`colstats_buffer`): the statistics
+    pass over the activation is skipped.  Both or neither for a two-source input."""
     if _TAPE is not None and _TAPE.active:
         return _TAPE.groupnorm(x, gamma, beta, B, HW, eps, silu=silu, groups=groups, x2=x2, out=out)
     _chk(x, BF16, "groupnorm.x", 2)
@@ -246,9 +276,16 @@ def groupnorm(x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, out=No
         raise ValueError("groupnorm: inputs must be contiguous")
     if out is None:
         out = torch.empty(B * HW, C, dtype=BF16, device=x.device)
+    if colstats is not None and (x2 is None) != (colstats2 is None):
+        colstats = colstats2 = None   # statistics of only one of the two sources: fall back to the kernel's own pass
+    if colstats is not None:
+        for t, c, n in ((colstats, C1, "colstats"), (colstats2, C - C1, "colstats2")):
+            if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != (B * HW // 32, c, 2) or not t.is_contiguous() or HW % 32):
+                raise ValueError(f"groupnorm: {n} must be a contiguous fp32 [{B * HW // 32}, {c}, 2] buffer (HW % 32 == 0), got {tuple(t.shape)}")
     ws = torch.empty(lib.ae_groupnorm_workspace_floats(B, HW, C, groups), dtype=torch.float32, device=x.device)
     check(lib.ae_groupnorm_nhwc_bf16(_p(x), _p(x2), C1, _p(gamma), _p(beta), _p(out), B, HW, C, groups, eps,
-                                     1 if silu else 0, _p(ws), _p(_gn_counters(x.device, B)), _p(stat_out), _s()), "ae_groupnorm_nhwc_bf16")
+                                     1 if silu else 0, _p(ws), _p(_gn_counters(x.device, B)), _p(stat_out), _p(colstats), _p(colstats2), _s()),
+          "ae_groupnorm_nhwc_bf16")
     return out
 
 
@@ -1023,7 +1060,7 @@ def _ln_label(_r, x, *a, **_):
     return f"layernorm_kernel|M={_r.shape[0]} C={_r.shape[1]}", 0.0, 2.0 * _r.numel() * 2
 
 
-def _ln_gemm_label(_r, x, w, bias, residual, gamma, beta, eps, epilogue, o, M, N, K):
+def _ln_gemm_label(_r, x, w, bias, residual, gamma, beta, eps, epilogue, o, M, N, K, colstats=None):
     nb = 2 * (M * K + N * K) + _r.numel() * 2 + (2 * M * N if residual is not None else 0)
     return f"gemm_rowpanel_kernel<K=320,LN{',geglu' if epilogue == EPI_GEGLU else ''}>|M={M} N={N}", 2.0 * M * N * K, nb
 

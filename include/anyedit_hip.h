@@ -42,10 +42,13 @@ int ae_device_info(int* cus, long* hbm_bytes, int* clock_khz);
  * :49-76 FeedForward/GEGLU, :296-318 proj_in/proj_out; openaimodel.py:233-240 skip 1x1, :526-531 time_embed, :214-219 emb_layers).
  *   C[M,N] = epi(A[M,K] @ W[N,K]^T); A2 != NULL: columns [Ksplit,K) of A come from A2 (skip-concat, openaimodel.py:780).
  *   K % 8 == 0, N % 4 == 0, rows 16-byte aligned.  addvec: fp32 [M/rows_per_batch, N] with row stride addvec_ld (0 = N).
- *   out_f32: C is fp32.                                                                                                   */
+ *   out_f32: C is fp32.
+ *   colstats (optional, fp32 [ceil(M/32)][N][2]): per-channel (sum, sum of squares) of the stored bf16 output over each 32-row
+ *   slab, produced by the GEMM's own epilogue where the tile plan allows (one extra pass over the L2-resident output otherwise):
+ *   hand it to ae_groupnorm_nhwc_bf16 and the GroupNorm that consumes C (util.py:217-219) runs without its statistics pass.  */
 int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, int Ksplit, const void* W, long ldw, void* C, long ldc,
                  int M, int N, int K, const float* bias, const void* residual, long ldr, const float* addvec, long addvec_ld,
-                 int rows_per_batch, int epilogue, int out_f32, void* stream);
+                 int rows_per_batch, int epilogue, int out_f32, float* colstats, void* stream);
 
 /* Row-panel GEMM for the short-K (K = 320) Linear layers of the 64x64 UNet level, with the LayerNorm of BasicTransformerBlock
  * (attention.py:263-265, 271-275: norm1 -> to_q|k|v, norm2 -> to_q, norm3 -> GEGLU projection) optionally fused in front:
@@ -56,7 +59,7 @@ int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, int Ksplit,
 int ae_ln_gemm_supported(int M, int N, int K, int epilogue);
 int ae_ln_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias,
                     const void* residual, long ldr, const float* ln_gamma, const float* ln_beta, float ln_eps, int epilogue,
-                    void* stream);
+                    float* colstats /* as for ae_gemm_bf16; NULL = none */, void* stream);
 
 /* 3x3 convolution, padding 1, as implicit GEMM (ResBlock in/out convs openaimodel.py:200-231, stem :536-542, head :726-730,
  * Downsample stride 2 :157-159, Upsample nearest-x2 + conv :108-118 via upsample2x=1).
@@ -68,7 +71,7 @@ int ae_ln_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, l
 long ae_conv3x3_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride, int upsample2x);
 int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float* addvec, long addvec_ld, const void* residual,
                     void* y, int B, int H, int W, int Cin, int Cout, int stride, int upsample2x, int out_f32, float* workspace,
-                    void* stream);
+                    float* colstats /* as for ae_gemm_bf16 (M = B*Ho*Wo, N = Cout); NULL = none */, void* stream);
 
 /* GroupNorm32 (+SiLU) (util.py:217-219 eps 1e-5; attention.py:88-89 eps 1e-6); input may be the channel-concat [x | x2].
  * workspace: fp32, ae_groupnorm_workspace_floats(B,HW,C,groups) elements.  act: 0 none, 1 SiLU.
@@ -79,8 +82,12 @@ int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float
  * stat_out: optional fp32 [B][groups][2] (mean, rstd) kept for ae_groupnorm_bwd_nhwc_bf16.                                      */
 int ae_groupnorm_rows_per_chunk(int HW, int C);
 long ae_groupnorm_workspace_floats(int B, int HW, int C, int groups);
+ * colstats / colstats2: optional per-channel slab statistics of x / x2 as written by the kernels that PRODUCED them (the `colstats`
+ * output of ae_gemm_bf16 / ae_ln_gemm_bf16 / ae_conv3x3_bf16: [B*HW/32][C1][2] and [B*HW/32][C-C1][2]; HW % 32 == 0).  With them the
+ * statistics pass over the activation is skipped: one block per (sample, group) folds the slab sums, then the apply launch runs.    */
 int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, const float* gamma, const float* beta, void* y, int B, int HW,
-                           int C, int groups, float eps, int act, float* workspace, int* counters, float* stat_out, void* stream);
+                           int C, int groups, float eps, int act, float* workspace, int* counters, float* stat_out,
+                           const float* colstats, const float* colstats2, void* stream);
 
 /* nn.LayerNorm over the last dim (attention.py:263-265 eps 1e-5; SAM image_encoder.py:166-182 / common.py:30-43 eps 1e-6). */
 int ae_layernorm_bf16(const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps, void* stream);

@@ -293,6 +293,91 @@ def test_groupnorm_shapes_and_concat(ops, B, HW, C, C1):
     check_close(y.reshape(B, HW, C), ref, what="groupnorm nhwc")
 
 
+def _slab_stats(y):
+    """fp32 reference of the producer statistics: per-channel (sum, sum of squares) of a bf16 [M, N] tensor over 32-row slabs."""
+    M, N = y.shape
+    yf = y.float().cpu().double()
+    pad = (-M) % 32
+    if pad:
+        yf = torch.cat([yf, torch.zeros(pad, N, dtype=torch.double)])
+    yf = yf.reshape(-1, 32, N)
+    return torch.stack([yf.sum(1), (yf * yf).sum(1)], -1)
+
+
+@pytest.mark.parametrize("kind,shape", [("conv", (12, 64, 64, 320, 320)),      # un-split 192x320 tile: statistics from the epilogue
+                                        ("conv", (12, 32, 32, 640, 640)),      # 8-wave 128x128 tile (32x32 level)
+                                        ("conv", (2, 32, 32, 64, 96)),         # small grid: stand-alone statistics pass
+                                        ("conv_s2", (12, 64, 64, 320, 320)),   # split-K plan (down-sampling conv): stand-alone pass
+                                        ("gemm", (12288, 640, 640)),           # proj_out of the 32x32 level: 128x128 dense tile
+                                        ("gemm", (49152, 320, 320)),           # proj_out of the 64x64 level: row-panel kernel + pass
+                                        ("gemm", (1000, 72, 64))])             # ragged: M % 32 != 0, N % 16 != 0
+def test_producer_colstats(ops, kind, shape):
+    """The per-channel slab statistics a producer hands to the consuming GroupNorm (`colstats=`) equal the statistics of the bf16
+    tensor it stored, whichever route produced them (CS epilogue or the stand-alone pass); the output itself is unchanged by asking."""
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    if kind.startswith("conv"):
+        B, H, W, Cin, Cout = shape
+        stride = 2 if kind == "conv_s2" else 1
+        x = torch.randn(B * H * W, Cin, generator=g, device=DEV).to(BF)
+        w = ops.pack_conv3x3(torch.randn(Cout, Cin, 3, 3, generator=g, device=DEV) / (3 * Cin ** 0.5))
+        bias = torch.randn(Cout, generator=g, device=DEV)
+        Ho = (H - 1) // stride + 1
+        res = torch.randn(B * Ho * Ho, Cout, generator=g, device=DEV).to(BF)
+        emb = torch.randn(B, Cout, generator=g, device=DEV)
+        y0, _, _ = ops.conv3x3(x, w, bias, B, H, W, addvec=emb, residual=res, stride=stride)
+        cs = ops.colstats_buffer(B * Ho * Ho, Cout, DEV)
+        cs.fill_(float("nan"))
+        y1, _, _ = ops.conv3x3(x, w, bias, B, H, W, addvec=emb, residual=res, stride=stride, colstats=cs)
+    else:
+        M, N, K = shape
+        a = torch.randn(M, K, generator=g, device=DEV).to(BF)
+        w = (torch.randn(N, K, generator=g, device=DEV) / K ** 0.5).to(BF)
+        bias = torch.randn(N, generator=g, device=DEV)
+        res = torch.randn(M, N, generator=g, device=DEV).to(BF)
+        y0 = ops.gemm(a, w, bias, residual=res)
+        cs = ops.colstats_buffer(M, N, DEV)
+        cs.fill_(float("nan"))
+        y1 = ops.gemm(a, w, bias, residual=res, colstats=cs)
+    assert torch.equal(y0, y1), "asking for statistics must not change the output"
+    ref = _slab_stats(y1)
+    got = cs.cpu().double()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max()), f"{kind} {shape}: {(got - ref).abs().max()} vs {ref.abs().max()}"
+
+
+@pytest.mark.parametrize("B,HW,C,C1", [(12, 4096, 320, None), (3, 1024, 960, 640), (2, 1024, 1920, 1280), (2, 4096, 640, 320)])
+def test_groupnorm_from_producer_statistics(ops, B, HW, C, C1):
+    """GroupNorm(+SiLU) fed with the producers' slab statistics (one or two sources; a group may straddle the concat boundary:
+    960 = 640 + 320 channels, 30 per group) against the fp32 reference and against the kernel's own statistics pass."""
+    from oracle import ldm_ref as L
+    g = torch.Generator().manual_seed(C + HW)
+    x = q(torch.randn(B, HW, C, generator=g) * 2 + 0.5)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    ref = L.silu(L.group_norm_nhwc_manual(x, gamma, beta, 1e-5))
+    xd = x.reshape(B * HW, C).to(DEV, BF)
+    parts = [xd] if C1 is None else [xd[:, :C1].contiguous(), xd[:, C1:].contiguous()]
+    stats = []
+    for t in parts:
+        cs = ops.colstats_buffer(t.shape[0], t.shape[1], DEV)
+        # the stand-alone producer (what ae_gemm_bf16 / ae_conv3x3_bf16 run when their tile plan has no statistics epilogue)
+        cs.copy_(_slab_stats(t).float().to(DEV))
+        stats.append(cs)
+    kw = dict(colstats=stats[0]) if C1 is None else dict(x2=parts[1], colstats=stats[0], colstats2=stats[1])
+    y = ops.groupnorm(parts[0], gamma.to(DEV), beta.to(DEV), B, HW, 1e-5, silu=True, **kw)
+    y_own = ops.groupnorm(parts[0], gamma.to(DEV), beta.to(DEV), B, HW, 1e-5, silu=True, **({} if C1 is None else dict(x2=parts[1])))
+    check_close(y.reshape(B, HW, C), ref, what="groupnorm from producer statistics")
+    assert rel_l2(y.float().cpu(), y_own.float().cpu()) < 2e-3      # a few bf16 outputs flip on the last statistics bit
+    stat = torch.empty(B, 32, 2, dtype=torch.float32, device=DEV)
+    ops.groupnorm(parts[0], gamma.to(DEV), beta.to(DEV), B, HW, 1e-5, silu=True, stat_out=stat, **kw)
+    xg = x.reshape(B, HW, 32, C // 32)
+    mean = xg.mean(dim=(1, 3))
+    assert float((stat[:, :, 0].cpu() - mean).abs().max()) < 1e-4
+    # a concat with statistics for only ONE source falls back to the kernel's own pass (same result as no statistics at all)
+    if C1 is not None:
+        y_half = ops.groupnorm(parts[0], gamma.to(DEV), beta.to(DEV), B, HW, 1e-5, silu=True, x2=parts[1], colstats=stats[0])
+        assert torch.equal(y_half, y_own)
+
+
 @pytest.mark.parametrize("M,C,eps", [(10, 64, 1e-5), (4096, 320, 1e-5), (777, 1280, 1e-6), (5, 2048, 1e-5)])
 def test_layernorm(ops, M, C, eps):
     g = torch.Generator().manual_seed(M + C)

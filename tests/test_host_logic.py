@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_error_reporting_without_gpu():
     from anyedit_amd import _lib
-    rc = _lib.lib.ae_gemm_bf16(None, 0, None, 0, 0, None, 0, None, 0, 1, 4, 64, None, None, 0, None, 0, 0, 0, 0, None)
+    rc = _lib.lib.ae_gemm_bf16(None, 0, None, 0, 0, None, 0, None, 0, 1, 4, 64, None, None, 0, None, 0, 0, 0, 0, None, None)
     assert rc == -1 and b"null pointer" in _lib.lib.ae_last_error()
     rc = _lib.lib.ae_ddim_step_f32(1, 1, None, 1, None, None, 10, 7, 0, 0, 0, 0, 0, 0, 0, 0, None)
     assert rc == -1 and b"branches" in _lib.lib.ae_last_error()
@@ -406,16 +406,16 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
         msg = lib.ae_last_error().decode()
         assert fragment in msg, msg
 
-    expect(lib.ae_gemm_bf16(None, 64, None, 0, 0, p16, 64, p16, 64, 8, 8, 64, None, None, 0, None, 0, 0, 0, 0, None), "null pointer")
-    expect(lib.ae_gemm_bf16(p16, 64, None, 0, 0, p16, 64, p16, 64, 0, 8, 64, None, None, 0, None, 0, 0, 0, 0, None), "must be positive")       # empty M
-    expect(lib.ae_gemm_bf16(p16, 64, None, 0, 0, p16, 64, p16, 64, 8, 8, 60, None, None, 0, None, 0, 0, 0, 0, None), "multiple of 8")           # ragged K
-    expect(lib.ae_gemm_bf16(p16 + 2, 64, None, 0, 0, p16, 64, p16, 64, 8, 8, 64, None, None, 0, None, 0, 0, 0, 0, None), "16-byte aligned")    # misaligned A
-    expect(lib.ae_gemm_bf16(p16, 64, None, 0, 0, p16, 64, p16, 64, 8, 8, 64, None, None, 0, None, 0, 0, 9, 0, None), "bad epilogue")
-    expect(lib.ae_conv3x3_bf16(p16, p16, None, None, 0, None, p16, 0, 8, 8, 64, 64, 1, 0, 0, None, None), "bad shape")                           # empty batch
-    expect(lib.ae_conv3x3_bf16(p16, p16, None, None, 0, None, p16, 1, 8, 8, 60, 64, 1, 0, 0, None, None), "multiple of 8")
-    expect(lib.ae_conv3x3_bf16(p16, p16, None, None, 0, None, p16, 1, 8, 8, 64, 64, 3, 0, 0, None, None), "stride must be 1 or 2")
-    expect(lib.ae_groupnorm_nhwc_bf16(p16, None, 0, p16, p16, p16, 1, 64, 60, 32, 1e-5, 0, p16, None, None, None), "bad shape")                  # C % groups
-    expect(lib.ae_groupnorm_nhwc_bf16(p16, None, 0, p16, p16, p16, 1, 64, 64, 32, 1e-5, 7, p16, None, None, None), "act must be")
+    expect(lib.ae_gemm_bf16(None, 64, None, 0, 0, p16, 64, p16, 64, 8, 8, 64, None, None, 0, None, 0, 0, 0, 0, None, None), "null pointer")
+    expect(lib.ae_gemm_bf16(p16, 64, None, 0, 0, p16, 64, p16, 64, 0, 8, 64, None, None, 0, None, 0, 0, 0, 0, None, None), "must be positive")       # empty M
+    expect(lib.ae_gemm_bf16(p16, 64, None, 0, 0, p16, 64, p16, 64, 8, 8, 60, None, None, 0, None, 0, 0, 0, 0, None, None), "multiple of 8")           # ragged K
+    expect(lib.ae_gemm_bf16(p16 + 2, 64, None, 0, 0, p16, 64, p16, 64, 8, 8, 64, None, None, 0, None, 0, 0, 0, 0, None, None), "16-byte aligned")    # misaligned A
+    expect(lib.ae_gemm_bf16(p16, 64, None, 0, 0, p16, 64, p16, 64, 8, 8, 64, None, None, 0, None, 0, 0, 9, 0, None, None), "bad epilogue")
+    expect(lib.ae_conv3x3_bf16(p16, p16, None, None, 0, None, p16, 0, 8, 8, 64, 64, 1, 0, 0, None, None, None), "bad shape")                           # empty batch
+    expect(lib.ae_conv3x3_bf16(p16, p16, None, None, 0, None, p16, 1, 8, 8, 60, 64, 1, 0, 0, None, None, None), "multiple of 8")
+    expect(lib.ae_conv3x3_bf16(p16, p16, None, None, 0, None, p16, 1, 8, 8, 64, 64, 3, 0, 0, None, None, None), "stride must be 1 or 2")
+    expect(lib.ae_groupnorm_nhwc_bf16(p16, None, 0, p16, p16, p16, 1, 64, 60, 32, 1e-5, 0, p16, None, None, None, None, None), "bad shape")                  # C % groups
+    expect(lib.ae_groupnorm_nhwc_bf16(p16, None, 0, p16, p16, p16, 1, 64, 64, 32, 1e-5, 7, p16, None, None, None, None, None), "act must be")
     expect(lib.ae_layernorm_bf16(p16, p16, p16, p16, 4, 60, 1e-5, None), "multiple of 8")
     expect(lib.ae_expert_kv_fwd(p16, p16, p16, p16, 2, 9, 64, 64, 2, None), "unsupported shape")                                                 # more than 8 tokens per sample
     expect(lib.ae_split_channels_bf16(p16, 12, 8, p16, p16, 4, 0, 0, None), "bad arguments")
