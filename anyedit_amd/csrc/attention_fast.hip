@@ -32,7 +32,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4v;
 
 constexpr int FKT = 64;  // keys per LDS tile
 #ifndef AE_ATTN_V_DEFAULT
-#define AE_ATTN_V_DEFAULT 0   // default variant of the plain long-sequence kernel (see launch_fast); decided by measurement
+#define AE_ATTN_V_DEFAULT 3   // default variant of the plain long-sequence kernel (see launch_fast): decided by measurement
 #endif
 constexpr float FLOG2E = 1.4426950408889634f;
 constexpr float RESCALE_THR = 8.0f;  // log2 units
@@ -483,16 +483,17 @@ int launch_fast(const AttnArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL((attn_fast_kernel<D, (D > 64 ? 2 : 3), true>), grid, block, 0, stream, a);  // 168 VGPRs spill at head_dim 80
         return ae_check_launch("ae_attn_fwd_bf16(fast)");
     }
-    // Variants of the plain long-sequence kernel (tuning knob AE_ATTN_V, bit flags): 1 = conflict-free V image (VSPLIT), 2 = two query
-    // groups per wave (QG = 2: 64 queries per wave, 256 per block) for sequences long enough to fill the chip with the larger blocks.
+    // Variants of the plain long-sequence kernel (tuning knob AE_ATTN_V): 0 = one 32-query group per wave, V rows of 2 D bytes (round 2);
+    // 1 = conflict-free V image (VSPLIT); 3 = VSPLIT + two query groups per wave (QG = 2: 64 queries per wave, 256 per block) where the
+    // sequence is long enough to fill the chip with the larger blocks.  Measured (kbench, UNet batch 12, N = 4096, d = 40, one box):
+    // 388.5 / 376.9 / 361.2 us for 0 / 1 / 3; in situ 13.78 -> 13.67 ms per UNet step (profiles/r03_v2_*).  QG = 2 on the row-major V
+    // image (the former value 2) measured 367.7 us and is not kept: one variant fewer to validate.
     static const int var_env = getenv("AE_ATTN_V") ? atoi(getenv("AE_ATTN_V")) : AE_ATTN_V_DEFAULT;
     const bool qg2 = (var_env & 2) && (long)((a.Nq + 255) / 256) * a.B * a.H >= 1024;
-    const bool vs = (var_env & 1) != 0;
     if (qg2) {
         dim3 grid2((unsigned)((long)((a.Nq + 255) / 256) * a.B * a.H));
-        if (vs) hipLaunchKernelGGL((attn_fast_kernel<D, 2, false, 0, 0, 2, true>), grid2, block, 0, stream, a);
-        else hipLaunchKernelGGL((attn_fast_kernel<D, 2, false, 0, 0, 2, false>), grid2, block, 0, stream, a);
-    } else if (vs) hipLaunchKernelGGL((attn_fast_kernel<D, 3, false, 0, 0, 1, true>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((attn_fast_kernel<D, 2, false, 0, 0, 2, true>), grid2, block, 0, stream, a);
+    } else if (var_env & 1) hipLaunchKernelGGL((attn_fast_kernel<D, 3, false, 0, 0, 1, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((attn_fast_kernel<D, 3, false>), grid, block, 0, stream, a);
     return ae_check_launch("ae_attn_fwd_bf16(fast)");
 }

@@ -65,7 +65,68 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const MsdaArgs p) {
     }
 }
 
+// ---- fp32 Linear for the four small projections of MultiScaleDeformableAttention (ms_deform_attn.py:281-288, 330-352: value_proj,
+// sampling_offsets, attention_weights, output_proj).  GroundingDINO runs in fp32 and its sampling offsets feed bilinear gathers, so
+// these stay EXACT fp32: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate = an fmaf chain; 1/16 of the bf16 MFMA rate, far above what
+// the 13 k-token x 256-channel problems need).  C[M,N] = A[M,K] W[N,K]^T + bias.  One wave owns a 32 x 32 output tile; the K order
+// inside a 16-wide step is permuted identically on both operands (lane group g carries k = 4 g .. 4 g + 3 of the step as ONE
+// 16-byte load and feeds component s to MFMA s), so no LDS staging is needed.  D[i][j]: lane holds i = 4 g + r, j = l15.
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* A, long lda, const float* W, long ldw, const float* bias, float* C,
+                                                         long ldc, int M, int N, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int ntn = (N + 63) / 64;
+    const int m0 = (blockIdx.x / ntn) * 64 + (wave >> 1) * 32, n0 = (blockIdx.x % ntn) * 64 + (wave & 1) * 32;
+    const float* a0 = A + (long)min(m0 + l15, M - 1) * lda + 4 * g;        // clamped rows / columns: their products are never stored
+    const float* a1 = A + (long)min(m0 + 16 + l15, M - 1) * lda + 4 * g;
+    const float* w0 = W + (long)min(n0 + l15, N - 1) * ldw + 4 * g;
+    const float* w1 = W + (long)min(n0 + 16 + l15, N - 1) * ldw + 4 * g;
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const f32x4_t av[2] = {*reinterpret_cast<const f32x4_t*>(a0 + k0), *reinterpret_cast<const f32x4_t*>(a1 + k0)};
+        const f32x4_t wv[2] = {*reinterpret_cast<const f32x4_t*>(w0 + k0), *reinterpret_cast<const f32x4_t*>(w1 + k0)};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][s4], wv[j][s4], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + 16 * j + l15;
+            if (n >= N) continue;
+            const float bz = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * i + 4 * g + r;
+                if (m < M) C[(long)m * ldc + n] = acc[i][j][r] + bz;
+            }
+        }
+}
+
 }  // namespace
+
+// nn.Linear in exact fp32 (A [M,K], W [N,K], bias [N] or NULL -> C [M,N]); K % 16 == 0, rows of A and W 16-byte aligned.
+extern "C" int ae_linear_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc, int M, int N, int K,
+                             void* stream) {
+    AE_REQUIRE(A && W && C, "ae_linear_f32: null pointer");
+    AE_REQUIRE(M > 0 && N > 0 && K > 0 && K % 16 == 0, "ae_linear_f32: M=%d N=%d must be positive, K=%d a positive multiple of 16", M, N, K);
+    AE_REQUIRE(lda % 4 == 0 && ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0,
+               "ae_linear_f32: rows of A and W must be 16-byte aligned");
+    const long blocks = (long)((M + 63) / 64) * ((N + 63) / 64);
+    AE_REQUIRE(blocks < (1L << 31), "ae_linear_f32: grid too large");
+    hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, A, lda, W, ldw, bias, C, ldc, M, N, K);
+    return ae_check_launch("ae_linear_f32");
+}
 
 // Drop-in for `_C.ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)`
 // (csrc/vision.cpp:53-56): same tensors as raw device pointers (spatial_shapes / level_start_index are int64 as the reference

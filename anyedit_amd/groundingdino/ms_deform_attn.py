@@ -3,8 +3,8 @@ GroundingDINO/groundingdino/models/GroundingDINO/ms_deform_attn.py:136-352 (SURV
 
 Same constructor, parameter names (`sampling_offsets`, `attention_weights`, `value_proj`, `output_proj`) and forward contract, so
 a GroundingDINO checkpoint's encoder / decoder layers load unchanged.  The sampling core — the reference's only native operator,
-`_C.ms_deform_attn_forward` — is `ae_ms_deform_attn_fwd_f32`; the four small fp32 projections stay nn.Linear (plain library
-GEMMs: GroundingDINO runs in fp32 and is outside the bf16 denoising path).
+`_C.ms_deform_attn_forward` — is `ae_ms_deform_attn_fwd_f32`; the four small projections are exact-fp32 MFMA GEMMs (`ae_linear_f32`:
+GroundingDINO runs in fp32 and the sampling offsets are coordinates, so they do not go through the bf16 GEMM).
 """
 import math
 import warnings
@@ -97,14 +97,15 @@ class MultiScaleDeformableAttention(nn.Module):
         bs, nq, _ = q.shape
         ns = src.shape[1]
         assert int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum()) == ns
-        v = self.value_proj(src)
+        lin = lambda m, t: ops.linear_f32(t.float(), m.weight, m.bias)   # exact fp32 (f32-input MFMA), no torch / library GEMM
+        v = lin(self.value_proj, src)
         if key_padding_mask is not None:
             v = v.masked_fill(key_padding_mask[..., None], 0.0)
         H, L, P = self.num_heads, self.num_levels, self.num_points
-        offsets = self.sampling_offsets(q).view(bs, nq, H, L, P, 2)
-        weights = self.attention_weights(q).view(bs, nq, H, L * P).softmax(-1).view(bs, nq, H, L, P)
+        offsets = lin(self.sampling_offsets, q).view(bs, nq, H, L, P, 2)
+        weights = lin(self.attention_weights, q).view(bs, nq, H, L * P).softmax(-1).view(bs, nq, H, L, P)
         loc = self._locations(reference_points, offsets, spatial_shapes)
         out = multi_scale_deformable_attn(v.view(bs, ns, H, -1).float(), spatial_shapes, level_start_index, loc.float(),
                                           weights.float(), self.im2col_step)
-        out = self.output_proj(out.to(v.dtype))
+        out = lin(self.output_proj, out).to(query.dtype)
         return out if self.batch_first else out.permute(1, 0, 2)

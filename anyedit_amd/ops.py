@@ -610,6 +610,25 @@ def ms_deform_attn(value, spatial_shapes, level_start_index, sampling_locations,
     return out
 
 
+def linear_f32(x, w, bias=None):
+    """nn.Linear in exact fp32 on the f32-input MFMA (ae_linear_f32): x [..., K] fp32, w [N, K] fp32, bias [N] -> [..., N] fp32.
+    For layers the reference runs in fp32 and whose outputs are coordinates (GroundingDINO MSDeformAttn); K % 16 == 0."""
+    _chk(x, torch.float32, "linear_f32.x")
+    _chk(w, torch.float32, "linear_f32.w", 2)
+    K = x.shape[-1]
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"linear_f32: x has {K} features, w has {w.shape[1]}")
+    x2 = _tmp(x.reshape(-1, K).contiguous())
+    w2 = _tmp(w.detach().contiguous())
+    b2 = _tmp(bias.detach().float().contiguous()) if bias is not None else None
+    M = x2.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    if M > 0:
+        check(lib.ae_linear_f32(_p(x2), K, _p(w2), K, _p(b2), _p(out), N, M, N, K, _s()), "ae_linear_f32")
+    return out.reshape(*x.shape[:-1], N)
+
+
 def layernorm_act(x, gamma, beta, eps=1e-6, gelu=True, out=None):
     """LayerNorm over a narrow last dim (C <= 512) with fused GELU: the LayerNorm2d + GELU of the SAM mask decoder on rows."""
     _chk(x, BF16, "layernorm_act.x", 2)

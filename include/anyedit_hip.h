@@ -249,6 +249,11 @@ int ae_gaussian_moments_f32(const float* moments, const float* noise, float* z, 
  * [bs, Q, heads, L, P, 2] in [0,1] (x, y), attn_weight [bs, Q, heads, L, P]; out [bs, Q, heads*d] fp32.                      */
 int ae_ms_deform_attn_fwd_f32(const float* value, const long* spatial_shapes, const long* level_start_index, const float* sampling_loc,
                               const float* attn_weight, float* out, int bs, int S, int heads, int d, int Q, int L, int P, void* stream);
+/* nn.Linear in EXACT fp32 (v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate) for the four projections of GroundingDINO's
+ * MultiScaleDeformableAttention (ms_deform_attn.py:281-288, 330-352: value_proj, sampling_offsets, attention_weights, output_proj),
+ * which run in fp32 in the reference and feed bilinear sampling locations.  C[M,N] = A[M,K] W[N,K]^T + bias; K % 16 == 0.       */
+int ae_linear_f32(const float* A, long lda, const float* W, long ldw, const float* bias, float* C, long ldc, int M, int N, int K,
+                  void* stream);
 
 /* DPM-Solver / DPM-Solver++ multistep step (ldm/models/diffusion/dpm_solver/dpm_solver.py:246-316 guidance, :352-365 data prediction,
  * :469-513 first-order and :723-777 second-order multistep updates): m = predict_x0 ? (x - sigma_s e)/alpha_s : e with e the guided

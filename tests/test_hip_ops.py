@@ -467,6 +467,27 @@ def test_attention_key_permutation_invariance_full_size(ops):
     assert float((shift - a - 3.0).abs().max()) < 6e-2
 
 
+def test_attention_two_query_groups_vs_oracle(ops):
+    """The 64-queries-per-wave variant of the long-sequence kernel (attention_fast.hip, QG = 2) only runs on grids of >= 1024 blocks
+    of 256 queries — no small test reaches it.  B*H = 64 heads of N = 4096, d = 40 (the UNet's 64x64-level shape at a smaller batch):
+    six of the heads, and the last query block, against the fp32 oracle."""
+    from oracle import ldm_ref as L
+    g = torch.Generator().manual_seed(640)
+    BH, N, D = 64, 4096, 40
+    qq, kk, vv = (torch.randn(BH, N, D, generator=g).to(BF) for _ in range(3))
+    kk[:, 100] *= 6.0          # one key far above the rest: the lazy offset moves in SOME query groups only
+    out = ops.attention_bhnd(qq.to(DEV), kk.to(DEV), vv.to(DEV)).float().cpu()
+    for h in (0, 1, 17, 31, 32, 63):
+        ref = L.sdpa_core(qq[h:h + 1].float(), kk[h:h + 1].float(), vv[h:h + 1].float(), D ** -0.5)
+        check_close(out[h:h + 1], ref, rl2=6e-3, mabs=3e-2, what=f"attention QG=2 head {h}")
+    # ragged query count: the second query group of the last wave is partly / wholly out of range
+    Nq = 4096 - 40
+    out2 = ops.attention_bhnd(qq[:, :Nq].contiguous().to(DEV), kk.to(DEV), vv.to(DEV)).float().cpu()
+    assert torch.equal(out2[:, :3840], out[:, :3840]), "rows must not depend on how many other queries the launch holds"
+    # (the last block's waves hold clamped duplicate rows instead of rows 4056..4095: they may move the shared lazy offset at other tiles)
+    check_close(out2[:, 3840:], out[:, 3840:Nq], rl2=4e-3, mabs=2e-2, what="attention QG=2 ragged tail block")
+
+
 def test_conv3x3_linearity_and_groupnorm_scale_invariance_full_size(ops):
     """BASELINE-size layer ([12, 320, 64, 64] -> 320): conv(x1 + x2) = conv(x1) + conv(x2) - bias; GroupNorm(c x) = GroupNorm(x)."""
     g = torch.Generator(device=DEV).manual_seed(22)
@@ -639,6 +660,19 @@ def test_ms_deform_attn_forward(ops):
     ref = MS.ms_deform_attn(value, shapes, start, loc, w)
     out = ops.ms_deform_attn(value.to(DEV), shapes.to(DEV), start.to(DEV), loc.to(DEV), w.to(DEV))
     check_close(out, ref, rl2=1e-5, mabs=1e-5, what="ms_deform_attn 900 queries x 4 levels")
+
+
+@pytest.mark.parametrize("M,N,K", [(13294, 256, 256), (900, 128, 256), (100, 48, 64), (1, 4, 16), (65, 96, 64)])
+def test_linear_f32_exact(ops, M, N, K):
+    """ae_linear_f32 (f32-input MFMA, the MSDeformAttn projections) against fp64: fp32 round-off only — these layers feed sampling
+    COORDINATES, so they must not go through the bf16 GEMM."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    ref = (x.double() @ w.double().t() + b.double()).float()
+    out = ops.linear_f32(x.to(DEV), w.to(DEV), b.to(DEV))
+    check_close(out, ref, rl2=2e-6, mabs=1e-5, what=f"linear_f32 {M}x{N}x{K}")
+    out3 = ops.linear_f32(x.reshape(1, M, K).to(DEV), w.to(DEV))          # leading dims, no bias
+    check_close(out3.reshape(M, N), (x.double() @ w.double().t()).float(), rl2=2e-6, mabs=1e-5, what="linear_f32 no bias")
 
 
 def test_ms_deform_attn_module_golden():
