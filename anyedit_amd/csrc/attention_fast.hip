@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     int seg_nk = p.Nk;
     int kcur = 0, klast = 0, vcur = 0, vlast = 0;
 
+    u32x4 hold = {0u, 0u, 0u, 0u};  // QG = 2: P registers of the previous block's last K-step (see the end of block())
     // one 32-key block of the current tile
     auto block = [&](auto blk_tag, int k0, bool first, bool tail) {
         constexpr int B2 = decltype(blk_tag)::value;
@@ -219,40 +220,44 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
             for (int gq = 0; gq < QG; ++gq)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[gq][r] = -(float)(r + l31) - mt[gq];
-        } else
+        } else {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int ka = (QSLOT && ks == KS - 1) ? klast + BO : kcur + BO + ks * 32;
-            const bf16x8_t kf = as_bf16x8(*reinterpret_cast<const u32x4*>(smem + ka));   // one K fragment feeds every query group
+            for (int ks = 0; ks < KS; ++ks) {
+                const int ka = (QSLOT && ks == KS - 1) ? klast + BO : kcur + BO + ks * 32;
+                const bf16x8_t kf = as_bf16x8(*reinterpret_cast<const u32x4*>(smem + ka));   // one K fragment feeds every query group
 #pragma unroll
-            for (int gq = 0; gq < QG; ++gq) {
-                if (ks == 0 && QSLOT) {
-                    f32x16 z;
+                for (int gq = 0; gq < QG; ++gq) {
+                    if (ks == 0 && QSLOT) {
+                        f32x16 z;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                    s[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[gq][ks]), z, 0, 0, 0);
-                } else if (BIAS2 && ks == 0) {
-                    f32x16 c0;
-                    const float hb = rh_tile - mt[gq];
+                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                        s[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[gq][ks]), z, 0, 0, 0);
+                    } else if (BIAS2 && ks == 0) {
+                        f32x16 c0;
+                        const float hb = rh_tile - mt[gq];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) c0[r] = wb[BIAS2 ? B2 : 0][r] + hb;
-                    s[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[gq][ks]), c0, 0, 0, 0);
-                } else if (BIAS1 && ks == 0) {
-                    f32x16 c0;
-                    const float* row = sbias + (wave * 32 + l31) * 33;
+                        for (int r = 0; r < 16; ++r) c0[r] = wb[BIAS2 ? B2 : 0][r] + hb;
+                        s[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[gq][ks]), c0, 0, 0, 0);
+                    } else if (BIAS1 && ks == 0) {
+                        f32x16 c0;
+                        const float* row = sbias + (wave * 32 + l31) * 33;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        // key -> (row, column) of the key grid without an integer division: (key + 0.5) / kW is never closer than
-                        // 0.5 / kW to an integer, far above the fp32 error for a grid of at most 16 x 16
-                        const int key = min(k0 + B2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, seg_nk - 1);
-                        const int kh = (int)(((float)key + 0.5f) * inv_kw);
-                        c0[r] = row[kh] + row[16 + key - kh * p.kW] - mt[gq];
+                        for (int r = 0; r < 16; ++r) {
+                            // key -> (row, column) of the key grid without an integer division: (key + 0.5) / kW is never closer than
+                            // 0.5 / kW to an integer, far above the fp32 error for a grid of at most 16 x 16
+                            const int key = min(k0 + B2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, seg_nk - 1);
+                            const int kh = (int)(((float)key + 0.5f) * inv_kw);
+                            c0[r] = row[kh] + row[16 + key - kh * p.kW] - mt[gq];
+                        }
+                        s[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[gq][ks]), c0, 0, 0, 0);
+                    } else {
+                        s[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[gq][ks]), ks == 0 ? cinit[gq] : s[gq], 0, 0, 0);
                     }
-                    s[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[gq][ks]), c0, 0, 0, 0);
-                } else {
-                    s[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[gq][ks]), ks == 0 ? cinit[gq] : s[gq], 0, 0, 0);
                 }
             }
+            // the P registers of the previous block's last K-step (`hold`) are free from here on: six more MFMAs are in the pipe behind
+            // the one that read them
+            if (QG > 1) asm volatile("" ::"v"(hold));
         }
         if (ABL == 10 || ABL == 12) __builtin_amdgcn_s_setprio(0);
         if (ABL == 11) __builtin_amdgcn_s_setprio(1);
@@ -323,13 +328,13 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
                     va = (db == LDB ? vlast : vcur + db * 64) + BO + kk * 16 * ROWB;
                     vstep = 8 * ROWB;
                 }
-                if (ABL == 3) {  // no V reads, no PV MFMA (P kept alive)
+                if (ABL == 3) {  // lab: no V reads, no PV MFMA (P kept alive)
 #pragma unroll
                     for (int gq = 0; gq < QG; ++gq) asm volatile("" ::"v"(pk[gq][4 * kk]), "v"(pk[gq][4 * kk + 3]));
                     continue;
                 }
                 bf16x8_t vf;
-                if (ABL == 5) vf = as_bf16x8(qf[0][0]);  // no V reads
+                if (ABL == 5) vf = as_bf16x8(qf[0][0]);  // lab: no V reads
                 else vf = cat_tr(lds_tr16(smem + va), lds_tr16(smem + va + vstep));
 #pragma unroll
                 for (int gq = 0; gq < QG; ++gq) {
@@ -337,6 +342,20 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
                     o[gq][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[gq][db], 0, 0, 0);
                 }
             }
+        }
+        if (QG > 1) {
+            // gfx950 / hipcc hazard (found with tools/diag_attn.py, profiles/r03_attn_qg2_hazard.txt): with two query groups the
+            // scheduler lays group B's exp2 / convert work between group A's PV MFMAs and REUSES A's P registers for it — a VALU
+            // write to an MFMA's SrcB registers one instruction after that v_mfma_f32_32x32x16_bf16 was issued.  The MFMA has not
+            // finished reading the operand by then: lanes 16-31 / 48-63 (query columns 16-31) pick up the new value, run-to-run
+            // different.  hipcc inserts no wait states for this write-after-read.  So every P register of the block stays a live
+            // value until the block's last MFMA has been issued (these empty asm statements are uses), and the last K-step's until
+            // the next block's QK^T MFMAs are out (`hold`).
+#pragma unroll
+            for (int gq = 0; gq < QG; ++gq)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(pk[gq][j]));
+            hold = (u32x4){pk[0][4], pk[0][7], pk[QG - 1][4], pk[QG - 1][7]};
         }
     };
 
@@ -489,10 +508,12 @@ int launch_fast(const AttnArgs& a, hipStream_t stream) {
     // 388.5 / 376.9 / 361.2 us for 0 / 1 / 3; in situ 13.78 -> 13.67 ms per UNet step (profiles/r03_v2_*).  QG = 2 on the row-major V
     // image (the former value 2) measured 367.7 us and is not kept: one variant fewer to validate.
     static const int var_env = getenv("AE_ATTN_V") ? atoi(getenv("AE_ATTN_V")) : AE_ATTN_V_DEFAULT;
-    const bool qg2 = (var_env & 2) && (long)((a.Nq + 255) / 256) * a.B * a.H >= 1024;
+    const bool qg2 = (var_env & 2) && D <= 48 && (long)((a.Nq + 255) / 256) * a.B * a.H >= 1024;   // head_dim 80 would spill with two groups
     if (qg2) {
-        dim3 grid2((unsigned)((long)((a.Nq + 255) / 256) * a.B * a.H));
-        hipLaunchKernelGGL((attn_fast_kernel<D, 2, false, 0, 0, 2, true>), grid2, block, 0, stream, a);
+        if constexpr (D <= 48) {
+            dim3 grid2((unsigned)((long)((a.Nq + 255) / 256) * a.B * a.H));
+            hipLaunchKernelGGL((attn_fast_kernel<D, 3, false, 0, 0, 2, true>), grid2, block, 0, stream, a);   // 3 waves per SIMD: 168 VGPRs
+        }
     } else if (var_env & 1) hipLaunchKernelGGL((attn_fast_kernel<D, 3, false, 0, 0, 1, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((attn_fast_kernel<D, 3, false>), grid, block, 0, stream, a);
     return ae_check_launch("ae_attn_fwd_bf16(fast)");

@@ -11,6 +11,7 @@
 // (16-byte loads/stores), SiLU fused.  The input may be the channel-concat
 // of two tensors (decoder skip connections, openaimodel.py:780) — read in place, never materialised.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -695,6 +696,59 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, const f
     }
 }
 
+// LayerNorm with L lanes per row and NCH 16-byte chunks per lane (C = 8 L NCH: 320 / 640 / 1280 / 2560 channels as 8 / 16 / 32 / 64
+// lanes x 5 chunks): 64 / L rows per wave, every lane busy, NCH loads in flight per lane, gamma / beta as 16-byte loads at their use.
+// The one-row-per-wave kernel above leaves 48 of 64 lanes idle on its second chunk at C = 640 and keeps one row per wave in flight:
+// 12.8 us for the 31 MB of a [12288, 640] LayerNorm (2.4 TB/s, profiles/r03_v1_kernels_by_shape.json).
+template <int L, int NCH>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int M, int C,
+                                                             float eps) {
+    const int lane = threadIdx.x & 63, sub = lane % L;
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / L) + lane / L;
+    const bool live = row < M;
+    const long rowc = live ? row : (long)M - 1;
+    u32x4 v[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) v[i] = *reinterpret_cast<const u32x4*>(x + rowc * C + (sub + i * L) * 8);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += bf16lo(w[e]) + bf16hi(w[e]);
+    }
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mu = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = bf16lo(w[e]) - mu, c = bf16hi(w[e]) - mu;
+            q += a * a + c * c;
+        }
+    }
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c0 = (sub + i * L) * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0), g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c0), b1 = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
+        const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        u32x4 o;
+        o.x = pack_bf16x2((bf16lo(w[0]) - mu) * rstd * g0[0] + b0[0], (bf16hi(w[0]) - mu) * rstd * g0[1] + b0[1]);
+        o.y = pack_bf16x2((bf16lo(w[1]) - mu) * rstd * g0[2] + b0[2], (bf16hi(w[1]) - mu) * rstd * g0[3] + b0[3]);
+        o.z = pack_bf16x2((bf16lo(w[2]) - mu) * rstd * g1[0] + b1[0], (bf16hi(w[2]) - mu) * rstd * g1[1] + b1[1]);
+        o.w = pack_bf16x2((bf16lo(w[3]) - mu) * rstd * g1[2] + b1[2], (bf16hi(w[3]) - mu) * rstd * g1[3] + b1[3]);
+        *reinterpret_cast<u32x4*>(y + row * C + c0) = o;
+    }
+}
+
 // LayerNorm over a narrow last dim (C <= 512) with an optional fused GELU: L = pow2 lanes per row, 64 / L rows per wave, so the
 // LayerNorm2d + GELU pairs of the SAM mask decoder (mask_decoder.py:53-60; C = 64 over 16384*B pixels) keep every lane busy.
 template <int L, int ACT>
@@ -867,6 +921,18 @@ extern "C" int ae_layernorm_bf16(const void* x, const float* gamma, const float*
     dim3 grid((M + 3) / 4), block(256);
     const int ncc = C / 8;
     hipStream_t s = (hipStream_t)stream;
+    // C = 40 L channels (the UNet's 320 / 640 / 1280, SAM's 1280): several rows per wave, all lanes busy.  AE_LN_ROWS=0: round-2 kernel (A/B)
+    static const int rows_kernel = getenv("AE_LN_ROWS") ? atoi(getenv("AE_LN_ROWS")) : 1;
+    const bool al16 = (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0;
+    if (rows_kernel && al16 && ncc % 5 == 0 && (ncc == 40 || ncc == 80 || ncc == 160 || ncc == 320)) {
+        const int L = ncc / 5, rpb = 4 * (64 / L);
+        dim3 g2((unsigned)((M + rpb - 1) / rpb));
+        if (L == 8) hipLaunchKernelGGL((layernorm_rows_kernel<8, 5>), g2, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);
+        else if (L == 16) hipLaunchKernelGGL((layernorm_rows_kernel<16, 5>), g2, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);
+        else if (L == 32) hipLaunchKernelGGL((layernorm_rows_kernel<32, 5>), g2, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);
+        else hipLaunchKernelGGL((layernorm_rows_kernel<64, 5>), g2, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);
+        return ae_check_launch("ae_layernorm_bf16");
+    }
     if (ncc <= 64) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);
     else if (ncc <= 128) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);
     else if (ncc <= 192) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);

@@ -73,6 +73,21 @@ def test_unet_full_size_vs_oracle_with_bf16_control(latent):
     assert e_hip <= 2e-2 and psnr(got, ref) >= 45.0
 
 
+def test_unet_full_size_run_to_run_determinism():
+    """The SD-1.5-shaped UNet at the bench batch (12) gives bit-identical outputs over repeated evaluations: every kernel on the path
+    sums in a fixed order, and no launch may depend on timing (see tests/test_hip_ops.py::test_attention_run_to_run_determinism_full_size)."""
+    moe, _ = _model()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(12, 8, 64, 64, generator=g).to(DEV)
+    t = torch.randint(0, 1000, (12,), generator=g).to(DEV)
+    ctx = torch.randn(12, 77, 768, generator=g).to(DEV)
+    with torch.no_grad():
+        first = moe.unet(x, t, context=ctx)
+        for i in range(5):
+            again = moe.unet(x, t, context=ctx)
+            assert torch.equal(again, first), f"evaluation {i + 1} differs from evaluation 0 in {int((again != first).sum())} elements"
+
+
 def test_masked_edit_5_steps_cfg_full_size_96():
     """configs[4] geometry: B = 1 edit, 3 CFG branches (7.5 / 1.5), 5 DDIM steps, mask / x0 blend at 96x96 latents, AnySD routing
     and adapters on; HIP pipeline vs oracle.ddim_ref.ip2p_edit_loop on the same weights and the same blend noise."""

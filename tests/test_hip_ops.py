@@ -467,6 +467,27 @@ def test_attention_key_permutation_invariance_full_size(ops):
     assert float((shift - a - 3.0).abs().max()) < 6e-2
 
 
+def test_attention_run_to_run_determinism_full_size(ops):
+    """Bit-identical results over repeated launches at the BASELINE shape.  Guards a hazard met while building the two-query-group
+    kernel (attention_fast.hip: a VALU write to the SrcB registers of a just-issued v_mfma_f32_32x32x16_bf16 changed query columns
+    16-31 of the second group in ~1 of 6 launches, profiles/r03_attn_qg2_hazard.txt) — a parity test that compares one launch with
+    the oracle passes most of the time with such a bug."""
+    g = torch.Generator(device=DEV).manual_seed(23)
+    BH, N, D = 96, 4096, 40
+    qq = torch.randn(BH, N, D, generator=g, device=DEV).to(BF)
+    kk = torch.randn(BH, N, D, generator=g, device=DEV).to(BF)
+    vv = (torch.randn(BH, N, D, generator=g, device=DEV) + 3.0).to(BF)
+    first = ops.attention_bhnd(qq, kk, vv)
+    for i in range(40):
+        again = ops.attention_bhnd(qq, kk, vv)
+        assert torch.equal(again, first), f"launch {i + 1} differs from launch 0 in {int((again != first).sum())} elements"
+    for (BHs, Ns, Ds) in ((96, 1024, 80), (96, 256, 160)):
+        q2, k2, v2 = (torch.randn(BHs, Ns, Ds, generator=g, device=DEV).to(BF) for _ in range(3))
+        f2 = ops.attention_bhnd(q2, k2, v2)
+        for _ in range(10):
+            assert torch.equal(ops.attention_bhnd(q2, k2, v2), f2)
+
+
 def test_attention_two_query_groups_vs_oracle(ops):
     """The 64-queries-per-wave variant of the long-sequence kernel (attention_fast.hip, QG = 2) only runs on grids of >= 1024 blocks
     of 256 queries — no small test reaches it.  B*H = 64 heads of N = 4096, d = 40 (the UNet's 64x64-level shape at a smaller batch):
