@@ -85,13 +85,13 @@ constexpr int epilogue_passes(int FM, int bytes_per_frag_row, int lds_bytes) {
 // CS = true: the epilogue also emits the per-channel statistics of its output (GemmArgs::colstats).  The wave tile is then staged in
 // 32-row passes (one statistics slab per pass) and the output loop gives every lane a FIXED 8-column chunk, so a lane can carry the
 // column sums of its rows in registers; the R = 64 / (WN / 8) row-lanes of a chunk are folded through the wave's own staging slice.
-// HYB (two-stage LDS-DMA pipeline only): 1 = the A tile, 2 = the W tile travels global -> VGPR -> ds_write_b128 while the other operand
-// stays on the LDS-DMA path.  Rationale: the measured K-step time of the DMA kernels (~4600 cycles for the 64 KiB of a 192x320 step,
-// ~2100 for the 32 KiB of a 128x128 step, against 1920 / 1024 MFMA cycles) equals bytes / ~14 B/clk/CU — the rate the guide quotes for
-// LDS-DMA streaming — whatever the tile; splitting the bytes over BOTH load paths is the experiment (AE_GEMM_HYB).
-template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false, int WAVES_K = 1, int STAGES = 2, bool CS = false, int HYB = 0>
+// (Round 3, measured and removed: a hybrid loader — one operand global -> VGPR -> ds_write_b128, the other by LDS-DMA — to test whether
+// the K-step time of these kernels (~4600 cycles for the 64 KiB of a 192x320 step, ~2100 for the 32 KiB of a 128x128 step = bytes /
+// ~14 B/clk/CU) is the LDS-DMA path's rate.  It is not that simple: 192x320 conv 87.8 -> 92.6 us (A through registers) / 96.2 (W),
+// 128x128 conv 105.9 -> 115.9 / 118.1, dense 128x128 +3..+10 %, UNet step 14.44 -> 14.51-14.60 ms (profiles/r03_v3_hybrid_loader.txt).)
+// LAB (AE_GEMM_LAB builds only, tools/ubench): 1 = no DMA after the first tile, 2 = no LDS reads / MFMAs, 3 = MFMAs on stale registers (no LDS reads)
+template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false, int WAVES_K = 1, int STAGES = 2, bool CS = false, int LAB = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(const GemmArgs p) {
-    static_assert(HYB == 0 || (GLDS && STAGES == 2 && WAVES_K == 1), "the hybrid loader is a variant of the two-stage LDS-DMA pipeline");
     static_assert(STAGES == 2 || (GLDS && WAVES_K == 1), "the deep LDS ring exists only for the LDS-DMA loader");
     static_assert(WAVES_K == 1 || WAVES_K == 2, "K groups: 1 or 2");
     constexpr int NT = 64 * WAVES_M * WAVES_N * WAVES_K;
@@ -290,6 +290,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto compute_tile = [&](int cur) {
+        if (LAB == 2) return;
         const bf16_t* cA = sA + cur * BM * BK + (wm * WM) * BK;
         const bf16_t* cB = sB + cur * BN * BK + (wn * WN) * BK;
 #pragma unroll
@@ -300,12 +301,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int row = i * 16 + l15;  // (wm*(BM/2)) is a multiple of 8 -> same swizzle phase
-                af[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(cA + row * BK + ((ch ^ (row & 7)) << 3)));
+                if (LAB == 3) af[i] = as_bf16x8((u32x4){(uint32_t)(i + cur), 0x3f803f80u, (uint32_t)lane, 0u});
+                else af[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(cA + row * BK + ((ch ^ (row & 7)) << 3)));
             }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const int row = j * 16 + l15;
-                bfr[j] = as_bf16x8(*reinterpret_cast<const u32x4*>(cB + row * BK + ((ch ^ (row & 7)) << 3)));
+                if (LAB == 3) bfr[j] = as_bf16x8((u32x4){(uint32_t)(j + kk), 0x3f803f80u, (uint32_t)lane, 0u});
+                else bfr[j] = as_bf16x8(*reinterpret_cast<const u32x4*>(cB + row * BK + ((ch ^ (row & 7)) << 3)));
             }
 #pragma unroll
             for (int i = 0; i < FM; ++i)
@@ -338,13 +341,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
         int fa_cur[A_CH];  // conv: this tap's per-lane gather offset (OOB for halo pixels)
         auto dma_tile = [&](int kt, int buf) {
             const int k0 = (kt_begin + kt) * BK;
-            // HYB: the register loads are issued AFTER every DMA piece of the tile.  LDS-DMA pieces and ordinary loads each retire in
-            // order among themselves but not relative to each other, and hipcc waits for its loads with counted
-            // vmcnt(n): with the loads youngest in the queue, "at most n outstanding" can only be reached once the awaited load itself
-            // has retired (all older entries are DMA pieces, at most that many of them can be what is still in flight).
-            const bool second = AMODE == A_DENSE && k0 >= p.Ksplit;
-            int tap_off = 0;
-            if (AMODE == A_CONV3) {
+            if (AMODE == A_DENSE) {
+                const bool second = k0 >= p.Ksplit;
+#pragma unroll
+                for (int i = 0; i < A_CH; ++i) {
+                    bf16_t* dst = sA + buf * BM * BK + (wave + (NT / 64) * i) * 8 * BK;
+                    if (!second) lds_dma16(rsA, dst, fa_off[i], k0 * 2);
+                    else lds_dma16(rsA2, dst, fa2_off[i], (k0 - p.Ksplit) * 2);
+                }
+            } else {
                 const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
                 if (ld_ci == 0 || kt == 0) {  // a new tap: the per-lane part (halo mask, upsample source pixel) changes only here
 #pragma unroll
@@ -357,62 +362,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                         fa_cur[i] = ((fa_mask[i] >> ld_tap) & 1u) ? src : OOB;
                     }
                 }
-                tap_off = ld_ci * 2;  // wave-uniform -> SGPR offset
-                ld_ci += BK;
-                if (ld_ci >= p.CinPad) { ld_ci = 0; ++ld_tap; }
-            }
-            if (HYB != 1) {
+                const int tap_off = ld_ci * 2;  // wave-uniform -> SGPR offset
+                if (!(LAB == 4 && (kt % 9) >= 2)) {   // LAB 4: the A tile only on 2 of 9 steps (= the DMA volume of a slab loader, 42 of 216 KiB)
 #pragma unroll
                 for (int i = 0; i < A_CH; ++i) {
                     bf16_t* dst = sA + buf * BM * BK + (wave + (NT / 64) * i) * 8 * BK;
-                    if (AMODE == A_CONV3) lds_dma16(rsA, dst, fa_cur[i], tap_off);
-                    else if (!second) lds_dma16(rsA, dst, fa_off[i], k0 * 2);
-                    else lds_dma16(rsA2, dst, fa2_off[i], (k0 - p.Ksplit) * 2);
+                    lds_dma16(rsA, dst, fa_cur[i], tap_off);
                 }
-            }
-            if (HYB != 2) {
-#pragma unroll
-                for (int i = 0; i < B_CH; ++i) {
-                    bf16_t* dst = sB + buf * BN * BK + (wave + (NT / 64) * i) * 8 * BK;
-                    lds_dma16(rsW, dst, fb_off[i], k0 * 2);
                 }
+                ld_ci += BK;
+                if (ld_ci >= p.CinPad) { ld_ci = 0; ++ld_tap; }
             }
-            if (HYB == 1) {  // same per-lane source chunk as the DMA (swizzled on the source side): the register copy lands lane-linear too
 #pragma unroll
-                for (int i = 0; i < A_CH; ++i) {
-                    if (AMODE == A_CONV3) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, fa_cur[i], tap_off, 0);
-                    else ra[i] = second ? __builtin_amdgcn_raw_buffer_load_b128(rsA2, fa2_off[i], (k0 - p.Ksplit) * 2, 0)
-                                        : __builtin_amdgcn_raw_buffer_load_b128(rsA, fa_off[i], k0 * 2, 0);
-                }
-            }
-            if (HYB == 2) {
-#pragma unroll
-                for (int i = 0; i < B_CH; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsW, fb_off[i], k0 * 2, 0);
-            }
-        };
-        // HYB: the register-staged operand of the tile loaded by the last dma_tile() goes to its LDS stage — lane-linear, exactly where
-        // the DMA would have put it (piece (wave + 8 i) of the stage, lane * 16 bytes)
-        auto hyb_store = [&](int buf) {
-            if (HYB == 1) {
-#pragma unroll
-                for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4*>(sA + buf * BM * BK + (wave + (NT / 64) * i) * 8 * BK + lane * 8) = ra[i];
-            } else if (HYB == 2) {
-#pragma unroll
-                for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4*>(sB + buf * BN * BK + (wave + (NT / 64) * i) * 8 * BK + lane * 8) = rb[i];
+            for (int i = 0; i < B_CH; ++i) {
+                bf16_t* dst = sB + buf * BN * BK + (wave + (NT / 64) * i) * 8 * BK;
+                lds_dma16(rsW, dst, fb_off[i], k0 * 2);
             }
         };
         if constexpr (STAGES == 2) {
             dma_tile(0, 0);
-            hyb_store(0);
             __syncthreads();
             GL_T(0);
             for (int kt = 0; kt < KT; ++kt) {
                 const int cur = kt & 1;
-                if (kt + 1 < KT) dma_tile(kt + 1, cur ^ 1);  // stage cur^1 was last read before the previous barrier
+                if (LAB != 1 && kt + 1 < KT) dma_tile(kt + 1, cur ^ 1);  // stage cur^1 was last read before the previous barrier
                 GL_T(1);
                 compute_tile(cur);
                 GL_T(2);
-                if (HYB != 0 && kt + 1 < KT) hyb_store(cur ^ 1);
                 __syncthreads();
                 GL_T(3);
 #ifdef AE_GEMM_LAB
@@ -940,9 +916,9 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     const bool cs_epi_ok = a.colstats && a.epi != EPI_GEGLU && !a.out_f32 && a.splitk <= 1 && a.N % 8 == 0 && a.ldc % 8 == 0 &&
                            (!a.res || (a.ldr % 8 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0));
     bool cs_done = false;
-    // tuning knob (bit flags): hybrid loader — 1 / 2: 192x320 conv with A / W through registers; 4 / 8: 128x128 conv / dense with A through
-    // registers; 16 / 32: 128x128 conv / dense with W through registers.  Kernels that emit column statistics keep the all-DMA loader.
-    static const int hyb = getenv("AE_GEMM_HYB") ? atoi(getenv("AE_GEMM_HYB")) : 0;
+#ifdef AE_GEMM_ABLATE
+    static const int lab_abl = getenv("AE_GEMM_ABL") ? atoi(getenv("AE_GEMM_ABL")) : 0;   // lab build only (tools/build_ablate.sh): main-loop ablations
+#endif
     // (192x320 with FOUR waves of 96x160 — 0.27 LDS fragment reads per MFMA instead of 0.37, 240 accumulator registers per lane — was
     // instantiated and measured: hipcc places the accumulators in AGPRs and brackets the MFMAs with v_accvgpr moves, 166-206 TFLOP/s
     // against 911-1123 for the 8-wave form.  Bigger wave tiles need hand-scheduled AGPR code; not kept.)
@@ -962,12 +938,14 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
             else if (cs_epi_ok && AMODE == A_CONV3) {
                 if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
                 cs_done = true;
-            } else if (conv && (hyb & 3)) {
-                if constexpr (AMODE == A_CONV3) {
-                    if (hyb & 1) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 1>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
-                    else rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 2>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
-                }
-            } else rc = launch_kernel(gemm_kernel<192, 320, AMODE, 2, 4, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
+            }
+#ifdef AE_GEMM_ABLATE
+            else if (conv && lab_abl == 1) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 1>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what); }
+            else if (conv && lab_abl == 2) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 2>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what); }
+            else if (conv && lab_abl == 3) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 3>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what); }
+            else if (conv && lab_abl == 4) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 4>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what); }
+#endif
+            else rc = launch_kernel(gemm_kernel<192, 320, AMODE, 2, 4, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
             done = true;
         }
     }
@@ -1017,11 +995,14 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         else if (pick == 0 && w8 == 2 && cs_epi_ok && glds) {
             rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, true>, grid, 512, lds_of(128, 128, 2), stream, a, what);
             cs_done = true;
-        } else if (pick == 0 && w8 == 2 && glds && ((conv && (hyb & 4)) || (!conv && (hyb & 8)))) {
-            rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, false, 1>, grid, 512, lds_of(128, 128, 2), stream, a, what);
-        } else if (pick == 0 && w8 == 2 && glds && ((conv && (hyb & 16)) || (!conv && (hyb & 32)))) {
-            rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, false, 2>, grid, 512, lds_of(128, 128, 2), stream, a, what);
-        } else if (pick == 0 && w8 == 2) AE_LAUNCH(128, 128, 4, 2, 512);
+        }
+#ifdef AE_GEMM_ABLATE
+        else if (pick == 0 && w8 == 2 && glds && lab_abl == 1) rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, false, 1>, grid, 512, lds_of(128, 128, 2), stream, a, what);
+        else if (pick == 0 && w8 == 2 && glds && lab_abl == 2) rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, false, 2>, grid, 512, lds_of(128, 128, 2), stream, a, what);
+        else if (pick == 0 && w8 == 2 && glds && lab_abl == 3) rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, false, 3>, grid, 512, lds_of(128, 128, 2), stream, a, what);
+        else if (pick == 0 && w8 == 2 && glds && lab_abl == 4) rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, false, 4>, grid, 512, lds_of(128, 128, 2), stream, a, what);
+#endif
+        else if (pick == 0 && w8 == 2) AE_LAUNCH(128, 128, 4, 2, 512);
         else if (pick == 0) AE_LAUNCH(128, 128, 2, 2, 256);
         else if (pick == 1 && w8 && !conv) AE_LAUNCH(128, 64, 4, 2, 512);
         else if (pick == 1) AE_LAUNCH(128, 64, 2, 2, 256);
