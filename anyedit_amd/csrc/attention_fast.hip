@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     int seg_nk = p.Nk;
     int kcur = 0, klast = 0, vcur = 0, vlast = 0;
 
-    u32x4 hold = {0u, 0u, 0u, 0u};  // QG = 2: P registers of the previous block's last K-step (see the end of block())
+    u32x4 hold[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};  // QG = 2: ALL P registers of the previous block's last K-step (see the end of block())
     // one 32-key block of the current tile
     auto block = [&](auto blk_tag, int k0, bool first, bool tail) {
         constexpr int B2 = decltype(blk_tag)::value;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
             }
             // the P registers of the previous block's last K-step (`hold`) are free from here on: six more MFMAs are in the pipe behind
             // the one that read them
-            if (QG > 1) asm volatile("" ::"v"(hold));
+            if (QG > 1) asm volatile("" ::"v"(hold[0]), "v"(hold[1]));
         }
         if (ABL == 10 || ABL == 12) __builtin_amdgcn_s_setprio(0);
         if (ABL == 11) __builtin_amdgcn_s_setprio(1);
@@ -355,7 +355,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
             for (int gq = 0; gq < QG; ++gq)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(pk[gq][j]));
-            hold = (u32x4){pk[0][4], pk[0][7], pk[QG - 1][4], pk[QG - 1][7]};
+            hold[0] = (u32x4){pk[0][4], pk[0][5], pk[0][6], pk[0][7]};
+            hold[1] = (u32x4){pk[QG - 1][4], pk[QG - 1][5], pk[QG - 1][6], pk[QG - 1][7]};
         }
     };
 

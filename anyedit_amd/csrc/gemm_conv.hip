@@ -906,8 +906,10 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
 
     // 192x320 tile, one block per CU (128 KiB LDS), 8 waves with 96x80 (or 48x160 for the GEGLU column pairing) wave tiles:
     // 0.37-0.43 LDS fragment reads per MFMA instead of 0.75.  Used when the tile grid fills whole rounds of 256 CUs.
-    static const int t320 = getenv("AE_GEMM_T320") ? atoi(getenv("AE_GEMM_T320")) : 3;  // tuning knob, bit flags: 1 convs, 2 GEGLU GEMMs with K >= 640, 4 GEGLU K = 320, 8 other dense K >= 640.  Isolated (kbench) the
-    // dense flags gain 4..20 %, inside the UNet evaluation (in-situ A/B, one box) 4 and 8 are neutral-to-negative (0.5 %): default 3
+    static const int t320 = getenv("AE_GEMM_T320") ? atoi(getenv("AE_GEMM_T320")) : 11;  // tuning knob, bit flags: 1 convs, 2 GEGLU GEMMs with K >= 640, 4 GEGLU K = 320, 8 other dense K >= 640.  Isolated (kbench) the
+    // dense flags gain 4..20 %; inside the UNet evaluation flag 4 is neutral-to-negative.  Flag 8 (round 3: default on) only ever fires where the
+    // 192x320 grid fills whole rounds of CUs — at UNet batch 12 the 64x64-level ff2 (M = 49152, N = 320, K = 1280: 62.6 -> 49.2 us) and the
+    // decoder's skip 1x1 convs (K = 960: 45.0 -> 36.4 us): 13.82 -> 13.72 ms per UNet step, two runs each way (profiles/r03_v10_ab.txt)
     // (the same tile for the K = 320 dense GEMMs of the 64x64 level was A/B-ed too: N = 320 44.5 vs 34 us, N = 960 78 vs 63 us —
     // five K iterations do not amortise the big tile's prologue / epilogue.)
     bool done = false;

@@ -979,7 +979,7 @@ def _tile_label(M, N, conv=False, K=0, geglu=False, dma_ok=True):
     """Mirror of the tile choice in csrc/gemm_conv.hip::launch / make_plan (for labelling only)."""
     if conv and dma_ok and _conv_t320_split(M, N, K):
         return "192x320,splitK"
-    if dma_ok and N % 320 == 0 and (conv or (geglu and K >= 640)):
+    if dma_ok and N % 320 == 0 and (conv or K >= 640):   # convs, GEGLU GEMMs with K >= 640 and (round 3) the other dense GEMMs with K >= 640
         tm = -(-M // 192)
         t = tm * (N // 320)
         if t / (-(-t // 256) * 256) * (M / (tm * 192)) >= 0.85 and not (conv and _conv_splitk(M, N, K) > 1):
