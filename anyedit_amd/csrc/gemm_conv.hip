@@ -319,6 +319,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
         }
     };
 
+    // Main-loop variants of the two-stage LDS-DMA pipeline that were built, verified against the tests and measured in round 3
+    // (profiles/r03_v11_midb_ilv_regstage.txt) and are NOT kept:
+    //  - mid-step refill: wait(tile kt) + barrier, first K half, second half's LDS reads, barrier, second half's MFMAs, DMA of tile kt + 2
+    //    into the stage just read (two tiles in flight on two stages, counted vmcnt).  Isolated: 128x128 conv -3 %, 192x320 conv +7..11 %,
+    //    dense +-4 %; UNet step 13.86 -> 13.84 ms (noise).
+    //  - interleaved issue: the A_CH + B_CH pieces of tile kt + 1 issued one after every third MFMA of the first K half instead of as a
+    //    burst at the top of the step (sched_barrier fences or sched_group_barrier, last step peeled).  Isolated (operands L2-hot) the
+    //    192x320 launches gain 2..8 % (ff2 M = 49152 N = 320 K = 1280: 52.5 -> 48.0 us); inside the UNet evaluation, where each layer's
+    //    weights arrive cold, the later pieces no longer land before the step's barrier: 14.01 -> 14.13 ms, two runs each way.
+    //  - register-staged loader on the 192x320 conv tile (buffer_load -> 32 staging VGPRs -> ds_write_b128, 246 VGPRs, no spills):
+    //    259 -> 308 us on the K = 8640 conv, 86 -> 106 us on K = 2880.
+    // Together with the ablations in profiles/r03_v7*.txt: the DMA burst costs the waves ~0.7 us of a 1.9 us step, none of the three
+    // re-arrangements hides it, and the arrangement below (burst at the top, one barrier per step) is the best of the measured ones.
     // Software pipeline: global loads of tile t+1 are issued into registers before tile t is multiplied out of LDS
     // (issue-early / write-late), one barrier per K tile.  (A two-tile-deep register ring was measured slower: it pushes
     // the 128x128 variant to 256 VGPRs + spills.)
@@ -946,6 +959,7 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
             else if (conv && lab_abl == 2) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 2>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what); }
             else if (conv && lab_abl == 3) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 3>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what); }
             else if (conv && lab_abl == 4) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 4>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what); }
+            else if (conv && lab_abl == 20) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, false>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what); }  // register-staged loader
 #endif
             else rc = launch_kernel(gemm_kernel<192, 320, AMODE, 2, 4, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
             done = true;
