@@ -488,7 +488,7 @@ int launch_attn(const AttnArgs& a, hipStream_t stream) {
     dim3 grid((unsigned)blocks), block(NT);
     if (a.rel_h && a.key_mask) { ae_set_error("ae_attn_fwd_bf16: rel-pos bias together with key_mask is not supported"); return AE_ERR_UNSUPPORTED; }
     if (a.k2) {
-        if constexpr (D <= 96) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, 0, false, true>), grid, block, 0, stream, a);
+        if constexpr (D <= 96 || (D == 160 && QF == 1)) hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, 0, false, true>), grid, block, 0, stream, a);
     } else if (a.rel_h && NW == 8 && a.kW == KT && a.Nk % KT == 0 && sam_occ() == 4) {
         hipLaunchKernelGGL((attn_kernel<D, QF, NW, DBUF, 2, false, false, NW == 8>), grid, block, 0, stream, a);
     } else if (a.rel_h && NW == 8 && !(a.kW == KT && a.Nk % KT == 0) && sam_occ() >= 1) {
@@ -530,7 +530,7 @@ extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
     a.scale = scale; a.rel_h = rel_h; a.rel_w = rel_w; a.kH = kH; a.kW = kW; a.key_mask = key_mask;
     a.out_scale = out_scale; a.accum = accumulate;
     if (k2) {
-        AE_REQUIRE(v2 && scale2 && Nk2 > 0 && D <= 96, "ae_attn_fwd_bf16: second segment needs v2, scale2, Nk2 > 0 and head_dim <= 96");
+        AE_REQUIRE(v2 && scale2 && Nk2 > 0 && (D <= 96 || D == 160), "ae_attn_fwd_bf16: second segment needs v2, scale2, Nk2 > 0 and head_dim <= 96 or 160");
         AE_REQUIRE(!rel_h && !key_mask && !accumulate && !out_scale, "ae_attn_fwd_bf16: second segment excludes bias / mask / accumulate / out_scale");
         AE_REQUIRE((k2_sb | k2_sh | k2_sn | v2_sb | v2_sh | v2_sn) % 8 == 0 && ((uintptr_t)k2 & 15) == 0 && ((uintptr_t)v2 & 15) == 0,
                    "ae_attn_fwd_bf16: second segment alignment");
@@ -574,7 +574,9 @@ extern "C" int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
             return (w8 || rel_h) ? launch_attn<80, 1, true, 8>(a, s) : launch_attn<80, 2, true>(a, s);
         case 96: return launch_attn<96, 2, true>(a, s);
         case 128: return launch_attn<128, 2, false>(a, s);
-        case 160: return short_kv ? launch_attn<160, 1, false>(a, s) : launch_attn<160, 2, false>(a, s);
+        // two segments at d = 160 (the 16x16-level cross-attention + expert tokens): one query fragment per wave keeps both output
+        // accumulators in registers (256 + 170 of the wave's 512, no spills; two fragments spill 78)
+        case 160: return (short_kv || k2) ? launch_attn<160, 1, false>(a, s) : launch_attn<160, 2, false>(a, s);
         default:
             ae_set_error("ae_attn_fwd_bf16: unsupported head_dim %d (supported: 8,16,32,40,48,64,80,96,128,160)", D);
             return AE_ERR_UNSUPPORTED;

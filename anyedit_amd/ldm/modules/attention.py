@@ -5,6 +5,8 @@ Public signatures, sub-module names and state-dict keys are the reference's, so 
 feature maps, any float dtype) and return the same; internally everything moves as channels-last bf16 rows through
 `*_rows` methods, which is what UNetModel calls (no layout changes between layers).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -13,6 +15,7 @@ from anyedit_amd.ldm.util import default, exists
 from anyedit_amd.ldm.modules.diffusionmodules.util import Linear, Conv2d, LayerNorm, checkpoint  # noqa: F401
 
 BF16 = torch.bfloat16
+_SEG2_160 = os.environ.get("AE_ATTN_SEG2_160", "1") != "0"  # tuning knob (A/B): 0 = the d = 160 expert segment as a second, accumulating launch
 
 
 def zero_module(module):
@@ -157,7 +160,7 @@ class CrossAttention(nn.Module):
             Nk = kv.shape[0] // B
             qs = (N * inner, d, inner)
             ks = (Nk * 2 * inner, d, 2 * inner)
-            if adapter is not None and d <= 96 and key_mask is None:
+            if adapter is not None and (d <= 96 or (d == 160 and _SEG2_160)) and key_mask is None:
                 # both softmaxes in ONE launch: Q read once, O written once (the 4-token expert segment used to cost as much
                 # as the 77-token text segment because it re-read Q and read-modify-wrote O)
                 kv_ip, gate = adapter

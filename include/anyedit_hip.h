@@ -98,7 +98,7 @@ int ae_layernorm_bf16(const void* x, const float* gamma, const float* beta, void
  * decomposed relative-position bias (image_encoder.py:325-361), Nk == kH*kW.  key_mask: optional uint8 [B,Nk], 0 = masked
  * (attention.py:183-187).  out_scale: optional fp32 [B]; accumulate != 0: out += out_scale[b] * result (decoupled adapter
  * attention, ip_adapter/attention_processor.py:141-173 — the shape template of AnySD's expert K/V, SURVEY.md A9).
- * k2/v2 (optional, head_dim <= 96): a second key/value segment with its own softmax fused into the same launch:
+ * k2/v2 (optional, head_dim <= 96 or 160): a second key/value segment with its own softmax fused into the same launch:
  * out = Attn(q,k,v) + scale2[b] * Attn(q,k2,v2).                                                                           */
 int ae_attn_fwd_bf16(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk, int D,
                      long q_sb, long q_sh, long q_sn, long k_sb, long k_sh, long k_sn, long v_sb, long v_sh, long v_sn,

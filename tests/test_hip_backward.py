@@ -276,10 +276,10 @@ def test_adamw_matches_torch(ops):
     check_close(pd, pt.detach(), rl2=1e-6, mabs=1e-5, what="adamw")
 
 
-@pytest.mark.parametrize("fused,D", [(True, 40), (False, 160), (False, 40), (True, 80)])
+@pytest.mark.parametrize("fused,D", [(True, 40), (False, 160), (True, 160), (False, 40), (True, 80)])
 def test_tape_adapter_attention_two_segments(ops, fused, D):
-    """out = Attn(q, K, V) + g_b * Attn(q, K_ip, V_ip): the fused two-segment launch (head_dim <= 96) and the un-fused
-    accumulate path (head_dim 160), gradients w.r.t. q, the text K|V, the expert K|V and the gate against autograd."""
+    """out = Attn(q, K, V) + g_b * Attn(q, K_ip, V_ip): the fused two-segment launch (head_dim <= 96, and 160 with one query
+    fragment per wave) and the un-fused accumulate path, gradients w.r.t. q, the text K|V, the expert K|V and the gate against autograd."""
     from anyedit_amd.autodiff import Tape
     from oracle import ldm_ref as L
     g = torch.Generator().manual_seed(9 + D)
