@@ -84,7 +84,7 @@ __device__ unsigned long long g_attn_dbg[4];  // lab only: sum of per-block shad
 // per-lane SOURCE offset of the LDS-DMA pieces.
 template <int D, int OCC, bool SEG2 = false, int ABL = 0, int BIAS = 0, int QG = 1, bool VSPLIT = false>
 __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
-    static_assert(D % 8 == 0 && D <= 96, "head_dim: multiple of 8, <= 96");
+    static_assert(D % 8 == 0 && (D <= 96 || D == 160), "head_dim: multiple of 8, <= 96, or 160");
     static_assert(QG == 1 || QG == 2, "one or two 32-query groups per wave");
     static_assert(BIAS == 0 || QG == 1, "the rel-pos variants keep one query group per wave");
     constexpr int KS = (D + 15) / 16;        // K=16 steps of S^T = K Q^T
@@ -500,7 +500,7 @@ int launch_fast(const AttnArgs& a, hipStream_t stream) {
         }
     }
     if (a.k2) {
-        hipLaunchKernelGGL((attn_fast_kernel<D, (D > 64 ? 2 : 3), true>), grid, block, 0, stream, a);  // 168 VGPRs spill at head_dim 80
+        hipLaunchKernelGGL((attn_fast_kernel<D, (D > 96 ? 1 : (D > 64 ? 2 : 3)), true>), grid, block, 0, stream, a);  // 168 VGPRs spill at head_dim 80
         return ae_check_launch("ae_attn_fwd_bf16(fast)");
     }
     // Variants of the plain long-sequence kernel (tuning knob AE_ATTN_V): 0 = one 32-query group per wave, V rows of 2 D bytes (round 2);
@@ -508,6 +508,10 @@ int launch_fast(const AttnArgs& a, hipStream_t stream) {
     // sequence is long enough to fill the chip with the larger blocks.  Measured (kbench, UNet batch 12, N = 4096, d = 40, one box):
     // 388.5 / 376.9 / 361.2 us for 0 / 1 / 3; in situ 13.78 -> 13.67 ms per UNet step (profiles/r03_v2_*).  QG = 2 on the row-major V
     // image (the former value 2) measured 367.7 us and is not kept: one variant fewer to validate.
+    if constexpr (D > 96) {  // head_dim 160 (16x16 / 8x8 UNet levels): six 32-row output blocks per wave, two waves per SIMD
+        hipLaunchKernelGGL((attn_fast_kernel<D, 2, false>), grid, block, 0, stream, a);
+        return ae_check_launch("ae_attn_fwd_bf16(fast)");
+    }
     static const int var_env = getenv("AE_ATTN_V") ? atoi(getenv("AE_ATTN_V")) : AE_ATTN_V_DEFAULT;
     const bool qg2 = (var_env & 2) && D <= 48 && (long)((a.Nq + 255) / 256) * a.B * a.H >= 1024;   // head_dim 80 would spill with two groups
     if (qg2) {
@@ -534,6 +538,10 @@ int ae_attn_fast_launch(const AttnArgs& a, int D, hipStream_t stream) {
     switch (D) {
         case 40: return launch_fast<40>(a, stream);
         case 80: return launch_fast<80>(a, stream);
+        case 160: {  // the 16x16 / 8x8 UNet levels (tuning knob AE_ATTN_FAST160=0: general kernel, for A/B)
+            static const int f160 = getenv("AE_ATTN_FAST160") ? atoi(getenv("AE_ATTN_FAST160")) : 1;
+            return (a.rel_h || !f160) ? AE_ERR_UNSUPPORTED : launch_fast<160>(a, stream);
+        }
         default: return AE_ERR_UNSUPPORTED;
     }
 }
