@@ -19,6 +19,7 @@ struct AttnArgs {
     const float* scale2;
     // optional [B, H, Nq] fp32 outputs for the backward pass: log2-domain log-sum-exp of each segment's softmax
     float* lse; float* lse2;
+    int ng = 1;  // attention_fast.hip, short-K/V variant: 128-query groups per block (filled in by its launcher)
 };
 
 // attention_fast.hip: returns AE_OK when it launched, AE_ERR_UNSUPPORTED when the shape / options are outside its envelope

@@ -82,8 +82,13 @@ __device__ unsigned long long g_attn_dbg[4];  // lab only: sum of per-block shad
 // then 256 contiguous bytes — every bank once (rows of 80 / 160 bytes put rows 0 and 3 on the same banks: 22 % of the LDS
 // instruction cycles were bank conflicts, profiles/r02_pmc_attn_fast_d40_b.txt).  The re-arrangement costs nothing: it is the
 // per-lane SOURCE offset of the LDS-DMA pieces.
-template <int D, int OCC, bool SEG2 = false, int ABL = 0, int BIAS = 0, int QG = 1, bool VSPLIT = false>
+// SKV ("short K/V", cross-attention: 77 text tokens + task token, optionally the expert tokens as second segment): every key of the
+// launch fits three tile buffers (two text tiles + one second-segment tile).  They are copied ONCE per block by one LDS-DMA burst
+// behind one barrier, and the block then walks p.ng groups of 128 queries over them — no per-tile DMA round trip, no per-tile
+// barrier, a quarter of the blocks (the 64x64 level: 3072 blocks in four rounds -> 768 blocks in one).
+template <int D, int OCC, bool SEG2 = false, int ABL = 0, int BIAS = 0, int QG = 1, bool VSPLIT = false, bool SKV = false>
 __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
+    static_assert(!SKV || (QG == 1 && BIAS == 0 && !VSPLIT), "short-K/V variant: one query group per wave, no bias, row-major V image");
     static_assert(D % 8 == 0 && (D <= 96 || D == 160), "head_dim: multiple of 8, <= 96, or 160");
     static_assert(QG == 1 || QG == 2, "one or two 32-query groups per wave");
     static_assert(BIAS == 0 || QG == 1, "the rel-pos variants keep one query group per wave");
@@ -95,7 +100,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     constexpr int CH = D / 8;                // 16-byte chunks per row = 1-KiB DMA pieces per 64-row tile
     constexpr int TILEB = FKT * ROWB;
     constexpr int BUFB = 2 * TILEB;          // K tile then V tile
-    constexpr int ONES_OFF = 2 * BUFB;       // "ones tile": 64 rows of ROWB bytes, each starting with bf16 {1,0,0,0,0,0,0,0}
+    constexpr int NTB = SKV ? 3 : 2;         // tile buffers (SKV: text tiles 0 / 1 + the second segment's tile)
+    constexpr int ONES_OFF = NTB * BUFB;     // "ones tile": 64 rows of ROWB bytes, each starting with bf16 {1,0,0,0,0,0,0,0}
     constexpr int NFULL = D / 32, REM = D % 32;          // VSPLIT: full 32-wide d-blocks, remainder columns
     constexpr int RS = REM * 2 > 16 ? REM * 2 : 16;      // VSPLIT: row bytes of the remainder image (and of its ones tile)
     constexpr int RC = REM / 8;                          // 16-byte chunks per row of the remainder image
@@ -113,11 +119,11 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5, l15 = lane & 15, g = lane >> 4;
     constexpr int QB = 128 * QG;
-    const int nqb = (p.Nq + QB - 1) / QB;
+    const int nqb = SKV ? (p.Nq + QB * p.ng - 1) / (QB * p.ng) : (p.Nq + QB - 1) / QB;
     const int vb = xcd_remap(blockIdx.x, nqb * p.B * p.H);
     const int bh = vb / nqb, qb = vb - bh * nqb;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = qb * QB + wave * 32 * QG;   // group gq of the wave holds queries q0 + 32 gq .. + 31
+    int q0 = (SKV ? qb * QB * p.ng : qb * QB) + wave * 32 * QG;   // group gq of the wave holds queries q0 + 32 gq .. + 31
 
     if (tid < FKT) *reinterpret_cast<u32x4*>(smem + ONES_OFF + tid * ROWB) = (u32x4){0x00003F80u, 0u, 0u, 0u};
     if (VSPLIT && tid < FKT) *reinterpret_cast<u32x4*>(smem + VONES_OFF + tid * RS) = (u32x4){0x00003F80u, 0u, 0u, 0u};
@@ -126,6 +132,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     const bf16_t* qp = p.q + (long)b * p.q_sb + (long)h * p.q_sh;
     const float c = p.scale * FLOG2E;
     u32x4 qf[QG][KS];
+    auto load_q = [&]() {
 #pragma unroll
     for (int gq = 0; gq < QG; ++gq) {
         const int qrow = min(q0 + 32 * gq + l31, p.Nq - 1);
@@ -140,6 +147,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
             qf[gq][ks].w = pack_bf16x2(bf16lo(t.w) * c, bf16hi(t.w) * c);
         }
     }
+    };
+    load_q();
 
     // ---- per-lane LDS read addresses (tile-buffer offset added per tile; key-block / K-step / d-block offsets are immediates)
     const int kaddr = l31 * ROWB + hi * 16;
@@ -363,6 +372,83 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     f32x16 o_first[SEG2 ? QG : 1][SEG2 ? NDB : 1];  // SEG2: normalised result of the first segment while the second runs
     const int lds0 = (int)(uintptr_t)((__attribute__((address_space(3))) char*)smem);  // LDS byte address of the tile buffers
     constexpr int NSEG = SEG2 ? 2 : 1;
+
+    // one 64-key tile sitting in tile buffer `buf`: LDS read addresses, then its one or two 32-key blocks
+    auto tile = [&](int t, int buf) {
+        const int boff = buf * BUFB;
+        kcur = kaddr + boff;
+        klast = (QSLOT && hi) ? ONES_OFF + l31 * ROWB : kcur + (KS - 1) * 32;
+        vcur = vaddr + boff;
+        if (VSPLIT)
+            vlast = ones_lane ? VONES_OFF + vrow * RS : (zero_lane ? VONES_OFF + vrow * RS + 8 : TILEB + boff + NFULL * 4096 + vrow * RS + (16 * (g & 1) + 4 * (l15 & 3)) * 2);
+        else
+            vlast = ones_lane ? ONES_OFF + vrow * ROWB : (zero_lane ? ONES_OFF + vrow * ROWB + 8 : vcur + LDB * 64);
+        const bool tail = (t + 1) * FKT > seg_nk;
+        if (BIAS2) rh_tile = rh_row[t] * FLOG2E;
+        block(std::integral_constant<int, 0>{}, t * FKT, t == 0, tail);
+        if (t * FKT + 32 < seg_nk) block(std::integral_constant<int, 1>{}, t * FKT, false, tail);
+    };
+    // SEG2, end of the first segment: park its normalised output, restart the online softmax
+    auto park = [&]() {
+#pragma unroll
+        for (int gq = 0; gq < QG; ++gq) {
+            const float l0 = __shfl(o[gq][LDB][LREG], l31, 64);
+            const float inv0 = 1.0f / l0;
+            const int qr = q0 + 32 * gq + l31;
+            // log2-domain log-sum-exp of the first segment (kept for ae_attn_bwd_bf16): offset + log2(denominator)
+            if (p.lse && hi == 0 && qr < p.Nq) p.lse[((long)b * p.H + h) * p.Nq + qr] = mt[gq] + __builtin_amdgcn_logf(l0);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o_first[SEG2 ? gq : 0][SEG2 ? db : 0][r] = o[gq][db][r] * inv0;
+                    o[gq][db][r] = 0.f;
+                }
+            mt[gq] = 0.f;
+            if (QSLOT) {
+                if (hi) qf[gq][KS - 1].x &= 0xFFFF0000u;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cinit[gq][r] = 0.f;
+            }
+        }
+    };
+    // normalise and store: 4 consecutive d per lane -> 8-byte stores
+    bf16_t* op = p.o + (long)b * p.o_sb + (long)h * p.o_sh;
+    auto store_o = [&]() {
+#pragma unroll
+        for (int gq = 0; gq < QG; ++gq) {
+            const float lsum = __shfl(o[gq][LDB][LREG], l31, 64);
+            const float inv = (SEG2 ? p.scale2[b] : (p.out_scale ? p.out_scale[b] : 1.0f)) / lsum;
+            const int qrow = q0 + 32 * gq + l31;
+            {
+                float* lse_out = SEG2 ? p.lse2 : p.lse;  // v_log_f32 = log2
+                if (lse_out && hi == 0 && qrow < p.Nq) lse_out[((long)b * p.H + h) * p.Nq + qrow] = mt[gq] + __builtin_amdgcn_logf(lsum);
+            }
+            if (qrow < p.Nq) {
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int d = 32 * db + 8 * r4 + 4 * hi;
+                        if (d < D) {
+                            float r0 = o[gq][db][4 * r4] * inv, r1 = o[gq][db][4 * r4 + 1] * inv, r2 = o[gq][db][4 * r4 + 2] * inv, r3 = o[gq][db][4 * r4 + 3] * inv;
+                            if (SEG2) {
+                                r0 += o_first[SEG2 ? gq : 0][SEG2 ? db : 0][4 * r4]; r1 += o_first[SEG2 ? gq : 0][SEG2 ? db : 0][4 * r4 + 1];
+                                r2 += o_first[SEG2 ? gq : 0][SEG2 ? db : 0][4 * r4 + 2]; r3 += o_first[SEG2 ? gq : 0][SEG2 ? db : 0][4 * r4 + 3];
+                            }
+                            u32x2* dst = reinterpret_cast<u32x2*>(op + (long)qrow * p.o_sn + d);
+                            if (p.accum) {
+                                const u32x2 prev = *dst;
+                                r0 += bf16lo(prev.x); r1 += bf16hi(prev.x); r2 += bf16lo(prev.y); r3 += bf16hi(prev.y);
+                            }
+                            *dst = (u32x2){pack_bf16x2(r0, r1), pack_bf16x2(r2, r3)};
+                        }
+                    }
+            }
+        }
+    };
+
     for (int seg = 0; seg < NSEG; ++seg) {
         // ---- LDS-DMA plan: piece j of a tile (K pieces 0..CH-1, V pieces CH..2CH-1) is issued by wave j % 4
         const bf16_t* kp = seg == 0 ? p.k + (long)b * p.k_sb + (long)h * p.k_sh : p.k2 + (long)b * p.k2_sb + (long)h * p.k2_sh;
@@ -385,8 +471,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
             }
             voff[i] = row * (isK ? ksn2 : vsn2) + cc * 16;
         }
-        auto issue = [&](int t) {
-            const int boff = lds0 + (t & 1) * BUFB;
+        auto issue = [&](int t, int buf) {
+            const int boff = lds0 + buf * BUFB;
 #pragma unroll
             for (int i = 0; i < MAXP; ++i) {
                 const int j = wave + 4 * i;
@@ -397,48 +483,62 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
             }
         };
         const int ntiles = (seg_nk + FKT - 1) / FKT;
+        if (SKV) {  // every tile of every segment goes out in one burst (text tiles -> buffers 0 / 1, second segment -> buffer 2)
+#pragma unroll 1
+            for (int t = 0; t < ntiles; ++t) issue(t, seg == 0 ? t : 2);
+            continue;
+        }
         if (SEG2 && seg == 1) dma_wait_all_and_barrier();  // every wave is done with the first segment's last tile
-        issue(0);
+        issue(0, 0);
         for (int t = 0; t < ntiles; ++t) {
             dma_wait_all_and_barrier();  // tile t has landed (every wave's pieces); every wave is done with tile t - 1
-            if (t + 1 < ntiles) issue(t + 1);
-            const int boff = (t & 1) * BUFB;
-            kcur = kaddr + boff;
-            klast = (QSLOT && hi) ? ONES_OFF + l31 * ROWB : kcur + (KS - 1) * 32;
-            vcur = vaddr + boff;
-            if (VSPLIT)
-                vlast = ones_lane ? VONES_OFF + vrow * RS : (zero_lane ? VONES_OFF + vrow * RS + 8 : TILEB + boff + NFULL * 4096 + vrow * RS + (16 * (g & 1) + 4 * (l15 & 3)) * 2);
-            else
-                vlast = ones_lane ? ONES_OFF + vrow * ROWB : (zero_lane ? ONES_OFF + vrow * ROWB + 8 : vcur + LDB * 64);
-            const bool tail = (t + 1) * FKT > seg_nk;
-            if (BIAS2) rh_tile = rh_row[t] * FLOG2E;
-            block(std::integral_constant<int, 0>{}, t * FKT, t == 0, tail);
-            if (t * FKT + 32 < seg_nk) block(std::integral_constant<int, 1>{}, t * FKT, false, tail);
+            if (t + 1 < ntiles) issue(t + 1, (t + 1) & 1);
+            tile(t, t & 1);
         }
-        if (SEG2 && seg == 0) {  // park the first segment's normalised output, restart the online softmax
+        if (SEG2 && seg == 0) park();
+    }
+    if (SKV) {
+        dma_wait_all_and_barrier();  // every key of the launch is in LDS; nothing below writes LDS or waits for a load again
+        const int nt0 = (p.Nk + FKT - 1) / FKT;
+        u32x4 qraw[KS];  // the NEXT group's Q rows, in flight while this group is computed
+        for (int gi = 0; gi < p.ng; ++gi) {
+            if (gi) {  // next 128-query group of the block: new Q operand, fresh softmax state
+                q0 += 128;
+                if (q0 - wave * 32 >= p.Nq) break;  // block-uniform: the group lies past the last query
 #pragma unroll
-            for (int gq = 0; gq < QG; ++gq) {
-                const float l0 = __shfl(o[gq][LDB][LREG], l31, 64);
-                const float inv0 = 1.0f / l0;
-                const int qr = q0 + 32 * gq + l31;
-                // log2-domain log-sum-exp of the first segment (kept for ae_attn_bwd_bf16): offset + log2(denominator)
-                if (p.lse && hi == 0 && qr < p.Nq) p.lse[((long)b * p.H + h) * p.Nq + qr] = mt[gq] + __builtin_amdgcn_logf(l0);
+                for (int ks = 0; ks < KS; ++ks) {
+                    const u32x4 t = (16 * ks + 8 * hi < D) ? qraw[ks] : (u32x4){0u, 0u, 0u, 0u};
+                    qf[0][ks].x = pack_bf16x2(bf16lo(t.x) * c, bf16hi(t.x) * c);
+                    qf[0][ks].y = pack_bf16x2(bf16lo(t.y) * c, bf16hi(t.y) * c);
+                    qf[0][ks].z = pack_bf16x2(bf16lo(t.z) * c, bf16hi(t.z) * c);
+                    qf[0][ks].w = pack_bf16x2(bf16lo(t.w) * c, bf16hi(t.w) * c);
+                }
 #pragma unroll
                 for (int db = 0; db < NDB; ++db)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        o_first[SEG2 ? gq : 0][SEG2 ? db : 0][r] = o[gq][db][r] * inv0;
-                        o[gq][db][r] = 0.f;
-                    }
-                mt[gq] = 0.f;
-                if (QSLOT) {
-                    if (hi) qf[gq][KS - 1].x &= 0xFFFF0000u;
-                } else {
+                    for (int r = 0; r < 16; ++r) o[0][db][r] = 0.f;
+                mt[0] = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) cinit[gq][r] = 0.f;
+                for (int r = 0; r < 16; ++r) cinit[0][r] = 0.f;
+            }
+            if (gi + 1 < p.ng) {  // (rows past Nq are clamped; their group is never computed)
+                const int qrow = min(q0 + 128 + l31, p.Nq - 1);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int d0 = 16 * ks + 8 * hi;
+                    qraw[ks] = *reinterpret_cast<const u32x4*>(qp + (long)qrow * p.q_sn + (d0 < D ? d0 : 0));
                 }
             }
+            seg_nk = p.Nk;
+            for (int t = 0; t < nt0; ++t) tile(t, t);
+            if (SEG2) {
+                park();
+                seg_nk = p.Nk2;
+                tile(0, 2);
+            }
+            store_o();
         }
+        return;
     }
 
 #ifdef AE_ATTN_LAB
@@ -448,39 +548,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
         atomicAdd(&g_attn_dbg[2], 1ull);
     }
 #endif
-    // ---- normalise and store: 4 consecutive d per lane -> 8-byte stores
-    bf16_t* op = p.o + (long)b * p.o_sb + (long)h * p.o_sh;
-#pragma unroll
-    for (int gq = 0; gq < QG; ++gq) {
-        const float lsum = __shfl(o[gq][LDB][LREG], l31, 64);
-        const float inv = (SEG2 ? p.scale2[b] : (p.out_scale ? p.out_scale[b] : 1.0f)) / lsum;
-        const int qrow = q0 + 32 * gq + l31;
-        {
-            float* lse_out = SEG2 ? p.lse2 : p.lse;  // v_log_f32 = log2
-            if (lse_out && hi == 0 && qrow < p.Nq) lse_out[((long)b * p.H + h) * p.Nq + qrow] = mt[gq] + __builtin_amdgcn_logf(lsum);
-        }
-        if (qrow < p.Nq) {
-#pragma unroll
-            for (int db = 0; db < NDB; ++db)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int d = 32 * db + 8 * r4 + 4 * hi;
-                    if (d < D) {
-                        float r0 = o[gq][db][4 * r4] * inv, r1 = o[gq][db][4 * r4 + 1] * inv, r2 = o[gq][db][4 * r4 + 2] * inv, r3 = o[gq][db][4 * r4 + 3] * inv;
-                        if (SEG2) {
-                            r0 += o_first[SEG2 ? gq : 0][SEG2 ? db : 0][4 * r4]; r1 += o_first[SEG2 ? gq : 0][SEG2 ? db : 0][4 * r4 + 1];
-                            r2 += o_first[SEG2 ? gq : 0][SEG2 ? db : 0][4 * r4 + 2]; r3 += o_first[SEG2 ? gq : 0][SEG2 ? db : 0][4 * r4 + 3];
-                        }
-                        u32x2* dst = reinterpret_cast<u32x2*>(op + (long)qrow * p.o_sn + d);
-                        if (p.accum) {
-                            const u32x2 prev = *dst;
-                            r0 += bf16lo(prev.x); r1 += bf16hi(prev.x); r2 += bf16lo(prev.y); r3 += bf16hi(prev.y);
-                        }
-                        *dst = (u32x2){pack_bf16x2(r0, r1), pack_bf16x2(r2, r3)};
-                    }
-                }
-        }
-    }
+    store_o();
 }
 
 template <int D>
@@ -498,6 +566,22 @@ int launch_fast(const AttnArgs& a, hipStream_t stream) {
             else hipLaunchKernelGGL((attn_fast_kernel<D, 2, false, 0, 1>), grid, block, 0, stream, a);
             return ae_check_launch("ae_attn_fwd_bf16(fast, rel-pos)");
         }
+    }
+    // Short K/V (cross-attention): all keys resident, p.ng 128-query groups per block (see SKV at the kernel).  Tuning knobs:
+    // AE_ATTN_SKV=0 off; AE_ATTN_SKV_NG=n forces the groups per block (default: the largest of 8/4/2/1 that still fills 3/4 of the block slots).
+    static const int skv_env = getenv("AE_ATTN_SKV") ? atoi(getenv("AE_ATTN_SKV")) : 1;
+    static const int skv_ng = getenv("AE_ATTN_SKV_NG") ? atoi(getenv("AE_ATTN_SKV_NG")) : 0;
+    if (skv_env && !a.rel_h && a.Nk <= 2 * FKT && (!a.k2 || a.Nk2 <= FKT)) {
+        AttnArgs b = a;
+        b.ng = 1;
+        constexpr int occ = D > 96 ? 1 : (D > 64 ? 2 : 3);
+        for (int n = 8; n > 1; n >>= 1)   // at least 3/4 of the chip's 256 x occ block slots stay filled
+            if ((long)((a.Nq + 128 * n - 1) / (128 * n)) * a.B * a.H >= 192 * occ) { b.ng = n; break; }
+        if (skv_ng > 0) b.ng = skv_ng;
+        dim3 gridk((unsigned)((long)((a.Nq + 128 * b.ng - 1) / (128 * b.ng)) * a.B * a.H));
+        if (a.k2) hipLaunchKernelGGL((attn_fast_kernel<D, (D > 96 ? 1 : (D > 64 ? 2 : 3)), true, 0, 0, 1, false, true>), gridk, block, 0, stream, b);
+        else hipLaunchKernelGGL((attn_fast_kernel<D, (D > 96 ? 1 : (D > 64 ? 2 : 3)), false, 0, 0, 1, false, true>), gridk, block, 0, stream, b);
+        return ae_check_launch("ae_attn_fwd_bf16(fast, short K/V)");
     }
     if (a.k2) {
         hipLaunchKernelGGL((attn_fast_kernel<D, (D > 96 ? 1 : (D > 64 ? 2 : 3)), true>), grid, block, 0, stream, a);  // 168 VGPRs spill at head_dim 80

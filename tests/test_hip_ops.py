@@ -488,6 +488,33 @@ def test_attention_run_to_run_determinism_full_size(ops):
             assert torch.equal(ops.attention_bhnd(q2, k2, v2), f2)
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,T,D", [(12, 8, 4096, 78, 4, 40), (16, 8, 1100, 78, 4, 40), (12, 8, 1024, 78, 0, 80), (64, 8, 300, 128, 64, 80)])
+def test_attention_short_kv_query_groups_vs_oracle(ops, B, H, Nq, Nk, T, D):
+    """Cross-attention shapes (text tokens + task token, optionally the expert tokens as a second softmax segment) on the short-K/V
+    variant of attention_fast.hip: all keys resident in LDS, several 128-query groups per block once the grid is large enough
+    (>= 512 blocks: 4 groups at the UNet's 64x64 level, 2 at Nq = 1100 with a ragged last block) — a size no small test reaches.
+    Sampled heads against the fp32 oracle: out = Attn(q, K, V) + g_b * Attn(q, K_ip, V_ip)."""
+    from oracle import ldm_ref as L
+    g = torch.Generator().manual_seed(B * 7 + Nq + D)
+    inner = H * D
+    qq = q(torch.randn(B * Nq, inner, generator=g))
+    kv = q(torch.randn(B * Nk, 2 * inner, generator=g))
+    kvip = q(torch.randn(B * max(T, 1), 2 * inner, generator=g))
+    gate = torch.rand(B, generator=g) + 0.25
+    qs, ks, ks2 = (Nq * inner, D, inner), (Nk * 2 * inner, D, 2 * inner), (T * 2 * inner, D, 2 * inner)
+    qd, kvd, kvipd = qq.to(DEV, BF), kv.to(DEV, BF), kvip.to(DEV, BF)
+    seg2 = (kvipd, kvipd[:, inner:], T, ks2, ks2, gate.to(DEV)) if T else None
+    out = ops.attention(qd, kvd, kvd[:, inner:], B, H, Nq, Nk, D, D ** -0.5, qs, ks, ks, seg2=seg2).float().cpu().view(B, Nq, H, D)
+    for (b, h) in ((0, 0), (B - 1, H - 1), (B // 2, 3), (1, H - 2)):
+        qh = qq.view(B, Nq, H, D)[b, :, h][None]
+        kh, vh = kv.view(B, Nk, 2, H, D)[b, :, 0, h][None], kv.view(B, Nk, 2, H, D)[b, :, 1, h][None]
+        ref = L.sdpa_core(qh, kh, vh, D ** -0.5)
+        if T:
+            k2, v2 = kvip.view(B, T, 2, H, D)[b, :, 0, h][None], kvip.view(B, T, 2, H, D)[b, :, 1, h][None]
+            ref = ref + gate[b] * L.sdpa_core(qh, k2, v2, D ** -0.5)
+        check_close(out[b, :, h][None], ref, rl2=6e-3, what=f"short-K/V attention b={b} h={h}")
+
+
 def test_attention_two_query_groups_vs_oracle(ops):
     """The 64-queries-per-wave variant of the long-sequence kernel (attention_fast.hip, QG = 2) only runs on grids of >= 1024 blocks
     of 256 queries — no small test reaches it.  B*H = 64 heads of N = 4096, d = 40 (the UNet's 64x64-level shape at a smaller batch):
