@@ -1060,11 +1060,15 @@ def _conv_label(_r, x, w, bias, B, H, W, addvec=None, residual=None, stride=1, u
 
 
 def _attn_label(_r, q, k, v, B, H, Nq, Nk, D, *a, **kw):
-    # attention_fast.hip takes head dims 40 / 80 without mask / log-sum-exp outputs (rel-pos bias only in its kW == 64 form)
-    fast = D in (40, 80) and kw.get("key_mask") is None and os.environ.get("AE_ATTN_FAST", "1") != "0" and \
+    # mirror of ae_attn_fast_launch: attention_fast.hip takes head dims 40 / 80 / 160 without key mask (rel-pos bias at d = 80 only, in its
+    # kW == 64 or small-window forms); with <= 128 keys (and <= 64 in a second segment) its short-K/V variant runs
+    fast = D in (40, 80, 160) and kw.get("key_mask") is None and os.environ.get("AE_ATTN_FAST", "1") != "0" and \
+        (D != 160 or os.environ.get("AE_ATTN_FAST160", "1") != "0") and \
         (kw.get("rel_h") is None or (D == 80 and ((kw.get("kW") == 64 and Nk % 64 == 0) or (kw.get("kH", 99) <= 16 and kw.get("kW", 99) <= 16))))
-    name = "attn_fast_kernel" if fast else "attn_kernel"
-    return f"{name}<D={D}>|Nq={Nq} Nk={Nk}", 4.0 * B * H * Nq * Nk * D, 2.0 * B * H * D * (2 * Nq + 2 * Nk)
+    seg2 = kw.get("seg2")
+    skv = fast and kw.get("rel_h") is None and Nk <= 128 and (seg2 is None or seg2[2] <= 64) and os.environ.get("AE_ATTN_SKV", "1") != "0"
+    name = ("attn_fast_kernel" if fast else "attn_kernel")
+    return f"{name}<D={D}{',shortKV' if skv else ''}>|Nq={Nq} Nk={Nk}", 4.0 * B * H * Nq * Nk * D, 2.0 * B * H * D * (2 * Nq + 2 * Nk)
 
 
 def _attn8_label(_r, q, k, v, B, H, Nq, Nk, D, *a, **kw):
