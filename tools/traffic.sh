@@ -61,12 +61,13 @@ for k, d in out.items():
     res["kernels"][k] = {"launches": d.get("FETCH_SIZE", d.get("WRITE_SIZE"))["launches"],
                          "fetch_bytes": None if f is None else 2.0 * 1024.0 * f, "write_bytes": None if w is None else 1024.0 * w,
                          "fetch_raw_kib": f, "write_raw_kib": w}
-ln = res["kernels"].get("layernorm_kernel")
+ln_name = "layernorm_rows_kernel" if "layernorm_rows_kernel" in res["kernels"] else "layernorm_kernel"   # round 3: the UNet's LayerNorms run the rows kernel
+ln = res["kernels"].get(ln_name)
 if ln:
     # per evaluation: 15 LN at [12288,640] + 15 at [3072,1280] (+ 3 at [768,1280]; the level-1 LayerNorms are fused into the row-panel
     # GEMM since round 2): expected mean
     exp = (15 * 12288 * 640 + 15 * 3072 * 1280 + 3 * 768 * 1280) * 2.0 / 33.0
-    res["calibration"] = {"kernel": "layernorm_kernel", "expected_bytes_each_way_approx": exp,
+    res["calibration"] = {"kernel": ln_name, "expected_bytes_each_way_approx": exp,
                           "fetch_over_expected": ln["fetch_bytes"] / exp if ln["fetch_bytes"] else None,
                           "write_over_expected": ln["write_bytes"] / exp if ln["write_bytes"] else None}
 json.dump(res, open(f"{R}/gpurun_out/traffic.json", "w"), indent=1)
