@@ -44,6 +44,8 @@ struct GemmArgs {
     float* partial;  // [splitk][M][N] fp32
     float* colstats; // optional [ceil(M/32)][N][2] fp32: per-channel (sum, sum of squares) of the bf16-rounded OUTPUT over each 32-row slab, written
                      // by the epilogue (CS instantiations) so that the GroupNorm that consumes this tensor needs no statistics pass
+    int kmajor;      // conv: K ordered (64-channel chunk, tap, channel) instead of (tap, channel): the nine taps of a chunk in consecutive K
+                     // tiles, so that a block's activation window (~40 KB) is re-read from L2, not from the MALL (weights packed to match)
     int m_fast;      // tile order inside an XCD's run: 1 = M tiles fastest (tiles sharing a WEIGHT panel are neighbours: small-M layers whose
                      // weights outweigh the activations), 0 = N tiles fastest (tiles sharing an ACTIVATION panel are neighbours)
 };
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
     const int klast = p.K - 8;
     // conv: tap / channel offset of the NEXT tile to load
     int ld_tap = (kt_begin * BK) / (AMODE == A_CONV3 ? p.CinPad : 1 << 30), ld_ci = (AMODE == A_CONV3) ? (kt_begin * BK) % p.CinPad : 0;
+    if (AMODE == A_CONV3 && p.kmajor) { ld_tap = kt_begin % 9; ld_ci = (kt_begin / 9) * BK; }  // (chunk, tap) order: LDS-DMA loader only
 
     auto load_tile = [&](int kt) {
         const int k0 = (kt_begin + kt) * BK;
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                 }
             } else {
                 const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
-                if (ld_ci == 0 || kt == 0) {  // a new tap: the per-lane part (halo mask, upsample source pixel) changes only here
+                if (ld_ci == 0 || kt == 0 || p.kmajor) {  // a new tap: the per-lane part (halo mask, upsample source pixel) changes only here
 #pragma unroll
                     for (int i = 0; i < A_CH; ++i) {
                         int src = fa_off[i] + ((ky * p.Wd + kx) * p.Cin) * 2;  // >= 0 for every in-image tap (voffset is bounds-checked unsigned)
@@ -383,8 +386,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                     lds_dma16(rsA, dst, fa_cur[i], tap_off);
                 }
                 }
-                ld_ci += BK;
-                if (ld_ci >= p.CinPad) { ld_ci = 0; ++ld_tap; }
+                if (p.kmajor) {
+                    if (++ld_tap == 9) { ld_tap = 0; ld_ci += BK; }
+                } else {
+                    ld_ci += BK;
+                    if (ld_ci >= p.CinPad) { ld_ci = 0; ++ld_tap; }
+                }
             }
 #pragma unroll
             for (int i = 0; i < B_CH; ++i) {
@@ -914,6 +921,7 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // LDS-DMA loaders need whole-tile decisions: no K tail, no mixed-source tile, no upsample gather / padded channels
     static const int glds_env = getenv("AE_GEMM_GLDS") ? atoi(getenv("AE_GEMM_GLDS")) : 1;  // tuning knob (A/B on hardware)
     const bool glds = glds_env && (conv ? (a.Cin == a.CinPad) : (a.K % BK == 0 && (!a.A2 || a.Ksplit % BK == 0)));
+    if (conv && a.kmajor && !glds) { ae_set_error("%s: the chunk-major K order exists only in the LDS-DMA loader (AE_GEMM_GLDS=0 is set)", what); return AE_ERR_UNSUPPORTED; }
     auto lds_of = [](int bm, int bn, int st) { return (size_t)st * (bm + bn) * BK * sizeof(bf16_t); };
     int rc = 0;
 
@@ -1096,8 +1104,10 @@ extern "C" long ae_conv3x3_workspace_floats(int B, int H, int W, int Cin, int Co
 
 extern "C" int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float* addvec, long addvec_ld,
                                const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int stride, int upsample2x,
-                               int out_f32, float* workspace, float* colstats, void* stream) {
+                               int out_f32, float* workspace, float* colstats, int k_order, void* stream) {
     AE_REQUIRE(x && w && y, "ae_conv3x3_bf16: null pointer");
+    AE_REQUIRE(k_order == 0 || k_order == 1, "ae_conv3x3_bf16: k_order must be 0 (tap, channel) or 1 (64-channel chunk, tap, channel)");
+    AE_REQUIRE(k_order == 0 || (Cin % 64 == 0 && !upsample2x), "ae_conv3x3_bf16: the chunk-major K order needs Cin %% 64 == 0 and no upsampling (Cin=%d)", Cin);
     if (colstats) AE_REQUIRE(!out_f32 && Cout % 8 == 0 && (reinterpret_cast<uintptr_t>(colstats) & 15) == 0, "ae_conv3x3_bf16: column statistics need a bf16 output with Cout %% 8 == 0");
     AE_REQUIRE(B > 0 && H > 0 && W > 0, "ae_conv3x3_bf16: bad shape B=%d H=%d W=%d", B, H, W);
     AE_REQUIRE(Cin % 8 == 0, "ae_conv3x3_bf16: Cin=%d must be a multiple of 8", Cin);
@@ -1121,5 +1131,6 @@ extern "C" int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, 
     a.splitk = workspace ? make_plan(a.M, a.N, a.K, true).splitk : 1;  // without a workspace the kernel runs unsplit
     a.partial = workspace;
     a.colstats = colstats;
+    a.kmajor = k_order;
     return launch<A_CONV3>(a, (hipStream_t)stream);
 }

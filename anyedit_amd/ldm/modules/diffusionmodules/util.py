@@ -136,8 +136,15 @@ class Conv2d(nn.Conv2d, _Packed):
         pk = self._packed()
         if self.kernel_size[0] == 1:
             return ops.gemm(x, pk["w"], pk["b"], residual=residual, out_f32=out_f32, a2=a2, colstats=colstats), H, W
-        return ops.conv3x3(x, pk["w"], pk["b"], B, H, W, addvec=addvec, residual=residual, stride=self.stride[0],
-                           upsample2x=upsample2x, out_f32=out_f32, colstats=colstats)
+        Ho, Wo = self.out_hw(H, W, upsample2x)
+        ko = ops.conv_k_order(B * Ho * Wo, self.in_channels, self.out_channels, self.stride[0], upsample2x)
+        w = pk["w"]
+        if ko:  # second pack of the same weights in the chunk-major K order, made on first use (the 64x64-level convs: 2-6 MB each)
+            if "w_kmajor" not in pk:
+                pk["w_kmajor"] = ops.pack_conv3x3(self.weight, k_order=1)
+            w = pk["w_kmajor"]
+        return ops.conv3x3(x, w, pk["b"], B, H, W, addvec=addvec, residual=residual, stride=self.stride[0],
+                           upsample2x=upsample2x, out_f32=out_f32, colstats=colstats, k_order=ko)
 
     def out_hw(self, H, W, upsample2x=False):
         """Output extent of `rows` for an H x W input."""

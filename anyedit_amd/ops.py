@@ -86,13 +86,31 @@ def pack_linear(w):
     return w.detach().reshape(w.shape[0], -1).to(BF16).contiguous()
 
 
-def pack_conv3x3(w, cin_pad=None):
-    """[Cout, Cin, 3, 3] -> bf16 [Cout, 9*Cin_pad], K ordered (ky, kx, cin) to match the implicit-GEMM gather."""
+def pack_conv3x3(w, cin_pad=None, k_order=0):
+    """[Cout, Cin, 3, 3] -> bf16 [Cout, 9*Cin_pad], K ordered (ky, kx, cin) to match the implicit-GEMM gather; k_order = 1: K ordered
+    (cin // 64, ky, kx, cin % 64) — the chunk-major order of `conv3x3(..., k_order=1)` (same values, another column order)."""
     cout, cin = w.shape[0], w.shape[1]
     cin_pad = cin_pad or ((cin + 63) // 64 * 64)
     wp = torch.zeros(cout, 3, 3, cin_pad, dtype=BF16, device=w.device)
     wp[..., :cin] = w.detach().permute(0, 2, 3, 1).to(BF16)
+    if k_order == 1:
+        wp = wp.reshape(cout, 9, cin_pad // 64, 64).permute(0, 2, 1, 3)
     return wp.reshape(cout, 9 * cin_pad).contiguous()
+
+
+_CONV_KMAJOR = int(os.environ.get("AE_CONV_KMAJOR", "1"))  # tuning knob: 0 off, 1 un-split 192x320 plan, 2 + its split-K form, 3 every eligible conv
+
+
+def conv_k_order(M, Cin, Cout, stride=1, upsample2x=False):
+    """Which packed K order `conv3x3` should be given for this launch (the planner's mirror): the chunk-major order where the 192x320 tile
+    runs (64x64 UNet level at batch >= 12: a block's nine tap windows are then re-read from L2 instead of the MALL), the tap-major order
+    elsewhere (measured slower there) and always under the tape (the backward passes use rotated tap-major packs)."""
+    if _CONV_KMAJOR == 0 or upsample2x or Cin % 64 != 0 or (_TAPE is not None and _TAPE.active) or os.environ.get("AE_GEMM_GLDS", "1") == "0":
+        return 0
+    if _CONV_KMAJOR >= 3:
+        return 1
+    label = _tile_label(M, Cout, True, 9 * Cin, False, True)
+    return 1 if (label == "192x320" or (_CONV_KMAJOR >= 2 and label == "192x320,splitK")) else 0
 
 
 def pack_geglu(w, b):
@@ -210,10 +228,12 @@ def ln_gemm(x, gamma, beta, eps, w, bias=None, residual=None, epilogue=EPI_NONE,
     return gemm(layernorm(x, gamma, beta, eps), w, bias, residual=residual, epilogue=epilogue, out=out, colstats=colstats)
 
 
-def conv3x3(x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2x=False, out_f32=False, out=None, colstats=None):
-    """x: [B*H*W, Cin] bf16 channels-last, w: packed [Cout, 9*Cin].  Returns ([B*Ho*Wo, Cout], Ho, Wo).
+def conv3x3(x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2x=False, out_f32=False, out=None, colstats=None, k_order=0):
+    """x: [B*H*W, Cin] bf16 channels-last, w: packed [Cout, 9*Cin] (`pack_conv3x3` with the same k_order).  Returns ([B*Ho*Wo, Cout], Ho, Wo).
     colstats: optional `colstats_buffer(B*Ho*Wo, Cout)` that receives the per-channel slab statistics of the output."""
     if _TAPE is not None and _TAPE.active:
+        if k_order:
+            raise ValueError("conv3x3: the tape records convolutions on tap-major packed weights (k_order=0)")
         return _TAPE.conv3x3(x, w, bias, B, H, W, addvec=addvec, residual=residual, stride=stride, upsample2x=upsample2x, out_f32=out_f32, out=out)
     _chk(x, BF16, "conv3x3.x", 2)
     _chk(w, BF16, "conv3x3.w", 2)
@@ -238,7 +258,7 @@ def conv3x3(x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2
         if tuple(colstats.shape) != ((B * Ho * Wo + 31) // 32, Cout, 2) or not colstats.is_contiguous():
             raise ValueError(f"conv3x3: colstats must be a contiguous [{(B * Ho * Wo + 31) // 32}, {Cout}, 2] fp32 buffer")
     check(lib.ae_conv3x3_bf16(_p(x), _p(w), _p(bias), _p(addvec), addvec.stride(0) if addvec is not None else 0, _p(residual),
-                              _p(out), B, H, W, Cin, Cout, stride, int(upsample2x), 1 if out_f32 else 0, _p(ws), _p(colstats), _s()),
+                              _p(out), B, H, W, Cin, Cout, stride, int(upsample2x), 1 if out_f32 else 0, _p(ws), _p(colstats), int(k_order), _s()),
           "ae_conv3x3_bf16")
     return out, Ho, Wo
 

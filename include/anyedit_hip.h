@@ -67,11 +67,13 @@ int ae_ln_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, l
  *   rounded up to 64 (zero filled), y [B,Ho,Wo,Cout];
  *   addvec fp32 [B,Cout] (time-embedding add, openaimodel.py:262-272), residual bf16 [B,Ho,Wo,Cout] (skip, :274).
  *   workspace: NULL or ae_conv3x3_workspace_floats(...) fp32 elements (0 = not needed): enables split-K for the small-M,
- *   huge-K layers (8x8 / 16x16 latents) that cannot fill 256 CUs with output tiles alone.                                  */
+ *   huge-K layers (8x8 / 16x16 latents) that cannot fill 256 CUs with output tiles alone.
+ *   k_order: 0 = w packed (ky,kx,cin) as above; 1 = w packed (cin / 64, ky, kx, cin % 64) — the nine taps of a 64-channel chunk
+ *   in consecutive K tiles, so a block re-reads its activation window from L2 (Cin % 64 == 0, no upsampling); same result.   */
 long ae_conv3x3_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride, int upsample2x);
 int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float* addvec, long addvec_ld, const void* residual,
                     void* y, int B, int H, int W, int Cin, int Cout, int stride, int upsample2x, int out_f32, float* workspace,
-                    float* colstats /* as for ae_gemm_bf16 (M = B*Ho*Wo, N = Cout); NULL = none */, void* stream);
+                    float* colstats /* as for ae_gemm_bf16 (M = B*Ho*Wo, N = Cout); NULL = none */, int k_order, void* stream);
 
 /* GroupNorm32 (+SiLU) (util.py:217-219 eps 1e-5; attention.py:88-89 eps 1e-6); input may be the channel-concat [x | x2].
  * workspace: fp32, ae_groupnorm_workspace_floats(B,HW,C,groups) elements.  act: 0 none, 1 SiLU.

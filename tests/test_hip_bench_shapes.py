@@ -60,6 +60,14 @@ def test_conv3x3_bench_plan_vs_conv2d(B, H, W, Cin, Cout, ups):
     m = float((got - ref).abs().max()) / float(ref.abs().max())
     print(f"\nconv3x3 [{B},{Cin},{H},{W}] -> {Cout} (ups={ups}): rel-L2 {e:.3e}, max-abs/max {m:.3e}")
     assert e <= 4e-3 and m <= 2e-2          # bf16 output rounding alone is ~1.1e-3 (tests/test_hip_ops.py tolerances)
+    ko = ops.conv_k_order(M, Cin, Cout, 1, ups)
+    assert ko == (0 if ups else 1), "the un-split 192x320 plan takes the chunk-major K order (not the upsampling conv)"
+    if ko:  # what the UNet module actually launches at this shape: the same tile on the chunk-major weight pack
+        y1, _, _ = ops.conv3x3(ops.nchw_to_rows(x.to(DEV)), ops.pack_conv3x3(w.to(DEV), k_order=1), bias.to(DEV), B, H, W, addvec=emb.to(DEV), k_order=1)
+        got1 = ops.rows_to_nchw(y1, B, Ho, Wo).cpu()
+        e1 = rel_l2(got1, ref)
+        print(f"   chunk-major K order: rel-L2 {e1:.3e}; against the tap-major result {rel_l2(got1, got):.3e}")
+        assert e1 <= 4e-3 and float((got1 - ref).abs().max()) / float(ref.abs().max()) <= 2e-2
 
 
 # ------------------------------------------------------------------------------------------------- UNet batch 12 / 24

@@ -252,6 +252,25 @@ def test_conv3x3(ops, B, H, W, Cin, Cout, stride, ups):
     check_close(ops.rows_to_nchw(y, B, Ho, Wo), ref, what="conv3x3")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(2, 8, 8, 64, 64, 1), (1, 7, 9, 64, 64, 2), (3, 5, 6, 128, 72, 1), (1, 64, 64, 320, 320, 1),
+                                                   (12, 16, 16, 256, 1280, 1), (12, 16, 16, 320, 640, 1), (12, 8, 8, 1280, 1280, 1)])
+def test_conv3x3_chunk_major_k_order(ops, B, H, W, Cin, Cout, stride):
+    """K ordered (64-channel chunk, tap, channel) instead of (tap, channel) — `k_order=1` with the matching weight pack — on every tile
+    plan (64x64, 128x128, the three-stage ring with split-K, the split 192x320 tile): the same convolution, another accumulation order."""
+    g = torch.Generator().manual_seed(B + H * 3 + Cin + Cout + stride + 100)
+    x = q(torch.randn(B, Cin, H, W, generator=g))
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5))
+    bias, emb = torch.randn(Cout, generator=g), torch.randn(B, Cout, generator=g)
+    ref = F.conv2d(x, w, bias, stride=stride, padding=1) + emb[:, :, None, None]
+    rows = ops.nchw_to_rows(x.to(DEV))
+    y1, Ho, Wo = ops.conv3x3(rows, ops.pack_conv3x3(w.to(DEV), k_order=1), bias.to(DEV), B, H, W, addvec=emb.to(DEV), stride=stride, out_f32=True, k_order=1)
+    y0, _, _ = ops.conv3x3(rows, ops.pack_conv3x3(w.to(DEV)), bias.to(DEV), B, H, W, addvec=emb.to(DEV), stride=stride, out_f32=True)
+    check_close(ops.rows_to_nchw(y1, B, Ho, Wo), ref, rl2=1e-3, what="conv3x3 chunk-major K order")
+    assert rel_l2(y1.cpu(), y0.cpu()) <= 2e-6, "the two K orders differ only by the order of the fp32 accumulation"
+    with pytest.raises(RuntimeError, match="Cin %% 64|Cin % 64"):
+        ops.conv3x3(ops.nchw_to_rows(x[:, :8].contiguous().to(DEV)), ops.pack_conv3x3(w[:, :8].contiguous().to(DEV)), None, B, H, W, stride=stride, k_order=1)
+
+
 def test_conv3x3_fused_epilogue(ops):
     """+bias +time-embedding vector (openaimodel.py:262-272) +skip residual (:274), fp32 output variant."""
     g = torch.Generator().manual_seed(3)

@@ -411,9 +411,9 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     expect(lib.ae_gemm_bf16(p16, 64, None, 0, 0, p16, 64, p16, 64, 8, 8, 60, None, None, 0, None, 0, 0, 0, 0, None, None), "multiple of 8")           # ragged K
     expect(lib.ae_gemm_bf16(p16 + 2, 64, None, 0, 0, p16, 64, p16, 64, 8, 8, 64, None, None, 0, None, 0, 0, 0, 0, None, None), "16-byte aligned")    # misaligned A
     expect(lib.ae_gemm_bf16(p16, 64, None, 0, 0, p16, 64, p16, 64, 8, 8, 64, None, None, 0, None, 0, 0, 9, 0, None, None), "bad epilogue")
-    expect(lib.ae_conv3x3_bf16(p16, p16, None, None, 0, None, p16, 0, 8, 8, 64, 64, 1, 0, 0, None, None, None), "bad shape")                           # empty batch
-    expect(lib.ae_conv3x3_bf16(p16, p16, None, None, 0, None, p16, 1, 8, 8, 60, 64, 1, 0, 0, None, None, None), "multiple of 8")
-    expect(lib.ae_conv3x3_bf16(p16, p16, None, None, 0, None, p16, 1, 8, 8, 64, 64, 3, 0, 0, None, None, None), "stride must be 1 or 2")
+    expect(lib.ae_conv3x3_bf16(p16, p16, None, None, 0, None, p16, 0, 8, 8, 64, 64, 1, 0, 0, None, None, 0, None), "bad shape")                           # empty batch
+    expect(lib.ae_conv3x3_bf16(p16, p16, None, None, 0, None, p16, 1, 8, 8, 60, 64, 1, 0, 0, None, None, 0, None), "multiple of 8")
+    expect(lib.ae_conv3x3_bf16(p16, p16, None, None, 0, None, p16, 1, 8, 8, 64, 64, 3, 0, 0, None, None, 0, None), "stride must be 1 or 2")
     expect(lib.ae_groupnorm_nhwc_bf16(p16, None, 0, p16, p16, p16, 1, 64, 60, 32, 1e-5, 0, p16, None, None, None, None, None), "bad shape")                  # C % groups
     expect(lib.ae_groupnorm_nhwc_bf16(p16, None, 0, p16, p16, p16, 1, 64, 64, 32, 1e-5, 7, p16, None, None, None, None, None), "act must be")
     expect(lib.ae_layernorm_bf16(p16, p16, p16, p16, 4, 60, 1e-5, None), "multiple of 8")
