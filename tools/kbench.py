@@ -82,11 +82,12 @@ def main():
                                              (64, 320, 320, 2, False, "down L1"), (32, 640, 640, 1, True, "up ->64"),
                                              (64, 8, 320, 1, False, "stem"), (64, 320, 4, 1, False, "head")):
         x = rnd(B * H * H, Cin)
-        w = ops.pack_conv3x3(torch.randn(Cout, Cin, 3, 3, device=DEV) * 0.02)
-        bias = torch.randn(Cout, device=DEV)
         Ho = (2 * H if ups else H) // stride
-        case(f"conv3x3 {tag} {Cin}->{Cout} @{H} s{stride}{' up' if ups else ''}",
-             lambda x=x, w=w, bias=bias, H=H, stride=stride, ups=ups: ops.conv3x3(x, w, bias, B, H, H, stride=stride, upsample2x=ups),
+        ko = ops.conv_k_order(B * Ho * Ho, Cin, Cout, stride, ups)   # the K order the UNet module gives this launch
+        w = ops.pack_conv3x3(torch.randn(Cout, Cin, 3, 3, device=DEV) * 0.02, k_order=ko)
+        bias = torch.randn(Cout, device=DEV)
+        case(f"conv3x3 {tag} {Cin}->{Cout} @{H} s{stride}{' up' if ups else ''}{' kmajor' if ko else ''}",
+             lambda x=x, w=w, bias=bias, H=H, stride=stride, ups=ups, ko=ko: ops.conv3x3(x, w, bias, B, H, H, stride=stride, upsample2x=ups, k_order=ko),
              2.0 * B * Ho * Ho * Cout * 9 * Cin, 2.0 * (B * H * H * Cin + 9 * Cin * Cout + B * Ho * Ho * Cout))
     # ---- norms
     for (HW, C, C1) in ((4096, 320, None), (4096, 960, 640), (1024, 640, None), (256, 1280, None), (64, 2560, 1280)):
