@@ -98,7 +98,7 @@ def pack_conv3x3(w, cin_pad=None, k_order=0):
     return wp.reshape(cout, 9 * cin_pad).contiguous()
 
 
-_CONV_KMAJOR = int(os.environ.get("AE_CONV_KMAJOR", "1"))  # tuning knob: 0 off, 1 un-split 192x320 plan, 2 + its split-K form, 3 every eligible conv
+_CONV_KMAJOR = int(os.environ.get("AE_CONV_KMAJOR", "1"))  # tuning knob: 0 off, 1 un-split 192x320 plan, 2 + its split-K form, 3 every eligible conv, 4 un-split 192x320 and 128x128 plans
 
 
 def conv_k_order(M, Cin, Cout, stride=1, upsample2x=False):
@@ -107,9 +107,11 @@ def conv_k_order(M, Cin, Cout, stride=1, upsample2x=False):
     elsewhere (measured slower there) and always under the tape (the backward passes use rotated tap-major packs)."""
     if _CONV_KMAJOR == 0 or upsample2x or Cin % 64 != 0 or (_TAPE is not None and _TAPE.active) or os.environ.get("AE_GEMM_GLDS", "1") == "0":
         return 0
-    if _CONV_KMAJOR >= 3:
+    if _CONV_KMAJOR == 3:
         return 1
     label = _tile_label(M, Cout, True, 9 * Cin, False, True)
+    if _CONV_KMAJOR == 4:   # (A/B only) the un-split plans of the 64x64 and 32x32 levels
+        return 1 if label in ("192x320", "128x128") else 0
     return 1 if (label == "192x320" or (_CONV_KMAJOR >= 2 and label == "192x320,splitK")) else 0
 
 

@@ -5,6 +5,7 @@
 set -u
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
 R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT
+( timeout 600 python -c "import __graft_entry__ as g; g.build(); g.smoke()" ) > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
 ( timeout 900 python -m pytest tests -m gpu -q -s -p no:cacheprovider --durations=8 ) > $OUT/pytest_gpu_full.log 2>&1; echo "pytest rc=$?"
 grep -E "passed|failed|rel-L2|slowest|s call" $OUT/pytest_gpu_full.log | tail -20
 E2E=""; [ "${AE_EVIDENCE_CPU_E2E:-0}" = "1" ] && E2E="--cpu-e2e"
