@@ -22,6 +22,9 @@
 
 namespace {
 
+#ifndef AE_GEMM_WA_DEFAULT
+#define AE_GEMM_WA_DEFAULT 3
+#endif
 constexpr int BK = 64;  // 64 bf16 = 128 B per tile row = 8 chunks of 16 B
 
 enum { A_DENSE = 0, A_CONV3 = 1 };
@@ -92,9 +95,10 @@ constexpr int epilogue_passes(int FM, int bytes_per_frag_row, int lds_bytes) {
 // ~14 B/clk/CU) is the LDS-DMA path's rate.  It is not that simple: 192x320 conv 87.8 -> 92.6 us (A through registers) / 96.2 (W),
 // 128x128 conv 105.9 -> 115.9 / 118.1, dense 128x128 +3..+10 %, UNet step 14.44 -> 14.51-14.60 ms (profiles/r03_v3_hybrid_loader.txt).)
 // LAB (AE_GEMM_LAB builds only, tools/ubench): 1 = no DMA after the first tile, 2 = no LDS reads / MFMAs, 3 = MFMAs on stale registers (no LDS reads)
-template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false, int WAVES_K = 1, int STAGES = 2, bool CS = false, int LAB = 0>
+template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false, int WAVES_K = 1, int STAGES = 2, bool CS = false, int LAB = 0, bool WA = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(const GemmArgs p) {
     static_assert(STAGES == 2 || (GLDS && WAVES_K == 1), "the deep LDS ring exists only for the LDS-DMA loader");
+    static_assert(!WA || (GLDS && STAGES == 2 && WAVES_K == 1), "weights-ahead is a variant of the two-stage LDS-DMA pipeline");
     static_assert(WAVES_K == 1 || WAVES_K == 2, "K groups: 1 or 2");
     constexpr int NT = 64 * WAVES_M * WAVES_N * WAVES_K;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
@@ -292,10 +296,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto compute_tile = [&](int cur) {
+    auto compute_tile = [&](int cur, int curB = -1) {
         if (LAB == 2) return;
         const bf16_t* cA = sA + cur * BM * BK + (wm * WM) * BK;
-        const bf16_t* cB = sB + cur * BN * BK + (wn * WN) * BK;
+        const bf16_t* cB = sB + (curB < 0 ? cur : curB) * BN * BK + (wn * WN) * BK;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             if (WAVES_K == 2 && kk != wk) continue;  // wave-uniform: this K half belongs to the other group
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
         // lane-linear, so the XOR swizzle is applied to the per-lane SOURCE chunk instead (same involution as the ds_read
         // side).  hipcc drains the DMA (vmcnt(0)) in front of each __syncthreads().
         int fa_cur[A_CH];  // conv: this tap's per-lane gather offset (OOB for halo pixels)
-        auto dma_tile = [&](int kt, int buf) {
+        auto dma_a = [&](int kt, int buf) {
             const int k0 = (kt_begin + kt) * BK;
             if (AMODE == A_DENSE) {
                 const bool second = k0 >= p.Ksplit;
@@ -393,13 +397,46 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                     if (ld_ci >= p.CinPad) { ld_ci = 0; ++ld_tap; }
                 }
             }
+        };
+        auto dma_w = [&](int kt, int buf) {
+            const int k0 = (kt_begin + kt) * BK;
 #pragma unroll
             for (int i = 0; i < B_CH; ++i) {
                 bf16_t* dst = sB + buf * BN * BK + (wave + (NT / 64) * i) * 8 * BK;
                 lds_dma16(rsW, dst, fb_off[i], k0 * 2);
             }
         };
-        if constexpr (STAGES == 2) {
+        auto dma_tile = [&](int kt, int buf) { dma_a(kt, buf); dma_w(kt, buf); };
+        if constexpr (WA) {
+            // Weights two tiles ahead (three W stages, two A stages): inside a UNet evaluation a layer's weights arrive from HBM, its
+            // activations from L2 / the Infinity Cache (tools/cold_weight_probe.py: cold weights cost the 32x32 / 8x8-level launches
+            // 5-11 %).  Per step the A tile of step kt + 1 and the W tile of step kt + 2 are issued, in that order; DMA pieces retire in
+            // issue order, so vmcnt(B_CH) at the end of the step proves A(kt + 1) and W(kt + 1) have landed while W(kt + 2) keeps flying.
+            dma_a(0, 0);
+            dma_w(0, 0);
+            if (KT > 1) dma_w(1, 1);
+            if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_CH) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // unrolled by six (lcm of the two ring lengths): every stage index is a compile-time constant, as in the two-stage loop
+            for (int kt0 = 0; kt0 < KT; kt0 += 6) {
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int kt = kt0 + u;
+                    if (kt >= KT) break;
+                    constexpr int dummy = 0; (void)dummy;
+                    const int cur = u & 1, wcur = u % 3, w2 = (u + 2) % 3;
+                    if (kt + 1 < KT) dma_a(kt + 1, cur ^ 1);        // A stage cur^1 was last read before the previous barrier
+                    if (kt + 2 < KT) dma_w(kt + 2, w2);             // the W stage read in step kt - 1
+                    compute_tile(cur, wcur);
+                    if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_CH) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+            }
+        } else if constexpr (STAGES == 2) {
             dma_tile(0, 0);
             __syncthreads();
             GL_T(0);
@@ -923,6 +960,12 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     const bool glds = glds_env && (conv ? (a.Cin == a.CinPad) : (a.K % BK == 0 && (!a.A2 || a.Ksplit % BK == 0)));
     if (conv && a.kmajor && !glds) { ae_set_error("%s: the chunk-major K order exists only in the LDS-DMA loader (AE_GEMM_GLDS=0 is set)", what); return AE_ERR_UNSUPPORTED; }
     auto lds_of = [](int bm, int bn, int st) { return (size_t)st * (bm + bn) * BK * sizeof(bf16_t); };
+    auto lds_wa = [](int bm, int bn) { return (size_t)(2 * bm + 3 * bn) * BK * sizeof(bf16_t); };  // weights-ahead: two A stages, three W stages
+    // tuning knob (bit flags): weights two tiles ahead on the 8-wave 128x128 two-stage kernel — 1 convs, 2 dense (80 KiB per block: still two
+    // blocks per CU).  Measured (profiles/r03_v30_weights_ahead.txt): with the weight rotated through a pool larger than the Infinity Cache the
+    // 32x32-level conv 640 -> 640 runs 112.3 -> 103.9 us (hot: 101.6 -> 99.1), qkv / ff2 of that level 46.5 -> 44.9 / 47.7 -> 46.7 us; UNet step
+    // 14.50 -> 14.36 ms, two runs each way on one box.  Default on for both.
+    static const int wa = getenv("AE_GEMM_WA") ? atoi(getenv("AE_GEMM_WA")) : AE_GEMM_WA_DEFAULT;
     int rc = 0;
 
     // 192x320 tile, one block per CU (128 KiB LDS), 8 waves with 96x80 (or 48x160 for the GEGLU column pairing) wave tiles:
@@ -1017,8 +1060,11 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         else if (pick == 0 && w8 == 1) AE_LAUNCH(128, 128, 2, 4, 512);
         else if (pick == 0 && wk_env && glds) rc = launch_kernel(gemm_kernel<128, 128, AMODE, 2, 2, true, 2>, grid, 512, lds_of(128, 128, 2), stream, a, what);
         else if (pick == 0 && w8 == 2 && cs_epi_ok && glds) {
-            rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, true>, grid, 512, lds_of(128, 128, 2), stream, a, what);
+            if (wa & (conv ? 1 : 2)) rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, true, 0, true>, grid, 512, lds_wa(128, 128), stream, a, what);
+            else rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, true>, grid, 512, lds_of(128, 128, 2), stream, a, what);
             cs_done = true;
+        } else if (pick == 0 && w8 == 2 && glds && (wa & (conv ? 1 : 2)) && kt_block >= 3) {
+            rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, false, 0, true>, grid, 512, lds_wa(128, 128), stream, a, what);
         }
 #ifdef AE_GEMM_ABLATE
         else if (pick == 0 && w8 == 2 && glds && lab_abl == 1) rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, false, 1>, grid, 512, lds_of(128, 128, 2), stream, a, what);
