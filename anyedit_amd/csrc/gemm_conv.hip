@@ -22,6 +22,9 @@
 
 namespace {
 
+#ifndef AE_GEMM_AA_DEFAULT
+#define AE_GEMM_AA_DEFAULT 1
+#endif
 #ifndef AE_GEMM_WA_DEFAULT
 #define AE_GEMM_WA_DEFAULT 3
 #endif
@@ -95,10 +98,11 @@ constexpr int epilogue_passes(int FM, int bytes_per_frag_row, int lds_bytes) {
 // ~14 B/clk/CU) is the LDS-DMA path's rate.  It is not that simple: 192x320 conv 87.8 -> 92.6 us (A through registers) / 96.2 (W),
 // 128x128 conv 105.9 -> 115.9 / 118.1, dense 128x128 +3..+10 %, UNet step 14.44 -> 14.51-14.60 ms (profiles/r03_v3_hybrid_loader.txt).)
 // LAB (AE_GEMM_LAB builds only, tools/ubench): 1 = no DMA after the first tile, 2 = no LDS reads / MFMAs, 3 = MFMAs on stale registers (no LDS reads)
-template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false, int WAVES_K = 1, int STAGES = 2, bool CS = false, int LAB = 0, bool WA = false>
+template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false, int WAVES_K = 1, int STAGES = 2, bool CS = false, int LAB = 0, int WA = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(const GemmArgs p) {
     static_assert(STAGES == 2 || (GLDS && WAVES_K == 1), "the deep LDS ring exists only for the LDS-DMA loader");
-    static_assert(!WA || (GLDS && STAGES == 2 && WAVES_K == 1), "weights-ahead is a variant of the two-stage LDS-DMA pipeline");
+    static_assert(!WA || (GLDS && STAGES == 2 && WAVES_K == 1), "operand-ahead is a variant of the two-stage LDS-DMA pipeline");
+    static_assert(WA >= 0 && WA <= 2, "WA: 0 none, 1 weights two tiles ahead (three W stages), 2 activations two tiles ahead (three A stages)");
     static_assert(WAVES_K == 1 || WAVES_K == 2, "K groups: 1 or 2");
     constexpr int NT = 64 * WAVES_M * WAVES_N * WAVES_K;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];  // 2 * (BM + BN) * BK bf16 (dynamic: > 64 KiB for 128x160)
     bf16_t* const smem = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* sA = smem;
-    bf16_t* sB = smem + STAGES * BM * BK;
+    bf16_t* sB = smem + (WA == 2 ? 3 : STAGES) * BM * BK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef AE_GEMM_LAB
@@ -407,29 +411,37 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
             }
         };
         auto dma_tile = [&](int kt, int buf) { dma_a(kt, buf); dma_w(kt, buf); };
-        if constexpr (WA) {
-            // Weights two tiles ahead (three W stages, two A stages): inside a UNet evaluation a layer's weights arrive from HBM, its
-            // activations from L2 / the Infinity Cache (tools/cold_weight_probe.py: cold weights cost the 32x32 / 8x8-level launches
-            // 5-11 %).  Per step the A tile of step kt + 1 and the W tile of step kt + 2 are issued, in that order; DMA pieces retire in
-            // issue order, so vmcnt(B_CH) at the end of the step proves A(kt + 1) and W(kt + 1) have landed while W(kt + 2) keeps flying.
-            dma_a(0, 0);
-            dma_w(0, 0);
-            if (KT > 1) dma_w(1, 1);
-            if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_CH) : "memory");
+        if constexpr (WA != 0) {
+            // One operand two tiles ahead (three stages of it, two of the other), for the operand that arrives COLD inside a UNet evaluation:
+            //   WA 1: the weights (32x32 / 8x8 levels: a layer's weights come from HBM, its activations from L2 / the Infinity Cache;
+            //         tools/cold_weight_probe.py: cold weights cost those launches 5-11 %);
+            //   WA 2: the activations (64x64 level on the 192x320 tile: 31-126 MB tensors that no cache holds; 3 x 24 + 2 x 40 = 152 KiB).
+            // Per step the near operand's tile of step kt + 1 and then the far operand's tile of step kt + 2 are issued; DMA pieces retire in
+            // issue order, so vmcnt(FAR pieces) at the end of the step proves everything of step kt + 1 has landed while the far tile of
+            // step kt + 2 keeps flying.  The loop is unrolled by six (lcm of the ring lengths): every stage index is a constant (with a
+            // run-time index hipcc cannot tell the stages apart and waits for the fresh pieces in front of the step's own LDS reads).
+            constexpr int FAR = WA == 1 ? B_CH : A_CH;
+            if (WA == 1) { dma_a(0, 0); dma_w(0, 0); if (KT > 1) dma_w(1, 1); }
+            else { dma_w(0, 0); dma_a(0, 0); if (KT > 1) dma_a(1, 1); }
+            if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FAR) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            // unrolled by six (lcm of the two ring lengths): every stage index is a compile-time constant, as in the two-stage loop
             for (int kt0 = 0; kt0 < KT; kt0 += 6) {
 #pragma unroll
                 for (int u = 0; u < 6; ++u) {
                     const int kt = kt0 + u;
                     if (kt >= KT) break;
-                    constexpr int dummy = 0; (void)dummy;
-                    const int cur = u & 1, wcur = u % 3, w2 = (u + 2) % 3;
-                    if (kt + 1 < KT) dma_a(kt + 1, cur ^ 1);        // A stage cur^1 was last read before the previous barrier
-                    if (kt + 2 < KT) dma_w(kt + 2, w2);             // the W stage read in step kt - 1
-                    compute_tile(cur, wcur);
-                    if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_CH) : "memory");
+                    const int near_cur = u & 1, far_cur = u % 3, far_next = (u + 2) % 3;   // far_next: the stage read in step kt - 1
+                    if (WA == 1) {
+                        if (kt + 1 < KT) dma_a(kt + 1, near_cur ^ 1);
+                        if (kt + 2 < KT) dma_w(kt + 2, far_next);
+                        compute_tile(near_cur, far_cur);
+                    } else {
+                        if (kt + 1 < KT) dma_w(kt + 1, near_cur ^ 1);
+                        if (kt + 2 < KT) dma_a(kt + 2, far_next);
+                        compute_tile(far_cur, near_cur);
+                    }
+                    if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FAR) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
@@ -966,6 +978,13 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // 32x32-level conv 640 -> 640 runs 112.3 -> 103.9 us (hot: 101.6 -> 99.1), qkv / ff2 of that level 46.5 -> 44.9 / 47.7 -> 46.7 us; UNet step
     // 14.50 -> 14.36 ms, two runs each way on one box.  Default on for both.
     static const int wa = getenv("AE_GEMM_WA") ? atoi(getenv("AE_GEMM_WA")) : AE_GEMM_WA_DEFAULT;
+    // tuning knob: ACTIVATIONS two tiles ahead on the dense (non-GEGLU) 192x320 launches (three A stages + two W stages = 152 KiB): the
+    // 64x64-level ff2 (A = the 126 MB GEGLU output, straight from HBM) 70.8 -> 63.0 us in situ, UNet step 14.51 -> 14.47 ms.  The same
+    // variant on the convs of that tile measured 20 % SLOWER (un-split 100 -> 119 us, split-K 105 -> 123 us: their per-tap gather offsets
+    // are VGPR operands of the DMA pieces, and hipcc waits for the pieces in flight before it rewrites them), on the GEGLU launches it
+    // spills (4 x 2 waves); neither is instantiated (profiles/r03_v30_weights_ahead.txt).
+    auto lds_aa = [](int bm, int bn) { return (size_t)(3 * bm + 2 * bn) * BK * sizeof(bf16_t); };
+    static const int aa = getenv("AE_GEMM_AA") ? atoi(getenv("AE_GEMM_AA")) : AE_GEMM_AA_DEFAULT;
     int rc = 0;
 
     // 192x320 tile, one block per CU (128 KiB LDS), 8 waves with 96x80 (or 48x160 for the GEGLU column pairing) wave tiles:
@@ -1004,6 +1023,8 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
             else if (cs_epi_ok && AMODE == A_CONV3) {
                 if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
                 cs_done = true;
+            } else if (!conv && aa) {
+                if constexpr (AMODE == A_DENSE) rc = launch_kernel(gemm_kernel<192, 320, A_DENSE, 2, 4, true, 1, 2, false, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
             }
 #ifdef AE_GEMM_ABLATE
             else if (conv && lab_abl == 1) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 1>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what); }
@@ -1060,11 +1081,11 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         else if (pick == 0 && w8 == 1) AE_LAUNCH(128, 128, 2, 4, 512);
         else if (pick == 0 && wk_env && glds) rc = launch_kernel(gemm_kernel<128, 128, AMODE, 2, 2, true, 2>, grid, 512, lds_of(128, 128, 2), stream, a, what);
         else if (pick == 0 && w8 == 2 && cs_epi_ok && glds) {
-            if (wa & (conv ? 1 : 2)) rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, true, 0, true>, grid, 512, lds_wa(128, 128), stream, a, what);
+            if (wa & (conv ? 1 : 2)) rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, true, 0, 1>, grid, 512, lds_wa(128, 128), stream, a, what);
             else rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, true>, grid, 512, lds_of(128, 128, 2), stream, a, what);
             cs_done = true;
         } else if (pick == 0 && w8 == 2 && glds && (wa & (conv ? 1 : 2)) && kt_block >= 3) {
-            rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, false, 0, true>, grid, 512, lds_wa(128, 128), stream, a, what);
+            rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, false, 0, 1>, grid, 512, lds_wa(128, 128), stream, a, what);
         }
 #ifdef AE_GEMM_ABLATE
         else if (pick == 0 && w8 == 2 && glds && lab_abl == 1) rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, false, 1>, grid, 512, lds_of(128, 128, 2), stream, a, what);
