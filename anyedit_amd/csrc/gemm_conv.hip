@@ -23,7 +23,7 @@
 namespace {
 
 #ifndef AE_GEMM_AA_DEFAULT
-#define AE_GEMM_AA_DEFAULT 1
+#define AE_GEMM_AA_DEFAULT 3
 #endif
 #ifndef AE_GEMM_WA_DEFAULT
 #define AE_GEMM_WA_DEFAULT 3
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
     int ld_tap = (kt_begin * BK) / (AMODE == A_CONV3 ? p.CinPad : 1 << 30), ld_ci = (AMODE == A_CONV3) ? (kt_begin * BK) % p.CinPad : 0;
     if (AMODE == A_CONV3 && p.kmajor) { ld_tap = kt_begin % 9; ld_ci = (kt_begin / 9) * BK; }  // (chunk, tap) order: LDS-DMA loader only
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt) __attribute__((always_inline)) {
         const int k0 = (kt_begin + kt) * BK;
         const bool full_k = k0 + BK <= p.K;
         if (AMODE == A_DENSE && full_k && (k0 + BK <= p.Ksplit || k0 >= p.Ksplit)) {
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
         }
     };
 
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
             const int id = tid + i * NT, row = id >> 3, c = id & 7;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto compute_tile = [&](int cur, int curB = -1) {
+    auto compute_tile = [&](int cur, int curB = -1) __attribute__((always_inline)) {
         if (LAB == 2) return;
         const bf16_t* cA = sA + cur * BM * BK + (wm * WM) * BK;
         const bf16_t* cB = sB + (curB < 0 ? cur : curB) * BN * BK + (wn * WN) * BK;
@@ -362,8 +362,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
         // LDS stage — no staging VGPRs, no ds_write_b128 pass (the slowest LDS instruction, ~79 B/clk/CU).  The LDS image is
         // lane-linear, so the XOR swizzle is applied to the per-lane SOURCE chunk instead (same involution as the ds_read
         // side).  hipcc drains the DMA (vmcnt(0)) in front of each __syncthreads().
-        int fa_cur[A_CH];  // conv: this tap's per-lane gather offset (OOB for halo pixels)
-        auto dma_a = [&](int kt, int buf) {
+        // conv: this tap's per-lane gather offset (OOB for halo pixels).  The offsets are VGPR operands of the DMA pieces, and hipcc waits
+        // for the pieces that read a register before it rewrites it: WA 2 (A tiles two ahead) therefore rotates three register sets with the
+        // A stages — the set rewritten in step kt was last read by pieces issued three steps earlier, long landed.
+        int fa_cur[WA == 2 ? 3 : 1][A_CH];
+        // (always_inline: out of line, the by-reference captures — ld_tap, ld_ci, fa_cur — live in scratch memory, and a scratch load inside the
+        // loop is a VMEM operation hipcc waits for with vmcnt(0): it drained the whole DMA queue once per step in the unrolled operand-ahead loop)
+        auto dma_a = [&](int kt, int buf) __attribute__((always_inline)) {
+            const int fs = WA == 2 ? buf : 0;
             const int k0 = (kt_begin + kt) * BK;
             if (AMODE == A_DENSE) {
                 const bool second = k0 >= p.Ksplit;
@@ -374,8 +380,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                     else lds_dma16(rsA2, dst, fa2_off[i], (k0 - p.Ksplit) * 2);
                 }
             } else {
-                const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
-                if (ld_ci == 0 || kt == 0 || p.kmajor) {  // a new tap: the per-lane part (halo mask, upsample source pixel) changes only here
+                // operand-ahead loops and deep rings: the (tap, channel) position is derived from kt — carried as loop state (ld_tap / ld_ci, captured by
+                // reference) it ended up in scratch memory in the unrolled loop, and every scratch load is a VMEM operation hipcc waits for
+                // with vmcnt(0): the whole DMA queue drained once per step
+                int cur_tap = ld_tap, cur_ci = ld_ci;
+                constexpr bool STATELESS = WA != 0 || STAGES > 2;   // every loop with counted waits: a drained queue costs it its lookahead
+                if (STATELESS) {
+                    const int lin = kt_begin + kt;
+                    if (p.kmajor) { cur_tap = lin % 9; cur_ci = (lin / 9) * BK; }
+                    else { const int per = p.CinPad / BK; cur_tap = lin / per; cur_ci = (lin - cur_tap * per) * BK; }
+                }
+                const int ky = cur_tap / 3, kx = cur_tap - ky * 3;
+                if (cur_ci == 0 || kt == 0 || p.kmajor || WA == 2) {  // a new tap: the per-lane part (halo mask, upsample source pixel) changes only here
 #pragma unroll
                     for (int i = 0; i < A_CH; ++i) {
                         int src = fa_off[i] + ((ky * p.Wd + kx) * p.Cin) * 2;  // >= 0 for every in-image tap (voffset is bounds-checked unsigned)
@@ -383,18 +399,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                             const int cc = ((tid + i * NT) & 7) ^ (((tid + i * NT) >> 3) & 7);
                             src = (int)((a_base[i] + (long)(max(a_iy[i] + ky, 0) >> 1) * p.Wd + (max(a_ix[i] + kx, 0) >> 1)) * p.Cin + cc * 8) * 2;
                         }
-                        fa_cur[i] = ((fa_mask[i] >> ld_tap) & 1u) ? src : OOB;
+                        fa_cur[fs][i] = ((fa_mask[i] >> cur_tap) & 1u) ? src : OOB;
                     }
                 }
-                const int tap_off = ld_ci * 2;  // wave-uniform -> SGPR offset
+                const int tap_off = cur_ci * 2;  // wave-uniform -> SGPR offset
                 if (!(LAB == 4 && (kt % 9) >= 2)) {   // LAB 4: the A tile only on 2 of 9 steps (= the DMA volume of a slab loader, 42 of 216 KiB)
 #pragma unroll
                 for (int i = 0; i < A_CH; ++i) {
                     bf16_t* dst = sA + buf * BM * BK + (wave + (NT / 64) * i) * 8 * BK;
-                    lds_dma16(rsA, dst, fa_cur[i], tap_off);
+                    lds_dma16(rsA, dst, fa_cur[fs][i], tap_off);
                 }
                 }
-                if (p.kmajor) {
+                if (STATELESS) {
+                } else if (p.kmajor) {
                     if (++ld_tap == 9) { ld_tap = 0; ld_ci += BK; }
                 } else {
                     ld_ci += BK;
@@ -402,7 +419,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                 }
             }
         };
-        auto dma_w = [&](int kt, int buf) {
+        auto dma_w = [&](int kt, int buf) __attribute__((always_inline)) {
             const int k0 = (kt_begin + kt) * BK;
 #pragma unroll
             for (int i = 0; i < B_CH; ++i) {
@@ -410,7 +427,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                 lds_dma16(rsW, dst, fb_off[i], k0 * 2);
             }
         };
-        auto dma_tile = [&](int kt, int buf) { dma_a(kt, buf); dma_w(kt, buf); };
+        auto dma_tile = [&](int kt, int buf) __attribute__((always_inline)) { dma_a(kt, buf); dma_w(kt, buf); };
         if constexpr (WA != 0) {
             // One operand two tiles ahead (three stages of it, two of the other), for the operand that arrives COLD inside a UNet evaluation:
             //   WA 1: the weights (32x32 / 8x8 levels: a layer's weights come from HBM, its activations from L2 / the Infinity Cache;
@@ -974,15 +991,16 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     auto lds_of = [](int bm, int bn, int st) { return (size_t)st * (bm + bn) * BK * sizeof(bf16_t); };
     auto lds_wa = [](int bm, int bn) { return (size_t)(2 * bm + 3 * bn) * BK * sizeof(bf16_t); };  // weights-ahead: two A stages, three W stages
     // tuning knob (bit flags): weights two tiles ahead on the 8-wave 128x128 two-stage kernel — 1 convs, 2 dense (80 KiB per block: still two
-    // blocks per CU).  Measured (profiles/r03_v30_weights_ahead.txt): with the weight rotated through a pool larger than the Infinity Cache the
-    // 32x32-level conv 640 -> 640 runs 112.3 -> 103.9 us (hot: 101.6 -> 99.1), qkv / ff2 of that level 46.5 -> 44.9 / 47.7 -> 46.7 us; UNet step
-    // 14.50 -> 14.36 ms, two runs each way on one box.  Default on for both.
+    // blocks per CU).  Measured (profiles/r03_v30_weights_ahead.txt, final form): 32x32-level conv 640 -> 640 hot 101.9 -> 87.9 us, with the
+    // weight rotated through a pool larger than the Infinity Cache 113.4 -> 89.6 us; 1920 -> 640: 327 -> 251 us; in situ 126 -> 96 us;
+    // UNet step 14.70 -> 14.33 ms (two runs each way, one box).  Default on for both.
     static const int wa = getenv("AE_GEMM_WA") ? atoi(getenv("AE_GEMM_WA")) : AE_GEMM_WA_DEFAULT;
-    // tuning knob: ACTIVATIONS two tiles ahead on the dense (non-GEGLU) 192x320 launches (three A stages + two W stages = 152 KiB): the
-    // 64x64-level ff2 (A = the 126 MB GEGLU output, straight from HBM) 70.8 -> 63.0 us in situ, UNet step 14.51 -> 14.47 ms.  The same
-    // variant on the convs of that tile measured 20 % SLOWER (un-split 100 -> 119 us, split-K 105 -> 123 us: their per-tap gather offsets
-    // are VGPR operands of the DMA pieces, and hipcc waits for the pieces in flight before it rewrites them), on the GEGLU launches it
-    // spills (4 x 2 waves); neither is instantiated (profiles/r03_v30_weights_ahead.txt).
+    // tuning knob (bit flags): ACTIVATIONS two tiles ahead on the 192x320 tile (three A stages + two W stages = 152 KiB) — 1 dense non-GEGLU
+    // (the 64x64-level ff2: A = the 126 MB GEGLU output, straight from HBM: 70.8 -> 63.0 us in situ), 2 un-split convs without upsampling
+    // (100.9 vs 103.1 us, 173.5 vs 177.5: the counted-wait loop instead of the per-step drain), 4 split-K convs (105 -> 102.6 us; off: one
+    // more instantiation for 0.02 ms).  The GEGLU form (4 x 2 waves) spills and is not instantiated.  The first measurement of the conv
+    // forms was 20 % SLOWER: out of line, the loader lambdas kept ld_tap / ld_ci in scratch memory, and hipcc waits vmcnt(0) for every
+    // scratch load — the DMA queue drained once per step (profiles/r03_v30_weights_ahead.txt).
     auto lds_aa = [](int bm, int bn) { return (size_t)(3 * bm + 2 * bn) * BK * sizeof(bf16_t); };
     static const int aa = getenv("AE_GEMM_AA") ? atoi(getenv("AE_GEMM_AA")) : AE_GEMM_AA_DEFAULT;
     int rc = 0;
@@ -1009,7 +1027,8 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // against 911-1123 for the 8-wave form.  Bigger wave tiles need hand-scheduled AGPR code; not kept.)
     if (conv && a.splitk > 1 && glds && make_plan(a.M, a.N, a.K, true).tile == 4) {  // split-K under the 192x320 tile (make_plan)
         const long t = (long)(a.M / 192) * (a.N / 320) * a.splitk;
-        rc = launch_kernel(gemm_kernel<192, 320, AMODE, 2, 4, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
+        if ((aa & 4) && !a.ups) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); }
+        else rc = launch_kernel(gemm_kernel<192, 320, AMODE, 2, 4, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
         done = true;
     }
     if (!done && t320 && glds && a.splitk <= 1 && a.N % 320 == 0 && ((conv && (t320 & 1)) || (!conv && a.epi == EPI_GEGLU && a.K >= 640 && (t320 & 2)) || (!conv && a.epi == EPI_GEGLU && a.K < 640 && a.K >= 320 && (t320 & 4)) ||
@@ -1021,9 +1040,14 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         if (fill >= 0.85) {
             if (a.epi == EPI_GEGLU) rc = launch_kernel(gemm_kernel<192, 320, AMODE, 4, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
             else if (cs_epi_ok && AMODE == A_CONV3) {
-                if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
+                if constexpr (AMODE == A_CONV3) {
+                    if ((aa & 2) && !a.ups) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
+                    else rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
+                }
                 cs_done = true;
-            } else if (!conv && aa) {
+            } else if (conv && (aa & 2) && !a.ups) {
+                if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
+            } else if (!conv && (aa & 1)) {
                 if constexpr (AMODE == A_DENSE) rc = launch_kernel(gemm_kernel<192, 320, A_DENSE, 2, 4, true, 1, 2, false, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
             }
 #ifdef AE_GEMM_ABLATE
