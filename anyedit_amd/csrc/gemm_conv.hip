@@ -923,7 +923,7 @@ Plan make_plan(int M, int N, int K, bool can_split) {
     // small conv grids (<= 128 output tiles: 8x8 level, stride-2 convs, training batches): split only until the grid reaches one block
     // per CU and run those blocks under the three-stage ring, instead of splitting to two blocks per CU.  In situ: M = 768 convs
     // 46 -> 43 us, inference step unchanged, training step -3 %.  (For 240-tile grids the unsplit ring LOSES: 127 -> 158 us.)
-    static const int conv_deep = getenv("AE_CONV_DEEP") ? atoi(getenv("AE_CONV_DEEP")) : 1;
+    static const int conv_deep = getenv("AE_CONV_DEEP") ? atoi(getenv("AE_CONV_DEEP")) : 0;  // round 3: off — with the weights-ahead 128x128 kernel two blocks per CU win again (13.60 -> 13.55 ms, two runs each way)
     if (waste128 <= 1.10 && t128 < 256) {
         int s = force_s > 0 ? force_s : (int)((480 + t128 - 1) / t128);
         if (conv_deep && force_s <= 0 && t128 <= 128) s = (int)(256 / t128);   // grid <= 256: every block alone on its CU, latency hidden by the ring
@@ -1096,7 +1096,7 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         // 64x64 grids up to three blocks per CU keep the ring too (its 48 KiB leave room for three resident blocks): training batch
         // M = 1024 x N = 1280 x K = 1280 (320 blocks) 31.7 -> ~20 us, training step 29.0 -> 28.0 ms.  AE_GEMM_DEEP64_MAX=256 restores round 1.
         static const int deep64_max = getenv("AE_GEMM_DEEP64_MAX") ? atoi(getenv("AE_GEMM_DEEP64_MAX")) : 768;
-        static const int conv_deep_l = getenv("AE_CONV_DEEP") ? atoi(getenv("AE_CONV_DEEP")) : 1;
+        static const int conv_deep_l = getenv("AE_CONV_DEEP") ? atoi(getenv("AE_CONV_DEEP")) : 0;
         // (a FOURTH stage — three tiles in flight, 128 KiB — measured the same on the 8x8-level convs: 41.9 vs 40.4 us; these launches are
         // not latency-bound by ring depth but by LDS bandwidth: 0.75 ds_read_b128 per MFMA x 8 cycles each against 16-cycle MFMAs)
         if (conv && conv_deep_l && pick == 0 && glds && grid <= 256)

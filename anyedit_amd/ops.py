@@ -1007,7 +1007,7 @@ def _tile_label(M, N, conv=False, K=0, geglu=False, dma_ok=True):
         if t / (-(-t // 256) * 256) * (M / (tm * 192)) >= 0.85 and not (conv and _conv_splitk(M, N, K) > 1):
             return "192x320"
     if conv and _conv_splitk(M, N, K) > 1:  # small grids: one block per CU under the three-stage ring (a different kernel symbol)
-        return "128x128,ring3,splitK" if dma_ok and -(-M // 128) * -(-N // 128) <= 128 else "128x128,splitK"
+        return "128x128,ring3,splitK" if dma_ok and _CONV_DEEP and -(-M // 128) * -(-N // 128) * _conv_splitk(M, N, K) <= 256 else "128x128,splitK"
     if conv and N % 160 == 0 and N % 128 != 0 and -(-M // 128) * (N // 160) >= 256:
         return "128x160"
     if not conv and not geglu and dma_ok and N % 128 == 0 and K >= 1280 and 128 <= -(-M // 128) * (N // 128) <= 256:
@@ -1023,6 +1023,9 @@ def _tile_label(M, N, conv=False, K=0, geglu=False, dma_ok=True):
     if not conv and dma_ok and K >= 1280 and -(-M // 64) * -(-N // 64) <= 768:
         return "64x64,ring3"
     return "64x64"
+
+
+_CONV_DEEP = os.environ.get("AE_CONV_DEEP", "0") != "0"  # mirror of the library's knob (small conv grids under the three-stage ring; default off since round 3)
 
 
 def _conv_t320_split(M, N, K):
@@ -1046,7 +1049,7 @@ def _conv_splitk(M, N, K):
     if kt < 32 or picked_big or is160:
         return 1
     if -(-N // 128) * 128 / N <= 1.10 and t128 < 256:
-        s_ = min((256 // t128) if t128 <= 128 else -(-480 // t128), 8, kt // 8)
+        s_ = min((256 // t128) if (t128 <= 128 and _CONV_DEEP) else -(-480 // t128), 8, kt // 8)
         return s_ if s_ >= 2 else 1
     return 1
 
