@@ -97,6 +97,9 @@ constexpr int epilogue_passes(int FM, int bytes_per_frag_row, int lds_bytes) {
 // the K-step time of these kernels (~4600 cycles for the 64 KiB of a 192x320 step, ~2100 for the 32 KiB of a 128x128 step = bytes /
 // ~14 B/clk/CU) is the LDS-DMA path's rate.  It is not that simple: 192x320 conv 87.8 -> 92.6 us (A through registers) / 96.2 (W),
 // 128x128 conv 105.9 -> 115.9 / 118.1, dense 128x128 +3..+10 %, UNet step 14.44 -> 14.51-14.60 ms (profiles/r03_v3_hybrid_loader.txt).)
+// WA (round 3): operand-ahead loop on the two-stage LDS-DMA pipeline — 1: three W stages (weights two K tiles ahead), 2: three A stages
+// (activations two tiles ahead); counted vmcnt + raw s_barrier instead of the per-step drain, unrolled by six so that every stage index is a
+// constant.  See the comment at the loop, DESIGN.md §7a and profiles/r03_v30_weights_ahead.txt.
 // LAB (AE_GEMM_LAB builds only, tools/ubench): 1 = no DMA after the first tile, 2 = no LDS reads / MFMAs, 3 = MFMAs on stale registers (no LDS reads)
 template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false, int WAVES_K = 1, int STAGES = 2, bool CS = false, int LAB = 0, int WA = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(const GemmArgs p) {
