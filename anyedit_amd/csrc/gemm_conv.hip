@@ -387,7 +387,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                 // reference) it ended up in scratch memory in the unrolled loop, and every scratch load is a VMEM operation hipcc waits for
                 // with vmcnt(0): the whole DMA queue drained once per step
                 int cur_tap = ld_tap, cur_ci = ld_ci;
-                constexpr bool STATELESS = WA != 0 || STAGES > 2;   // every loop with counted waits: a drained queue costs it its lookahead
+                constexpr bool STATELESS = true;   // (the two-stage loops too: their scratch load of the tap state sat in front of every step's DMA issue)
                 if (STATELESS) {
                     const int lin = kt_begin + kt;
                     if (p.kmajor) { cur_tap = lin % 9; cur_ci = (lin / 9) * BK; }
