@@ -343,6 +343,50 @@ def test_dpm_solver_sampler():
     close(P.multistep_sample(_analytic_eps_float_t, ac, x_T, 6, c, uc, 3.0, order=1, t_start=0.8, t_end=0.05), g["o1.samples"], tol=2e-5)
 
 
+DPM_GENERAL_CASES = {  # tag -> (predict_x0, DPM_Solver.sample arguments) — the cases tools/gen_golden.py::gen_dpm_solver_general ran in the reference
+    "m3.x0": (True, dict(steps=15, order=3, method="multistep", skip_type="time_uniform")),
+    "m3.eps.taylor": (False, dict(steps=16, order=3, method="multistep", skip_type="logSNR", solver_type="taylor")),
+    "m3.x0.nolof": (True, dict(steps=9, order=3, method="multistep", skip_type="time_quadratic", lower_order_final=False, denoise_to_zero=True)),
+    "s3.eps": (False, dict(steps=10, order=3, method="singlestep", skip_type="logSNR")),
+    "s3.x0.taylor": (True, dict(steps=9, order=3, method="singlestep", skip_type="logSNR", solver_type="taylor")),
+    "s3.eps.taylor": (False, dict(steps=11, order=3, method="singlestep", skip_type="logSNR", solver_type="taylor", denoise_to_zero=True)),
+    "s3.x0": (True, dict(steps=12, order=3, method="singlestep", skip_type="logSNR")),
+    "s2.eps": (False, dict(steps=7, order=2, method="singlestep", skip_type="logSNR")),
+    "s2.x0.taylor": (True, dict(steps=6, order=2, method="singlestep", skip_type="logSNR", solver_type="taylor")),
+    "s2.eps.taylor": (False, dict(steps=8, order=2, method="singlestep", skip_type="logSNR", solver_type="taylor")),
+    "f3.eps": (False, dict(steps=9, order=3, method="singlestep_fixed", skip_type="time_uniform")),
+    "f2.x0": (True, dict(steps=8, order=2, method="singlestep_fixed", skip_type="logSNR")),
+    "a2.eps": (False, dict(order=2, method="adaptive")),
+    "a3.eps": (False, dict(order=3, method="adaptive", atol=0.01, rtol=0.1)),
+    "a3.x0.taylor": (True, dict(order=3, method="adaptive", solver_type="taylor", t_end=0.01)),
+}
+
+
+def test_dpm_solver_general_variants():
+    """N4: the DPM_Solver.sample variants outside DPMSolverSampler's fixed settings — singlestep orders 2 / 3 with the reference's order
+    plan, singlestep_fixed, multistep order 3, adaptive step size (incl. its evaluation count) — against outputs of the reference solver
+    (classifier-free-guided analytic eps; samples grow to |x| ~ 5e2 under that toy network, so the bound is relative)."""
+    from oracle import dpm_ref as P
+    g = load_golden("dpm_solver_general")
+    ac = S.register_schedule("linear", 1000, 0.00085, 0.0120)["alphas_cumprod"].float()
+    ns = P.NoiseSchedule(ac)
+    for steps, order in ((10, 3), (9, 3), (11, 3), (7, 2), (6, 2), (5, 1)):
+        ts, orders = P.singlestep_plan(ns, steps, order, "logSNR", 1.0, 0.001)
+        assert list(orders) == list(g[f"plan.{steps}.{order}.logSNR.orders"])
+        close(ts, g[f"plan.{steps}.{order}.logSNR.ts"], tol=1e-6)
+    # the skip types the reference's plan cannot run (its cumsum lacks the dim): the evident intent, indices = cumulative orders
+    ts, orders = P.singlestep_plan(ns, 10, 3, "time_uniform", 1.0, 0.001)
+    assert orders == [3, 3, 3, 1] and torch.equal(ts, torch.linspace(1.0, 0.001, 11)[[0, 3, 6, 9, 10]])
+    x_T, c, uc = T(g["x_T"]), T(g["c"]), T(g["uc"])
+    for tag, (px0, kw) in DPM_GENERAL_CASES.items():
+        out = P.general_sample(_analytic_eps_float_t, ac, x_T, c, uc, 3.0, predict_x0=px0, **kw)
+        if kw["method"] == "adaptive":
+            out, nfe = out
+            assert nfe == int(g[f"{tag}.nfe"]), (tag, nfe)
+        ref = T(g[f"{tag}.samples"])
+        assert float((out - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), tag
+
+
 SD2_TINY = dict(image_size=8, in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[1, 2],
                 channel_mult=[1, 2], num_head_channels=16, use_spatial_transformer=True, use_linear_in_transformer=True,
                 transformer_depth=1, context_dim=24, legacy=False)

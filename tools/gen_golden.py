@@ -573,6 +573,59 @@ class AnalyticEpsModel:
 
 
 @torch.no_grad()
+def gen_dpm_solver_general():
+    """The solver variants DPMSolverSampler never reaches but DPM_Solver.sample offers (dpm_solver.py:405-462 order / time-step plan of the
+    singlestep solver, :515-722 singlestep second / third updates, :780-826 multistep third update, :878-937 adaptive step size, :939-1101
+    dispatch): classifier-free-guided analytic eps model, both parameterisations, both solver types, all step spacings."""
+    print("[dpm_solver_general]")
+    import io
+    import contextlib
+    from ldm.models.diffusion.dpm_solver import dpm_solver as rdpm
+    model = AnalyticEpsModel()
+    g = G(93)
+    B = 2
+    x_T = torch.randn(B, 4, 8, 8, generator=g)
+    c = torch.randn(B, 4, generator=g) * 0.2
+    uc = torch.randn(B, 4, generator=g) * 0.2
+    arrs = {"x_T": x_T, "c": c, "uc": uc}
+    ns = rdpm.NoiseScheduleVP('discrete', alphas_cumprod=model.alphas_cumprod)
+    mf = rdpm.model_wrapper(lambda x, t, cc: model.apply_model(x, t, cc), ns, model_type="noise", guidance_type="classifier-free",
+                            condition=c, unconditional_condition=uc, guidance_scale=3.0)
+    plan = rdpm.DPM_Solver(mf, ns)
+    # (the reference's plan only runs with skip_type 'logSNR': its other branch calls torch.cumsum without a dim — dpm_solver.py:457 — and raises)
+    for steps, order, st in ((10, 3, "logSNR"), (9, 3, "logSNR"), (11, 3, "logSNR"), (7, 2, "logSNR"), (6, 2, "logSNR"), (5, 1, "logSNR")):
+        ts, orders = plan.get_orders_and_timesteps_for_singlestep_solver(steps, order, st, 1.0, 0.001, "cpu")
+        arrs[f"plan.{steps}.{order}.{st}.ts"], arrs[f"plan.{steps}.{order}.{st}.orders"] = ts, np.asarray(orders, dtype=np.int64)
+    cases = {  # tag -> (predict_x0, kwargs of DPM_Solver.sample)
+        # (order 3 with fewer than 15 steps and lower_order_final raises in the reference: the second-order update unpacks a three-entry history, :740)
+        "m3.x0": (True, dict(steps=15, order=3, method="multistep", skip_type="time_uniform")),
+        "m3.eps.taylor": (False, dict(steps=16, order=3, method="multistep", skip_type="logSNR", solver_type="taylor")),
+        "m3.x0.nolof": (True, dict(steps=9, order=3, method="multistep", skip_type="time_quadratic", lower_order_final=False, denoise_to_zero=True)),
+        "s3.eps": (False, dict(steps=10, order=3, method="singlestep", skip_type="logSNR")),
+        "s3.x0.taylor": (True, dict(steps=9, order=3, method="singlestep", skip_type="logSNR", solver_type="taylor")),
+        "s3.eps.taylor": (False, dict(steps=11, order=3, method="singlestep", skip_type="logSNR", solver_type="taylor", denoise_to_zero=True)),
+        "s3.x0": (True, dict(steps=12, order=3, method="singlestep", skip_type="logSNR")),
+        "s2.eps": (False, dict(steps=7, order=2, method="singlestep", skip_type="logSNR")),
+        "s2.x0.taylor": (True, dict(steps=6, order=2, method="singlestep", skip_type="logSNR", solver_type="taylor")),
+        "s2.eps.taylor": (False, dict(steps=8, order=2, method="singlestep", skip_type="logSNR", solver_type="taylor")),
+        # (singlestep order 1 cannot run in the reference either: K = 1 outer interval for `steps` entries of `orders`, :1086 IndexError)
+        "f3.eps": (False, dict(steps=9, order=3, method="singlestep_fixed", skip_type="time_uniform")),
+        "f2.x0": (True, dict(steps=8, order=2, method="singlestep_fixed", skip_type="logSNR")),
+        "a2.eps": (False, dict(order=2, method="adaptive")),
+        "a3.eps": (False, dict(order=3, method="adaptive", atol=0.01, rtol=0.1)),
+        "a3.x0.taylor": (True, dict(order=3, method="adaptive", solver_type="taylor", t_end=0.01)),
+    }
+    for tag, (px0, kw) in cases.items():
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+            out = rdpm.DPM_Solver(mf, ns, predict_x0=px0).sample(x_T, **kw)
+        arrs[f"{tag}.samples"] = out
+        if kw.get("method") == "adaptive":  # the reference prints its evaluation count
+            arrs[f"{tag}.nfe"] = np.asarray(int(buf.getvalue().strip().split()[-1]), dtype=np.int64)
+    npz("dpm_solver_general", **arrs)
+
+
+@torch.no_grad()
 def gen_plms():
     """PLMSSampler (ldm/models/diffusion/plms.py) arithmetic + bookkeeping on the analytic eps model (the reference's PLMS only
     accepts tensor conditioning, which the hybrid tiny UNet cannot take)."""
@@ -881,7 +934,7 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])  # e.g. `python tools/gen_golden.py ddim_encode` regenerates one fixture
     for name, fn in (("schedule", gen_schedule), ("norms", gen_norms), ("attention", gen_attention), ("transformer", gen_transformer),
                      ("resblock", gen_resblock), ("unet", gen_unet), ("unet_sd2", gen_unet_sd2), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode), ("ddim_hacked", gen_ddim_hacked),
-                     ("vae", gen_vae), ("plms", gen_plms), ("dpm_solver", gen_dpm_solver), ("cldm", gen_cldm), ("msda", gen_msda), ("sam", gen_sam), ("sam_decoder", gen_sam_decoder),
+                     ("vae", gen_vae), ("plms", gen_plms), ("dpm_solver", gen_dpm_solver), ("dpm_solver_general", gen_dpm_solver_general), ("cldm", gen_cldm), ("msda", gen_msda), ("sam", gen_sam), ("sam_decoder", gen_sam_decoder),
                      ("misc", gen_ldm_misc)):
         if not only or name in only:
             fn()
