@@ -94,6 +94,8 @@ SIGNATURES = {
     "ae_sam_preprocess_f32": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "ae_patchify_f32_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ae_mse_f32": [c_void_p, c_void_p, c_void_p, c_long, c_void_p],
+    "ae_lincomb4_f32": [c_void_p, c_void_p, c_float, c_void_p, c_float, c_void_p, c_float, c_void_p, c_float, c_long, c_void_p],
+    "ae_dpm_adaptive_err_f32": [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_long, c_void_p, c_void_p],
     "ae_task_gate": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
 }
 _RESTYPES = {"ae_last_error": ctypes.c_char_p, "ae_groupnorm_workspace_floats": c_long, "ae_conv3x3_workspace_floats": c_long,

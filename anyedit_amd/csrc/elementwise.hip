@@ -413,6 +413,53 @@ inline unsigned grid_for(long n, int per_thread = 1) {
 
 }  // namespace
 
+// DPM-Solver general updates (dpm_solver.py:469-722 singlestep first / second / third, :780-826 multistep third): every one of them is
+// x_t = c0 x + c1 m_a + c2 m_b + c3 m_c with host-side fp32 scalars — one launch instead of the reference's 6-15 elementwise torch ops.
+__global__ __launch_bounds__(256) void lincomb4_kernel(float* __restrict__ out, const float* x0, float c0, const float* x1, float c1,
+                                                        const float* x2, float c2, const float* x3, float c3, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(x0 + i);
+        f32x4 r = {a[0] * c0, a[1] * c0, a[2] * c0, a[3] * c0};
+        if (x1) { const f32x4 b = *reinterpret_cast<const f32x4*>(x1 + i); for (int e = 0; e < 4; ++e) r[e] = fmaf(b[e], c1, r[e]); }
+        if (x2) { const f32x4 b = *reinterpret_cast<const f32x4*>(x2 + i); for (int e = 0; e < 4; ++e) r[e] = fmaf(b[e], c2, r[e]); }
+        if (x3) { const f32x4 b = *reinterpret_cast<const f32x4*>(x3 + i); for (int e = 0; e < 4; ++e) r[e] = fmaf(b[e], c3, r[e]); }
+        *reinterpret_cast<f32x4*>(out + i) = r;
+    } else {
+        for (long j = i; j < n; ++j) {
+            float r = x0[j] * c0;
+            if (x1) r = fmaf(x1[j], c1, r);
+            if (x2) r = fmaf(x2[j], c2, r);
+            if (x3) r = fmaf(x3[j], c3, r);
+            out[j] = r;
+        }
+    }
+}
+
+// Error estimate of the adaptive DPM-Solver (dpm_solver.py:925-927): per sample sqrt(mean(((x_higher - x_lower) / delta)^2)) with
+// delta = max(atol, rtol * max(|x_lower|, |x_prev|)).  One block per sample, fixed-order reduction (deterministic).
+__global__ __launch_bounds__(1024) void dpm_adaptive_err_kernel(const float* __restrict__ xl, const float* __restrict__ xh,
+                                                                const float* __restrict__ xp, float atol, float rtol, long n, float* out) {
+    __shared__ float red[16];
+    const long base = (long)blockIdx.x * n;
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const float l = xl[base + i];
+        const float delta = fmaxf(atol, rtol * fmaxf(fabsf(l), fabsf(xp[base + i])));
+        const float v = (xh[base + i] - l) / delta;
+        acc = fmaf(v, v, acc);
+    }
+    acc = wave_reduce_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        out[blockIdx.x] = sqrtf(t / (float)n);
+    }
+}
+
 extern "C" int ae_transpose_last2(const void* in, void* out, int B, int X, int Y, int Xpad, int in_bf16, int out_bf16, void* stream) {
     AE_REQUIRE(in && out && B > 0 && X > 0 && Y > 0 && Xpad >= X, "ae_transpose_last2: bad arguments");
     AE_REQUIRE(B <= 65535, "ae_transpose_last2: batch %d too large", B);
@@ -573,6 +620,25 @@ extern "C" int ae_patchify_f32_bf16(const float* x, void* y, int B, int Cin, int
     const long total = (long)B * Cin * H * W;
     hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, x, (bf16_t*)y, B, Cin, H, W, P);
     return ae_check_launch("ae_patchify_f32_bf16");
+}
+
+extern "C" int ae_lincomb4_f32(float* out, const float* x0, float c0, const float* x1, float c1, const float* x2, float c2,
+                               const float* x3, float c3, long n, void* stream) {
+    AE_REQUIRE(out && x0 && n > 0, "ae_lincomb4_f32: null pointer / empty tensor");
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    AE_REQUIRE(al16(out) && al16(x0) && (!x1 || al16(x1)) && (!x2 || al16(x2)) && (!x3 || al16(x3)), "ae_lincomb4_f32: pointers must be 16-byte aligned");
+    const long blocks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(lincomb4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, x0, c0, x1, c1, x2, c2, x3, c3, n);
+    return ae_check_launch("ae_lincomb4_f32");
+}
+
+extern "C" int ae_dpm_adaptive_err_f32(const float* x_lower, const float* x_higher, const float* x_prev, float atol, float rtol, int B,
+                                       long n_per_sample, float* out, void* stream) {
+    AE_REQUIRE(x_lower && x_higher && x_prev && out && B > 0 && n_per_sample > 0, "ae_dpm_adaptive_err_f32: null pointer / empty tensor");
+    AE_REQUIRE(atol > 0.f && rtol >= 0.f, "ae_dpm_adaptive_err_f32: atol must be positive, rtol non-negative");
+    hipLaunchKernelGGL(dpm_adaptive_err_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, x_lower, x_higher, x_prev, atol, rtol,
+                       n_per_sample, out);
+    return ae_check_launch("ae_dpm_adaptive_err_f32");
 }
 
 extern "C" int ae_mse_f32(const float* a, const float* b, float* out, long n, void* stream) {

@@ -1,13 +1,21 @@
-"""DPM-Solver / DPM-Solver++ multistep sampling on the HIP path — mirror of ldm/models/diffusion/dpm_solver/dpm_solver.py for the
-configurations its sampler front end reaches: the discrete-time VP noise schedule (NoiseScheduleVP :7-160),
-classifier-free-guided noise / v prediction (model_wrapper :161-316) and the multistep solver of orders 1-2 in both parameterisations,
-both solver types and all three step spacings (DPM_Solver :319-404, 463-514, 723-777, 855-877, 1040-1073).
+"""DPM-Solver / DPM-Solver++ sampling on the HIP path — mirror of ldm/models/diffusion/dpm_solver/dpm_solver.py: the
+discrete-time VP noise schedule (NoiseScheduleVP :7-160), classifier-free-guided noise / v prediction (model_wrapper :161-316) and
+DPM_Solver.sample with every `method` — 'multistep' (orders 1-3, :723-826, 855-877, 1040-1073), 'singlestep' / 'singlestep_fixed' (orders
+1-3 with the order plan of :405-461; updates :469-722, 827-853, 1075-1098) and 'adaptive' (:878-937) — in both parameterisations, both
+solver types and all three step spacings.
 
 Structure: every per-step quantity that does not depend on the latent (log-alpha interpolation, lambda, sigma, the update coefficients)
 is a handful of fp32 scalars computed on the host with the reference's expressions; the latent-sized work of one step — guidance
 combine, conversion to the data prediction, history difference and the x update — is ONE kernel launch after each network evaluation
-(ae_dpm_multistep_f32), instead of the reference's ~20 elementwise torch ops.  Anything outside that set raises NotImplementedError
-rather than running differently: singlestep / adaptive solvers, order 3, continuous-time schedules, classifier guidance, thresholding.
+(ae_dpm_multistep_f32), instead of the reference's ~20 elementwise torch ops: that is the path DPMSolverSampler takes (multistep, order
+<= 2).  The other variants evaluate the network through the same kernel (guidance combine + conversion to the data prediction) and apply
+each update — a linear combination of x and up to three model values with host-side scalars — as ONE ae_lincomb4_f32 launch; the adaptive
+solver's error norm is ae_dpm_adaptive_err_f32.  Still outside (NotImplementedError rather than running differently): continuous-time
+schedules, classifier guidance, x_start networks, dynamic thresholding.
+Where the reference itself cannot run, this module follows its evident intent and says so: the singlestep order plan with a step spacing
+other than 'logSNR' (the reference's torch.cumsum call lacks the dim, :457), singlestep order 1 (its outer grid has one interval for
+`steps` entries, :1086) and multistep order 3 with `lower_order_final` and fewer than 15 steps (its second-order update unpacks a
+three-entry history, :740).
 """
 import torch
 
@@ -120,7 +128,7 @@ def model_wrapper(model, noise_schedule, model_type="noise", model_kwargs={}, gu
 
 
 class DPM_Solver:
-    """:319-1101, multistep orders 1-2."""
+    """:319-1101."""
 
     def __init__(self, model_fn, noise_schedule, predict_x0=False, thresholding=False, max_val=1.):
         if thresholding:
@@ -194,16 +202,226 @@ class DPM_Solver:
     def denoise_to_zero_fn(self, x, s):
         return self.data_prediction_fn(x, s)
 
-    def sample(self, x, steps=20, t_start=None, t_end=None, order=3, skip_type='time_uniform', method='singlestep',
-               lower_order_final=True, denoise_to_zero=False, solver_type='dpm_solver', atol=0.0078, rtol=0.05):
-        """:939-1101 for method='multistep': S network evaluations for S steps; evaluation i yields the history value m_i and, in the same
-        kernel, x at the next step time."""
-        if method != 'multistep':
-            raise NotImplementedError(f"DPM_Solver.sample: method '{method}' is not on the AnyEdit path (sampler.py:82 uses 'multistep')")
-        if order not in (1, 2):
-            raise NotImplementedError("DPM_Solver.sample: multistep orders 1 and 2 are implemented (sampler.py:82 uses order 2)")
+    # ---- general updates: host-side scalars with the reference's expressions, one ae_lincomb4_f32 launch per update
+    def _ab(self, s, t):
+        """(a, b) of x_t = a x - b (...): :480-512 — (sigma_t / sigma_s, alpha_t) for the data prediction, (alpha_t / alpha_s, sigma_t) for noise."""
+        ns = self.noise_schedule
+        if self.predict_x0:
+            return ns.marginal_std(t) / ns.marginal_std(s), torch.exp(ns.marginal_log_mean_coeff(t))
+        return torch.exp(ns.marginal_log_mean_coeff(t) - ns.marginal_log_mean_coeff(s)), ns.marginal_std(t)
+
+    def dpm_solver_first_update(self, x, s, t, model_s=None, return_intermediate=False):
+        """:469-513."""
+        ns = self.noise_schedule
+        sg = -1.0 if self.predict_x0 else 1.0
+        h = ns.marginal_lambda(t) - ns.marginal_lambda(s)
+        a, b = self._ab(s, t)
+        if model_s is None:
+            model_s = self.model_fn(x, s)
+        x_t = ops.lincomb([(x, a), (model_s, -(b * torch.expm1(sg * h)))])
+        return (x_t, {'model_s': model_s}) if return_intermediate else x_t
+
+    def singlestep_dpm_solver_second_update(self, x, s, t, r1=0.5, model_s=None, return_intermediate=False, solver_type='dpm_solver'):
+        """:515-597."""
         if solver_type not in ['dpm_solver', 'taylor']:
             raise ValueError("'solver_type' must be either 'dpm_solver' or 'taylor', got {}".format(solver_type))
+        r1 = 0.5 if r1 is None else r1
+        ns = self.noise_schedule
+        sg = -1.0 if self.predict_x0 else 1.0
+        lambda_s = ns.marginal_lambda(s)
+        h = ns.marginal_lambda(t) - lambda_s
+        s1 = ns.inverse_lambda(lambda_s + r1 * h)
+        if model_s is None:
+            model_s = self.model_fn(x, s)
+        a1, b1 = self._ab(s, s1)
+        x_s1 = ops.lincomb([(x, a1), (model_s, -(b1 * torch.expm1(sg * r1 * h)))])
+        model_s1 = self.model_fn(x_s1, s1)
+        a, b = self._ab(s, t)
+        base = b * torch.expm1(sg * h)
+        if solver_type == 'dpm_solver':
+            k = (0.5 / r1) * base
+        elif self.predict_x0:
+            k = -(1. / r1) * b * ((torch.exp(-h) - 1.) / h + 1.)
+        else:
+            k = (1. / r1) * b * ((torch.exp(h) - 1.) / h - 1.)
+        x_t = ops.lincomb([(x, a), (model_s, -base + k), (model_s1, -k)])      # a x - base m_s - k (m_s1 - m_s)
+        return (x_t, {'model_s': model_s, 'model_s1': model_s1}) if return_intermediate else x_t
+
+    def singlestep_dpm_solver_third_update(self, x, s, t, r1=1. / 3., r2=2. / 3., model_s=None, model_s1=None, return_intermediate=False,
+                                           solver_type='dpm_solver'):
+        """:599-721."""
+        if solver_type not in ['dpm_solver', 'taylor']:
+            raise ValueError("'solver_type' must be either 'dpm_solver' or 'taylor', got {}".format(solver_type))
+        r1 = 1. / 3. if r1 is None else r1
+        r2 = 2. / 3. if r2 is None else r2
+        ns = self.noise_schedule
+        sg = -1.0 if self.predict_x0 else 1.0
+        lambda_s = ns.marginal_lambda(s)
+        h = ns.marginal_lambda(t) - lambda_s
+        s1, s2 = ns.inverse_lambda(lambda_s + r1 * h), ns.inverse_lambda(lambda_s + r2 * h)
+        phi_11, phi_12, phi_1 = torch.expm1(sg * r1 * h), torch.expm1(sg * r2 * h), torch.expm1(sg * h)
+        phi_22 = torch.expm1(sg * r2 * h) / (r2 * h) - sg
+        phi_2 = phi_1 / h - sg
+        phi_3 = phi_2 / h - 0.5
+        if model_s is None:
+            model_s = self.model_fn(x, s)
+        if model_s1 is None:
+            a1, b1 = self._ab(s, s1)
+            model_s1 = self.model_fn(ops.lincomb([(x, a1), (model_s, -(b1 * phi_11))]), s1)
+        a2, b2 = self._ab(s, s2)
+        q = sg * (r2 / r1) * b2 * phi_22
+        x_s2 = ops.lincomb([(x, a2), (model_s, -(b2 * phi_12) + q), (model_s1, -q)])
+        model_s2 = self.model_fn(x_s2, s2)
+        a, b = self._ab(s, t)
+        if solver_type == 'dpm_solver':
+            pp = sg * (1. / r2) * b * phi_2
+            x_t = ops.lincomb([(x, a), (model_s, -(b * phi_1) + pp), (model_s2, -pp)])
+        else:  # x_t = a x - b phi_1 m_s - sg b phi_2 D1 - b phi_3 D2, D1 / D2 linear in (m_s1 - m_s), (m_s2 - m_s)
+            cu = -sg * b * phi_2 * (r2 / r1) / (r2 - r1) + b * phi_3 * 2. / (r1 * (r2 - r1))
+            cw = sg * b * phi_2 * (r1 / r2) / (r2 - r1) - b * phi_3 * 2. / (r2 * (r2 - r1))
+            x_t = ops.lincomb([(x, a), (model_s, -(b * phi_1) - cu - cw), (model_s1, cu), (model_s2, cw)])
+        return (x_t, {'model_s': model_s, 'model_s1': model_s1, 'model_s2': model_s2}) if return_intermediate else x_t
+
+    def singlestep_dpm_solver_update(self, x, s, t, order, return_intermediate=False, solver_type='dpm_solver', r1=None, r2=None):
+        """:827-853."""
+        if order == 1:
+            return self.dpm_solver_first_update(x, s, t, return_intermediate=return_intermediate)
+        if order == 2:
+            return self.singlestep_dpm_solver_second_update(x, s, t, return_intermediate=return_intermediate, solver_type=solver_type, r1=r1)
+        if order == 3:
+            return self.singlestep_dpm_solver_third_update(x, s, t, return_intermediate=return_intermediate, solver_type=solver_type, r1=r1, r2=r2)
+        raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
+
+    def multistep_dpm_solver_update(self, x, model_prev_list, t_prev_list, t, order, solver_type='dpm_solver'):
+        """:855-877 with :723-826.  Orders 1 and 2 read the newest one / two history entries (the reference's second-order update unpacks the
+        whole list, which fails on a three-entry history: :740)."""
+        ns = self.noise_schedule
+        sg = -1.0 if self.predict_x0 else 1.0
+        if order == 1:
+            return self.dpm_solver_first_update(x, t_prev_list[-1], t, model_s=model_prev_list[-1])
+        if solver_type not in ['dpm_solver', 'taylor']:
+            raise ValueError("'solver_type' must be either 'dpm_solver' or 'taylor', got {}".format(solver_type))
+        t0 = t_prev_list[-1]
+        lam = [ns.marginal_lambda(tt) for tt in t_prev_list]
+        h = ns.marginal_lambda(t) - lam[-1]
+        a, b = self._ab(t0, t)
+        e = torch.exp(sg * h) - 1.
+        if order == 2:
+            m1, m0 = model_prev_list[-2:]
+            r0 = (lam[-1] - lam[-2]) / h
+            k = 0.5 * b * e if solver_type == 'dpm_solver' else sg * b * (e / h - sg)
+            return ops.lincomb([(x, a), (m0, -(b * e) - k / r0), (m1, k / r0)])      # a x - b e m0 - k (m0 - m1) / r0
+        if order == 3:
+            m2, m1, m0 = model_prev_list
+            r0, r1 = (lam[-1] - lam[-2]) / h, (lam[-2] - lam[-3]) / h
+            P = -sg * b * (e / h - sg)
+            Q = -b * ((e - sg * h) / h ** 2 - 0.5)
+            al = P * (1. + r0 / (r0 + r1)) + Q / (r0 + r1)      # coefficient of D1_0 = (m0 - m1) / r0
+            be = -P * r0 / (r0 + r1) - Q / (r0 + r1)            # coefficient of D1_1 = (m1 - m2) / r1
+            return ops.lincomb([(x, a), (m0, -(b * e) + al / r0), (m1, -al / r0 + be / r1), (m2, -be / r1)])
+        raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
+
+    def get_orders_and_timesteps_for_singlestep_solver(self, steps, order, skip_type, t_T, t_0, device):
+        """:405-461.  The non-logSNR branch indexes the `steps`-step grid at the cumulative orders (the reference omits cumsum's dim)."""
+        if order == 3:
+            K = steps // 3 + 1
+            orders = [3] * (K - 2) + [2, 1] if steps % 3 == 0 else ([3] * (K - 1) + [1] if steps % 3 == 1 else [3] * (K - 1) + [2])
+        elif order == 2:
+            K = steps // 2 if steps % 2 == 0 else steps // 2 + 1
+            orders = [2] * K if steps % 2 == 0 else [2] * (K - 1) + [1]
+        elif order == 1:
+            K, orders = 1, [1] * steps
+        else:
+            raise ValueError("'order' must be '1' or '2' or '3'.")
+        if skip_type == 'logSNR':
+            timesteps_outer = self.get_time_steps(skip_type, t_T, t_0, K, device)
+        else:
+            timesteps_outer = self.get_time_steps(skip_type, t_T, t_0, steps, device)[torch.cumsum(torch.tensor([0, ] + orders), 0)]
+        return timesteps_outer, orders
+
+    def dpm_solver_adaptive(self, x, order, t_T, t_0, h_init=0.05, atol=0.0078, rtol=0.05, theta=0.9, t_err=1e-5, solver_type='dpm_solver'):
+        """:878-937.  The accept / reject decision needs the error norm on the host: one device-to-host read per trial step (inherent to
+        the method); `self.last_nfe` keeps the evaluation count the reference prints."""
+        ns = self.noise_schedule
+        if order not in (2, 3):
+            raise ValueError("For adaptive step size solver, order must be 2 or 3, got {}".format(order))
+        s = torch.ones((1,)) * t_T
+        lambda_s, lambda_0 = ns.marginal_lambda(s), ns.marginal_lambda(torch.ones((1,)) * t_0)
+        h = torch.ones((1,)) * h_init
+        x_prev, nfe = x, 0
+        while float(torch.abs(s - t_0).mean()) > t_err:
+            t = ns.inverse_lambda(lambda_s + h)
+            if order == 2:
+                x_lower, mid = self.dpm_solver_first_update(x, s, t, return_intermediate=True)
+                x_higher = self.singlestep_dpm_solver_second_update(x, s, t, r1=0.5, solver_type=solver_type, **mid)
+            else:
+                x_lower, mid = self.singlestep_dpm_solver_second_update(x, s, t, r1=1. / 3., return_intermediate=True, solver_type=solver_type)
+                x_higher = self.singlestep_dpm_solver_third_update(x, s, t, r1=1. / 3., r2=2. / 3., solver_type=solver_type, **mid)
+            E = ops.dpm_adaptive_err(x_lower, x_higher, x_prev, atol, rtol).max().cpu()
+            if bool(E <= 1.):
+                x, s, x_prev = x_higher, t, x_lower
+                lambda_s = ns.marginal_lambda(s)
+            h = torch.min(theta * h * torch.float_power(E, -1. / order).float(), lambda_0 - lambda_s)
+            nfe += order
+        self.last_nfe = nfe
+        return x
+
+    def _sample_general(self, x, steps, t_start, t_end, order, skip_type, method, lower_order_final, denoise_to_zero, solver_type, atol, rtol):
+        """:1037-1101 for everything but the fused multistep orders 1-2."""
+        t_0 = 1. / self.noise_schedule.total_N if t_end is None else t_end
+        t_T = self.noise_schedule.T if t_start is None else t_start
+        x = x.float().contiguous()
+        with torch.no_grad():
+            if method == 'adaptive':
+                x = self.dpm_solver_adaptive(x, order=order, t_T=t_T, t_0=t_0, atol=atol, rtol=rtol, solver_type=solver_type)
+            elif method == 'multistep':
+                assert steps >= order
+                ts = self.get_time_steps(skip_type=skip_type, t_T=t_T, t_0=t_0, N=steps, device=x.device)
+                model_prev_list, t_prev_list = [self.model_fn(x, ts[0:1])], [ts[0:1]]
+                for init_order in range(1, order):
+                    x = self.multistep_dpm_solver_update(x, model_prev_list, t_prev_list, ts[init_order:init_order + 1], init_order, solver_type=solver_type)
+                    model_prev_list.append(self.model_fn(x, ts[init_order:init_order + 1]))
+                    t_prev_list.append(ts[init_order:init_order + 1])
+                for step in range(order, steps + 1):
+                    t = ts[step:step + 1]
+                    step_order = min(order, steps + 1 - step) if (lower_order_final and steps < 15) else order
+                    x = self.multistep_dpm_solver_update(x, model_prev_list, t_prev_list, t, step_order, solver_type=solver_type)
+                    model_prev_list, t_prev_list = model_prev_list[1:] + [None], t_prev_list[1:] + [t]
+                    if step < steps:
+                        model_prev_list[-1] = self.model_fn(x, t)
+            else:
+                if method == 'singlestep':
+                    timesteps_outer, orders = self.get_orders_and_timesteps_for_singlestep_solver(steps, order, skip_type, t_T, t_0, x.device)
+                else:
+                    K = steps // order
+                    orders, timesteps_outer = [order] * K, self.get_time_steps(skip_type, t_T, t_0, K, x.device)
+                if len(timesteps_outer) != len(orders) + 1:   # (order 1: the reference builds a one-interval grid and fails at :1086)
+                    timesteps_outer = self.get_time_steps(skip_type, t_T, t_0, len(orders), x.device)
+                for i, o in enumerate(orders):
+                    s, t = timesteps_outer[i:i + 1], timesteps_outer[i + 1:i + 2]
+                    lambda_inner = self.noise_schedule.marginal_lambda(self.get_time_steps(skip_type, s.item(), t.item(), o, x.device))
+                    h = lambda_inner[-1] - lambda_inner[0]
+                    r1 = None if o <= 1 else (lambda_inner[1] - lambda_inner[0]) / h
+                    r2 = None if o <= 2 else (lambda_inner[2] - lambda_inner[0]) / h
+                    x = self.singlestep_dpm_solver_update(x, s, t, o, solver_type=solver_type, r1=r1, r2=r2)
+            if denoise_to_zero:
+                x = self.denoise_to_zero_fn(x, torch.ones((1,)) * t_0)
+        return x
+
+    def sample(self, x, steps=20, t_start=None, t_end=None, order=3, skip_type='time_uniform', method='singlestep',
+               lower_order_final=True, denoise_to_zero=False, solver_type='dpm_solver', atol=0.0078, rtol=0.05):
+        """:939-1101.  method='multistep' with order <= 2 (what DPMSolverSampler asks for) takes the fused path: S network evaluations for S
+        steps, evaluation i yields the history value m_i and, in the same kernel, x at the next step time; everything else goes through
+        `_sample_general`."""
+        if method not in ('multistep', 'singlestep', 'singlestep_fixed', 'adaptive'):
+            raise ValueError("Got wrong method {}".format(method))
+        if solver_type not in ['dpm_solver', 'taylor']:
+            raise ValueError("'solver_type' must be either 'dpm_solver' or 'taylor', got {}".format(solver_type))
+        if method != 'multistep' or order == 3:
+            return self._sample_general(x, steps, t_start, t_end, order, skip_type, method, lower_order_final, denoise_to_zero, solver_type,
+                                        atol, rtol)
+        if order not in (1, 2):
+            raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
         t_0 = 1. / self.noise_schedule.total_N if t_end is None else t_end
         t_T = self.noise_schedule.T if t_start is None else t_start
         assert steps >= order

@@ -759,6 +759,37 @@ def patchify(x, P):
     return out
 
 
+def lincomb(terms, out=None):
+    """sum_i c_i * x_i over up to four (fp32 tensor, scalar) terms of one shape (ae_lincomb4_f32): the general DPM-Solver updates."""
+    terms = [(t, float(c)) for t, c in terms if t is not None]
+    if not 1 <= len(terms) <= 4:
+        raise ValueError("lincomb: one to four terms")
+    x0 = terms[0][0]
+    for t, _ in terms:
+        _chk(t, torch.float32, "lincomb.term")
+        if t.shape != x0.shape or not t.is_contiguous():
+            raise ValueError("lincomb: terms must be contiguous tensors of one shape")
+    if out is None:
+        out = torch.empty_like(x0)
+    ptr = [(_p(t), c) for t, c in terms] + [(None, 0.0)] * (4 - len(terms))
+    check(lib.ae_lincomb4_f32(_p(out), ptr[0][0], ptr[0][1], ptr[1][0], ptr[1][1], ptr[2][0], ptr[2][1], ptr[3][0], ptr[3][1], x0.numel(), _s()),
+          "ae_lincomb4_f32")
+    return out
+
+
+def dpm_adaptive_err(x_lower, x_higher, x_prev, atol, rtol):
+    """Per-sample error norm of the adaptive DPM-Solver (ae_dpm_adaptive_err_f32) -> fp32 [B]."""
+    for t in (x_lower, x_higher, x_prev):
+        _chk(t, torch.float32, "dpm_adaptive_err")
+        if t.shape != x_lower.shape or not t.is_contiguous():
+            raise ValueError("dpm_adaptive_err: contiguous tensors of one shape")
+    B = x_lower.shape[0]
+    out = torch.empty(B, dtype=torch.float32, device=x_lower.device)
+    check(lib.ae_dpm_adaptive_err_f32(_p(x_lower), _p(x_higher), _p(x_prev), float(atol), float(rtol), B, x_lower.numel() // B, _p(out), _s()),
+          "ae_dpm_adaptive_err_f32")
+    return out
+
+
 def mse(a, b):
     out = torch.empty(1, dtype=torch.float32, device=a.device)
     check(lib.ae_mse_f32(_p(_tmp(a.float().contiguous())), _p(_tmp(b.float().contiguous())), _p(out), a.numel(), _s()), "ae_mse_f32")

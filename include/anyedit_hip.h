@@ -265,6 +265,15 @@ int ae_dpm_multistep_f32(const float* x, const float* model_out, const float* m_
                          float scale, int v_param, int predict_x0, float sigma_s, float alpha_s, int update, float a, float b, float c,
                          float inv_r0, void* stream);
 
+/* The DPM-Solver updates outside the multistep-2 fast path (dpm_solver.py:469-722 singlestep first / second / third update, :780-826
+ * multistep third update): each is out = c0 x0 + c1 x1 + c2 x2 + c3 x3 with host-side fp32 scalars (x1..x3 may be NULL).              */
+int ae_lincomb4_f32(float* out, const float* x0, float c0, const float* x1, float c1, const float* x2, float c2, const float* x3, float c3,
+                    long n, void* stream);
+/* Error estimate of the adaptive step-size solver (dpm_solver.py:925-927): out[b] = sqrt(mean(((x_higher - x_lower) / delta)^2)) over the
+ * n_per_sample elements of sample b, delta = max(atol, rtol * max(|x_lower|, |x_prev|)).                                            */
+int ae_dpm_adaptive_err_f32(const float* x_lower, const float* x_higher, const float* x_prev, float atol, float rtol, int B,
+                            long n_per_sample, float* out, void* stream);
+
 /* ---- SAM prompt encoder / mask decoder (SURVEY.md §8f N3): the non-GEMM kernels behind SamPredictor.predict_torch
  * (segment_anything/predictor.py:168-245).
  * ae_layernorm_act_bf16: LayerNorm over a narrow last dim (C <= 512) with optional fused GELU (act 1) — the LayerNorm2d + GELU of

@@ -326,10 +326,53 @@ def test_dpm_solver_sampler_golden():
     eu = model.apply_model(x, torch.full((2,), 499.0), dev("uc"))
     ec = model.apply_model(x, torch.full((2,), 499.0), dev("c"))
     assert float((mf(x, t) - (eu + 3.0 * (ec - eu))).abs().max()) <= 1e-6
-    with pytest.raises(NotImplementedError):
-        DPM_Solver(mf, ns).sample(x, steps=6, method="singlestep")
+    with pytest.raises(ValueError):
+        DPM_Solver(mf, ns).sample(x, steps=6, method="no_such_method")
     with pytest.raises(NotImplementedError):
         NoiseScheduleVP('linear')
+
+
+def test_dpm_solver_general_variants_golden():
+    """DPM_Solver.sample beyond the sampler front end's settings — singlestep orders 2 / 3 with the order plan, singlestep_fixed, multistep
+    order 3, adaptive step size with its evaluation count — on the HIP path (network evaluation through ae_dpm_multistep_f32, every update one
+    ae_lincomb4_f32 launch, the adaptive error norm ae_dpm_adaptive_err_f32) against outputs of the reference solver on the analytic eps
+    model.  Samples grow to |x| ~ 5e2 under that toy network: the bound is relative; the update coefficients are applied to the model
+    values themselves rather than to their differences, which costs a few fp32 ulps of |m|."""
+    from anyedit_amd.ldm.models.diffusion.dpm_solver.dpm_solver import NoiseScheduleVP, model_wrapper, DPM_Solver
+    from oracle import schedule_ref as S
+    from dpm_cases import DPM_GENERAL_CASES
+    g = load_golden("dpm_solver_general")
+    ac = S.register_schedule("linear", 1000, 0.00085, 0.0120)["alphas_cumprod"].float()
+
+    def apply_model(x, t, c):
+        xc, tc, cc = x.detach().float().cpu(), t.float().cpu(), c.float().cpu()
+        return (torch.sin(xc * 1.7 + tc[:, None, None, None] * 0.01) * 0.5 + cc[:, :, None, None] * xc).to(x.device)
+
+    ns = NoiseScheduleVP('discrete', alphas_cumprod=ac)
+    dev = lambda k: T(g[k]).to(DEV)
+    mf = model_wrapper(apply_model, ns, model_type="noise", guidance_type="classifier-free", condition=dev("c"),
+                       unconditional_condition=dev("uc"), guidance_scale=3.0)
+    plan = DPM_Solver(mf, ns)
+    for steps, order in ((10, 3), (9, 3), (11, 3), (7, 2), (6, 2), (5, 1)):
+        ts, orders = plan.get_orders_and_timesteps_for_singlestep_solver(steps, order, "logSNR", 1.0, 0.001, DEV)
+        assert list(orders) == list(g[f"plan.{steps}.{order}.logSNR.orders"])
+        assert float((ts.cpu() - T(g[f"plan.{steps}.{order}.logSNR.ts"])).abs().max()) <= 1e-6
+    for tag, (px0, kw) in DPM_GENERAL_CASES.items():
+        solver = DPM_Solver(mf, ns, predict_x0=px0)
+        out = solver.sample(dev("x_T"), **kw)
+        ref = T(g[f"{tag}.samples"])
+        err = float((out.cpu() - ref).abs().max()) / float(ref.abs().max())
+        assert err <= 2e-5, (tag, err)
+        if kw["method"] == "adaptive":
+            assert solver.last_nfe == int(g[f"{tag}.nfe"]), (tag, solver.last_nfe)
+    # paths the reference cannot run (it raises): its evident intent
+    out = DPM_Solver(mf, ns, predict_x0=True).sample(dev("x_T"), steps=8, order=3, method="multistep")          # lower_order_final, < 15 steps
+    assert torch.isfinite(out).all()
+    out = DPM_Solver(mf, ns).sample(dev("x_T"), steps=10, order=3, method="singlestep", skip_type="time_uniform")
+    assert torch.isfinite(out).all()
+    out1 = DPM_Solver(mf, ns, predict_x0=True).sample(dev("x_T"), steps=5, order=1, method="singlestep", skip_type="time_uniform")
+    outm = DPM_Solver(mf, ns, predict_x0=True).sample(dev("x_T"), steps=5, order=1, method="multistep", skip_type="time_uniform")
+    assert float((out1 - outm).abs().max()) <= 2e-5 * float(outm.abs().max())     # order 1 is DDIM either way
 
 
 def test_dpm_solver_tiny_unet_vs_oracle(tiny_unet):
