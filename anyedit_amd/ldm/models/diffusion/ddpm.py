@@ -42,13 +42,23 @@ class DiffusionWrapper(nn.Module):
             xc = torch.cat([x] + c_concat, dim=1)
             cc = torch.cat(c_crossattn, 1)
             return self._run(xc, t, cc)
-        raise NotImplementedError(f"conditioning_key={self.conditioning_key} (class-conditional paths are not on the AnyEdit hot path)")
+        if self.conditioning_key == 'hybrid-adm':       # ddpm.py:1349-1353
+            assert c_adm is not None
+            return self._run(torch.cat([x] + c_concat, dim=1), t, torch.cat(c_crossattn, 1), y=c_adm)
+        if self.conditioning_key == 'crossattn-adm':    # :1354-1357
+            assert c_adm is not None
+            return self._run(x, t, torch.cat(c_crossattn, 1), y=c_adm)
+        if self.conditioning_key == 'adm':              # :1358-1360
+            return dm(x, t, y=c_crossattn[0])
+        raise NotImplementedError()
 
-    def _run(self, x, t, cc):
+    def _run(self, x, t, cc, y=None):
         dm = self.diffusion_model
         if hasattr(dm, "forward_rows"):
+            if y is not None:
+                return dm.forward_rows(x, t, dm.context_rows(cc), kv_cache=self.kv_cache, y=y)
             return dm.forward_rows(x, t, dm.context_rows(cc), kv_cache=self.kv_cache)
-        return dm(x, t, context=cc)
+        return dm(x, t, context=cc) if y is None else dm(x, t, context=cc, y=y)
 
 
 class DDPM(nn.Module):

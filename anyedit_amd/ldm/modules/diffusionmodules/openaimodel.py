@@ -225,8 +225,10 @@ class UNetModel(nn.Module):
         assert context_dim is not None, "use_spatial_transformer needs context_dim (openaimodel.py:474-475)"
         if not isinstance(context_dim, (int, type(None))):
             context_dim = list(context_dim)
-        if num_classes is not None or n_embed is not None or resblock_updown or use_scale_shift_norm or dims != 2:
-            raise NotImplementedError("num_classes / n_embed / resblock_updown / scale-shift / dims!=2 are outside the AnyEdit hot path")
+        if n_embed is not None or resblock_updown or use_scale_shift_norm or dims != 2:
+            raise NotImplementedError("n_embed / resblock_updown / scale-shift / dims!=2 are outside the AnyEdit hot path")
+        if num_classes is not None and not isinstance(num_classes, int):
+            raise NotImplementedError("num_classes='continuous' (a Linear(1, 4*mc) label embedding, openaimodel.py:536-538) has no in-tree caller")
         if num_heads_upsample == -1:
             num_heads_upsample = num_heads
         if num_heads == -1:
@@ -274,6 +276,8 @@ class UNetModel(nn.Module):
 
         time_embed_dim = model_channels * 4
         self.time_embed = nn.Sequential(linear(model_channels, time_embed_dim), nn.SiLU(), linear(time_embed_dim, time_embed_dim))
+        if num_classes is not None:  # openaimodel.py:533-535 (created here: the reference's parameter order, seed-reproducible init)
+            self.label_emb = nn.Embedding(num_classes, time_embed_dim)
         self.input_blocks = nn.ModuleList([TimestepEmbedSequential(conv_nd(dims, in_channels, model_channels, 3, padding=1))])
         self._feature_size = model_channels
         input_block_chans = [model_channels]
@@ -357,12 +361,20 @@ class UNetModel(nn.Module):
             return [self.context_rows(c) for c in context]
         return context.reshape(-1, context.shape[-1]).to(BF16).contiguous()
 
-    def forward_rows(self, x, timesteps, context_rows, kv_cache=None):
-        """x: [B, Cin, H, W] fp32/bf16 NCHW; context_rows: bf16 [B*L, Dc].  Returns eps [B, Cout, H, W] fp32."""
+    def forward_rows(self, x, timesteps, context_rows, kv_cache=None, y=None):
+        """x: [B, Cin, H, W] fp32/bf16 NCHW; context_rows: bf16 [B*L, Dc]; y: class labels [B] of a class-conditional model
+        (openaimodel.py:764-772).  Returns eps [B, Cout, H, W] fp32."""
         B, C, H, W = x.shape
+        assert (y is not None) == (self.num_classes is not None), "must specify y if and only if the model is class-conditional"
         t_emb = ops.timestep_embedding(timesteps, self.model_channels)                 # bf16 [B, mc]
         emb = self.time_embed[0].rows(t_emb, epilogue=ops.EPI_SILU)                   # Linear + SiLU fused
-        emb_silu = self.time_embed[2].rows(emb, epilogue=ops.EPI_SILU)                # SiLU(emb): what every ResBlock consumes
+        if y is None:
+            emb_silu = self.time_embed[2].rows(emb, epilogue=ops.EPI_SILU)            # SiLU(emb): what every ResBlock consumes
+        else:  # emb + label_emb(y) in fp32 (the table lookup is indexing), then the SiLU every ResBlock starts with
+            assert y.shape == (B,)
+            e32 = self.time_embed[2].rows(emb, out_f32=True)
+            lab = self.label_emb.weight.detach().float()[y.long().to(e32.device)].contiguous()
+            emb_silu = ops.silu_to_bf16(ops.lincomb([(e32, 1.0), (lab, 1.0)]))
         emb_silu = self._emb_pack(emb_silu)
         f = Feat(ops.nchw_to_rows(x, (C + 7) // 8 * 8), B, H, W)
         hs = []
@@ -388,5 +400,5 @@ class UNetModel(nn.Module):
     def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
         """openaimodel.py:754-786."""
         assert (y is not None) == (self.num_classes is not None), "must specify y if and only if the model is class-conditional"
-        out = self.forward_rows(x, timesteps, self.context_rows(context) if context is not None else None)
+        out = self.forward_rows(x, timesteps, self.context_rows(context) if context is not None else None, y=y)
         return out.to(x.dtype) if x.dtype != torch.float32 else out

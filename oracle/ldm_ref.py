@@ -233,13 +233,16 @@ def _run_layers(sd, prefix, layers, h, emb, context, use_linear, adapters=None):
     return h
 
 
-def unet_forward(sd, cfg, x, timesteps, context, adapters=None):
-    """openaimodel.py:754-786."""
+def unet_forward(sd, cfg, x, timesteps, context, adapters=None, y=None):
+    """openaimodel.py:754-786; y: class labels of a class-conditional model (num_classes an int: :533-535, 770-772)."""
     inp, mid, out = unet_plan(cfg)
     use_linear = cfg.get("use_linear_in_transformer", False)
     t_emb = timestep_embedding(timesteps, cfg["model_channels"])
     emb = F.linear(t_emb, sd["time_embed.0.weight"], sd["time_embed.0.bias"])
     emb = F.linear(silu(emb), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
+    assert (y is not None) == (cfg.get("num_classes") is not None), "must specify y if and only if the model is class-conditional"
+    if y is not None:
+        emb = emb + sd["label_emb.weight"][y.long()]
     hs = []
     h = _st(x.float())
     context = None if context is None else _st(context)
@@ -254,8 +257,14 @@ def unet_forward(sd, cfg, x, timesteps, context, adapters=None):
     return F.conv2d(h, sd["out.2.weight"], sd["out.2.bias"], padding=1)
 
 
-def diffusion_wrapper(sd, cfg, x, t, c_concat=None, c_crossattn=None, conditioning_key="hybrid"):
-    """ldm/models/diffusion/ddpm.py:1332-1363 (the keys in-tree callers use)."""
+def diffusion_wrapper(sd, cfg, x, t, c_concat=None, c_crossattn=None, conditioning_key="hybrid", c_adm=None):
+    """ldm/models/diffusion/ddpm.py:1332-1363."""
+    if conditioning_key == "hybrid-adm":
+        return unet_forward(sd, cfg, torch.cat([x] + c_concat, dim=1), t, torch.cat(c_crossattn, 1), y=c_adm)
+    if conditioning_key == "crossattn-adm":
+        return unet_forward(sd, cfg, x, t, torch.cat(c_crossattn, 1), y=c_adm)
+    if conditioning_key == "adm":
+        return unet_forward(sd, cfg, x, t, None, y=c_crossattn[0])
     if conditioning_key is None:
         return unet_forward(sd, cfg, x, t, None)
     if conditioning_key == "concat":

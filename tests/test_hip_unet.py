@@ -268,6 +268,32 @@ def test_ddim_hacked_sampler_golden():
     assert float((x.cpu() - T(g["enc.x_orig"])).abs().max()) <= 2e-5
 
 
+def test_unet_class_conditional_and_adm_keys_golden():
+    """Class-conditional UNet (label_emb, openaimodel.py:533-535, 764-772) behind DiffusionWrapper's 'hybrid-adm' / 'crossattn-adm' keys
+    (ddpm.py:1349-1358) against the reference's outputs; bf16-storage tolerance of the tiny UNet tests."""
+    from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from anyedit_amd.ldm.models.diffusion.ddpm import DiffusionWrapper
+    from test_oracle_golden import SD2_TINY
+    g = load_golden("unet_adm_tiny")
+    with torch.device(DEV):
+        unet = UNetModel(**dict(SD2_TINY, num_classes=5, in_channels=6))
+    unet.load_state_dict({k: v.to(DEV) for k, v in sub_sd(g, "w.").items()})
+    unet.eval().requires_grad_(False)
+    dev = lambda k: T(g[k]).to(DEV)
+    x, cc, t, ctx, y = dev("x"), dev("cc"), dev("t"), dev("ctx"), dev("y")
+    w = DiffusionWrapper(unet, "hybrid-adm")
+    with torch.no_grad():
+        out = w(x, t, c_concat=[cc], c_crossattn=[ctx], c_adm=y)
+        assert rel_l2(out.cpu(), T(g["out.hybrid_adm"])) <= 2e-2
+        w.conditioning_key = "crossattn-adm"
+        out2 = w(torch.cat([x, cc], 1), t, c_crossattn=[ctx[:, :4], ctx[:, 4:]], c_adm=y)
+        assert rel_l2(out2.cpu(), T(g["out.crossattn_adm"])) <= 2e-2
+        other = w(torch.cat([x, cc], 1), t, c_crossattn=[ctx], c_adm=(y + 1) % 5)
+        assert rel_l2(other.cpu(), out2.cpu()) > 1e-3                      # the label matters
+        with pytest.raises(AssertionError):
+            unet(torch.cat([x, cc], 1), t, context=ctx)                  # class-conditional model without y
+
+
 def test_dpm_solver_sampler_golden():
     """DPMSolverSampler (DPM-Solver++ 2M, CFG) and the other multistep variants on the HIP path vs the reference solver (golden from the
     analytic eps model: identical eps on both sides isolates the solver arithmetic, history handling and step bookkeeping)."""

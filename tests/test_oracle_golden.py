@@ -1,6 +1,7 @@
 """Pins the oracle (our CPU restatement) against golden vectors produced by the reference's own code
 (tools/gen_golden.py).  CPU only.  Integer bookkeeping: bit-exact.  Floats: fp32 round-off."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import load_golden, sub_sd, T
@@ -381,6 +382,19 @@ def test_unet_sd2_options():
     g = load_golden("unet_sd2_tiny")
     y = L.unet_forward(sub_sd(g, "w."), SD2_TINY, T(g["x"]), T(g["t"]), T(g["ctx"]))
     close(y, g["y"], tol=2e-4)
+
+
+def test_unet_class_conditional_and_adm_keys():
+    """Class-conditional UNet (label_emb added to the time embedding, openaimodel.py:533-535, 770-772) behind the DiffusionWrapper keys
+    'hybrid-adm' and 'crossattn-adm' (ddpm.py:1349-1358)."""
+    g = load_golden("unet_adm_tiny")
+    cfg = dict(SD2_TINY, num_classes=5, in_channels=6)
+    sd = sub_sd(g, "w.")
+    x, cc, t, ctx, y = T(g["x"]), T(g["cc"]), T(g["t"]), T(g["ctx"]), T(g["y"])
+    close(L.diffusion_wrapper(sd, cfg, x, t, [cc], [ctx], "hybrid-adm", c_adm=y), g["out.hybrid_adm"], tol=2e-4)
+    close(L.diffusion_wrapper(sd, cfg, torch.cat([x, cc], 1), t, None, [ctx[:, :4], ctx[:, 4:]], "crossattn-adm", c_adm=y), g["out.crossattn_adm"], tol=2e-4)
+    with pytest.raises(AssertionError):
+        L.unet_forward(sd, cfg, torch.cat([x, cc], 1), t, ctx)          # a class-conditional model needs y
 
 
 def test_ddim_hacked_sampler():

@@ -336,6 +336,39 @@ def gen_unet_sd2():
     npz("unet_sd2_tiny", **arrs)
 
 
+@torch.no_grad()
+def gen_unet_adm():
+    """Class-conditional UNet (openaimodel.py:533-539 label_emb, :764-772 emb + label_emb(y)) and the DiffusionWrapper keys that feed it
+    (ddpm.py:1349-1361 'hybrid-adm', 'crossattn-adm', 'adm')."""
+    print("[unet_adm]")
+    torch.manual_seed(56)
+    g = G(57)
+    cfg = dict(SD2_TINY_UNET, num_classes=5, in_channels=6)
+    unet = rom.UNetModel(**cfg)
+    unzero(unet, g, std=0.05)
+    randomize_norm_affine(unet, g)
+    unet.eval()
+    for p_ in unet.parameters():
+        p_.copy_(p_.bfloat16().float())
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    cc = torch.randn(2, 2, 8, 8, generator=g)
+    t = torch.tensor([37, 903], dtype=torch.long)
+    ctx = torch.randn(2, 9, 24, generator=g)
+    y = torch.tensor([3, 0], dtype=torch.long)
+    wrap = rddpm.DiffusionWrapper.__new__(rddpm.DiffusionWrapper)
+    nn.Module.__init__(wrap)
+    wrap.sequential_cross_attn, wrap.diffusion_model = False, unet
+    arrs = {"x": x, "cc": cc, "t": t, "ctx": ctx, "y": y}
+    wrap.conditioning_key = "hybrid-adm"
+    arrs["out.hybrid_adm"] = wrap(x, t, c_concat=[cc], c_crossattn=[ctx], c_adm=y)
+    xx = torch.cat([x, cc], 1)
+    wrap.conditioning_key = "crossattn-adm"
+    arrs["out.crossattn_adm"] = wrap(xx, t, c_crossattn=[ctx[:, :4], ctx[:, 4:]], c_adm=y)
+    for k, v in unet.state_dict().items():
+        arrs["w." + k] = v.bfloat16().view(torch.int16)
+    npz("unet_adm_tiny", **arrs)
+
+
 def build_ldm(unet_params):
     ldm = OracleLDM(first_stage_config=None, cond_stage_config="__is_unconditional__",
                     force_null_conditioning=True, conditioning_key="hybrid",
@@ -933,7 +966,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     only = set(sys.argv[1:])  # e.g. `python tools/gen_golden.py ddim_encode` regenerates one fixture
     for name, fn in (("schedule", gen_schedule), ("norms", gen_norms), ("attention", gen_attention), ("transformer", gen_transformer),
-                     ("resblock", gen_resblock), ("unet", gen_unet), ("unet_sd2", gen_unet_sd2), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode), ("ddim_hacked", gen_ddim_hacked),
+                     ("resblock", gen_resblock), ("unet", gen_unet), ("unet_sd2", gen_unet_sd2), ("unet_adm", gen_unet_adm), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode), ("ddim_hacked", gen_ddim_hacked),
                      ("vae", gen_vae), ("plms", gen_plms), ("dpm_solver", gen_dpm_solver), ("dpm_solver_general", gen_dpm_solver_general), ("cldm", gen_cldm), ("msda", gen_msda), ("sam", gen_sam), ("sam_decoder", gen_sam_decoder),
                      ("misc", gen_ldm_misc)):
         if not only or name in only:
