@@ -82,6 +82,7 @@ SIGNATURES = {
     "ae_softmax_rows_f32_bf16": [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_float, c_void_p],
     "ae_gaussian_moments_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p],
     "ae_ms_deform_attn_fwd_f32": [c_void_p] * 6 + [c_int] * 7 + [c_void_p],
+    "ae_ms_deform_attn_bwd_f32": [c_void_p] * 9 + [c_int] * 7 + [c_void_p],
     "ae_linear_f32": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p],
     "ae_dpm_multistep_f32": [c_void_p] * 5 + [c_long, c_int, c_float, c_int, c_int, c_float, c_float, c_int, c_float, c_float, c_float,
                              c_float, c_void_p],

@@ -23,9 +23,31 @@ def _is_power_of_2(n):
     return (n & (n - 1) == 0) and n != 0
 
 
+class MultiScaleDeformableAttnFunction(torch.autograd.Function):
+    """ms_deform_attn.py:42-90: forward = `_C.ms_deform_attn_forward`, backward = `_C.ms_deform_attn_backward` (once-differentiable;
+    gradients for value, sampling_locations and attention_weights, None for the shape tensors and im2col_step)."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, im2col_step):
+        ctx.im2col_step = im2col_step
+        out = ops.ms_deform_attn(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, starts, loc, w = ctx.saved_tensors
+        gv, gl, gw = ops.ms_deform_attn_bwd(value, shapes, starts, loc, w, grad_output, ctx.im2col_step)
+        return gv, None, None, gl.to(loc.dtype), gw.to(w.dtype), None
+
+
 def multi_scale_deformable_attn(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
                                 im2col_step=64):
     """Functional entry with the argument list of MultiScaleDeformableAttnFunction.forward (ms_deform_attn.py:42-60)."""
+    if torch.is_grad_enabled() and (value.requires_grad or sampling_locations.requires_grad or attention_weights.requires_grad):
+        return MultiScaleDeformableAttnFunction.apply(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                                      attention_weights, im2col_step)
     return ops.ms_deform_attn(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights, im2col_step)
 
 

@@ -632,6 +632,26 @@ def ms_deform_attn(value, spatial_shapes, level_start_index, sampling_locations,
     return out
 
 
+def ms_deform_attn_bwd(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, grad_output, im2col_step=None):
+    """Drop-in for `_C.ms_deform_attn_backward` (GroundingDINO ms_deform_attn.py:68-90): returns (grad_value [bs, S, heads, d],
+    grad_sampling_loc [bs, Q, heads, L, P, 2], grad_attn_weight [bs, Q, heads, L, P]), fp32."""
+    _chk(value, torch.float32, "ms_deform_attn_bwd.value", 4)
+    bs, S, heads, d = value.shape
+    _, Q, _, L, P, _ = sampling_locations.shape
+    value = value.contiguous()
+    loc = sampling_locations.float().contiguous()
+    w = attention_weights.float().contiguous()
+    go = grad_output.float().contiguous()
+    if tuple(go.shape) != (bs, Q, heads * d):
+        raise ValueError(f"ms_deform_attn_bwd: grad_output {tuple(go.shape)} != {(bs, Q, heads * d)}")
+    shapes = spatial_shapes.to(torch.int64).contiguous()
+    starts = level_start_index.to(torch.int64).contiguous()
+    gv, gl, gw = torch.empty_like(value), torch.empty_like(loc), torch.empty_like(w)
+    check(lib.ae_ms_deform_attn_bwd_f32(_p(value), _p(shapes), _p(starts), _p(loc), _p(w), _p(go), _p(gv), _p(gl), _p(gw), bs, S, heads, d,
+                                        Q, L, P, _s()), "ae_ms_deform_attn_bwd_f32")
+    return gv, gl, gw
+
+
 def linear_f32(x, w, bias=None):
     """nn.Linear in exact fp32 on the f32-input MFMA (ae_linear_f32): x [..., K] fp32, w [N, K] fp32, bias [N] -> [..., N] fp32.
     For layers the reference runs in fp32 and whose outputs are coordinates (GroundingDINO MSDeformAttn); K % 16 == 0."""

@@ -251,6 +251,13 @@ int ae_gaussian_moments_f32(const float* moments, const float* noise, float* z, 
  * [bs, Q, heads, L, P, 2] in [0,1] (x, y), attn_weight [bs, Q, heads, L, P]; out [bs, Q, heads*d] fp32.                      */
 int ae_ms_deform_attn_fwd_f32(const float* value, const long* spatial_shapes, const long* level_start_index, const float* sampling_loc,
                               const float* attn_weight, float* out, int bs, int S, int heads, int d, int Q, int L, int P, void* stream);
+/* Backward of the same operator: `_C.ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+ * grad_output, im2col_step)` (csrc/vision.cpp:57, ms_deform_attn.h:43-64; called from MultiScaleDeformableAttnFunction.backward,
+ * ms_deform_attn.py:68-90).  grad_out [bs, Q, heads*d] -> grad_value [bs, S, heads, d], grad_sampling_loc [bs, Q, heads, L, P, 2],
+ * grad_attn_weight [bs, Q, heads, L, P]; all three fully overwritten.  grad_value accumulates with float atomics.              */
+int ae_ms_deform_attn_bwd_f32(const float* value, const long* spatial_shapes, const long* level_start_index, const float* sampling_loc,
+                              const float* attn_weight, const float* grad_out, float* grad_value, float* grad_sampling_loc,
+                              float* grad_attn_weight, int bs, int S, int heads, int d, int Q, int L, int P, void* stream);
 /* nn.Linear in EXACT fp32 (v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate) for the four projections of GroundingDINO's
  * MultiScaleDeformableAttention (ms_deform_attn.py:281-288, 330-352: value_proj, sampling_offsets, attention_weights, output_proj),
  * which run in fp32 in the reference and feed bilinear sampling locations.  C[M,N] = A[M,K] W[N,K]^T + bias; K % 16 == 0.       */

@@ -729,6 +729,46 @@ def test_ms_deform_attn_forward(ops):
     check_close(out, ref, rl2=1e-5, mabs=1e-5, what="ms_deform_attn 900 queries x 4 levels")
 
 
+def test_ms_deform_attn_backward(ops):
+    """ae_ms_deform_attn_bwd_f32 (the reference's `_C.ms_deform_attn_backward`) against autograd through the reference's PyTorch statement
+    (golden; case c has d/4 = 3 = the float-atomics reduction instead of the shuffle tree) and, at an 800x1066 image's four levels with 900
+    queries, against the oracle's explicit float64 restatement.  grad_value is a sum of float atomics: fp32 round-off, any order."""
+    from oracle import msda_ref as MS
+    from anyedit_amd.groundingdino.ms_deform_attn import MultiScaleDeformableAttnFunction, multi_scale_deformable_attn
+    g = load_golden("msda_bwd")
+    for tag in ("a", "b", "c"):
+        a = [T(g[f"{tag}.{k}"]).to(DEV) for k in ("value", "shapes", "start", "loc", "w", "go")]
+        gv, gl, gw = ops.ms_deform_attn_bwd(*a, 64)
+        check_close(gv, T(g[f"{tag}.gv"]), rl2=1e-5, mabs=2e-5, what=f"msda bwd golden {tag}: grad_value")
+        check_close(gl, T(g[f"{tag}.gl"]), rl2=2e-5, mabs=2e-4, what=f"msda bwd golden {tag}: grad_sampling_loc")
+        check_close(gw, T(g[f"{tag}.gw"]), rl2=1e-5, mabs=2e-5, what=f"msda bwd golden {tag}: grad_attn_weight")
+    # the autograd Function of ms_deform_attn.py:42-90: forward + backward through torch's engine
+    a = [T(g[f"a.{k}"]).to(DEV) for k in ("value", "shapes", "start", "loc", "w", "go")]
+    v, loc, w = a[0].clone().requires_grad_(True), a[3].clone().requires_grad_(True), a[4].clone().requires_grad_(True)
+    out = MultiScaleDeformableAttnFunction.apply(v, a[1], a[2], loc, w, 64)
+    check_close(out.detach(), T(g["a.out"]), rl2=1e-5, mabs=1e-5, what="msda Function forward")
+    out.backward(a[5])
+    check_close(v.grad, T(g["a.gv"]), rl2=1e-5, mabs=2e-5, what="msda Function: value.grad")
+    check_close(loc.grad, T(g["a.gl"]), rl2=2e-5, mabs=2e-4, what="msda Function: sampling_locations.grad")
+    check_close(w.grad, T(g["a.gw"]), rl2=1e-5, mabs=2e-5, what="msda Function: attention_weights.grad")
+    v2 = a[0].clone().requires_grad_(True)                                   # the functional entry routes through it when a gradient is wanted
+    multi_scale_deformable_attn(v2, a[1], a[2], a[3], a[4]).backward(a[5])
+    check_close(v2.grad, T(g["a.gv"]), rl2=1e-5, mabs=2e-5, what="msda functional entry: value.grad")
+    gen = torch.Generator().manual_seed(6)
+    shapes = torch.tensor([(100, 134), (50, 67), (25, 34), (13, 17)], dtype=torch.long)
+    S = int(shapes.prod(1).sum())
+    start = torch.cat([shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]])
+    value = torch.randn(2, S, 8, 32, generator=gen)
+    loc = torch.rand(2, 900, 8, 4, 4, 2, generator=gen) * 1.2 - 0.1
+    w = torch.softmax(torch.randn(2, 900, 8, 16, generator=gen), -1).view(2, 900, 8, 4, 4)
+    go = torch.randn(2, 900, 256, generator=gen)
+    rv, rl, rw = MS.ms_deform_attn_backward(value, shapes, start, loc, w, go)
+    gv, gl, gw = ops.ms_deform_attn_bwd(value.to(DEV), shapes.to(DEV), start.to(DEV), loc.to(DEV), w.to(DEV), go.to(DEV))
+    check_close(gv, rv, rl2=1e-5, mabs=5e-5, what="msda bwd 900 queries: grad_value")
+    check_close(gl, rl, rl2=2e-5, mabs=2e-4, what="msda bwd 900 queries: grad_sampling_loc")
+    check_close(gw, rw, rl2=1e-5, mabs=5e-5, what="msda bwd 900 queries: grad_attn_weight")
+
+
 @pytest.mark.parametrize("M,N,K", [(13294, 256, 256), (900, 128, 256), (100, 48, 64), (1, 4, 16), (65, 96, 64)])
 def test_linear_f32_exact(ops, M, N, K):
     """ae_linear_f32 (f32-input MFMA, the MSDeformAttn projections) against fp64: fp32 round-off only — these layers feed sampling

@@ -833,6 +833,39 @@ def gen_msda():
     npz("msda", **arrs)
 
 
+def gen_msda_bwd():
+    """Gradients of GroundingDINO's multi_scale_deformable_attn_pytorch (ms_deform_attn.py:93-133) by autograd = what
+    `_C.ms_deform_attn_backward` returns (MultiScaleDeformableAttnFunction.backward, :68-90): grad_value, grad_sampling_loc,
+    grad_attn_weight for a given grad_output."""
+    print("[msda_bwd]")
+    import warnings
+    path = os.path.join(REF, "GroundingDINO", "groundingdino", "models", "GroundingDINO", "ms_deform_attn.py")
+    spec = importlib.util.spec_from_file_location("ref_ms_deform_attn_b", path)
+    mod = importlib.util.module_from_spec(spec)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        spec.loader.exec_module(mod)
+    g = G(81)
+    arrs = {}
+    for tag, (bs, heads, d, Q, P, shapes) in {"a": (2, 4, 8, 37, 4, [(8, 8), (4, 4), (2, 3)]),
+                                              "b": (1, 8, 32, 100, 4, [(20, 27), (10, 14), (5, 7), (3, 4)]),
+                                              "c": (2, 2, 12, 19, 2, [(6, 5), (3, 3)])}.items():      # d/4 = 3: the atomics path
+        S = sum(h * w for h, w in shapes)
+        value = torch.randn(bs, S, heads, d, generator=g).requires_grad_(True)
+        shp = torch.tensor(shapes, dtype=torch.long)
+        start = torch.cat([shp.new_zeros(1), shp.prod(1).cumsum(0)[:-1]])
+        loc = (torch.rand(bs, Q, heads, len(shapes), P, 2, generator=g) * 1.3 - 0.15).requires_grad_(True)
+        w = torch.softmax(torch.randn(bs, Q, heads, len(shapes) * P, generator=g), -1).view(bs, Q, heads, len(shapes), P)
+        w = w.detach().requires_grad_(True)
+        go = torch.randn(bs, Q, heads * d, generator=g)
+        out = mod.multi_scale_deformable_attn_pytorch(value, shp, loc, w)
+        gv, gl, gw = torch.autograd.grad(out, (value, loc, w), go)
+        for k, v in (("value", value.detach()), ("shapes", shp), ("start", start), ("loc", loc.detach()), ("w", w.detach()), ("go", go),
+                     ("out", out.detach()), ("gv", gv), ("gl", gl), ("gw", gw)):
+            arrs[f"{tag}.{k}"] = v
+    npz("msda_bwd", **arrs)
+
+
 @torch.no_grad()
 def gen_sam():
     print("[sam]")
@@ -967,7 +1000,7 @@ if __name__ == "__main__":
     only = set(sys.argv[1:])  # e.g. `python tools/gen_golden.py ddim_encode` regenerates one fixture
     for name, fn in (("schedule", gen_schedule), ("norms", gen_norms), ("attention", gen_attention), ("transformer", gen_transformer),
                      ("resblock", gen_resblock), ("unet", gen_unet), ("unet_sd2", gen_unet_sd2), ("unet_adm", gen_unet_adm), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode), ("ddim_hacked", gen_ddim_hacked),
-                     ("vae", gen_vae), ("plms", gen_plms), ("dpm_solver", gen_dpm_solver), ("dpm_solver_general", gen_dpm_solver_general), ("cldm", gen_cldm), ("msda", gen_msda), ("sam", gen_sam), ("sam_decoder", gen_sam_decoder),
+                     ("vae", gen_vae), ("plms", gen_plms), ("dpm_solver", gen_dpm_solver), ("dpm_solver_general", gen_dpm_solver_general), ("cldm", gen_cldm), ("msda", gen_msda), ("msda_bwd", gen_msda_bwd), ("sam", gen_sam), ("sam_decoder", gen_sam_decoder),
                      ("misc", gen_ldm_misc)):
         if not only or name in only:
             fn()
