@@ -765,7 +765,15 @@ def test_ms_deform_attn_backward(ops):
     rv, rl, rw = MS.ms_deform_attn_backward(value, shapes, start, loc, w, go)
     gv, gl, gw = ops.ms_deform_attn_bwd(value.to(DEV), shapes.to(DEV), start.to(DEV), loc.to(DEV), w.to(DEV), go.to(DEV))
     check_close(gv, rv, rl2=1e-5, mabs=5e-5, what="msda bwd 900 queries: grad_value")
-    check_close(gl, rl, rl2=2e-5, mabs=2e-4, what="msda bwd 900 queries: grad_sampling_loc")
+    # the location gradient is DISCONTINUOUS where a sample crosses a pixel centre (the bilinear cell changes), and whether x*W - 0.5 lands
+    # on one side or the other of an integer within float rounding differs between the float64 oracle, the fp32 kernel (one fma) and the
+    # reference's grid_sample arithmetic: samples within 1e-4 pixel of a cell boundary (about 4e-4 of them) are left out of THIS comparison
+    # only — grad_value and grad_attn_weight are continuous there and are compared everywhere
+    wh = torch.stack([shapes[:, 1], shapes[:, 0]], -1).double().view(1, 1, 1, 4, 1, 2)
+    px = loc.double() * wh - 0.5
+    keep = ~((px - px.round()).abs() < 1e-4).any(-1, keepdim=True)
+    assert float((~keep).float().mean()) < 2e-3
+    check_close(gl.cpu() * keep, rl * keep, rl2=2e-5, mabs=2e-4, what="msda bwd 900 queries: grad_sampling_loc")
     check_close(gw, rw, rl2=1e-5, mabs=5e-5, what="msda bwd 900 queries: grad_attn_weight")
 
 
