@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from anyedit_amd import ops
+from anyedit_amd.ldm.util import warn_conditioning_batch
 from anyedit_amd.ldm.modules.diffusionmodules.util import (make_ddim_sampling_parameters, make_ddim_timesteps,
                                                            extract_into_tensor)
 
@@ -71,21 +72,7 @@ class DDIMSampler(object):
                corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100, unconditional_guidance_scale=1.,
                unconditional_conditioning=None, dynamic_threshold=None, ucg_schedule=None, **kwargs):
         """ddim.py:54-120."""
-        if conditioning is not None:
-            if isinstance(conditioning, dict):
-                ctmp = conditioning[list(conditioning.keys())[0]]
-                while isinstance(ctmp, list):
-                    ctmp = ctmp[0]
-                cbs = ctmp.shape[0]
-                if cbs != batch_size:
-                    print(f"Warning: Got {cbs} conditionings but batch-size is {batch_size}")
-            elif isinstance(conditioning, list):
-                for ctmp in conditioning:
-                    if ctmp.shape[0] != batch_size:
-                        print(f"Warning: Got {ctmp.shape[0]} conditionings but batch-size is {batch_size}")
-            else:
-                if conditioning.shape[0] != batch_size:
-                    print(f"Warning: Got {conditioning.shape[0]} conditionings but batch-size is {batch_size}")
+        warn_conditioning_batch(conditioning, batch_size)
         self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
         C, H, W = shape
         size = (batch_size, C, H, W)

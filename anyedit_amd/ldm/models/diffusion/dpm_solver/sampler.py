@@ -2,6 +2,7 @@
 `model.apply_model` with classifier-free guidance; typically 15-25 network evaluations per image instead of DDIM's 50."""
 import torch
 
+from anyedit_amd.ldm.util import warn_conditioning_batch
 from .dpm_solver import NoiseScheduleVP, model_wrapper, DPM_Solver
 
 MODEL_TYPES = {"eps": "noise", "v": "v"}
@@ -26,11 +27,7 @@ class DPMSolverSampler(object):
                corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100, unconditional_guidance_scale=1.,
                unconditional_conditioning=None, **kwargs):
         """sampler.py:26-86: returns (samples, None).  Like the reference, mask / x0 / callbacks are accepted and ignored."""
-        if conditioning is not None:
-            first = conditioning[list(conditioning.keys())[0]] if isinstance(conditioning, dict) else conditioning
-            cbs = (first[0] if isinstance(first, list) else first).shape[0]
-            if cbs != batch_size:
-                print(f"Warning: Got {cbs} conditionings but batch-size is {batch_size}")
+        warn_conditioning_batch(conditioning, batch_size)
         C, H, W = shape
         size = (batch_size, C, H, W)
         device = self.model.betas.device

@@ -552,6 +552,22 @@ def test_softmax_rows_and_gaussian_moments():
     z, m, lv, sd = ops.gaussian_moments(mom.to(DEV), noise.to(DEV), want_stats=True)
     assert torch.equal(m.cpu(), mean) and torch.equal(lv.cpu(), logvar)
     assert rel_l2(sd.cpu(), torch.exp(0.5 * logvar)) < 1e-6 and rel_l2(z.cpu(), mean + torch.exp(0.5 * logvar) * noise) < 1e-6
+    # DiagonalGaussianDistribution over it (distributions.py:24-62): sample with a replayed noise stream, mode, KL to N(0, I) and to
+    # another posterior, negative log-likelihood, and the deterministic variant — against the formulas written out in torch
+    from anyedit_amd.ldm.modules.distributions.distributions import DiagonalGaussianDistribution
+    mom2 = torch.randn(2, 8, 4, 4, generator=g)
+    p, q = DiagonalGaussianDistribution((mom * 0.1).to(DEV)), DiagonalGaussianDistribution(mom2.to(DEV))
+    p.randn = lambda shape, device=None: noise.to(device)
+    m1, lv1 = (mom * 0.1).chunk(2, 1)
+    m2, lv2 = mom2.chunk(2, 1)
+    assert torch.equal(p.mode().cpu(), m1) and rel_l2(p.sample().cpu(), m1 + torch.exp(0.5 * lv1) * noise) < 1e-6
+    assert rel_l2(p.kl().cpu(), 0.5 * (m1 ** 2 + lv1.exp() - 1 - lv1).sum((1, 2, 3))) < 1e-5
+    assert rel_l2(p.kl(q).cpu(), 0.5 * ((m1 - m2) ** 2 / lv2.exp() + lv1.exp() / lv2.exp() - 1 - lv1 + lv2).sum((1, 2, 3))) < 1e-5
+    xs = torch.randn(2, 4, 4, 4, generator=g)
+    nll = 0.5 * (np.log(2 * np.pi) + lv1 + (xs - m1) ** 2 / lv1.exp()).sum((1, 2, 3))
+    assert rel_l2(p.nll(xs.to(DEV)).cpu(), nll) < 1e-5
+    det = DiagonalGaussianDistribution(mom2.to(DEV), deterministic=True)
+    assert torch.equal(det.sample().cpu(), m2) and float(det.std.abs().max()) == 0.0 and float(det.kl()) == 0.0 and float(det.nll(xs)) == 0.0
 
 
 def test_latent_diffusion_first_stage_roundtrip(tiny_unet):

@@ -443,3 +443,64 @@ def test_c_abi_rejects_bad_arguments_before_touching_the_gpu():
     expect(lib.ae_expert_kv_fwd(p16, p16, p16, p16, 2, 9, 64, 64, 2, None), "unsupported shape")                                                 # more than 8 tokens per sample
     expect(lib.ae_split_channels_bf16(p16, 12, 8, p16, p16, 4, 0, 0, None), "bad arguments")
     assert lib.ae_ln_gemm_supported(49152, 320, 320, 0) == 1 and lib.ae_ln_gemm_supported(49152, 320, 640, 0) == 0
+
+
+def test_diffusion_wrapper_routes_every_conditioning_key():
+    """DiffusionWrapper.forward / LatentDiffusion.apply_model (ddpm.py:1336-1363, 854-869): which tensors reach the UNet for each
+    conditioning key — channel concat, context concat or list (sequential_crossattn), class vector from c_adm or c_crossattn[0]."""
+    from anyedit_amd.ldm.models.diffusion.ddpm import DiffusionWrapper, LatentDiffusion
+
+    class Probe(torch.nn.Module):
+        def forward(self, x, t, context=None, y=None):
+            self.seen = (x, context, y)
+            return x[:, :1]
+
+    x, t = torch.zeros(2, 4, 3, 3), torch.zeros(2, dtype=torch.long)
+    cc = [torch.ones(2, 4, 3, 3), 2 * torch.ones(2, 1, 3, 3)]
+    ca = [torch.ones(2, 5, 8), 2 * torch.ones(2, 3, 8)]
+    adm = torch.arange(2.)
+    for key, want_c, want_ctx, want_y in ((None, 4, None, None), ("concat", 9, None, None), ("crossattn", 4, 8, None),
+                                          ("hybrid", 9, 8, None), ("hybrid-adm", 9, 8, adm), ("crossattn-adm", 4, 8, adm),
+                                          ("adm", 4, None, ca[0])):
+        w = DiffusionWrapper(Probe(), key)
+        out = w(x, t, c_concat=cc, c_crossattn=ca, c_adm=adm)
+        sx, sctx, sy = w.diffusion_model.seen
+        assert out.shape == (2, 1, 3, 3) and sx.shape[1] == want_c, key
+        if want_c == 9:
+            assert torch.equal(sx[:, 4:8], cc[0]) and torch.equal(sx[:, 8:], cc[1])
+        assert (sctx is None) == (want_ctx is None) and (sctx is None or (sctx.shape == (2, want_ctx, 8) and torch.equal(sctx[:, 5:], ca[1]))), key
+        assert (sy is None) == (want_y is None) and (sy is None or sy is want_y), key
+    for key in ("hybrid-adm", "crossattn-adm"):
+        with pytest.raises(AssertionError):
+            DiffusionWrapper(Probe(), key)(x, t, c_concat=cc, c_crossattn=ca)
+    with pytest.raises(AssertionError):
+        DiffusionWrapper(Probe(), "bogus")
+    w = DiffusionWrapper(Probe(), "crossattn")
+    w.sequential_cross_attn = True
+    w(x, t, c_crossattn=ca)
+    assert w.diffusion_model.seen[1] is ca                      # the list itself, not a concatenation
+    # apply_model: a bare tensor or list lands in the slot the key reads; tuples are unwrapped unless return_ids
+    ldm = LatentDiffusion(Probe(), conditioning_key="crossattn")
+    ldm.apply_model(x, t, ca[0])
+    assert torch.equal(ldm.model.diffusion_model.seen[1], ca[0])
+    ldm.apply_model(x, t, ca)
+    assert ldm.model.diffusion_model.seen[1].shape == (2, 8, 8)
+    ldm = LatentDiffusion(Probe(), conditioning_key="concat")
+    ldm.apply_model(x, t, cc[0])
+    assert ldm.model.diffusion_model.seen[0].shape[1] == 8
+    ldm.model.forward = lambda *a, **k: ("eps", "ids")
+    assert ldm.apply_model(x, t, {}) == "eps" and ldm.apply_model(x, t, {}, return_ids=True) == ("eps", "ids")
+    # first-stage glue: frozen, eval, scale factor on encode / its inverse on decode
+    class VAE(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.ones(1))
+        def decode(self, z):
+            return z
+        def encode(self, x):
+            return x
+    ldm = LatentDiffusion(Probe(), scale_factor=0.5, first_stage_config=VAE())
+    assert not ldm.first_stage_model.training and not ldm.first_stage_model.p.requires_grad
+    assert float(ldm.decode_first_stage(torch.ones(1))) == 2.0 and float(ldm.get_first_stage_encoding(torch.ones(1))) == 0.5
+    with pytest.raises(NotImplementedError):
+        ldm.get_first_stage_encoding("latent")
