@@ -364,6 +364,11 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const GNArgs p, int ncc, 
     float mu[GP];
 #pragma unroll
     for (int gi = 0; gi < GP; ++gi) { mu[gi] = bc[0][gi] * inv_n; acc[gi] = 0.f; }
+    // hipcc otherwise keeps the 8 unpacked floats (and, GP > 1, the 8 decoded group indices) of every piece alive from one pass to the
+    // next (common subexpressions): 8-16 x MAXCH registers beside the packed slab, spilled under the 128-register cap of a 1024-thread
+    // block.  Re-unpacking is one VALU per value.
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) asm volatile("" : "+v"(v[k]), "+v"(grp[k]));
 #pragma unroll
     for (int k = 0; k < MAXCH; ++k) {
         if (grp[k] < 0) continue;
@@ -380,6 +385,8 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const GNArgs p, int ncc, 
         }
     }
     block_sum(acc, 1);
+#pragma unroll
+    for (int k = 0; k < MAXCH; ++k) asm volatile("" : "+v"(v[k]), "+v"(grp[k]));
     float rs[GP];
 #pragma unroll
     for (int gi = 0; gi < GP; ++gi) rs[gi] = rsqrtf(bc[1][gi] * inv_n + p.eps);
@@ -416,6 +423,7 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const GNArgs p, int ncc, 
         }
         *reinterpret_cast<u32x4*>(p.y + ((long)b * p.HW + row) * p.C + ch) =
             (u32x4){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        __builtin_amdgcn_sched_barrier(0);  // one piece's gamma / beta (16 registers) at a time: hoisting all MAXCH pieces' loads spilled
     }
 }
 

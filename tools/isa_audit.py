@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Static audit of the gfx950 code objects, no GPU needed: compiles every csrc/*.hip to device assembly (hipcc -S --cuda-device-only, the
+library's own flags) and lists, per kernel, registers / LDS / scratch / spills, and — the trap that cost the conv loops 20 % this round
+(DESIGN.md §7a "operand-ahead") — scratch loads or `s_waitcnt vmcnt(0)` inside loops that also issue LDS-DMA or global loads.
+
+  python tools/isa_audit.py [--keep DIR] [file.hip ...]        # default: every source of anyedit_amd/build.py
+"""
+import argparse
+import os
+import re
+import subprocess
+import sys
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def demangle(names):
+    out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+    return dict(zip(names, out))
+
+
+def audit(asm_path):
+    txt = open(asm_path).read()
+    meta = {}
+    for blk in re.split(r"\n  - \.agpr_count:", txt)[1:]:
+        blk = ".agpr_count:" + blk
+        get = lambda k: (re.search(r"\." + k + r":\s+(\S+)", blk) or [None, "?"])[1]
+        meta[get("name")] = {k: get(k) for k in ("vgpr_count", "agpr_count", "sgpr_count", "group_segment_fixed_size",
+                                                 "private_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count")}
+    # per-kernel body: loops = backward branches; report vmcnt(0) / scratch traffic between a loop label and its backward branch
+    bodies = {}
+    for m in re.finditer(r"^(\S+):\s*; @\1\n(.*?)^\s+s_endpgm", txt, re.S | re.M):
+        bodies[m.group(1)] = m.group(2)
+    rows = []
+    for name, md in meta.items():
+        body = bodies.get(name, "")
+        lines = body.split("\n")
+        label_at = {}
+        for i, l in enumerate(lines):
+            mm = re.match(r"^(\.LBB\d+_\d+):", l)
+            if mm:
+                label_at[mm.group(1)] = i
+        loops = []
+        for i, l in enumerate(lines):
+            mm = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", l) or re.search(r"s_branch\s+(\.LBB\d+_\d+)", l)
+            if mm and mm.group(1) in label_at and label_at[mm.group(1)] < i:
+                loops.append((label_at[mm.group(1)], i))
+        worst = None
+        for a, b in loops:
+            seg = lines[a:b]
+            n_mfma = sum("v_mfma" in x for x in seg)
+            n_vm0 = sum(bool(re.search(r"s_waitcnt.*vmcnt\(0\)", x)) for x in seg)
+            n_scr = sum(bool(re.search(r"scratch_(load|store)|buffer_(load|store)_dword.*off, s\[0:3\]", x)) for x in seg)
+            n_dma = sum(" lds" in x and "buffer_load" in x for x in seg)
+            n_gl = sum(bool(re.search(r"(global|buffer)_load", x)) for x in seg) - n_dma
+            if n_mfma and (worst is None or n_mfma > worst[0]):
+                worst = (n_mfma, n_vm0, n_scr, n_dma, n_gl, b - a)
+        rows.append((name, md, worst))
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--keep", default=None)
+    ap.add_argument("files", nargs="*")
+    a = ap.parse_args()
+    from anyedit_amd import build as B
+    srcs = a.files or B.SOURCES
+    outdir = a.keep or tempfile.mkdtemp(prefix="isa_")
+    os.makedirs(outdir, exist_ok=True)
+    hipcc = B._hipcc()
+
+    def comp(src):
+        out = os.path.join(outdir, os.path.basename(src).replace(".hip", ".s"))
+        flags = [f for f in B.FLAGS if f != "-fPIC"] + B.EXTRA.get(os.path.basename(src), [])
+        subprocess.run([hipcc] + flags + ["--cuda-device-only", "-S", os.path.join(B.CSRC, os.path.basename(src)), "-o", out], check=True,
+                       stderr=subprocess.DEVNULL)
+        return out
+
+    with ThreadPoolExecutor(8) as ex:
+        asms = list(ex.map(comp, srcs))
+    print(f"{'kernel':100s} vgpr agpr  lds_B scratch_B vspill | hottest MFMA loop: mfma vmcnt0 scratch dma gloads lines")
+    flagged = 0
+    for asm in asms:
+        rows = audit(asm)
+        dm = demangle([r[0] for r in rows])
+        for name, md, worst in sorted(rows, key=lambda r: dm[r[0]]):
+            # a vmcnt(0) inside an LDS-DMA loop is only counted, not flagged: the two-stage loops have one by design, and the operand-ahead
+            # loops have it on the branch of the last K step
+            bad = md["private_segment_fixed_size"] not in ("0", "?") or md["vgpr_spill_count"] not in ("0", "?") or (worst and worst[2] > 0)
+            flagged += bool(bad)
+            w = "%4d %6d %7d %3d %6d %5d" % worst if worst else "-"
+            print(f"{'!' if bad else ' '} {dm[name][:98]:98s} {md['vgpr_count']:>4s} {md['agpr_count']:>4s} {md['group_segment_fixed_size']:>6s} "
+                  f"{md['private_segment_fixed_size']:>9s} {md['vgpr_spill_count']:>6s} | {w}")
+    print(f"{flagged} kernel(s) flagged ('!': scratch memory or register spills; in-loop scratch traffic is the 'scratch' column)")
+
+
+if __name__ == "__main__":
+    main()
