@@ -11,8 +11,7 @@ import torch
 
 from anyedit_amd import ops
 from anyedit_amd.ldm.util import warn_conditioning_batch
-from anyedit_amd.ldm.modules.diffusionmodules.util import (make_ddim_sampling_parameters, make_ddim_timesteps,
-                                                           extract_into_tensor)
+from anyedit_amd.ldm.modules.diffusionmodules.util import make_ddim_sampling_parameters, make_ddim_timesteps
 
 
 def _f32(v):

@@ -8,7 +8,7 @@ import torch.nn as nn
 
 from anyedit_amd import ops
 from anyedit_amd.ldm.util import instantiate_from_config, exists
-from anyedit_amd.ldm.modules.diffusionmodules.util import make_beta_schedule, extract_into_tensor
+from anyedit_amd.ldm.modules.diffusionmodules.util import make_beta_schedule
 
 
 class DiffusionWrapper(nn.Module):

@@ -13,8 +13,7 @@ import torch.nn as nn
 from anyedit_amd import ops
 from anyedit_amd.ldm.util import exists
 from anyedit_amd.ldm.modules.attention import SpatialTransformer
-from anyedit_amd.ldm.modules.diffusionmodules.util import (conv_nd, linear, normalization, zero_module,
-                                                           timestep_embedding, checkpoint)  # noqa: F401
+from anyedit_amd.ldm.modules.diffusionmodules.util import conv_nd, linear, normalization, zero_module
 
 BF16 = torch.bfloat16
 

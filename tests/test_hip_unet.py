@@ -573,7 +573,6 @@ def test_softmax_rows_and_gaussian_moments():
 def test_latent_diffusion_first_stage_roundtrip(tiny_unet):
     """LatentDiffusion.encode_first_stage / get_first_stage_encoding / decode_first_stage (ddpm.py:655-662, 822-834) wired to the
     HIP AutoencoderKL through the reference's config reflection (`ldm.models.autoencoder.AutoencoderKL` resolves in-package)."""
-    from oracle import vae_ref as V
     unet, _ = tiny_unet
     g = load_golden("vae_tiny")
     cfg = dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 2], num_res_blocks=1,

@@ -1,4 +1,4 @@
-import os, sys, torch
+import sys, torch
 sys.path.insert(0, "/root/repo")
 from anyedit_amd import ops
 DEV, BF = "cuda", torch.bfloat16
