@@ -1,0 +1,71 @@
+"""Static checks on the gfx950 code of the hot-path kernels — no GPU: hipcc cross-compiles the three sources to device assembly and
+tools/isa_audit.py reads registers, scratch and the wait structure of the main loops.
+
+Why a test: the largest gain of round 3 came from removing two things no numerics test can see: loader lambdas that hipcc
+did not inline kept their state in SCRATCH, and every scratch load is preceded by `s_waitcnt vmcnt(0)` — the whole LDS-DMA queue drained
+once per K step, 20 % of the conv time.  These assertions fail if a change brings either back."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    import isa_audit as A
+    out = tmp_path_factory.mktemp("isa")
+    rows = []
+    for asm in A.compile_asm(["gemm_conv.hip", "attention_fast.hip", "gemm_rowpanel.hip", "norm.hip"], str(out)):
+        rows += A.audit_named(asm)
+    assert len(rows) > 100
+    return rows
+
+
+def _targs(name, kernel):
+    m = re.search(kernel + r"<(.*?)>\(", name)
+    return [x.strip() for x in m.group(1).split(",")] if m else None
+
+
+def test_operand_ahead_loops_keep_loads_in_flight(kernels):
+    """gemm_kernel<..., WA = 1 | 2>: no scratch, no spills, six unrolled K steps per loop trip, and every step's wait is a COUNTED vmcnt
+    (the far operand of the step after next stays in flight); the only vmcnt(0) sits on the branch of the last K step."""
+    seen = 0
+    for name, md, loop in kernels:
+        a = _targs(name, "gemm_kernel")
+        if not a or a[-1] not in ("1", "2"):
+            continue
+        seen += 1
+        assert md["private_segment_fixed_size"] == "0" and md["vgpr_spill_count"] == "0", name
+        n_mfma, n_vm0, n_scratch, n_dma, n_gloads, _, n_vmn = loop
+        bm, bn, wm, wn = int(a[0]), int(a[1]), int(a[3]), int(a[4])
+        per_step = (bm // wm // 16) * (bn // wn // 16) * 2           # 16x16x32 MFMAs of one wave per 64-deep K tile
+        assert n_mfma == 6 * per_step, (name, n_mfma)
+        assert n_scratch == 0 and n_gloads == 0 and n_dma > 0, (name, loop)
+        assert n_vmn >= 5 and n_vm0 <= 6, (name, loop)     # 5: hipcc rotates some loops, the sixth counted wait then sits above the loop label
+    assert seen >= 6, "operand-ahead instantiations not found: did the template signature change?"
+
+
+def test_hot_loops_have_no_scratch_traffic(kernels):
+    """Every attention, row-panel and GEMM / conv main loop of the denoising path: no scratch loads or stores inside the hottest MFMA loop;
+    the fast attention kernels and the single-launch GroupNorm of the bench's shapes do not spill at all."""
+    n = {"attn": 0, "rp": 0, "gemm": 0, "slab": 0}
+    for name, md, loop in kernels:
+        if "attn_fast_kernel<" in name:
+            n["attn"] += 1
+            assert md["private_segment_fixed_size"] == "0" and md["vgpr_spill_count"] == "0" and loop and loop[2] == 0, name
+        elif "gemm_rowpanel_kernel<" in name:
+            n["rp"] += 1
+            assert loop and loop[2] == 0, name                      # its LayerNorm prologue spills; the chunk loop must not touch scratch
+        elif "gemm_kernel<" in name and loop:
+            n["gemm"] += 1
+            assert loop[2] == 0, name
+        elif "gn_slab_kernel<" in name:
+            a = _targs(name, "gn_slab_kernel")
+            if int(a[0]) <= 8:
+                n["slab"] += 1
+                assert md["vgpr_spill_count"] == "0", name
+    assert n["attn"] >= 10 and n["rp"] >= 3 and n["gemm"] >= 20 and n["slab"] >= 9, n

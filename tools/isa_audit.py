@@ -56,20 +56,16 @@ def audit(asm_path):
             n_scr = sum(bool(re.search(r"scratch_(load|store)|buffer_(load|store)_dword.*off, s\[0:3\]", x)) for x in seg)
             n_dma = sum(" lds" in x and "buffer_load" in x for x in seg)
             n_gl = sum(bool(re.search(r"(global|buffer)_load", x)) for x in seg) - n_dma
+            n_vmn = sum(bool(re.search(r"s_waitcnt.*vmcnt\([1-9]\d*\)", x)) for x in seg)     # counted waits: loads left in flight
             if n_mfma and (worst is None or n_mfma > worst[0]):
-                worst = (n_mfma, n_vm0, n_scr, n_dma, n_gl, b - a)
+                worst = (n_mfma, n_vm0, n_scr, n_dma, n_gl, b - a, n_vmn)
         rows.append((name, md, worst))
     return rows
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--keep", default=None)
-    ap.add_argument("files", nargs="*")
-    a = ap.parse_args()
+def compile_asm(srcs, outdir):
+    """hipcc -S --cuda-device-only of csrc/<src> with the library's own flags -> list of .s paths (compiled in parallel)."""
     from anyedit_amd import build as B
-    srcs = a.files or B.SOURCES
-    outdir = a.keep or tempfile.mkdtemp(prefix="isa_")
     os.makedirs(outdir, exist_ok=True)
     hipcc = B._hipcc()
 
@@ -81,19 +77,33 @@ def main():
         return out
 
     with ThreadPoolExecutor(8) as ex:
-        asms = list(ex.map(comp, srcs))
-    print(f"{'kernel':100s} vgpr agpr  lds_B scratch_B vspill | hottest MFMA loop: mfma vmcnt0 scratch dma gloads lines")
+        return list(ex.map(comp, srcs))
+
+
+def audit_named(asm_path):
+    """audit() with demangled kernel names: list of (name, metadata dict, hottest-MFMA-loop tuple or None)."""
+    rows = audit(asm_path)
+    dm = demangle([r[0] for r in rows])
+    return [(dm[n], md, worst) for n, md, worst in rows]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--keep", default=None)
+    ap.add_argument("files", nargs="*")
+    a = ap.parse_args()
+    from anyedit_amd import build as B
+    asms = compile_asm(a.files or B.SOURCES, a.keep or tempfile.mkdtemp(prefix="isa_"))
+    print(f"{'kernel':100s} vgpr agpr  lds_B scratch_B vspill | hottest MFMA loop: mfma vmcnt0 scratch dma gloads lines vmcntN")
     flagged = 0
     for asm in asms:
-        rows = audit(asm)
-        dm = demangle([r[0] for r in rows])
-        for name, md, worst in sorted(rows, key=lambda r: dm[r[0]]):
+        for name, md, worst in sorted(audit_named(asm)):
             # a vmcnt(0) inside an LDS-DMA loop is only counted, not flagged: the two-stage loops have one by design, and the operand-ahead
             # loops have it on the branch of the last K step
             bad = md["private_segment_fixed_size"] not in ("0", "?") or md["vgpr_spill_count"] not in ("0", "?") or (worst and worst[2] > 0)
             flagged += bool(bad)
-            w = "%4d %6d %7d %3d %6d %5d" % worst if worst else "-"
-            print(f"{'!' if bad else ' '} {dm[name][:98]:98s} {md['vgpr_count']:>4s} {md['agpr_count']:>4s} {md['group_segment_fixed_size']:>6s} "
+            w = "%4d %6d %7d %3d %6d %5d %6d" % worst if worst else "-"
+            print(f"{'!' if bad else ' '} {name[:98]:98s} {md['vgpr_count']:>4s} {md['agpr_count']:>4s} {md['group_segment_fixed_size']:>6s} "
                   f"{md['private_segment_fixed_size']:>9s} {md['vgpr_spill_count']:>6s} | {w}")
     print(f"{flagged} kernel(s) flagged ('!': scratch memory or register spills; in-loop scratch traffic is the 'scratch' column)")
 
