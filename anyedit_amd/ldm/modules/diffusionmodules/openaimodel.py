@@ -226,8 +226,8 @@ class UNetModel(nn.Module):
             context_dim = list(context_dim)
         if n_embed is not None or resblock_updown or use_scale_shift_norm or dims != 2:
             raise NotImplementedError("n_embed / resblock_updown / scale-shift / dims!=2 are outside the AnyEdit hot path")
-        if num_classes is not None and not isinstance(num_classes, int):
-            raise NotImplementedError("num_classes='continuous' (a Linear(1, 4*mc) label embedding, openaimodel.py:536-538) has no in-tree caller")
+        if num_classes is not None and not isinstance(num_classes, int) and num_classes != "continuous":
+            raise ValueError(f"num_classes must be None, an int or 'continuous' (openaimodel.py:533-540), got {num_classes!r}")
         if num_heads_upsample == -1:
             num_heads_upsample = num_heads
         if num_heads == -1:
@@ -275,8 +275,8 @@ class UNetModel(nn.Module):
 
         time_embed_dim = model_channels * 4
         self.time_embed = nn.Sequential(linear(model_channels, time_embed_dim), nn.SiLU(), linear(time_embed_dim, time_embed_dim))
-        if num_classes is not None:  # openaimodel.py:533-535 (created here: the reference's parameter order, seed-reproducible init)
-            self.label_emb = nn.Embedding(num_classes, time_embed_dim)
+        if num_classes is not None:  # openaimodel.py:533-538 (created here: the reference's parameter order, seed-reproducible init)
+            self.label_emb = nn.Embedding(num_classes, time_embed_dim) if isinstance(num_classes, int) else nn.Linear(1, time_embed_dim)
         self.input_blocks = nn.ModuleList([TimestepEmbedSequential(conv_nd(dims, in_channels, model_channels, 3, padding=1))])
         self._feature_size = model_channels
         input_block_chans = [model_channels]
@@ -360,6 +360,18 @@ class UNetModel(nn.Module):
             return [self.context_rows(c) for c in context]
         return context.reshape(-1, context.shape[-1]).to(BF16).contiguous()
 
+    def _label_rows(self, y, device):
+        """label_emb(y) as fp32 rows [B, 4*mc]: a table lookup for integer classes (indexing), and for num_classes == "continuous" the
+        Linear(1, 4*mc) of openaimodel.py:536-538 through the exact-fp32 MFMA GEMM with K zero-padded from 1 to its 16-element step."""
+        if isinstance(self.num_classes, int):
+            return self.label_emb.weight.detach().float()[y.reshape(-1).long().to(device)].contiguous()
+        w, b = self.label_emb.weight.detach().float(), self.label_emb.bias.detach().float().contiguous()
+        yp = torch.zeros(y.shape[0], 16, dtype=torch.float32, device=device)
+        yp[:, 0] = y.reshape(-1).to(device=device, dtype=torch.float32)
+        wp = torch.zeros(w.shape[0], 16, dtype=torch.float32, device=device)
+        wp[:, 0] = w[:, 0]
+        return ops.linear_f32(yp, wp, b)
+
     def forward_rows(self, x, timesteps, context_rows, kv_cache=None, y=None):
         """x: [B, Cin, H, W] fp32/bf16 NCHW; context_rows: bf16 [B*L, Dc]; y: class labels [B] of a class-conditional model
         (openaimodel.py:764-772).  Returns eps [B, Cout, H, W] fp32."""
@@ -369,10 +381,10 @@ class UNetModel(nn.Module):
         emb = self.time_embed[0].rows(t_emb, epilogue=ops.EPI_SILU)                   # Linear + SiLU fused
         if y is None:
             emb_silu = self.time_embed[2].rows(emb, epilogue=ops.EPI_SILU)            # SiLU(emb): what every ResBlock consumes
-        else:  # emb + label_emb(y) in fp32 (the table lookup is indexing), then the SiLU every ResBlock starts with
-            assert y.shape == (B,)
+        else:  # emb + label_emb(y) in fp32, then the SiLU every ResBlock starts with
+            assert y.shape[0] == B
             e32 = self.time_embed[2].rows(emb, out_f32=True)
-            lab = self.label_emb.weight.detach().float()[y.long().to(e32.device)].contiguous()
+            lab = self._label_rows(y, e32.device)
             emb_silu = ops.silu_to_bf16(ops.lincomb([(e32, 1.0), (lab, 1.0)]))
         emb_silu = self._emb_pack(emb_silu)
         f = Feat(ops.nchw_to_rows(x, (C + 7) // 8 * 8), B, H, W)
@@ -382,8 +394,8 @@ class UNetModel(nn.Module):
                 f = module.rows(f, emb_silu, context_rows, kv_cache)
             else:  # stem conv
                 st = _stats_for(B, H, W, module[0].out_channels, f.t.device)
-                y, _, _ = module[0].rows(f.t, B, H, W, colstats=st)
-                f = Feat(y, B, H, W, st=st)
+                stem, _, _ = module[0].rows(f.t, B, H, W, colstats=st)
+                f = Feat(stem, B, H, W, st=st)
             hs.append(f)
         f = self.middle_block.rows(f, emb_silu, context_rows, kv_cache)
         for module in self.output_blocks:
@@ -393,8 +405,8 @@ class UNetModel(nn.Module):
             f = Feat(f.materialize(), f.B, f.H, f.W, t2=skip.materialize(), st=st_a, st2=st_b)  # th.cat([h, hs.pop()], 1), deferred
             f = module.rows(f, emb_silu, context_rows, kv_cache)
         h = self.out[0].rows(f.materialize(), f.B, f.H * f.W, silu=True, colstats=f.st if f.t2 is None else None)
-        y, _, _ = self.out[2].rows(h, f.B, f.H, f.W, out_f32=True)
-        return ops.rows_to_nchw(y, f.B, f.H, f.W, out_dtype=torch.float32)
+        eps, _, _ = self.out[2].rows(h, f.B, f.H, f.W, out_f32=True)
+        return ops.rows_to_nchw(eps, f.B, f.H, f.W, out_dtype=torch.float32)
 
     def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
         """openaimodel.py:754-786."""

@@ -234,7 +234,8 @@ def _run_layers(sd, prefix, layers, h, emb, context, use_linear, adapters=None):
 
 
 def unet_forward(sd, cfg, x, timesteps, context, adapters=None, y=None):
-    """openaimodel.py:754-786; y: class labels of a class-conditional model (num_classes an int: :533-535, 770-772)."""
+    """openaimodel.py:754-786; y: class labels [B] of a class-conditional model (num_classes an int: :533-535, 770-772) or real values
+    [B, 1] for num_classes == "continuous" (a Linear(1, 4*mc) label embedding, :536-538)."""
     inp, mid, out = unet_plan(cfg)
     use_linear = cfg.get("use_linear_in_transformer", False)
     t_emb = timestep_embedding(timesteps, cfg["model_channels"])
@@ -242,7 +243,10 @@ def unet_forward(sd, cfg, x, timesteps, context, adapters=None, y=None):
     emb = F.linear(silu(emb), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
     assert (y is not None) == (cfg.get("num_classes") is not None), "must specify y if and only if the model is class-conditional"
     if y is not None:
-        emb = emb + sd["label_emb.weight"][y.long()]
+        if cfg["num_classes"] == "continuous":
+            emb = emb + F.linear(y.float(), sd["label_emb.weight"], sd["label_emb.bias"])
+        else:
+            emb = emb + sd["label_emb.weight"][y.long()]
     hs = []
     h = _st(x.float())
     context = None if context is None else _st(context)

@@ -292,6 +292,19 @@ def test_unet_class_conditional_and_adm_keys_golden():
         assert rel_l2(other.cpu(), out2.cpu()) > 1e-3                      # the label matters
         with pytest.raises(AssertionError):
             unet(torch.cat([x, cc], 1), t, context=ctx)                  # class-conditional model without y
+    # num_classes = "continuous" (openaimodel.py:536-538): Linear(1, 4*mc) over a real-valued y [B, 1], same network otherwise
+    with torch.device(DEV):
+        unet_c = UNetModel(**dict(SD2_TINY, num_classes="continuous", in_channels=6))
+    unet_c.load_state_dict({k: v.to(DEV) for k, v in dict(sub_sd(g, "w."), **sub_sd(g, "wc.")).items()})
+    unet_c.eval().requires_grad_(False)
+    with torch.no_grad():
+        out3 = DiffusionWrapper(unet_c, "crossattn-adm")(torch.cat([x, cc], 1), t, c_crossattn=[ctx], c_adm=dev("y_cont"))
+        lab = unet_c._label_rows(dev("y_cont"), DEV)
+    assert rel_l2(out3.cpu(), T(g["out.continuous"])) <= 2e-2
+    ref_lab = torch.nn.functional.linear(T(g["y_cont"]), sub_sd(g, "wc.")["label_emb.weight"].float(), sub_sd(g, "wc.")["label_emb.bias"].float())
+    assert rel_l2(lab.cpu(), ref_lab) <= 1e-6                            # the label embedding itself: exact-fp32 GEMM
+    with pytest.raises(ValueError):
+        UNetModel(**dict(SD2_TINY, num_classes="sequential", in_channels=6))
 
 
 def test_dpm_solver_sampler_golden():

@@ -415,6 +415,9 @@ def test_unet_class_conditional_and_adm_keys():
     close(L.diffusion_wrapper(sd, cfg, torch.cat([x, cc], 1), t, None, [ctx[:, :4], ctx[:, 4:]], "crossattn-adm", c_adm=y), g["out.crossattn_adm"], tol=2e-4)
     with pytest.raises(AssertionError):
         L.unet_forward(sd, cfg, torch.cat([x, cc], 1), t, ctx)          # a class-conditional model needs y
+    sdc = dict(sd, **sub_sd(g, "wc."))                                   # num_classes = "continuous": Linear(1, 4*mc) over a real-valued y
+    close(L.diffusion_wrapper(sdc, dict(cfg, num_classes="continuous"), torch.cat([x, cc], 1), t, None, [ctx], "crossattn-adm",
+                              c_adm=T(g["y_cont"])), g["out.continuous"], tol=2e-4)
 
 
 def test_ddim_hacked_sampler():

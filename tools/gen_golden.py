@@ -366,6 +366,18 @@ def gen_unet_adm():
     arrs["out.crossattn_adm"] = wrap(xx, t, c_crossattn=[ctx[:, :4], ctx[:, 4:]], c_adm=y)
     for k, v in unet.state_dict().items():
         arrs["w." + k] = v.bfloat16().view(torch.int16)
+    # num_classes = "continuous" (openaimodel.py:536-538): the same network with a Linear(1, 4*mc) label embedding over a real-valued y [B, 1]
+    unet_c = rom.UNetModel(**dict(cfg, num_classes="continuous")).eval()
+    sd = {k: v for k, v in unet.state_dict().items() if not k.startswith("label_emb.")}
+    sd["label_emb.weight"] = (torch.randn(unet_c.label_emb.weight.shape, generator=g) * 0.3).bfloat16().float()
+    sd["label_emb.bias"] = (torch.randn(unet_c.label_emb.bias.shape, generator=g) * 0.1).bfloat16().float()
+    unet_c.load_state_dict(sd)
+    y_cont = torch.tensor([[0.3], [-1.2]])
+    wrap.diffusion_model = unet_c
+    arrs["y_cont"] = y_cont
+    arrs["out.continuous"] = wrap(xx, t, c_crossattn=[ctx], c_adm=y_cont)
+    arrs["wc.label_emb.weight"] = sd["label_emb.weight"].bfloat16().view(torch.int16)
+    arrs["wc.label_emb.bias"] = sd["label_emb.bias"].bfloat16().view(torch.int16)
     npz("unet_adm_tiny", **arrs)
 
 
