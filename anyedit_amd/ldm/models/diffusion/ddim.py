@@ -188,13 +188,31 @@ class DDIMSampler(object):
             raise NotImplementedError("quantize_denoised / score_corrector / noise_dropout are not used by any AnyEdit caller")
         if dynamic_threshold is not None:
             raise NotImplementedError()
-        if getattr(self.model, "parameterization", "eps") != "eps":
-            raise NotImplementedError("only eps-parameterisation is on the AnyEdit path")
+        param = getattr(self.model, "parameterization", "eps")
+        if param not in ("eps", "v"):
+            raise NotImplementedError("x0-parameterisation: DDIMSampler handles eps- and v-prediction models (ddim.py:214-217)")
         eps, branches = self._model_eps(x, c, t, unconditional_guidance_scale, unconditional_conditioning)
         noise = self.randn((1, *x.shape[1:]), device=device).repeat(b, 1, 1, 1) if repeat_noise else self.randn(x.shape, device=device)
         coeffs = self._coeffs(index, use_original_steps)
+        if param == "v":
+            return self._v_step(x.float().contiguous(), eps.float(), t, coeffs, branches, float(unconditional_guidance_scale),
+                                noise.float().contiguous(), float(temperature))
         x_prev, pred_x0 = ops.ddim_step(x.float(), eps.float(), coeffs, branches, s0=float(unconditional_guidance_scale),
                                         noise=noise.float().contiguous(), temperature=float(temperature))
+        return x_prev, pred_x0
+
+    def _v_step(self, x, out, t, coeffs, branches, scale, noise, temperature):
+        """ddim.py:212-217, 232-250 for a v-prediction network: guided v = v_u + s (v_c - v_u); eps and x0 from the MODEL's sqrt(acp_t)
+        tables at the network timestep (predict_eps_from_z_and_v / predict_start_from_z_and_v), then the usual DDIM combination."""
+        if branches == 2:
+            vu, vc = out[:x.shape[0]].contiguous(), out[x.shape[0]:].contiguous()
+            v = ops.lincomb([(vu, 1.0), (ops.lincomb([(vc, 1.0), (vu, -1.0)]), scale)])
+        else:
+            v = out.contiguous()
+        e_t = self.model.predict_eps_from_z_and_v(x, t, v)
+        pred_x0 = self.model.predict_start_from_z_and_v(x, t, v)
+        _, _, sqrt_a_prev, dir_coef, sigma = coeffs
+        x_prev = ops.lincomb([(pred_x0, sqrt_a_prev), (e_t, dir_coef), (noise, sigma * temperature)])
         return x_prev, pred_x0
 
     @torch.no_grad()

@@ -103,6 +103,22 @@ class DDPM(nn.Module):
         return ops.q_sample(x_start.float(), noise.float(), self.sqrt_alphas_cumprod.gather(-1, t),
                             self.sqrt_one_minus_alphas_cumprod.gather(-1, t))
 
+    def _acp_pair(self, t):
+        return self.sqrt_alphas_cumprod.gather(-1, t), self.sqrt_one_minus_alphas_cumprod.gather(-1, t)
+
+    # v-prediction (ddpm.py:290-302, 361-365): three per-sample two-term combinations = the q_sample kernel with other operands
+    def predict_start_from_z_and_v(self, x_t, t, v):
+        sa, s1 = self._acp_pair(t)
+        return ops.q_sample(x_t.float(), v.float(), sa, -s1)
+
+    def predict_eps_from_z_and_v(self, x_t, t, v):
+        sa, s1 = self._acp_pair(t)
+        return ops.q_sample(v.float(), x_t.float(), sa, s1)
+
+    def get_v(self, x, noise, t):
+        sa, s1 = self._acp_pair(t)
+        return ops.q_sample(noise.float(), x.float(), sa, -s1)
+
     def get_loss(self, pred, target, mean=True):
         """ddpm.py:367-380 (l2, mean) -> fp32 scalar on device."""
         if self.loss_type != 'l2' or not mean:
@@ -159,11 +175,12 @@ class LatentDiffusion(DDPM):
         return out[0] if isinstance(out, tuple) and not return_ids else out
 
     def p_losses(self, x_start, cond, t, noise=None):
-        """ddpm.py:889-932 reduced to loss_simple (eps target), what train.py:694-696 computes."""
-        if self.parameterization != "eps":
+        """ddpm.py:889-932 reduced to loss_simple (eps target = what train.py:694-696 computes; v target for v-prediction models)."""
+        if self.parameterization not in ("eps", "v"):
             raise NotImplementedError()
         if noise is None:
             noise = torch.randn_like(x_start)
-        eps = self.apply_model(self.q_sample(x_start, t, noise), t, cond)
-        loss = self.get_loss(eps, noise, mean=True)
+        out = self.apply_model(self.q_sample(x_start, t, noise), t, cond)
+        target = noise if self.parameterization == "eps" else self.get_v(x_start, noise, t)     # ddpm.py:897-902
+        loss = self.get_loss(out, target, mean=True)
         return loss, {"loss_simple": loss}

@@ -44,8 +44,24 @@ def _cat_cond(uc, c):
     return torch.cat([uc, c])
 
 
-def p_sample_ddim(apply_model, sched, x, c, t, index, scale=1.0, uc=None, temperature=1.0):
-    """ddim.py:180-251 (eps parameterisation)."""
+def get_v(buffers, x, noise, t):
+    """ddpm.py:361-365: the v-prediction target sqrt(acp_t) noise - sqrt(1 - acp_t) x."""
+    return extract(buffers["sqrt_alphas_cumprod"], t, x.shape) * noise - extract(buffers["sqrt_one_minus_alphas_cumprod"], t, x.shape) * x
+
+
+def predict_start_from_z_and_v(buffers, x_t, t, v):
+    """ddpm.py:290-296."""
+    return extract(buffers["sqrt_alphas_cumprod"], t, x_t.shape) * x_t - extract(buffers["sqrt_one_minus_alphas_cumprod"], t, x_t.shape) * v
+
+
+def predict_eps_from_z_and_v(buffers, x_t, t, v):
+    """ddpm.py:298-302."""
+    return extract(buffers["sqrt_alphas_cumprod"], t, x_t.shape) * v + extract(buffers["sqrt_one_minus_alphas_cumprod"], t, x_t.shape) * x_t
+
+
+def p_sample_ddim(apply_model, sched, x, c, t, index, scale=1.0, uc=None, temperature=1.0, v_buffers=None):
+    """ddim.py:180-251.  `v_buffers`: the model's schedule buffers when the network predicts v (parameterization == "v", :214-217,
+    :232-235): eps and x0 then come from the model's own sqrt(acp_t) tables at the network timestep, not from the DDIM tables."""
     b = x.shape[0]
     if uc is None or scale == 1.0:
         e_t = apply_model(x, t, c)
@@ -54,12 +70,18 @@ def p_sample_ddim(apply_model, sched, x, c, t, index, scale=1.0, uc=None, temper
         t_in = torch.cat([t] * 2)
         e_uncond, e_cond = apply_model(x_in, t_in, _cat_cond(uc, c)).chunk(2)
         e_t = e_uncond + scale * (e_cond - e_uncond)
+    model_output = e_t
+    if v_buffers is not None:
+        e_t = predict_eps_from_z_and_v(v_buffers, x, t, model_output)
     full = lambda v: torch.full((b, 1, 1, 1), v)  # torch.full casts python/np floats to float32 (G5)
     a_t = full(sched["ddim_alphas"][index])
     a_prev = full(sched["ddim_alphas_prev"][index])
     sigma_t = full(sched["ddim_sigmas"][index])
     sqrt_one_minus_at = full(sched["ddim_sqrt_one_minus_alphas"][index])
-    pred_x0 = (x - sqrt_one_minus_at * e_t) / a_t.sqrt()
+    if v_buffers is None:
+        pred_x0 = (x - sqrt_one_minus_at * e_t) / a_t.sqrt()
+    else:
+        pred_x0 = predict_start_from_z_and_v(v_buffers, x, t, model_output)
     dir_xt = (1.0 - a_prev - sigma_t ** 2).sqrt() * e_t
     noise = sigma_t * torch.randn(x.shape) * temperature
     x_prev = a_prev.sqrt() * pred_x0 + dir_xt + noise
@@ -67,7 +89,7 @@ def p_sample_ddim(apply_model, sched, x, c, t, index, scale=1.0, uc=None, temper
 
 
 def ddim_sample(apply_model, buffers, S_steps, shape, cond, eta=0.0, x_T=None, scale=1.0, uc=None,
-                mask=None, x0=None, log_every_t=100, temperature=1.0):
+                mask=None, x0=None, log_every_t=100, temperature=1.0, parameterization="eps"):
     """ddim.py:54-178.  Returns (img, intermediates, schedule)."""
     sched = S.make_ddim_schedule(buffers, S_steps, "uniform", eta)
     b = shape[0]
@@ -82,7 +104,8 @@ def ddim_sample(apply_model, buffers, S_steps, shape, cond, eta=0.0, x_T=None, s
         if mask is not None:
             img_orig = q_sample(buffers, x0, ts)
             img = img_orig * mask + (1.0 - mask) * img
-        img, pred_x0 = p_sample_ddim(apply_model, sched, img, cond, ts, index, scale, uc, temperature)
+        img, pred_x0 = p_sample_ddim(apply_model, sched, img, cond, ts, index, scale, uc, temperature,
+                                     v_buffers=buffers if parameterization == "v" else None)
         if index % log_every_t == 0 or index == total_steps - 1:
             inter["x_inter"].append(img)
             inter["pred_x0"].append(pred_x0)

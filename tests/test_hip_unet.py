@@ -224,6 +224,54 @@ def test_plms_sampler_golden():
         sampler.make_schedule(5, ddim_eta=0.5, verbose=False)
 
 
+def test_ddim_sampler_v_prediction_golden():
+    """DDIMSampler on a v-prediction model (ddim.py:214-217, 232-235) and DDPM's predict_start_from_z_and_v / predict_eps_from_z_and_v /
+    get_v (ddpm.py:290-302, 361-365) against the reference (golden from the analytic network read as v: identical network output on both
+    sides isolates the sampler arithmetic).  fp32 kernels, 2e-5."""
+    from anyedit_amd.ldm.models.diffusion.ddim import DDIMSampler
+    from anyedit_amd.ldm.models.diffusion.ddpm import DDPM
+    from oracle import schedule_ref as S
+
+    class AnalyticVModel:
+        parameterization = "v"
+        _acp_pair = DDPM._acp_pair
+        predict_start_from_z_and_v = DDPM.predict_start_from_z_and_v
+        predict_eps_from_z_and_v = DDPM.predict_eps_from_z_and_v
+        get_v = DDPM.get_v
+
+        def __init__(self, dev):
+            self.num_timesteps = 1000
+            for k, v in S.register_schedule("linear", 1000, 0.00085, 0.0120).items():
+                if isinstance(v, torch.Tensor):
+                    setattr(self, k, v.to(dev))
+            self.device = torch.device(dev)
+
+        def apply_model(self, x, t, c):
+            xc, tc, cc = x.detach().float().cpu(), t.cpu(), c.float().cpu()
+            return (torch.sin(xc * 1.7 + tc.float()[:, None, None, None] * 0.01) * 0.5 + cc[:, :, None, None] * xc).to(x.device)
+
+    g = load_golden("ddim_v")
+    model = AnalyticVModel(DEV)
+    sampler = DDIMSampler(model)
+    sampler.randn = lambda shape, device=None: torch.randn(shape).to(device)        # replay the CPU RNG stream of the golden run
+    dev = lambda k: T(g[k]).to(DEV)
+    for tag, steps, scale, eta in (("s6", 6, 1.0, 0.0), ("s8_cfg", 8, 5.0, 0.0), ("s5_cfg_eta1", 5, 3.0, 1.0)):
+        torch.manual_seed(4323)
+        samples, inter = sampler.sample(steps, 2, (4, 8, 8), dev("c"), eta=eta, x_T=dev("x_T"), verbose=False,
+                                        unconditional_guidance_scale=scale, unconditional_conditioning=dev("uc") if scale != 1.0 else None,
+                                        log_every_t=1)
+        assert np.array_equal(sampler.ddim_timesteps, g[f"{tag}.ddim_timesteps"])
+        assert float((samples.cpu() - T(g[f"{tag}.samples"])).abs().max()) <= 2e-5, tag
+        assert float((torch.stack(inter["pred_x0"]).cpu() - T(g[f"{tag}.pred_x0"])).abs().max()) <= 2e-5, tag
+    x, t, noise, v = dev("x_T"), dev("t"), dev("noise"), dev("v")
+    assert float((model.get_v(x, noise, t).cpu() - T(g["get_v"])).abs().max()) <= 1e-6
+    assert float((model.predict_start_from_z_and_v(x, t, v).cpu() - T(g["x0_from_v"])).abs().max()) <= 1e-6
+    assert float((model.predict_eps_from_z_and_v(x, t, v).cpu() - T(g["eps_from_v"])).abs().max()) <= 1e-6
+    model.parameterization = "x0"
+    with pytest.raises(NotImplementedError):
+        sampler.sample(2, 2, (4, 8, 8), dev("c"), x_T=dev("x_T"), verbose=False)
+
+
 def test_ddim_hacked_sampler_golden():
     """cldm.ddim_hacked.DDIMSampler (AnyDoor path) vs the reference's: two network calls per guided step, inversion at ddim_timesteps[i]."""
     from anyedit_amd.cldm.ddim_hacked import DDIMSampler

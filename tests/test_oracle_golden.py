@@ -420,6 +420,24 @@ def test_unet_class_conditional_and_adm_keys():
                               c_adm=T(g["y_cont"])), g["out.continuous"], tol=2e-4)
 
 
+def test_ddim_sampler_v_prediction():
+    """DDIM on a v-prediction model (ddim.py:214-217, 232-235) and the three v helpers of ddpm.py:290-302, 361-365."""
+    g = load_golden("ddim_v")
+    buffers = S.register_schedule("linear", 1000, 0.00085, 0.0120)
+    x_T, c, uc = T(g["x_T"]), T(g["c"]), T(g["uc"])
+    for tag, steps, scale, eta in (("s6", 6, 1.0, 0.0), ("s8_cfg", 8, 5.0, 0.0), ("s5_cfg_eta1", 5, 3.0, 1.0)):
+        torch.manual_seed(4323)
+        img, inter, sched = D.ddim_sample(_analytic_eps, buffers, steps, tuple(x_T.shape), c, eta=eta, x_T=x_T, scale=scale,
+                                          uc=uc if scale != 1.0 else None, log_every_t=1, parameterization="v")
+        assert np.array_equal(sched["ddim_timesteps"], g[f"{tag}.ddim_timesteps"])
+        close(img, g[f"{tag}.samples"], tol=1e-5)
+        close(torch.stack(inter["pred_x0"]), g[f"{tag}.pred_x0"], tol=1e-5)
+    t, noise, v = T(g["t"]), T(g["noise"]), T(g["v"])
+    assert torch.equal(D.get_v(buffers, x_T, noise, t), T(g["get_v"]))
+    assert torch.equal(D.predict_start_from_z_and_v(buffers, x_T, t, v), T(g["x0_from_v"]))
+    assert torch.equal(D.predict_eps_from_z_and_v(buffers, x_T, t, v), T(g["eps_from_v"]))
+
+
 def test_ddim_hacked_sampler():
     """N4: cldm/ddim_hacked.py — same sampling arithmetic as ldm's DDIM (two network calls instead of one batch), inversion queried at
     ddim_timesteps[i]."""

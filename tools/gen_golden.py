@@ -618,6 +618,44 @@ class AnalyticEpsModel:
 
 
 @torch.no_grad()
+def gen_ddim_v():
+    """DDIMSampler on a v-prediction model (ddim.py:214-217, 232-235; ddpm.py:290-302 predict_*_from_z_and_v, :361-365 get_v, :897-902 the
+    v target of p_losses): the analytic network's output is read as v.  Deterministic, guided and eta = 1 runs."""
+    print("[ddim_v]")
+    import io
+    import contextlib
+
+    class AnalyticVModel(AnalyticEpsModel):
+        parameterization = "v"
+        predict_start_from_z_and_v = rddpm.DDPM.predict_start_from_z_and_v
+        predict_eps_from_z_and_v = rddpm.DDPM.predict_eps_from_z_and_v
+        get_v = rddpm.DDPM.get_v
+
+    model = AnalyticVModel()
+    g = G(95)
+    B = 2
+    x_T = torch.randn(B, 4, 8, 8, generator=g)
+    c = torch.randn(B, 4, generator=g) * 0.2
+    uc = torch.randn(B, 4, generator=g) * 0.2
+    arrs = {"x_T": x_T, "c": c, "uc": uc}
+    sampler = CPUDDIMSampler(model)
+    for tag, S, scale, eta in (("s6", 6, 1.0, 0.0), ("s8_cfg", 8, 5.0, 0.0), ("s5_cfg_eta1", 5, 3.0, 1.0)):
+        torch.manual_seed(4323)
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            samples, inter = sampler.sample(S, B, (4, 8, 8), c, eta=eta, x_T=x_T, verbose=False, unconditional_guidance_scale=scale,
+                                            unconditional_conditioning=uc if scale != 1.0 else None, log_every_t=1)
+        arrs[f"{tag}.samples"] = samples
+        arrs[f"{tag}.pred_x0"] = torch.stack(inter["pred_x0"])
+        arrs[f"{tag}.ddim_timesteps"] = sampler.ddim_timesteps
+    t = torch.tensor([981, 21], dtype=torch.long)
+    noise = torch.randn(B, 4, 8, 8, generator=g)
+    vv = torch.randn(B, 4, 8, 8, generator=g)
+    arrs.update({"t": t, "noise": noise, "v": vv, "get_v": model.get_v(x_T, noise, t),
+                 "x0_from_v": model.predict_start_from_z_and_v(x_T, t, vv), "eps_from_v": model.predict_eps_from_z_and_v(x_T, t, vv)})
+    npz("ddim_v", **arrs)
+
+
+@torch.no_grad()
 def gen_dpm_solver_general():
     """The solver variants DPMSolverSampler never reaches but DPM_Solver.sample offers (dpm_solver.py:405-462 order / time-step plan of the
     singlestep solver, :515-722 singlestep second / third updates, :780-826 multistep third update, :878-937 adaptive step size, :939-1101
@@ -1011,7 +1049,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     only = set(sys.argv[1:])  # e.g. `python tools/gen_golden.py ddim_encode` regenerates one fixture
     for name, fn in (("schedule", gen_schedule), ("norms", gen_norms), ("attention", gen_attention), ("transformer", gen_transformer),
-                     ("resblock", gen_resblock), ("unet", gen_unet), ("unet_sd2", gen_unet_sd2), ("unet_adm", gen_unet_adm), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode), ("ddim_hacked", gen_ddim_hacked),
+                     ("resblock", gen_resblock), ("unet", gen_unet), ("unet_sd2", gen_unet_sd2), ("unet_adm", gen_unet_adm), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode), ("ddim_hacked", gen_ddim_hacked), ("ddim_v", gen_ddim_v),
                      ("vae", gen_vae), ("plms", gen_plms), ("dpm_solver", gen_dpm_solver), ("dpm_solver_general", gen_dpm_solver_general), ("cldm", gen_cldm), ("msda", gen_msda), ("msda_bwd", gen_msda_bwd), ("sam", gen_sam), ("sam_decoder", gen_sam_decoder),
                      ("misc", gen_ldm_misc)):
         if not only or name in only:
