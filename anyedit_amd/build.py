@@ -14,10 +14,12 @@ LIB = os.path.join(HERE, "libanyedit_hip.so")
 SOURCES = ["c_api.hip", "gemm_conv.hip", "gemm_rowpanel.hip", "attention.hip", "attention_fast.hip", "attention_fp8.hip", "attention_bwd.hip", "norm.hip", "elementwise.hip", "backward.hip", "gate.hip", "expert_kv.hip", "msda.hip",
            "sam_decoder.hip"]
 # attention: no NaN/Inf semantics are relied on (masked logits are a finite -1e30) -> lets fmaxf compile to bare v_max/v_max3
+# gemm_conv.hip / gemm_rowpanel.hip: the same flag on the epilogues' bias / activation / statistics arithmetic (47 000 packed ops in gemm_conv.s): 40 output
+# checksums identical, UNet step 13.50 -> 13.44 ms in two alternating A/B runs (profiles/r03_v50_gemm_no_slp.txt)
 # attention_fast.hip: -fno-slp-vectorize — hipcc's SLP pass packs the softmax's adjacent fp32 multiplies / adds into v_pk_mul_f32 / v_pk_add_f32,
 # which cost more than two plain VALU ops beside MFMAs (MI355X_MICROARCH.md, "price of one filler"): outputs bit-identical, self-attention
 # +1.1 % (d = 40), +1.5 % (d = 80), SAM global attention +2.2 % (profiles/r03_v49_attn_no_slp.txt)
-EXTRA = {"attention.hip": ["-ffinite-math-only"], "attention_fast.hip": ["-ffinite-math-only", "-fno-slp-vectorize"], "attention_fp8.hip": ["-ffinite-math-only"], "attention_bwd.hip": ["-ffinite-math-only"]}
+EXTRA = {"gemm_conv.hip": ["-fno-slp-vectorize"], "gemm_rowpanel.hip": ["-fno-slp-vectorize"], "attention.hip": ["-ffinite-math-only"], "attention_fast.hip": ["-ffinite-math-only", "-fno-slp-vectorize"], "attention_fp8.hip": ["-ffinite-math-only"], "attention_bwd.hip": ["-ffinite-math-only"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 
 
