@@ -19,7 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--parity", action="store_true", help="also run the CPU oracle (fp32, full ViT-H, ~1 min) and report rel-L2 / PSNR")
+    # full-size parity against the oracle lives in the GPU suite: tests/test_hip_bench_shapes.py::test_sam_vit_h_full_encoder_vs_oracle
     a = ap.parse_args()
     dev = "cuda"
     torch.manual_seed(0)
@@ -92,20 +92,6 @@ def main():
                             "latency_ms_p50_eager": 1e3 * t8[len(t8) // 2], "encoder_output_rel_l2_vs_bf16_attention": d8,
                             "attention_by_shape": {k: {"calls": v["calls"], "avg_us": v["avg_us"], "tflops": v["tflops"]}
                                                    for k, v in prof8.summary(by_shape=True).items() if "attn" in k}}
-    if a.parity:
-        # full-size parity of the HIP encoder against the oracle restatement (test infrastructure; here only as the checker)
-        from oracle import sam_ref as M
-        import math
-        torch.set_num_threads(min(os.cpu_count(), 32))
-        sd = {k: v.detach().float().cpu() for k, v in enc.state_dict().items()}
-        t0 = time.time()
-        with torch.no_grad():
-            ref = M.image_encoder(sd, "", x[:1].float().cpu(), 16, 32, 16, 14, (7, 15, 23, 31))
-        got = y[:1].float().cpu()
-        err = float((got - ref).norm() / ref.norm())
-        mse = float(((got - ref) ** 2).mean())
-        peak = float(ref.max() - ref.min())
-        out["parity"] = {"rel_l2_vs_oracle": err, "psnr_db": 10 * math.log10(peak * peak / mse), "oracle_cpu_seconds": time.time() - t0}
     print(json.dumps(out))
 
 

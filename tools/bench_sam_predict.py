@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """SamPredictor latency on MI355X: build_sam (ViT-H) with random-init weights, a synthetic 512x768 uint8 image,
 set_image (host resize + preprocess + image encoder) and predict_torch with box prompts as AnyEdit's mask tool issues them
-(tools/tool.py:182, 227-237).  --parity also runs the CPU oracle decoder from the same embedding.
-    python tools/bench_sam_predict.py [--boxes 3] [--iters 10] [--parity]"""
+(tools/tool.py:182, 227-237).  Parity against the oracle: tests/test_hip_bench_shapes.py::test_sam_predictor_end_to_end_vs_oracle.
+    python tools/bench_sam_predict.py [--boxes 3] [--iters 10]"""
 import argparse
 import json
 import os
@@ -34,7 +34,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--boxes", type=int, default=3)
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--parity", action="store_true")
     a = ap.parse_args()
     torch.manual_seed(0)
     with torch.device("cuda"):
@@ -64,19 +63,6 @@ def main():
     out["predict_torch_kernel_ms"] = sum(v["ms"] for v in summ.values())
     out["predict_torch_kernels"] = {k: {"calls": v["calls"], "ms": v["ms"]} for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:8]}
     assert masks.shape == (a.boxes, 1, 512, 768) and masks.dtype == torch.bool and torch.isfinite(low).all()
-    if a.parity:
-        from oracle import sam_decoder_ref as SD   # test infrastructure; here only as the checker
-        torch.set_num_threads(min(os.cpu_count(), 32))
-        sd = {k: v.detach().float().cpu() for k, v in sam.state_dict().items() if not k.startswith("image_encoder.")}
-        emb = pred.get_image_embedding().float().cpu()
-        t0 = time.time()
-        sparse, dense = SD.prompt_encoder(sd, None, tb.cpu(), None, (64, 64), (1024, 1024))
-        rlow, riou = SD.mask_decoder(sd, emb, SD.dense_pe(sd, (64, 64)), sparse, dense, False, 2, 8)
-        rfull = SD.postprocess_masks(rlow, 1024, pred.input_size, pred.original_size)
-        out["parity"] = {"low_res_rel_l2": float((low.cpu() - rlow).norm() / rlow.norm()),
-                         "iou_max_abs_err": float((iou.cpu() - riou).abs().max()),
-                         "mask_pixel_agreement": float((masks.cpu() == (rfull > 0)).float().mean()),
-                         "oracle_cpu_seconds": time.time() - t0}
     print(json.dumps(out))
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """First-stage (kl-f8 AutoencoderKL) decode / encode latency on MI355X — SURVEY.md §8(f) N1: the step on either side of the
 denoising loop (2.48 TFLOP decode + 1.08 TFLOP encode per 512x512 image).  Random-init weights of the SD kl-f8 geometry.
-    python tools/bench_vae.py [--batch 4] [--iters 5] [--parity]
+    python tools/bench_vae.py [--batch 4] [--iters 5]        (parity: tests/test_hip_bench_shapes.py::test_vae_kl_f8_full_size_vs_oracle)
 """
 import argparse
 import json
@@ -36,7 +36,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--parity", action="store_true")
     a = ap.parse_args()
     dev = "cuda"
     torch.manual_seed(0)
@@ -52,16 +51,6 @@ def main():
     out = {"what": "kl-f8 AutoencoderKL, 512x512", "batch": a.batch, "decode_ms": 1e3 * t_dec, "encode_ms": 1e3 * t_enc,
            "decode_tflops": 2.48 * a.batch / t_dec, "encode_tflops": 1.08 * a.batch / t_enc,
            "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
-    if a.parity:
-        from oracle import vae_ref as V  # checker only
-        torch.set_num_threads(min(os.cpu_count(), 32))
-        sd = {k: v.detach().float().cpu() for k, v in vae.state_dict().items()}
-        with torch.no_grad():
-            ref = V.decode(sd, z[:1].float().cpu())
-        got = y[:1].float().cpu()
-        mse = float(((got - ref) ** 2).mean())
-        peak = float(ref.max() - ref.min())
-        out["parity"] = {"decode_rel_l2_vs_oracle": float((got - ref).norm() / ref.norm()), "psnr_db": 10 * math.log10(peak * peak / mse)}
     print(json.dumps(out))
 
 
