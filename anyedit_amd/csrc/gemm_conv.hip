@@ -117,7 +117,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
     bf16_t* sA = smem;
     bf16_t* sB = smem + (WA == 2 ? 3 : STAGES) * BM * BK;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // The wave index as a SCALAR (v_readfirstlane once): tid >> 6 is wave-uniform but lives in a VGPR, and every LDS-DMA destination derived
+    // from it then costs a v_readfirstlane_b32 per piece per K step in front of its s_mov m0 (48-66 per six steps of the operand-ahead loops;
+    // VALU ops per six steps 86 -> 20 dense, 308 -> 260 conv on the 192x320 tile).  Outputs identical (40 checksums), UNet step
+    // 13.642 / 13.641 -> 13.552 / 13.559 ms in alternating A/B runs (profiles/r03_v52_wave_sgpr.txt).  -DAE_WAVE_SGPR=0 restores the old form.
+#ifndef AE_WAVE_SGPR
+#define AE_WAVE_SGPR 1
+#endif
+    const int tid = threadIdx.x, lane = tid & 63, wave = AE_WAVE_SGPR ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
 #ifdef AE_GEMM_LAB
     unsigned long long tlast = __builtin_readcyclecounter();
     const bool lab_me = blockIdx.x == gridDim.x / 2 && lane == 0 && (wave == 0 || wave == 4);
