@@ -22,6 +22,9 @@
 
 namespace {
 
+#ifndef AE_CONV_SPEC
+#define AE_CONV_SPEC 0
+#endif
 #ifndef AE_GEMM_AA_DEFAULT
 #define AE_GEMM_AA_DEFAULT 3
 #endif
@@ -393,19 +396,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                 // operand-ahead loops and deep rings: the (tap, channel) position is derived from kt — carried as loop state (ld_tap / ld_ci, captured by
                 // reference) it ended up in scratch memory in the unrolled loop, and every scratch load is a VMEM operation hipcc waits for
                 // with vmcnt(0): the whole DMA queue drained once per step
+                // AE_CONV_SPEC (build variant, prepared for an A/B): the activations-ahead conv instantiation is only launched for chunk-major K and
+                // no upsample, so both run-time flags fold away — no generic division for the tap-major position, no per-piece upsample branch
+                constexpr bool KM1 = AE_CONV_SPEC && WA == 2;
                 int cur_tap = ld_tap, cur_ci = ld_ci;
                 constexpr bool STATELESS = true;   // (the two-stage loops too: their scratch load of the tap state sat in front of every step's DMA issue)
                 if (STATELESS) {
                     const int lin = kt_begin + kt;
-                    if (p.kmajor) { cur_tap = lin % 9; cur_ci = (lin / 9) * BK; }
+                    if (KM1 || p.kmajor) { cur_tap = lin % 9; cur_ci = (lin / 9) * BK; }
                     else { const int per = p.CinPad / BK; cur_tap = lin / per; cur_ci = (lin - cur_tap * per) * BK; }
                 }
                 const int ky = cur_tap / 3, kx = cur_tap - ky * 3;
-                if (cur_ci == 0 || kt == 0 || p.kmajor || WA == 2) {  // a new tap: the per-lane part (halo mask, upsample source pixel) changes only here
+                if (cur_ci == 0 || kt == 0 || KM1 || p.kmajor || WA == 2) {  // a new tap: the per-lane part (halo mask, upsample source pixel) changes only here
 #pragma unroll
                     for (int i = 0; i < A_CH; ++i) {
                         int src = fa_off[i] + ((ky * p.Wd + kx) * p.Cin) * 2;  // >= 0 for every in-image tap (voffset is bounds-checked unsigned)
-                        if (p.ups) {  // nearest-x2 upsample folded into the gather: source pixel = virtual pixel >> 1 (3 of 64 convs per UNet call)
+                        if (!KM1 && p.ups) {  // nearest-x2 upsample folded into the gather: source pixel = virtual pixel >> 1 (3 of 64 convs per UNet call)
                             const int cc = ((tid + i * NT) & 7) ^ (((tid + i * NT) >> 3) & 7);
                             src = (int)((a_base[i] + (long)(max(a_iy[i] + ky, 0) >> 1) * p.Wd + (max(a_ix[i] + kx, 0) >> 1)) * p.Cin + cc * 8) * 2;
                         }
@@ -1037,7 +1043,7 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // against 911-1123 for the 8-wave form.  Bigger wave tiles need hand-scheduled AGPR code; not kept.)
     if (conv && a.splitk > 1 && glds && make_plan(a.M, a.N, a.K, true).tile == 4) {  // split-K under the 192x320 tile (make_plan)
         const long t = (long)(a.M / 192) * (a.N / 320) * a.splitk;
-        if ((aa & 4) && !a.ups) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); }
+        if ((aa & 4) && !a.ups && (!AE_CONV_SPEC || a.kmajor)) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); }
         else rc = launch_kernel(gemm_kernel<192, 320, AMODE, 2, 4, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
         done = true;
     }
@@ -1051,11 +1057,11 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
             if (a.epi == EPI_GEGLU) rc = launch_kernel(gemm_kernel<192, 320, AMODE, 4, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
             else if (cs_epi_ok && AMODE == A_CONV3) {
                 if constexpr (AMODE == A_CONV3) {
-                    if ((aa & 2) && !a.ups) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
+                    if ((aa & 2) && !a.ups && (!AE_CONV_SPEC || a.kmajor)) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
                     else rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
                 }
                 cs_done = true;
-            } else if (conv && (aa & 2) && !a.ups) {
+            } else if (conv && (aa & 2) && !a.ups && (!AE_CONV_SPEC || a.kmajor)) {
                 if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
             } else if (!conv && (aa & 1)) {
                 if constexpr (AMODE == A_DENSE) rc = launch_kernel(gemm_kernel<192, 320, A_DENSE, 2, 4, true, 1, 2, false, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
