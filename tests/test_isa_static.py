@@ -40,7 +40,7 @@ def test_operand_ahead_loops_keep_loads_in_flight(kernels):
             continue
         seen += 1
         assert md["private_segment_fixed_size"] == "0" and md["vgpr_spill_count"] == "0", name
-        n_mfma, n_vm0, n_scratch, n_dma, n_gloads, _, n_vmn = loop
+        n_mfma, n_vm0, n_scratch, n_dma, n_gloads, _, n_vmn = loop[:7]
         bm, bn, wm, wn = int(a[0]), int(a[1]), int(a[3]), int(a[4])
         per_step = (bm // wm // 16) * (bn // wn // 16) * 2           # 16x16x32 MFMAs of one wave per 64-deep K tile
         assert n_mfma == 6 * per_step, (name, n_mfma)

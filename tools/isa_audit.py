@@ -58,7 +58,12 @@ def audit(asm_path):
             n_gl = sum(bool(re.search(r"(global|buffer)_load", x)) for x in seg) - n_dma
             n_vmn = sum(bool(re.search(r"s_waitcnt.*vmcnt\([1-9]\d*\)", x)) for x in seg)     # counted waits: loads left in flight
             if n_mfma and (worst is None or n_mfma > worst[0]):
-                worst = (n_mfma, n_vm0, n_scr, n_dma, n_gl, b - a, n_vmn)
+                ops_ = [x.split()[0] for x in (y.strip() for y in seg) if x and x[0] not in ";."]
+                n_valu = sum(o.startswith("v_") and not o.startswith("v_mfma") for o in ops_)
+                n_salu = sum(o.startswith("s_") and not o.startswith(("s_waitcnt", "s_barrier", "s_nop", "s_cbranch", "s_branch")) for o in ops_)
+                n_lds = sum(o.startswith("ds_") for o in ops_)
+                n_br = sum(o.startswith(("s_cbranch", "s_branch")) for o in ops_)
+                worst = (n_mfma, n_vm0, n_scr, n_dma, n_gl, len(ops_), n_vmn, n_valu, n_salu, n_lds, n_br)
         rows.append((name, md, worst))
     return rows
 
@@ -94,7 +99,7 @@ def main():
     a = ap.parse_args()
     from anyedit_amd import build as B
     asms = compile_asm(a.files or B.SOURCES, a.keep or tempfile.mkdtemp(prefix="isa_"))
-    print(f"{'kernel':100s} vgpr agpr  lds_B scratch_B vspill | hottest MFMA loop: mfma vmcnt0 scratch dma gloads lines vmcntN")
+    print(f"{'kernel':100s} vgpr agpr  lds_B scratch_B vspill | hottest MFMA loop: mfma vmcnt0 scratch dma gloads instr vmcntN valu salu lds branch")
     flagged = 0
     for asm in asms:
         for name, md, worst in sorted(audit_named(asm)):
@@ -102,7 +107,7 @@ def main():
             # loops have it on the branch of the last K step
             bad = md["private_segment_fixed_size"] not in ("0", "?") or md["vgpr_spill_count"] not in ("0", "?") or (worst and worst[2] > 0)
             flagged += bool(bad)
-            w = "%4d %6d %7d %3d %6d %5d %6d" % worst if worst else "-"
+            w = "%4d %6d %7d %3d %6d %5d %6d %4d %4d %3d %6d" % worst if worst else "-"
             print(f"{'!' if bad else ' '} {name[:98]:98s} {md['vgpr_count']:>4s} {md['agpr_count']:>4s} {md['group_segment_fixed_size']:>6s} "
                   f"{md['private_segment_fixed_size']:>9s} {md['vgpr_spill_count']:>6s} | {w}")
     print(f"{flagged} kernel(s) flagged ('!': scratch memory or register spills; in-loop scratch traffic is the 'scratch' column)")
