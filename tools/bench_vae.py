@@ -5,7 +5,6 @@ denoising loop (2.48 TFLOP decode + 1.08 TFLOP encode per 512x512 image).  Rando
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
