@@ -224,6 +224,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
     const int KT = max(min(KT_all - kt_begin, kt_per), 0);  // K tiles of this block
     const int klast = p.K - 8;
     // conv: tap / channel offset of the NEXT tile to load
+    const int conv_per = AMODE == A_CONV3 ? p.CinPad / BK : 1;                                            // K tiles per filter tap (tap-major order)
+    const unsigned conv_per_magic = (AE_CONV_SPEC && conv_per > 1) ? 0xFFFFFFFFu / (unsigned)conv_per + 1u : 0u;   // ceil(2^32 / per)
     int ld_tap = (kt_begin * BK) / (AMODE == A_CONV3 ? p.CinPad : 1 << 30), ld_ci = (AMODE == A_CONV3) ? (kt_begin * BK) % p.CinPad : 0;
     if (AMODE == A_CONV3 && p.kmajor) { ld_tap = kt_begin % 9; ld_ci = (kt_begin / 9) * BK; }  // (chunk, tap) order: LDS-DMA loader only
 
@@ -404,7 +406,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                 if (STATELESS) {
                     const int lin = kt_begin + kt;
                     if (KM1 || p.kmajor) { cur_tap = lin % 9; cur_ci = (lin / 9) * BK; }
-                    else { const int per = p.CinPad / BK; cur_tap = lin / per; cur_ci = (lin - cur_tap * per) * BK; }
+                    else if (AE_CONV_SPEC) {   // tap-major: lin / per by the reciprocal set up once in front of the loops (exact for lin < 2^16, per <= 64)
+                        cur_tap = conv_per == 1 ? lin : (int)__umulhi((unsigned)lin, conv_per_magic);
+                        cur_ci = (lin - cur_tap * conv_per) * BK;
+                    } else { const int per = p.CinPad / BK; cur_tap = lin / per; cur_ci = (lin - cur_tap * per) * BK; }
                 }
                 const int ky = cur_tap / 3, kx = cur_tap - ky * 3;
                 if (cur_ci == 0 || kt == 0 || KM1 || p.kmajor || WA == 2) {  // a new tap: the per-lane part (halo mask, upsample source pixel) changes only here
