@@ -388,11 +388,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
             const int k0 = (kt_begin + kt) * BK;
             if (AMODE == A_DENSE) {
                 const bool second = k0 >= p.Ksplit;
+                if (AE_CONV_SPEC) {   // one wave-uniform branch per step instead of one per piece (hipcc keeps the test inside the unrolled piece loop)
+                    if (!second) {
+#pragma unroll
+                        for (int i = 0; i < A_CH; ++i) lds_dma16(rsA, sA + buf * BM * BK + (wave + (NT / 64) * i) * 8 * BK, fa_off[i], k0 * 2);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < A_CH; ++i) lds_dma16(rsA2, sA + buf * BM * BK + (wave + (NT / 64) * i) * 8 * BK, fa2_off[i], (k0 - p.Ksplit) * 2);
+                    }
+                } else {
 #pragma unroll
                 for (int i = 0; i < A_CH; ++i) {
                     bf16_t* dst = sA + buf * BM * BK + (wave + (NT / 64) * i) * 8 * BK;
                     if (!second) lds_dma16(rsA, dst, fa_off[i], k0 * 2);
                     else lds_dma16(rsA2, dst, fa2_off[i], (k0 - p.Ksplit) * 2);
+                }
                 }
             } else {
                 // operand-ahead loops and deep rings: the (tap, channel) position is derived from kt — carried as loop state (ld_tap / ld_ci, captured by
