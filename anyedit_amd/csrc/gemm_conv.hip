@@ -31,6 +31,15 @@ namespace {
 #ifndef AE_GEMM_WA_DEFAULT
 #define AE_GEMM_WA_DEFAULT 3
 #endif
+#ifndef AE_GEMM_PP_DEFAULT
+#define AE_GEMM_PP_DEFAULT 0
+#endif
+#ifndef AE_PP_PRIO
+#define AE_PP_PRIO 1        // s_setprio 1 around the MFMA intervals of the ping-pong loop
+#endif
+#ifndef AE_PP_DMA_FIRST
+#define AE_PP_DMA_FIRST 0   // ping-pong LOAD interval: DMA pieces in front of the fragment reads (1) or behind them (0)
+#endif
 constexpr int BK = 64;  // 64 bf16 = 128 B per tile row = 8 chunks of 16 B
 
 enum { A_DENSE = 0, A_CONV3 = 1 };
@@ -108,7 +117,8 @@ template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(const GemmArgs p) {
     static_assert(STAGES == 2 || (GLDS && WAVES_K == 1), "the deep LDS ring exists only for the LDS-DMA loader");
     static_assert(!WA || (GLDS && STAGES == 2 && WAVES_K == 1), "operand-ahead is a variant of the two-stage LDS-DMA pipeline");
-    static_assert(WA >= 0 && WA <= 2, "WA: 0 none, 1 weights two tiles ahead (three W stages), 2 activations two tiles ahead (three A stages)");
+    static_assert(WA >= 0 && WA <= 3, "WA: 0 none, 1 weights two tiles ahead (three W stages), 2 activations two tiles ahead (three A stages), 3 ping-pong (two wave groups)");
+    static_assert(WA != 3 || 64 * WAVES_M * WAVES_N * WAVES_K == 512, "the ping-pong loop pairs wave w with wave w + 4 (one SIMD's two waves)");
     static_assert(WAVES_K == 1 || WAVES_K == 2, "K groups: 1 or 2");
     constexpr int NT = 64 * WAVES_M * WAVES_N * WAVES_K;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];  // 2 * (BM + BN) * BK bf16 (dynamic: > 64 KiB for 128x160)
     bf16_t* const smem = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* sA = smem;
-    bf16_t* sB = smem + (WA == 2 ? 3 : STAGES) * BM * BK;
+    bf16_t* sB = smem + (WA >= 2 ? 3 : STAGES) * BM * BK;
 
     // The wave index as a SCALAR (v_readfirstlane once): tid >> 6 is wave-uniform but lives in a VGPR, and every LDS-DMA destination derived
     // from it then costs a v_readfirstlane_b32 per piece per K step in front of its s_mov m0 (48-66 per six steps of the operand-ahead loops;
@@ -226,6 +236,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
     // conv: tap / channel offset of the NEXT tile to load
     const int conv_per = AMODE == A_CONV3 ? p.CinPad / BK : 1;                                            // K tiles per filter tap (tap-major order)
     const unsigned conv_per_magic = (AE_CONV_SPEC && conv_per > 1) ? 0xFFFFFFFFu / (unsigned)conv_per + 1u : 0u;   // ceil(2^32 / per)
+    const unsigned pp_magic = (WA == 3 && conv_per > 1) ? 0xFFFFFFFFu / (unsigned)conv_per + 1u : 0u;                // the same reciprocal for the ping-pong loop (exact for lin < 2^16, per <= 64)
     int ld_tap = (kt_begin * BK) / (AMODE == A_CONV3 ? p.CinPad : 1 << 30), ld_ci = (AMODE == A_CONV3) ? (kt_begin * BK) % p.CinPad : 0;
     if (AMODE == A_CONV3 && p.kmajor) { ld_tap = kt_begin % 9; ld_ci = (kt_begin / 9) * BK; }  // (chunk, tap) order: LDS-DMA loader only
 
@@ -459,7 +470,123 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
             }
         };
         auto dma_tile = [&](int kt, int buf) __attribute__((always_inline)) { dma_a(kt, buf); dma_w(kt, buf); };
-        if constexpr (WA != 0) {
+        if constexpr (WA == 3) {
+            // ---- Ping-pong (round 4).  The eight waves form two groups — waves 0-3 and 4-7: wave w and w + 4 share a SIMD — that run the SAME
+            // instruction stream one barrier apart.  A K tile is two phases (its two 32-deep halves), a phase is a LOAD interval (the half's
+            // 11-13 fragment reads LDS -> registers, then this interval's LDS-DMA pieces, then the waits) and an MFMA interval (the half's
+            // FM x FN MFMAs on those registers, nothing else), each ended by a raw s_barrier.  Because of the one-barrier offset every SIMD
+            // always holds one wave in an MFMA interval (s_setprio 1) and one in a LOAD interval: the matrix pipe never waits for an LDS read, a
+            // DMA issue stall or a vmcnt wait of its OWN wave — in the lock-step loops above those costs add to the MFMA time
+            // (profiles/r03_v7_gemm_mainloop_ablations.txt: compute alone 158 us, DMA + barriers alone 196 us, together 256 us).
+            // Epochs (e = barriers passed); group 0: L(t,0) = 4t, M(t,0) = 4t + 1, L(t,1) = 4t + 2, M(t,1) = 4t + 3; group 1 one later.
+            //   LDS: three A stages + two W stages (152 KiB for 192x320).
+            //   L(t,0) issues W(t + 1) into W stage (t + 1) & 1: that stage held W(t - 1), last read by group 1 in epoch 4t - 1 with its
+            //          lgkmcnt(0) BEFORE the barrier that ends the epoch; the earliest issue is group 0's in epoch 4t.
+            //   L(t,1) issues A(t + 2) into A stage (t + 2) % 3 (held A(t - 1), same argument), then waits vmcnt(A_CH): DMA pieces retire in
+            //          issue order, so A(t + 1) and W(t + 1) have landed while A(t + 2) keeps flying; group 1's wait ends in epoch 4t + 3, the
+            //          first reader of tile t + 1 is group 0's L(t + 1,0) in epoch 4t + 4, behind the barrier.
+            // The DMA pieces go through inline asm (ae_dma16): hipcc does no bookkeeping for them, every wait below is placed by hand.
+            // Unrolled by six (lcm of the ring lengths) so that every stage offset is an immediate.
+            const int lds0 = (int)(uintptr_t)((__attribute__((address_space(3))) char*)smem_raw);
+            constexpr int A_ST = BM * BK * 2, W_ST = BN * BK * 2;   // stage sizes in bytes
+            const int ldsA = lds0 + wave * 1024, ldsW = lds0 + 3 * A_ST + wave * 1024;
+            const int grp = wave >> 2;
+            auto pp_w = [&](int kt, int st) __attribute__((always_inline)) {
+                const int k0 = (kt_begin + kt) * BK;
+#pragma unroll
+                for (int i = 0; i < B_CH; ++i) ae_dma16(rsW, ldsW + st * W_ST + i * (NT / 64) * 1024, fb_off[i], k0 * 2);
+            };
+            auto pp_a = [&](int kt, int st) __attribute__((always_inline)) {
+                const int lin = kt_begin + kt;
+                if constexpr (AMODE == A_DENSE) {
+                    const int k0 = lin * BK;
+                    if (k0 < p.Ksplit) {
+#pragma unroll
+                        for (int i = 0; i < A_CH; ++i) ae_dma16(rsA, ldsA + st * A_ST + i * (NT / 64) * 1024, fa_off[i], k0 * 2);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < A_CH; ++i) ae_dma16(rsA2, ldsA + st * A_ST + i * (NT / 64) * 1024, fa2_off[i], (k0 - p.Ksplit) * 2);
+                    }
+                } else {
+                    int tap, ci;
+                    if (p.kmajor) { tap = lin % 9; ci = (lin / 9) * BK; }
+                    else { tap = conv_per == 1 ? lin : (int)__umulhi((unsigned)lin, pp_magic); ci = (lin - tap * conv_per) * BK; }
+                    const int ky = tap / 3, kx = tap - ky * 3;
+                    const int tapbase = ((ky * p.Wd + kx) * p.Cin) * 2;
+#pragma unroll
+                    for (int i = 0; i < A_CH; ++i) {
+                        int src = fa_off[i] + tapbase;  // >= 0 for every in-image tap (voffset is bounds-checked unsigned)
+                        if (p.ups) {  // nearest-x2 upsample folded into the gather: source pixel = virtual pixel >> 1
+                            const int cc = ((tid + i * NT) & 7) ^ (((tid + i * NT) >> 3) & 7);
+                            src = (int)((a_base[i] + (long)(max(a_iy[i] + ky, 0) >> 1) * p.Wd + (max(a_ix[i] + kx, 0) >> 1)) * p.Cin + cc * 8) * 2;
+                        }
+                        ae_dma16(rsA, ldsA + st * A_ST + i * (NT / 64) * 1024, ((fa_mask[i] >> tap) & 1u) ? src : OOB, ci * 2);
+                    }
+                }
+            };
+            bf16x8_t af[FM], bfr[FN];
+            auto pp_read = [&](int kk, int sa, int sw) __attribute__((always_inline)) {
+                const bf16_t* cA = sA + sa * BM * BK + (wm * WM) * BK;
+                const bf16_t* cB = sB + sw * BN * BK + (wn * WN) * BK;
+                const int ch = kk * 4 + lg;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int row = i * 16 + l15;
+                    af[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(cA + row * BK + ((ch ^ (row & 7)) << 3)));
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int row = j * 16 + l15;
+                    bfr[j] = as_bf16x8(*reinterpret_cast<const u32x4*>(cB + row * BK + ((ch ^ (row & 7)) << 3)));
+                }
+            };
+            auto pp_mfma = [&]() __attribute__((always_inline)) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (AE_PP_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                if (AE_PP_PRIO) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            pp_w(0, 0); pp_a(0, 0);
+            if (KT > 1) { pp_a(1, 1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_CH) : "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (grp) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind
+            __builtin_amdgcn_sched_barrier(0);
+            for (int kt0 = 0; kt0 < KT; kt0 += 6) {
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const int kt = kt0 + u;
+                    if (kt >= KT) break;
+                    const int sa = u % 3, sw = u & 1;
+                    // L(t,0)
+                    if (AE_PP_DMA_FIRST && kt + 1 < KT) pp_w(kt + 1, sw ^ 1);
+                    pp_read(0, sa, sw);
+                    if (!AE_PP_DMA_FIRST && kt + 1 < KT) pp_w(kt + 1, sw ^ 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    pp_mfma();   // M(t,0)
+                    // L(t,1)
+                    if (AE_PP_DMA_FIRST && kt + 2 < KT) pp_a(kt + 2, (u + 2) % 3);
+                    pp_read(1, sa, sw);
+                    if (!AE_PP_DMA_FIRST && kt + 2 < KT) pp_a(kt + 2, (u + 2) % 3);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_CH) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    pp_mfma();   // M(t,1)
+                }
+            }
+            if (!grp) __builtin_amdgcn_s_barrier();  // group 0 waits for group 1's last MFMA interval: every wave has passed the same number of barriers
+            __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (WA != 0) {
             // One operand two tiles ahead (three stages of it, two of the other), for the operand that arrives COLD inside a UNet evaluation:
             //   WA 1: the weights (32x32 / 8x8 levels: a layer's weights come from HBM, its activations from L2 / the Infinity Cache;
             //         tools/cold_weight_probe.py: cold weights cost those launches 5-11 %);
@@ -1034,6 +1161,9 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // scratch load — the DMA queue drained once per step (profiles/r03_v30_weights_ahead.txt).
     auto lds_aa = [](int bm, int bn) { return (size_t)(3 * bm + 2 * bn) * BK * sizeof(bf16_t); };
     static const int aa = getenv("AE_GEMM_AA") ? atoi(getenv("AE_GEMM_AA")) : AE_GEMM_AA_DEFAULT;
+    // tuning knob (bit flags): the ping-pong main loop (WA = 3, round 4) on the 192x320 tile — 1 un-split convs, 2 split-K convs, 4 dense non-GEGLU,
+    // 8 GEGLU (4 x 2 waves).  Same LDS footprint as the activations-ahead loop (three A stages + two W stages).
+    static const int pp = getenv("AE_GEMM_PP") ? atoi(getenv("AE_GEMM_PP")) : AE_GEMM_PP_DEFAULT;
     int rc = 0;
 
     // 192x320 tile, one block per CU (128 KiB LDS), 8 waves with 96x80 (or 48x160 for the GEGLU column pairing) wave tiles:
@@ -1058,7 +1188,8 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // against 911-1123 for the 8-wave form.  Bigger wave tiles need hand-scheduled AGPR code; not kept.)
     if (conv && a.splitk > 1 && glds && make_plan(a.M, a.N, a.K, true).tile == 4) {  // split-K under the 192x320 tile (make_plan)
         const long t = (long)(a.M / 192) * (a.N / 320) * a.splitk;
-        if ((aa & 4) && !a.ups && (!AE_CONV_SPEC || a.kmajor)) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); }
+        if (pp & 2) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); }
+        else if ((aa & 4) && !a.ups && (!AE_CONV_SPEC || a.kmajor)) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); }
         else rc = launch_kernel(gemm_kernel<192, 320, AMODE, 2, 4, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
         done = true;
     }
@@ -1069,8 +1200,16 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         // 192x320 waves 2x4, or 4x2 for GEGLU (pairs of 16-column fragments must sit in one wave).  A 96x320 variant for the
         // 32x32 level (M = 12288) measured 9-13 % slower than the 128x128 tile there and was dropped.
         if (fill >= 0.85) {
-            if (a.epi == EPI_GEGLU) rc = launch_kernel(gemm_kernel<192, 320, AMODE, 4, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
-            else if (cs_epi_ok && AMODE == A_CONV3) {
+            if (a.epi == EPI_GEGLU && (pp & 8)) { if constexpr (AMODE == A_DENSE) rc = launch_kernel(gemm_kernel<192, 320, A_DENSE, 4, 2, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); }
+            else if (a.epi == EPI_GEGLU) rc = launch_kernel(gemm_kernel<192, 320, AMODE, 4, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
+            else if (conv && (pp & 1)) {
+                if constexpr (AMODE == A_CONV3) {
+                    if (cs_epi_ok) { rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); cs_done = true; }
+                    else rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
+                }
+            } else if (!conv && (pp & 4)) {
+                if constexpr (AMODE == A_DENSE) rc = launch_kernel(gemm_kernel<192, 320, A_DENSE, 2, 4, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
+            } else if (cs_epi_ok && AMODE == A_CONV3) {
                 if constexpr (AMODE == A_CONV3) {
                     if ((aa & 2) && !a.ups && (!AE_CONV_SPEC || a.kmajor)) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
                     else rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
