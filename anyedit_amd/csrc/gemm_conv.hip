@@ -23,7 +23,7 @@
 namespace {
 
 #ifndef AE_CONV_SPEC
-#define AE_CONV_SPEC 0
+#define AE_CONV_SPEC 1   // round 4: on (prepared in round 3, measured at the start of round 4: 40 checksums identical, UNet step 13.47 -> 13.44 ms over three alternating runs, profiles/r04_v2_cspec_ab.txt)
 #endif
 #ifndef AE_GEMM_AA_DEFAULT
 #define AE_GEMM_AA_DEFAULT 3
@@ -32,7 +32,10 @@ namespace {
 #define AE_GEMM_WA_DEFAULT 3
 #endif
 #ifndef AE_GEMM_PP_DEFAULT
-#define AE_GEMM_PP_DEFAULT 0
+#define AE_GEMM_PP_DEFAULT 15
+#endif
+#ifndef AE_PP_LAB
+#define AE_PP_LAB 0         // lab builds only (tools/ubench/conv_lab.hip): 1 no DMA after the prologue, 2 DMA + barriers only (no LDS reads, no MFMAs), 3 MFMAs on stale registers (no LDS reads)
 #endif
 #ifndef AE_PP_PRIO
 #define AE_PP_PRIO 1        // s_setprio 1 around the MFMA intervals of the ping-pong loop
@@ -85,8 +88,17 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, bf16_t* lds
 // [0] prologue, [1] DMA issue, [2] LDS reads + MFMAs, [3] barrier + DMA drain, [4] epilogue tail, [5] K tiles, [6] epilogue staging (bias /
 // activation + fp32 tile into LDS), [7] epilogue output (barrier, LDS reads, residual, global stores).  The stamps serialise the scalar
 // pipe: the split between [1] and [2] is pessimistic (un-instrumented, the DMA issue overlaps the first MFMAs); totals per phase are sound.
-__device__ unsigned long long g_gemm_dbg[16];
+// ping-pong loop (WA 3): [1] L(t,0) reads + DMA issue + lgkmcnt(0), [2] barrier behind it, [3] M(t,0) MFMA issue, [8] barrier behind it, [9] L(t,1) reads + DMA issue +
+// lgkmcnt(0), [10] its vmcnt wait, [11] barrier, [12] M(t,1), [13] barrier; wave 0 (group 0) in [0, 16), wave 4 (group 1) in [16, 32).
+__device__ unsigned long long g_gemm_dbg[32];
 #define GL_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (lab_me) g_gemm_dbg[lab_base + (i)] += t_ - tlast; tlast = t_; } while (0)
+#elif defined(AE_GEMM_TRACE)
+// trace build (tools/ubench/pp_lab.hip): every wave of one mid-grid block stamps the cycle counter at each point GL_T marks, for TR_T consecutive K tiles
+// from TR_K0 on, into the 8 KiB of LDS behind the ping-pong ring (no VMEM store inside the loop: it would count in vmcnt); dumped to g_pp_trace at the end.
+constexpr int TR_K0 = 18, TR_T = 6;
+__device__ unsigned long long g_pp_trace[8 * TR_T * 16];
+// (stamps are collected in scalar registers and written once per K tile: a store — or just the wait for s_memtime's result — at every stamp cost ~200 cycles each)
+#define GL_T(i) do { __builtin_amdgcn_sched_barrier(0); tr_t[(i)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define GL_T(i)
 #endif
@@ -117,7 +129,7 @@ template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(const GemmArgs p) {
     static_assert(STAGES == 2 || (GLDS && WAVES_K == 1), "the deep LDS ring exists only for the LDS-DMA loader");
     static_assert(!WA || (GLDS && STAGES == 2 && WAVES_K == 1), "operand-ahead is a variant of the two-stage LDS-DMA pipeline");
-    static_assert(WA >= 0 && WA <= 3, "WA: 0 none, 1 weights two tiles ahead (three W stages), 2 activations two tiles ahead (three A stages), 3 ping-pong (two wave groups)");
+    static_assert(WA >= 0 && WA <= 3, "WA: 0 none, 1 weights two tiles ahead (three W stages), 2 activations two tiles ahead (three A stages), 3 ping-pong (two wave groups one barrier apart)");
     static_assert(WA != 3 || 64 * WAVES_M * WAVES_N * WAVES_K == 512, "the ping-pong loop pairs wave w with wave w + 4 (one SIMD's two waves)");
     static_assert(WAVES_K == 1 || WAVES_K == 2, "K groups: 1 or 2");
     constexpr int NT = 64 * WAVES_M * WAVES_N * WAVES_K;
@@ -138,10 +150,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
 #define AE_WAVE_SGPR 1
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wave = AE_WAVE_SGPR ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
+#ifdef AE_GEMM_TRACE
+    const bool tr_blk = blockIdx.x == gridDim.x / 2 && WA == 3;
+    unsigned long long* const tr_lds = reinterpret_cast<unsigned long long*>(smem_raw + 152 * 1024);
+    int tr_kt = -1;
+    unsigned long long tr_t[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tr_t[q] = 0;
+#endif
 #ifdef AE_GEMM_LAB
     unsigned long long tlast = __builtin_readcyclecounter();
     const bool lab_me = blockIdx.x == gridDim.x / 2 && lane == 0 && (wave == 0 || wave == 4);
-    const int lab_base = wave == 0 ? 0 : 8;
+    const int lab_base = wave == 0 ? 0 : 16;
 #endif
     const int wk = wave / (WAVES_M * WAVES_N), wmn = wave % (WAVES_M * WAVES_N);  // K group, position inside the group
     const int wm = wmn / WAVES_N, wn = wmn % WAVES_N;
@@ -496,10 +516,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
 #pragma unroll
                 for (int i = 0; i < B_CH; ++i) ae_dma16(rsW, ldsW + st * W_ST + i * (NT / 64) * 1024, fb_off[i], k0 * 2);
             };
-            auto pp_a = [&](int kt, int st) __attribute__((always_inline)) {
+            // Activation pieces.  conv: the (tap, channel chunk) position of the NEXT tile to issue is carried as scalar state and advanced by a few
+            // s_add / s_cselect per tile — the stateless form (lin % 9, lin / 9, tap / 3, two multiplies, a branch per flag) cost the LOAD interval
+            // that issues them ~250 cycles more than the weight pieces' (barrier-arrival trace, profiles/r04_v7_pp_trace.txt; moving that arithmetic
+            // one interval ahead only moved the cost: profiles/r04_v8_pp_prep.txt).  The three per-lane offsets are worked out into separate
+            // registers first, then the pieces go out back to back (an offset register rewritten between two pieces waits for the first piece's issue).
+            // No upsampling gather here: the launcher keeps those three convs on the round-3 loop.
+            int cs_tap = 0, cs_kx = 0, cs_base = 0, cs_ci = 0;   // tap index 0..8, its kx, ((ky * W + kx) * Cin) * 2, channel offset (elements)
+            const int cs_cin2 = p.Cin * 2, cs_row2 = (p.Wd - 3) * p.Cin * 2;
+            auto cs_set = [&](int kt) __attribute__((always_inline)) {   // stateless (prologue only)
                 const int lin = kt_begin + kt;
+                if (p.kmajor) { cs_tap = lin % 9; cs_ci = (lin / 9) * BK; }
+                else { cs_tap = conv_per == 1 ? lin : (int)__umulhi((unsigned)lin, pp_magic); cs_ci = (lin - cs_tap * conv_per) * BK; }
+                const int ky = cs_tap / 3;
+                cs_kx = cs_tap - ky * 3;
+                cs_base = ((ky * p.Wd + cs_kx) * p.Cin) * 2;
+            };
+            auto cs_next = [&]() __attribute__((always_inline)) {
+                bool tap_step = true;
+                if (!p.kmajor) { cs_ci += BK; tap_step = cs_ci >= p.CinPad; cs_ci = tap_step ? 0 : cs_ci; }
+                if (tap_step) {
+                    ++cs_tap; ++cs_kx; cs_base += cs_cin2;
+                    if (cs_kx == 3) { cs_kx = 0; cs_base += cs_row2; }
+                    if (cs_tap == 9) { cs_tap = 0; cs_base = 0; cs_ci += BK; }   // (chunk-major order only: in the tap-major order the loop ends with tap 8)
+                }
+            };
+            auto pp_a = [&](int kt, int st) __attribute__((always_inline)) {
                 if constexpr (AMODE == A_DENSE) {
-                    const int k0 = lin * BK;
+                    const int k0 = (kt_begin + kt) * BK;
                     if (k0 < p.Ksplit) {
 #pragma unroll
                         for (int i = 0; i < A_CH; ++i) ae_dma16(rsA, ldsA + st * A_ST + i * (NT / 64) * 1024, fa_off[i], k0 * 2);
@@ -508,20 +552,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                         for (int i = 0; i < A_CH; ++i) ae_dma16(rsA2, ldsA + st * A_ST + i * (NT / 64) * 1024, fa2_off[i], (k0 - p.Ksplit) * 2);
                     }
                 } else {
-                    int tap, ci;
-                    if (p.kmajor) { tap = lin % 9; ci = (lin / 9) * BK; }
-                    else { tap = conv_per == 1 ? lin : (int)__umulhi((unsigned)lin, pp_magic); ci = (lin - tap * conv_per) * BK; }
-                    const int ky = tap / 3, kx = tap - ky * 3;
-                    const int tapbase = ((ky * p.Wd + kx) * p.Cin) * 2;
+                    int off[A_CH];
 #pragma unroll
-                    for (int i = 0; i < A_CH; ++i) {
-                        int src = fa_off[i] + tapbase;  // >= 0 for every in-image tap (voffset is bounds-checked unsigned)
-                        if (p.ups) {  // nearest-x2 upsample folded into the gather: source pixel = virtual pixel >> 1
-                            const int cc = ((tid + i * NT) & 7) ^ (((tid + i * NT) >> 3) & 7);
-                            src = (int)((a_base[i] + (long)(max(a_iy[i] + ky, 0) >> 1) * p.Wd + (max(a_ix[i] + kx, 0) >> 1)) * p.Cin + cc * 8) * 2;
-                        }
-                        ae_dma16(rsA, ldsA + st * A_ST + i * (NT / 64) * 1024, ((fa_mask[i] >> tap) & 1u) ? src : OOB, ci * 2);
-                    }
+                    for (int i = 0; i < A_CH; ++i) off[i] = ((fa_mask[i] >> cs_tap) & 1u) ? fa_off[i] + cs_base : OOB;   // halo / tail rows -> hardware zero
+#pragma unroll
+                    for (int i = 0; i < A_CH; ++i) asm volatile("" : "+v"(off[i]));   // all three offsets first ...
+#pragma unroll
+                    for (int i = 0; i < A_CH; ++i) ae_dma16(rsA, ldsA + st * A_ST + i * (NT / 64) * 1024, off[i], cs_ci * 2);   // ... then the pieces
+                    cs_next();
                 }
             };
             bf16x8_t af[FM], bfr[FN];
@@ -532,60 +570,94 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     const int row = i * 16 + l15;
-                    af[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(cA + row * BK + ((ch ^ (row & 7)) << 3)));
+                    if (AE_PP_LAB == 2 || AE_PP_LAB == 3) af[i] = as_bf16x8((u32x4){(uint32_t)(i + sa), 0x3f803f80u, (uint32_t)lane, 0u});
+                    else af[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(cA + row * BK + ((ch ^ (row & 7)) << 3)));
                 }
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
                     const int row = j * 16 + l15;
-                    bfr[j] = as_bf16x8(*reinterpret_cast<const u32x4*>(cB + row * BK + ((ch ^ (row & 7)) << 3)));
+                    if (AE_PP_LAB == 2 || AE_PP_LAB == 3) bfr[j] = as_bf16x8((u32x4){(uint32_t)(j + kk), 0x3f803f80u, (uint32_t)lane, 0u});
+                    else bfr[j] = as_bf16x8(*reinterpret_cast<const u32x4*>(cB + row * BK + ((ch ^ (row & 7)) << 3)));
                 }
             };
-            auto pp_mfma = [&]() __attribute__((always_inline)) {
+            auto pp_mfma = [&](int lab_m, int lab_b) __attribute__((always_inline)) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (AE_PP_PRIO) __builtin_amdgcn_s_setprio(1);
+                if (AE_PP_LAB != 2) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                }
                 if (AE_PP_PRIO) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
+                GL_T(lab_m);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+                GL_T(lab_b);
             };
+            if constexpr (AMODE == A_CONV3) cs_set(0);
             pp_w(0, 0); pp_a(0, 0);
             if (KT > 1) { pp_a(1, 1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_CH) : "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (grp) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind
             __builtin_amdgcn_sched_barrier(0);
+            GL_T(0);
             for (int kt0 = 0; kt0 < KT; kt0 += 6) {
 #pragma unroll
                 for (int u = 0; u < 6; ++u) {
                     const int kt = kt0 + u;
                     if (kt >= KT) break;
                     const int sa = u % 3, sw = u & 1;
+#ifdef AE_GEMM_TRACE
+                    tr_kt = kt;
+                    GL_T(0);
+#endif
                     // L(t,0)
-                    if (AE_PP_DMA_FIRST && kt + 1 < KT) pp_w(kt + 1, sw ^ 1);
+                    if (AE_PP_DMA_FIRST && AE_PP_LAB != 1 && kt + 1 < KT) pp_w(kt + 1, sw ^ 1);
                     pp_read(0, sa, sw);
-                    if (!AE_PP_DMA_FIRST && kt + 1 < KT) pp_w(kt + 1, sw ^ 1);
+                    if (!AE_PP_DMA_FIRST && AE_PP_LAB != 1 && kt + 1 < KT) pp_w(kt + 1, sw ^ 1);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
+                    GL_T(1);
                     __builtin_amdgcn_s_barrier();
-                    pp_mfma();   // M(t,0)
+                    GL_T(2);
+                    pp_mfma(3, 8);   // M(t,0)
                     // L(t,1)
-                    if (AE_PP_DMA_FIRST && kt + 2 < KT) pp_a(kt + 2, (u + 2) % 3);
+                    if (AE_PP_DMA_FIRST && AE_PP_LAB != 1 && kt + 2 < KT) pp_a(kt + 2, (u + 2) % 3);
                     pp_read(1, sa, sw);
-                    if (!AE_PP_DMA_FIRST && kt + 2 < KT) pp_a(kt + 2, (u + 2) % 3);
+                    if (!AE_PP_DMA_FIRST && AE_PP_LAB != 1 && kt + 2 < KT) pp_a(kt + 2, (u + 2) % 3);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    GL_T(9);
                     if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_CH) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
+                    GL_T(10);
                     __builtin_amdgcn_s_barrier();
-                    pp_mfma();   // M(t,1)
+                    GL_T(11);
+                    pp_mfma(12, 13);   // M(t,1)
+#ifdef AE_GEMM_TRACE
+                    if (tr_blk && kt >= TR_K0 && kt < TR_K0 + TR_T && lane == 0) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) tr_lds[(wave * TR_T + (kt - TR_K0)) * 16 + q] = tr_t[q];
+                    }
+#endif
+#ifdef AE_GEMM_LAB
+                    if (lab_me) g_gemm_dbg[lab_base + 5] += 1;
+#endif
                 }
             }
             if (!grp) __builtin_amdgcn_s_barrier();  // group 0 waits for group 1's last MFMA interval: every wave has passed the same number of barriers
             __builtin_amdgcn_sched_barrier(0);
+#ifdef AE_GEMM_TRACE
+            tr_kt = -1;
+            if (tr_blk) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                for (int q = tid; q < 8 * TR_T * 16; q += NT) g_pp_trace[q] = tr_lds[q];
+            }
+#endif
         } else if constexpr (WA != 0) {
             // One operand two tiles ahead (three stages of it, two of the other), for the operand that arrives COLD inside a UNet evaluation:
             //   WA 1: the weights (32x32 / 8x8 levels: a layer's weights come from HBM, its activations from L2 / the Infinity Cache;
@@ -1159,7 +1231,11 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // more instantiation for 0.02 ms).  The GEGLU form (4 x 2 waves) spills and is not instantiated.  The first measurement of the conv
     // forms was 20 % SLOWER: out of line, the loader lambdas kept ld_tap / ld_ci in scratch memory, and hipcc waits vmcnt(0) for every
     // scratch load — the DMA queue drained once per step (profiles/r03_v30_weights_ahead.txt).
+#ifdef AE_GEMM_TRACE
+    auto lds_aa = [](int bm, int bn) { return (size_t)(3 * bm + 2 * bn) * BK * sizeof(bf16_t) + 8192; };   // + the trace area
+#else
     auto lds_aa = [](int bm, int bn) { return (size_t)(3 * bm + 2 * bn) * BK * sizeof(bf16_t); };
+#endif
     static const int aa = getenv("AE_GEMM_AA") ? atoi(getenv("AE_GEMM_AA")) : AE_GEMM_AA_DEFAULT;
     // tuning knob (bit flags): the ping-pong main loop (WA = 3, round 4) on the 192x320 tile — 1 un-split convs, 2 split-K convs, 4 dense non-GEGLU,
     // 8 GEGLU (4 x 2 waves).  Same LDS footprint as the activations-ahead loop (three A stages + two W stages).
@@ -1188,7 +1264,7 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // against 911-1123 for the 8-wave form.  Bigger wave tiles need hand-scheduled AGPR code; not kept.)
     if (conv && a.splitk > 1 && glds && make_plan(a.M, a.N, a.K, true).tile == 4) {  // split-K under the 192x320 tile (make_plan)
         const long t = (long)(a.M / 192) * (a.N / 320) * a.splitk;
-        if (pp & 2) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); }
+        if ((pp & 2) && !a.ups) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); }
         else if ((aa & 4) && !a.ups && (!AE_CONV_SPEC || a.kmajor)) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); }
         else rc = launch_kernel(gemm_kernel<192, 320, AMODE, 2, 4, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
         done = true;
@@ -1202,7 +1278,7 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         if (fill >= 0.85) {
             if (a.epi == EPI_GEGLU && (pp & 8)) { if constexpr (AMODE == A_DENSE) rc = launch_kernel(gemm_kernel<192, 320, A_DENSE, 4, 2, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); }
             else if (a.epi == EPI_GEGLU) rc = launch_kernel(gemm_kernel<192, 320, AMODE, 4, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
-            else if (conv && (pp & 1)) {
+            else if (conv && (pp & 1) && !a.ups) {   // (the nearest-x2 gather's per-piece address arithmetic measured 283 vs 273 us under the first form of the ping-pong loop and is not instantiated)
                 if constexpr (AMODE == A_CONV3) {
                     if (cs_epi_ok) { rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); cs_done = true; }
                     else rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
