@@ -15,8 +15,10 @@
 //     O); the test is a v_max3 tree + one wave-wide compare, the rebase itself a rarely taken wave-uniform branch.  Softmax is
 //     invariant to the offset as long as P and the denominator use the same one — they do, the denominator is accumulated by the
 //     PV MFMA itself from a row of ones (below);
-//   * P goes from the 32x32 accumulator layout to the B operand of v_mfma_f32_16x16x32_bf16 (O^T = V^T P^T, head_dim padded to 48
-//     instead of 64) with four v_permlane16_swap per 32x32 block, no LDS round trip;
+//   * P stays where the QK^T MFMA left it: the 32x32 accumulator layout of S^T IS the B-operand layout of the same v_mfma_f32_32x32x16_bf16
+//     shape, so O^T = V^T P^T needs no cross-lane move (the key order inside a K step is permuted consistently on the V side); O^T is D / 32 + 1
+//     blocks of 32 rows — head_dim 40 runs 64 rows, i.e. 7 issued MFMAs per 32x32 logit block where 5 would be the un-padded work (1.40x).
+//     (Round 2 measured the alternative, 16x16x32 PV over 48 rows behind four v_permlane16_swap per block: 413 vs 406 us, not kept.);
 //   * K and V tiles (64 keys) are copied by LDS-DMA (buffer_load_dwordx4 ... lds) as compact row-major images — no staging
 //     registers, no ds_write, no transposing VALU; V^T operands come from ds_read_b64_tr_b16.  The lanes that would read the
 //     padding column head_dim .. head_dim+3 of V read a constant {1,0,0,0} instead: O^T row `head_dim` is sum_k P = the softmax
@@ -33,6 +35,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4v;
 constexpr int FKT = 64;  // keys per LDS tile
 #ifndef AE_ATTN_V_DEFAULT
 #define AE_ATTN_V_DEFAULT 3   // default variant of the plain long-sequence kernel (see launch_fast): decided by measurement
+#endif
+#ifndef AE_ATTN_FENCE_ALL
+#define AE_ATTN_FENCE_ALL 1   // the MFMA-source fences (P registers, `hold`, `srcring`) in every instantiation, not only the two-query-group one
 #endif
 constexpr float FLOG2E = 1.4426950408889634f;
 constexpr float RESCALE_THR = 8.0f;  // log2 units
@@ -216,6 +221,18 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     int kcur = 0, klast = 0, vcur = 0, vlast = 0;
 
     u32x4 hold[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};  // QG = 2: ALL P registers of the previous block's last K-step (see the end of block())
+    // The same exposure exists for SrcA (round 4, found by reading the listing: tools/isa_audit.py::mfma_source_overwrites — hipcc reused a V
+    // fragment's registers for the other query group's v_exp_f32 results ONE instruction after the MFMA that reads them, and reloads a K fragment
+    // by ds_read two instructions after its last MFMA).  The matrix pipe is in order and takes one MFMA at a time, so a fragment is safe once two
+    // further MFMAs have been issued: the last two fragments stay live values in this ring until then.
+    u32x4 srcring[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    auto retire_src = [&](bf16x8_t frag) __attribute__((always_inline)) {
+        union { bf16x8_t b; u32x4 u; } cv;
+        cv.b = frag;
+        asm volatile("" ::"v"(srcring[0]));
+        srcring[0] = srcring[1];
+        srcring[1] = cv.u;
+    };
     // one 32-key block of the current tile
     auto block = [&](auto blk_tag, int k0, bool first, bool tail) {
         constexpr int B2 = decltype(blk_tag)::value;
@@ -263,10 +280,11 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
                         s[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[gq][ks]), ks == 0 ? cinit[gq] : s[gq], 0, 0, 0);
                     }
                 }
+                retire_src(kf);
             }
             // the P registers of the previous block's last K-step (`hold`) are free from here on: six more MFMAs are in the pipe behind
             // the one that read them
-            if (QG > 1) asm volatile("" ::"v"(hold[0]), "v"(hold[1]));
+            if (AE_ATTN_FENCE_ALL || QG > 1) asm volatile("" ::"v"(hold[0]), "v"(hold[1]));
         }
         if (ABL == 10 || ABL == 12) __builtin_amdgcn_s_setprio(0);
         if (ABL == 11) __builtin_amdgcn_s_setprio(1);
@@ -350,9 +368,10 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
                     const bf16x8_t pb = as_bf16x8((u32x4){pk[gq][4 * kk], pk[gq][4 * kk + 1], pk[gq][4 * kk + 2], pk[gq][4 * kk + 3]});
                     o[gq][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[gq][db], 0, 0, 0);
                 }
+                retire_src(vf);
             }
         }
-        if (QG > 1) {
+        if (AE_ATTN_FENCE_ALL || QG > 1) {
             // gfx950 / hipcc hazard (found with tools/diag_attn.py, profiles/r03_attn_qg2_hazard.txt): with two query groups the
             // scheduler lays group B's exp2 / convert work between group A's PV MFMAs and REUSES A's P registers for it — a VALU
             // write to an MFMA's SrcB registers one instruction after that v_mfma_f32_32x32x16_bf16 was issued.  The MFMA has not
@@ -495,6 +514,10 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
             if (t + 1 < ntiles) issue(t + 1, (t + 1) & 1);
             tile(t, t & 1);
         }
+        // the last block's P registers stay live past the loop: park() / store_o() start with VALU work, and the last PV MFMAs (issued a few
+        // instructions ago) may still be reading their SrcB operands (see the end of block(); tests/test_isa_static.py checks the listing for it)
+        if (AE_ATTN_FENCE_ALL || QG > 1) asm volatile("" ::"v"(hold[0]), "v"(hold[1]));
+        asm volatile("" ::"v"(srcring[0]), "v"(srcring[1]));
         if (SEG2 && seg == 0) park();
     }
     if (SKV) {
@@ -548,6 +571,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
         atomicAdd(&g_attn_dbg[2], 1ull);
     }
 #endif
+    if (AE_ATTN_FENCE_ALL || QG > 1) asm volatile("" ::"v"(hold[0]), "v"(hold[1]));
+    asm volatile("" ::"v"(srcring[0]), "v"(srcring[1]));
     store_o();
 }
 

@@ -790,6 +790,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
     {
         constexpr int NCH = WN / 4;  // fp32 16-byte chunks per staged row
         // staging must fit in the main-loop LDS: split the wave tile's rows into passes if it does not (128x160 tile)
+        static_assert(!CS || 2 * (64 / (WN / 8)) <= 32, "column statistics: the R row-lanes of a chunk fold through 2 R rows of the wave's own 32-row staging slice");
         static_assert(!CS || (WAVES_K == 1 && FM % 2 == 0 && WN % 16 == 0 && WAVES_M * WAVES_N * 32 * WN * 4 <= STAGES * (BM + BN) * BK * 2),
                       "column statistics need 32-row staging passes that fit the main-loop LDS");
         constexpr int PASSES = CS ? FM / 2 : epilogue_passes(FM, WAVES_M * WAVES_N * 16 * WN * 4, STAGES * (BM + BN) * BK * 2);

@@ -889,6 +889,8 @@ extern "C" int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, con
         AE_REQUIRE(HW % 32 == 0, "ae_groupnorm_nhwc_bf16: producer statistics are kept per 32-row slab: HW=%d must be a multiple of 32", HW);
         AE_REQUIRE((x2 == nullptr) == (colstats2 == nullptr), "ae_groupnorm_nhwc_bf16: statistics are needed for both sources of a concat input");
         AE_REQUIRE(((uintptr_t)colstats & 7) == 0 && ((uintptr_t)colstats2 & 7) == 0, "ae_groupnorm_nhwc_bf16: colstats alignment");
+        // gn_finalize_cs_kernel finds (slab, channel) from a flat index by a float reciprocal: exact below 2^20 terms per group
+        AE_REQUIRE((long)(HW / 32) * (C / groups) < (1L << 20), "ae_groupnorm_nhwc_bf16: %ld slab sums per group exceed the 2^20 the statistics fold indexes exactly", (long)(HW / 32) * (C / groups));
         p.cs1 = colstats; p.cs2 = colstats2;
         hipLaunchKernelGGL(gn_finalize_cs_kernel, dim3(groups, B), dim3(256), 0, s, p);
         int rc0 = ae_check_launch("ae_groupnorm_nhwc_bf16(finalize from producer statistics)");

@@ -42,6 +42,47 @@ class MultiScaleDeformableAttnFunction(torch.autograd.Function):
         return gv, None, None, gl.to(loc.dtype), gw.to(w.dtype), None
 
 
+class _LinearF32(torch.autograd.Function):
+    """nn.Linear on `ae_linear_f32` with its adjoints on the same kernel (the raw kernel call has no autograd node, so the module's
+    projections dropped the gradients of query / src / weights silently and MultiScaleDeformableAttnFunction.backward was unreachable from the
+    module).  dX = dY W, dW = dY^T X, db = sum dY; the row count is zero-padded to the kernel's K % 16 == 0 for the weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return ops.linear_f32(x, w, b)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        K, N = w.shape[1], w.shape[0]
+        gy2 = gy.reshape(-1, N).float().contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.linear_f32(gy2, w.detach().t().contiguous()).reshape(x.shape)            # [M, N] x [K, N]^T
+        if ctx.needs_input_grad[1]:
+            x2 = x.reshape(-1, K).float()
+            M = x2.shape[0]
+            Mp = (M + 15) // 16 * 16
+            gyt = torch.zeros(N, Mp, dtype=torch.float32, device=gy2.device)
+            gyt[:, :M] = gy2.t()
+            xt = torch.zeros(K, Mp, dtype=torch.float32, device=gy2.device)
+            xt[:, :M] = x2.t()
+            gw = ops.linear_f32(gyt, xt)                                                        # [N, Mp] x [K, Mp]^T
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy2.sum(0)
+        return gx, gw, gb
+
+
+def _linear_f32(m, t):
+    t = t.float()
+    if torch.is_grad_enabled() and (t.requires_grad or m.weight.requires_grad or (m.bias is not None and m.bias.requires_grad)):
+        return _LinearF32.apply(t, m.weight, m.bias)
+    return ops.linear_f32(t, m.weight, m.bias)   # exact fp32 (f32-input MFMA), no torch / library GEMM
+
+
 def multi_scale_deformable_attn(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
                                 im2col_step=64):
     """Functional entry with the argument list of MultiScaleDeformableAttnFunction.forward (ms_deform_attn.py:42-60)."""
@@ -119,7 +160,7 @@ class MultiScaleDeformableAttention(nn.Module):
         bs, nq, _ = q.shape
         ns = src.shape[1]
         assert int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum()) == ns
-        lin = lambda m, t: ops.linear_f32(t.float(), m.weight, m.bias)   # exact fp32 (f32-input MFMA), no torch / library GEMM
+        lin = _linear_f32
         v = lin(self.value_proj, src)
         if key_padding_mask is not None:
             v = v.masked_fill(key_padding_mask[..., None], 0.0)

@@ -206,6 +206,8 @@ class DDIMSampler(object):
         tables at the network timestep (predict_eps_from_z_and_v / predict_start_from_z_and_v), then the usual DDIM combination."""
         if branches == 2:
             vu, vc = out[:x.shape[0]].contiguous(), out[x.shape[0]:].contiguous()
+            if vc.data_ptr() % 16:   # the conditional half is a slice: 16-byte aligned only when B*C*H*W % 4 == 0 (ops.lincomb takes 16-byte pointers)
+                vc = vc.clone()
             v = ops.lincomb([(vu, 1.0), (ops.lincomb([(vc, 1.0), (vu, -1.0)]), scale)])
         else:
             v = out.contiguous()

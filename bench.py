@@ -270,7 +270,9 @@ def main():
             "value": value, "unit": "edited-images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[1]: AnySD (SD-1.5 UNet in=8 + task embedding/expert adapters) 512x512 bf16, "
+            "config": {"workload": ("configs[1]: AnySD (SD-1.5 UNet in=8 + task embedding/expert adapters) 512x512 bf16, " if args.latent == 64 else
+                                    f"the denoising stage of configs[4] (local-edit path) at {8 * args.latent}x{8 * args.latent}: bf16 MFMA attention — the fp8 "
+                                    "attention kernel (ae_attn_fwd_fp8) exists for the SAM global blocks, is slower than bf16 and is NOT used; ") +
                                    f"{n_unet_steps} DDIM steps, batch={B}/GPU, 3-branch CFG (UNet batch {3 * B})",
                        "images_per_gpu": B, "ddim_steps": n_unet_steps, "cfg_branches": 3, "hip_graph": not args.no_graph,
                        "parallelism": f"dp{world} (image-sharded, no data-path collective)"},

@@ -35,8 +35,8 @@ def _threads():
 
 # ------------------------------------------------------------------------------------------------- dominant conv plan
 @pytest.mark.parametrize("B,H,W,Cin,Cout,ups", [(12, 64, 64, 320, 320, False), (12, 64, 64, 640, 320, False),
-                                                (12, 64, 64, 960, 320, False), (12, 32, 32, 1280, 1280, True),
-                                                (24, 64, 64, 320, 320, False)])
+                                                (12, 64, 64, 960, 320, False), (12, 32, 32, 640, 640, True),
+                                                (12, 16, 16, 1280, 1280, True), (24, 64, 64, 320, 320, False)])
 def test_conv3x3_bench_plan_vs_conv2d(B, H, W, Cin, Cout, ups):
     """The un-split 192x320 tile (bench.py's `roofline.kernel`) against fp32 F.conv2d on bf16-rounded operands."""
     from anyedit_amd import ops
@@ -229,3 +229,31 @@ def test_training_step_full_size_vs_oracle_autograd_with_control():
         assert math.isfinite(e_hip) and e_hip <= tol, f"grad {k}: HIP {e_hip:.3e} vs control {e_ctl:.3e}"
     assert worst > 0.0
     torch.cuda.empty_cache()
+
+
+def test_bench_under_the_drivers_launcher_one_rank():
+    """the first multi-GPU scaling run must not fail on plumbing.  This is the driver's own command line for N > 1
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`) with ONE rank
+    on RCCL: process-group init from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, the timing barriers, the MAX all-reduce and the all-gather
+    of the per-rank times, destroy — and ONE JSON line on rank 0 that carries the contract's keys."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--ddim-steps", "2",
+           "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert "per_rank_ms_per_step" in d and len(d["per_rank_ms_per_step"]["all"]) == 1

@@ -790,6 +790,48 @@ def test_linear_f32_exact(ops, M, N, K):
     check_close(out3.reshape(M, N), (x.double() @ w.double().t()).float(), rl2=2e-6, mabs=1e-5, what="linear_f32 no bias")
 
 
+def test_ms_deform_attn_module_backward_vs_oracle_autograd():
+    """gradients must flow THROUGH the module — its four projections run `ae_linear_f32` behind an autograd Function (dX, dW, db on
+    the same kernel) and the sampling core behind MultiScaleDeformableAttnFunction.  Every parameter's gradient and the gradients of query and
+    value against autograd through a CPU statement of the same module (F.linear + the oracle's differentiable sampling core, same weights)."""
+    from oracle import msda_ref as MS
+    from anyedit_amd.groundingdino.ms_deform_attn import MultiScaleDeformableAttention
+    gen = torch.Generator().manual_seed(9)
+    E, H, L, P, bs, nq = 64, 4, 3, 4, 2, 50
+    shapes = torch.tensor([(12, 16), (6, 8), (3, 4)], dtype=torch.long)
+    S = int(shapes.prod(1).sum())
+    start = torch.cat([shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]])
+    m = MultiScaleDeformableAttention(embed_dim=E, num_heads=H, num_levels=L, num_points=P, batch_first=True)
+    with torch.no_grad():   # the reference's initial state has zero offset / weight matrices: nothing would flow through them
+        for prm in m.parameters():
+            prm.copy_(torch.randn(prm.shape, generator=gen) * (0.05 if prm.dim() == 2 else 0.3))
+    query, value = torch.randn(bs, nq, E, generator=gen), torch.randn(bs, S, E, generator=gen)
+    ref2 = torch.rand(bs, nq, L, 2, generator=gen) * 0.8 + 0.1
+    go = torch.randn(bs, nq, E, generator=gen)
+    # CPU statement (autograd)
+    pc = {k: v.detach().clone().requires_grad_(True) for k, v in m.named_parameters()}
+    qc, vc = query.clone().requires_grad_(True), value.clone().requires_grad_(True)
+    v = F.linear(vc, pc["value_proj.weight"], pc["value_proj.bias"]).view(bs, S, H, E // H)
+    off = F.linear(qc, pc["sampling_offsets.weight"], pc["sampling_offsets.bias"]).view(bs, nq, H, L, P, 2)
+    w = F.linear(qc, pc["attention_weights.weight"], pc["attention_weights.bias"]).view(bs, nq, H, L * P).softmax(-1).view(bs, nq, H, L, P)
+    wh = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float()
+    loc = ref2[:, :, None, :, None, :] + off / wh[None, None, None, :, None, :]
+    outc = F.linear(MS.ms_deform_attn(v, shapes, start, loc, w), pc["output_proj.weight"], pc["output_proj.bias"])
+    outc.backward(go)
+    # HIP module
+    m = m.to(DEV)
+    qd, vd = query.to(DEV).requires_grad_(True), value.to(DEV).requires_grad_(True)
+    out = m(qd, value=vd, reference_points=ref2.to(DEV), spatial_shapes=shapes.to(DEV), level_start_index=start.to(DEV))
+    assert out.grad_fn is not None, "the module output must carry a grad_fn when its inputs / parameters require grad"
+    check_close(out.detach(), outc.detach(), rl2=2e-5, mabs=5e-5, what="MSDeformAttn module forward (random weights)")
+    out.backward(go.to(DEV))
+    check_close(qd.grad, qc.grad, rl2=2e-4, mabs=2e-4, what="MSDeformAttn module: query.grad")
+    check_close(vd.grad, vc.grad, rl2=2e-4, mabs=2e-4, what="MSDeformAttn module: value.grad")
+    for k, prm in m.named_parameters():
+        assert prm.grad is not None, k
+        check_close(prm.grad, pc[k].grad, rl2=2e-4, mabs=2e-4, what=f"MSDeformAttn module: {k}.grad")
+
+
 def test_ms_deform_attn_module_golden():
     """MultiScaleDeformableAttention mirror (state-dict compatible) vs the reference module's CPU output: 2-d and 4-d reference
     points, query_pos, key_padding_mask."""

@@ -187,7 +187,7 @@ def test_edit_pipeline_vs_oracle_loop_and_graph_replay():
                         s_txt=7.5, s_img=1.5, mask=mask.to(DEV), x0=x0.to(DEV))
         outs.append(out.cpu())
         assert np.array_equal(pipe.sampler.ddim_timesteps, S.make_ddim_timesteps("uniform", steps, 1000))
-        close(out, ref, rl2=8e-2, db=26.0, what=f"edit pipeline (graph={use_graph})")   # absolute cap
+        close(out, ref, rl2=8e-2, db=30.0, what=f"edit pipeline (graph={use_graph})")   # absolute cap (30 dB = north_star's bound)
         e_hip = rel_l2(out.float().cpu(), ref)
         assert e_hip <= 1.5 * e_ctl + 1e-3, f"edit pipeline: HIP {e_hip:.3e} vs bf16-storage control {e_ctl:.3e}"
     assert torch.equal(outs[0], outs[1]), "HIP-graph replay must reproduce the eager launches bit for bit"
@@ -305,6 +305,20 @@ def test_training_step_gradients_vs_oracle_autograd():
         trainer.optimizer_step(acc)
         assert trainer._micro == 0 and all(not torch.equal(before[k], trainer.params[k].detach()) for k in before)
         assert trainer.params["task_embs"]._version > v0, "optimizer steps must bump the parameter version (packed-weight caches key on it)"
+    # skipped step (overflow / NaN / gradient inspection): backward, NO optimizer step, zero_grad -> the next backward starts from zero
+    # (without zero_grad the second backward would add to the first one's sums — that accumulation is the documented contract)
+    trs = fresh()
+    _, ts1, ls1 = trs.forward_loss(*args)
+    g_first = {k: v.clone() for k, v in trs.backward(ts1, ls1).items()}
+    trs.zero_grad()
+    _, ts2, ls2 = trs.forward_loss(*args)
+    g_again = trs.backward(ts2, ls2)
+    for k in g_first:
+        assert torch.equal(g_again[k], g_first[k]), f"{k}: a skipped step followed by zero_grad must not leave stale sums"
+    _, ts3, ls3 = trs.forward_loss(*args)
+    g_twice = trs.backward(ts3, ls3)          # no zero_grad in between: accumulates (micro-batches)
+    k0 = "task_embs"
+    assert torch.equal(g_twice[k0], g_first[k0] + g_first[k0])
     try4 = fresh(always_exchange=True, bucket_bytes=1 << 12)
     _, t3, l3 = try4.forward_loss(*args)
     g3 = try4.backward(t3, l3)

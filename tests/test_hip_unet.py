@@ -131,7 +131,7 @@ def test_ddim_sampler_golden(tiny_unet):
                                         unconditional_conditioning=uncond if scale != 1.0 else None, log_every_t=1, **kw)
         assert np.array_equal(sampler.ddim_timesteps, g[f"{tag}.ddim_timesteps"])      # integer bookkeeping: bit-exact
         assert len(inter["x_inter"]) == g[f"{tag}.x_inter"].shape[0]
-        close(samples, g[f"{tag}.samples"], rl2=tol, db=26.0, what=f"DDIM {tag}")       # absolute cap (CFG amplifies bf16 noise x7.5)
+        close(samples, g[f"{tag}.samples"], rl2=tol, db=30.0, what=f"DDIM {tag}")       # absolute cap = north_star's "1e-3 PSNR-equivalent" (MSE / peak^2 <= 1e-3 <=> 30 dB); the derived bound below is what binds
         if not use_mask:
             # derived bound: the same sampler run of the oracle with bf16 STORAGE of activations / weights (fp32 arithmetic) is the
             # error any bf16-activation implementation must carry; the HIP path may add at most half of it again
@@ -480,7 +480,7 @@ def test_dpm_solver_tiny_unet_vs_oracle(tiny_unet):
     cpu = lambda c: {k: [v.cpu() for v in vs] for k, vs in c.items()}
     ac = S.register_schedule("linear", 1000, 0.00085, 0.0120)["alphas_cumprod"].float()
     ref = P.multistep_sample(apply_model, ac, T(g["x_T"]), 12, cpu(cond), cpu(uncond), 5.0)
-    close(samples, ref, rl2=6e-2, db=26.0, what="DPM-Solver++ 2M, 12 steps, tiny UNet")
+    close(samples, ref, rl2=6e-2, db=30.0, what="DPM-Solver++ 2M, 12 steps, tiny UNet")
 
 
 def test_unet_sd2_options_golden():
