@@ -1318,6 +1318,9 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // step 17.31 -> 17.22 ms.  A fourth stage adds nothing.  The same ring on grids with MORE than one block per CU loses (it evicts the
     // second resident block: SAM M = 4096 x N = 1280 x K = 5120 with 320 blocks 90 -> 109 us), as does a 256x128 tile under it
     // (M = 4096 x N = 5120: 93 -> 112 us).  AE_GEMM_DEEP=0 turns it off.
+    // (Round 4: the ping-pong loop on a 256x128 tile — 11.4 KiB of LDS-DMA per MFLOP against 15.6 for 128x128 — was instantiated for the 32x32-level
+    // launches and measured in the lab: convs 96.3 / 299.5 us against 94.8 / 293.0 for the two-blocks-per-CU 128x128 kernel, ff2 40.3 vs 43.4, qkv 44.0
+    // vs 41.2 (profiles/r04_v17_pp256x128_experiment.txt): its 16-MFMA intervals are too short for the two barriers each costs.  Not kept.)
     static const int deep_pref = getenv("AE_GEMM_DEEP") ? atoi(getenv("AE_GEMM_DEEP")) : 1;
     if (!done && deep_pref && !conv && glds && a.splitk <= 1 && a.epi != EPI_GEGLU && a.N % 128 == 0 && a.K >= 1280) {
         const long t128 = (long)((a.M + 127) / 128) * (a.N / 128);

@@ -114,6 +114,14 @@ int main(int argc, char** argv) {
     conv(12, 64, 960, 320, 1, "conv L1 960->320 @64 kmajor");
     conv(12, 16, 1280, 1280, 0, "conv L3 1280->1280 @16 splitK");
     dense(49152, 320, 1280, EPI_NONE, "gemm ff2 L1 49152x320x1280");
+    if (argc > 1 && argv[1][0] == 'm') {   // the 32x32-level shapes (128x128 tile today)
+        conv(12, 32, 640, 640, 0, "conv L2 640->640 @32");
+        conv(12, 32, 1920, 640, 0, "conv L2 1920->640 @32");
+        dense(12288, 640, 2560, EPI_NONE, "gemm ff2 L2 12288x640x2560");
+        dense(12288, 1920, 640, EPI_NONE, "gemm qkv L2 12288x1920x640");
+        dense(12288, 640, 640, EPI_NONE, "gemm proj L2 12288x640x640");
+        return 0;
+    }
     if (all) {
         conv(12, 16, 2560, 1280, 0, "conv L3 2560->1280 @16 splitK");
         dense(12288, 5120, 640, EPI_GEGLU, "gemm ff1 L2 geglu 12288x5120x640");
