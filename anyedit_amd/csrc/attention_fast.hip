@@ -91,9 +91,14 @@ __device__ unsigned long long g_attn_dbg[4];  // lab only: sum of per-block shad
 // launch fits three tile buffers (two text tiles + one second-segment tile).  They are copied ONCE per block by one LDS-DMA burst
 // behind one barrier, and the block then walks p.ng groups of 128 queries over them — no per-tile DMA round trip, no per-tile
 // barrier, a quarter of the blocks (the 64x64 level: 3072 blocks in four rounds -> 768 blocks in one).
-template <int D, int OCC, bool SEG2 = false, int ABL = 0, int BIAS = 0, int QG = 1, bool VSPLIT = false, bool SKV = false>
-__global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
-    static_assert(!SKV || (QG == 1 && BIAS == 0 && !VSPLIT), "short-K/V variant: one query group per wave, no bias, row-major V image");
+// NWV / SKT (round 4): waves per block and resident tile buffers of the short-K/V form.  SAM's 14 x 14 windows (196 queries = keys, head dim 80, the
+// small-grid rel-pos bias) run it with NWV = 7 (224 query slots: one block per (window, head)) and SKT = 4: the window's 196 keys land by ONE LDS-DMA
+// burst behind one barrier, where the tiled form pays a DMA round trip and a barrier per 64-key tile and loads the keys once per 128-query block.
+template <int D, int OCC, bool SEG2 = false, int ABL = 0, int BIAS = 0, int QG = 1, bool VSPLIT = false, bool SKV = false, int NWV = 4, int SKT = 3>
+__global__ __launch_bounds__(64 * NWV, OCC) void attn_fast_kernel(const AttnArgs p) {
+    static_assert(!SKV || (QG == 1 && BIAS != 2 && !VSPLIT), "short-K/V variant: one query group per wave, no row-per-tile bias, row-major V image");
+    static_assert(NWV == 4 || (SKV && !SEG2), "other wave counts exist for the short-K/V form only");
+    static_assert(!SEG2 || SKT >= 3, "the second segment's tile sits in buffer 2");
     static_assert(D % 8 == 0 && (D <= 96 || D == 160), "head_dim: multiple of 8, <= 96, or 160");
     static_assert(QG == 1 || QG == 2, "one or two 32-query groups per wave");
     static_assert(BIAS == 0 || QG == 1, "the rel-pos variants keep one query group per wave");
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     constexpr int CH = D / 8;                // 16-byte chunks per row = 1-KiB DMA pieces per 64-row tile
     constexpr int TILEB = FKT * ROWB;
     constexpr int BUFB = 2 * TILEB;          // K tile then V tile
-    constexpr int NTB = SKV ? 3 : 2;         // tile buffers (SKV: text tiles 0 / 1 + the second segment's tile)
+    constexpr int NTB = SKV ? SKT : 2;       // tile buffers (SKV: text tiles 0 / 1 + the second segment's tile; SAM windows: four tiles of keys)
     constexpr int ONES_OFF = NTB * BUFB;     // "ones tile": 64 rows of ROWB bytes, each starting with bf16 {1,0,0,0,0,0,0,0}
     constexpr int NFULL = D / 32, REM = D % 32;          // VSPLIT: full 32-wide d-blocks, remainder columns
     constexpr int RS = REM * 2 > 16 ? REM * 2 : 16;      // VSPLIT: row bytes of the remainder image (and of its ones tile)
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     constexpr int VONES_OFF = ONES_OFF + TILEB + 64;     // VSPLIT: ones tile with the remainder image's row stride
     constexpr int LDSB = VSPLIT ? VONES_OFF + 64 * RS : ONES_OFF + TILEB + 64;
     constexpr int NPIECE = 2 * CH;
-    constexpr int MAXP = (NPIECE + 3) / 4;
+    constexpr int MAXP = (NPIECE + NWV - 1) / NWV;
 
     __shared__ __attribute__((aligned(16))) char smem[LDSB];
 
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5, l15 = lane & 15, g = lane >> 4;
-    constexpr int QB = 128 * QG;
+    constexpr int QB = 32 * NWV * QG;
     const int nqb = SKV ? (p.Nq + QB * p.ng - 1) / (QB * p.ng) : (p.Nq + QB - 1) / QB;
     const int vb = xcd_remap(blockIdx.x, nqb * p.B * p.H);
     const int bh = vb / nqb, qb = vb - bh * nqb;
@@ -175,12 +180,45 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     //         2 x 16 key columns stays in registers, rel_h[q, kh] is one value per tile — one v_add per logit, no index arithmetic;
     // BIAS 1: small key grids (kH, kW <= 16: SAM's 14 x 14 windows): the block's rows of both tables sit in LDS (times log2e),
     //         every logit looks up rel_h[q, key / kW] + rel_w[q, key % kW].
-    constexpr bool BIAS2 = BIAS == 2, BIAS1 = BIAS == 1;
+    constexpr bool BIAS2 = BIAS == 2, BIAS1 = BIAS == 1, BIAS3 = BIAS == 3;
+    // BIAS 3 (round 4, SAM windows): the small-grid bias as TWO MORE K STEPS of the S^T MFMA chain.  rel_h[q, kh] + rel_w[q, kw] is an inner
+    //         product of the query's 32-vector (rel_h[q, 0..15], rel_w[q, 0..15]) with a one-hot vector of the key (1 at kh and at 16 + kw): the key
+    //         side is a table in LDS (64 bytes per key, the same for every window and head), the query side two operand registers per wave.
+    //         BIAS 1 spends ~10 VALU / LDS operations per logit on the (kh, kw) index arithmetic and the two look-ups — the windowed launches were
+    //         bound by that, not by their DMA round trips (resident keys alone: 48 vs 49 us, profiles/r04_v19_sam_win.txt).  The bias rides in
+    //         bf16 here (rel-pos values are O(1): 2^-9 relative, the rounding the logits' own q and k operands carry).
+    static_assert(!BIAS3 || (SKV && NTB * FKT * 64 <= 65536), "bias-as-K-steps exists in the resident-keys form");
+    __shared__ __attribute__((aligned(16))) char skhot[BIAS3 ? NTB * FKT * 64 : 16];
+    u32x4 qrel[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    if (BIAS3) {
+        // key table: row `key` = bf16 one-hot of kh in columns 0..15 and of kw in columns 16..31 (zero rows past Nk)
+        for (int i = tid; i < NTB * FKT * 4; i += 64 * NWV) {
+            const int key = i >> 2, c4 = i & 3;                   // 16-byte chunk c4 of the row: columns 8 c4 .. 8 c4 + 7
+            const int kh = key / p.kW, kw = key - kh * p.kW;
+            const int hot = key < p.Nk ? (c4 < 2 ? kh : 16 + kw) - 8 * c4 : -1;   // position of the 1 inside this chunk, if any
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (hot >= 0 && hot < 8) {
+                const uint32_t one = (hot & 1) ? 0x3F800000u : 0x00003F80u;
+                if ((hot >> 1) == 0) v.x = one; else if ((hot >> 1) == 1) v.y = one; else if ((hot >> 1) == 2) v.z = one; else v.w = one;
+            }
+            *reinterpret_cast<u32x4*>(skhot + key * 64 + c4 * 16) = v;
+        }
+        // query side: lane (q = l31, hi) holds rel_h[q, 8 hi .. 8 hi + 7] (step 0) and rel_w[q, 8 hi .. + 7] (step 1), times log2(e)
+        const long qc = (long)bh * p.Nq + min(q0 + l31, p.Nq - 1);
+        float rh[8], rw[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            rh[e] = (8 * hi + e < p.kH) ? p.rel_h[qc * p.kH + 8 * hi + e] * FLOG2E : 0.f;
+            rw[e] = (8 * hi + e < p.kW) ? p.rel_w[qc * p.kW + 8 * hi + e] * FLOG2E : 0.f;
+        }
+        qrel[0] = (u32x4){pack_bf16x2(rh[0], rh[1]), pack_bf16x2(rh[2], rh[3]), pack_bf16x2(rh[4], rh[5]), pack_bf16x2(rh[6], rh[7])};
+        qrel[1] = (u32x4){pack_bf16x2(rw[0], rw[1]), pack_bf16x2(rw[2], rw[3]), pack_bf16x2(rw[4], rw[5]), pack_bf16x2(rw[6], rw[7])};
+    }
     static_assert(BIAS == 0 || (!QSLOT && !SEG2), "the rel-pos variants are built for head dims that are multiples of 16, one segment");
-    __shared__ float sbias[BIAS1 ? 128 * 33 : 1];  // row stride 33: lanes (= queries) reading one column hit 32 different banks
+    __shared__ float sbias[BIAS1 ? 32 * NWV * 33 : 1];  // row stride 33: lanes (= queries) reading one column hit 32 different banks
     const float inv_kw = BIAS1 ? 1.0f / (float)p.kW : 0.f;
     if (BIAS1) {
-        for (int i = tid; i < 128 * 32; i += 256) {
+        for (int i = tid; i < 32 * NWV * 32; i += 64 * NWV) {
             const int ql = i >> 5, j = i & 31;
             const long qc = (long)bh * p.Nq + min(qb * QB + ql, p.Nq - 1);
             float v = 0.f;
@@ -218,7 +256,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     }
 
     int seg_nk = p.Nk;
-    int kcur = 0, klast = 0, vcur = 0, vlast = 0;
+    int kcur = 0, klast = 0, vcur = 0, vlast = 0, khot_row = 0;
 
     u32x4 hold[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};  // QG = 2: ALL P registers of the previous block's last K-step (see the end of block())
     // The same exposure exists for SrcA (round 4, found by reading the listing: tools/isa_audit.py::mfma_source_overwrites — hipcc reused a V
@@ -281,6 +319,16 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
                     }
                 }
                 retire_src(kf);
+            }
+            if (BIAS3) {
+                // (tile buffer index = kcur's buffer: the key row inside the resident image is buffer * 64 + B2 * 32 + l31)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const bf16x8_t hf = as_bf16x8(*reinterpret_cast<const u32x4*>(skhot + (khot_row + B2 * 32) * 64 + hi * 16 + kb * 32));
+#pragma unroll
+                    for (int gq = 0; gq < QG; ++gq) s[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf, as_bf16x8(qrel[kb]), s[gq], 0, 0, 0);
+                    retire_src(hf);
+                }
             }
             // the P registers of the previous block's last K-step (`hold`) are free from here on: six more MFMAs are in the pipe behind
             // the one that read them
@@ -395,6 +443,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     // one 64-key tile sitting in tile buffer `buf`: LDS read addresses, then its one or two 32-key blocks
     auto tile = [&](int t, int buf) {
         const int boff = buf * BUFB;
+        khot_row = buf * FKT + l31;
         kcur = kaddr + boff;
         klast = (QSLOT && hi) ? ONES_OFF + l31 * ROWB : kcur + (KS - 1) * 32;
         vcur = vaddr + boff;
@@ -469,7 +518,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
     };
 
     for (int seg = 0; seg < NSEG; ++seg) {
-        // ---- LDS-DMA plan: piece j of a tile (K pieces 0..CH-1, V pieces CH..2CH-1) is issued by wave j % 4
+        // ---- LDS-DMA plan: piece j of a tile (K pieces 0..CH-1, V pieces CH..2CH-1) is issued by wave j % NWV
         const bf16_t* kp = seg == 0 ? p.k + (long)b * p.k_sb + (long)h * p.k_sh : p.k2 + (long)b * p.k2_sb + (long)h * p.k2_sh;
         const bf16_t* vp = seg == 0 ? p.v + (long)b * p.v_sb + (long)h * p.v_sh : p.v2 + (long)b * p.v2_sb + (long)h * p.v2_sh;
         seg_nk = seg == 0 ? p.Nk : p.Nk2;
@@ -480,7 +529,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
         int voff[MAXP];
 #pragma unroll
         for (int i = 0; i < MAXP; ++i) {
-            const int j = wave + 4 * i;
+            const int j = wave + NWV * i;
             const bool isK = j < CH;
             const int cidx = (isK ? j : j - CH) * 64 + lane;
             int row = cidx / CH, cc = cidx - row * CH;
@@ -494,7 +543,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
             const int boff = lds0 + buf * BUFB;
 #pragma unroll
             for (int i = 0; i < MAXP; ++i) {
-                const int j = wave + 4 * i;
+                const int j = wave + NWV * i;
                 if (j < NPIECE) {
                     if (j < CH) dma16(rsK, boff + j * 1024, voff[i] + t * FKT * ksn2);
                     else dma16(rsV, boff + TILEB + (j - CH) * 1024, voff[i] + t * FKT * vsn2);
@@ -526,7 +575,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
         u32x4 qraw[KS];  // the NEXT group's Q rows, in flight while this group is computed
         for (int gi = 0; gi < p.ng; ++gi) {
             if (gi) {  // next 128-query group of the block: new Q operand, fresh softmax state
-                q0 += 128;
+                q0 += 32 * NWV;
                 if (q0 - wave * 32 >= p.Nq) break;  // block-uniform: the group lies past the last query
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
@@ -545,7 +594,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fast_kernel(const AttnArgs p) {
                 for (int r = 0; r < 16; ++r) cinit[0][r] = 0.f;
             }
             if (gi + 1 < p.ng) {  // (rows past Nq are clamped; their group is never computed)
-                const int qrow = min(q0 + 128 + l31, p.Nq - 1);
+                const int qrow = min(q0 + 32 * NWV + l31, p.Nq - 1);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const int d0 = 16 * ks + 8 * hi;
@@ -587,6 +636,19 @@ int launch_fast(const AttnArgs& a, hipStream_t stream) {
 #endif
     if constexpr (D % 16 == 0) {
         if (a.rel_h) {
+            // SAM windows (kH, kW <= 16; 196 tokens): one block of seven waves per (window, head), every key resident after one LDS-DMA burst, the
+            // rel-pos bias as two more K steps of the logit MFMA chain (BIAS 3).  ViT-H encoder, 28 windowed blocks: 49 -> 29 us per launch, encoder
+            // 11.35 -> 10.80 ms (profiles/r04_v19_sam_win.txt; resident keys with the look-up bias of BIAS 1 measured 48 us: the look-ups were the
+            // bound).  Tuning knob AE_ATTN_WIN=0: the tiled look-up form.
+            static const int win_env = getenv("AE_ATTN_WIN") ? atoi(getenv("AE_ATTN_WIN")) : 1;
+            if constexpr (D <= 96) {
+                if (win_env && a.kW != FKT && a.Nq <= 224 && a.Nk <= 4 * FKT) {
+                    AttnArgs b = a;
+                    b.ng = 1;
+                    hipLaunchKernelGGL((attn_fast_kernel<D, 2, false, 0, 3, 1, false, true, 7, 4>), dim3((unsigned)((long)a.B * a.H)), dim3(448), 0, stream, b);
+                    return ae_check_launch("ae_attn_fwd_bf16(fast, rel-pos, resident keys)");
+                }
+            }
             if (a.kW == FKT) hipLaunchKernelGGL((attn_fast_kernel<D, 2, false, 0, 2>), grid, block, 0, stream, a);
             else hipLaunchKernelGGL((attn_fast_kernel<D, 2, false, 0, 1>), grid, block, 0, stream, a);
             return ae_check_launch("ae_attn_fwd_bf16(fast, rel-pos)");
