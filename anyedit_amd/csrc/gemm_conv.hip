@@ -25,9 +25,6 @@ namespace {
 #ifndef AE_CONV_SPEC
 #define AE_CONV_SPEC 1   // round 4: on (prepared in round 3, measured at the start of round 4: 40 checksums identical, UNet step 13.47 -> 13.44 ms over three alternating runs, profiles/r04_v2_cspec_ab.txt)
 #endif
-#ifndef AE_GEMM_AA_DEFAULT
-#define AE_GEMM_AA_DEFAULT 3
-#endif
 #ifndef AE_GEMM_WA_DEFAULT
 #define AE_GEMM_WA_DEFAULT 3
 #endif
@@ -1226,18 +1223,14 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // weight rotated through a pool larger than the Infinity Cache 113.4 -> 89.6 us; 1920 -> 640: 327 -> 251 us; in situ 126 -> 96 us;
     // UNet step 14.70 -> 14.33 ms (two runs each way, one box).  Default on for both.
     static const int wa = getenv("AE_GEMM_WA") ? atoi(getenv("AE_GEMM_WA")) : AE_GEMM_WA_DEFAULT;
-    // tuning knob (bit flags): ACTIVATIONS two tiles ahead on the 192x320 tile (three A stages + two W stages = 152 KiB) — 1 dense non-GEGLU
-    // (the 64x64-level ff2: A = the 126 MB GEGLU output, straight from HBM: 70.8 -> 63.0 us in situ), 2 un-split convs without upsampling
-    // (100.9 vs 103.1 us, 173.5 vs 177.5: the counted-wait loop instead of the per-step drain), 4 split-K convs (105 -> 102.6 us; off: one
-    // more instantiation for 0.02 ms).  The GEGLU form (4 x 2 waves) spills and is not instantiated.  The first measurement of the conv
-    // forms was 20 % SLOWER: out of line, the loader lambdas kept ld_tap / ld_ci in scratch memory, and hipcc waits vmcnt(0) for every
-    // scratch load — the DMA queue drained once per step (profiles/r03_v30_weights_ahead.txt).
+    // (Round 3's activations-ahead loop on the 192x320 tile — three A stages, the round-3 default for its dense / un-split conv launches: ff2 of the
+    // 64x64 level 70.8 -> 63.0 us in situ — is superseded by the ping-pong loop below, which keeps its LDS layout (three A stages + two W stages =
+    // 152 KiB); its instantiations and the AE_GEMM_AA knob are gone, the loop itself remains as the weights-ahead form of the 128x128 kernel.)
 #ifdef AE_GEMM_TRACE
     auto lds_aa = [](int bm, int bn) { return (size_t)(3 * bm + 2 * bn) * BK * sizeof(bf16_t) + 8192; };   // + the trace area
 #else
     auto lds_aa = [](int bm, int bn) { return (size_t)(3 * bm + 2 * bn) * BK * sizeof(bf16_t); };
 #endif
-    static const int aa = getenv("AE_GEMM_AA") ? atoi(getenv("AE_GEMM_AA")) : AE_GEMM_AA_DEFAULT;
     // tuning knob (bit flags): the ping-pong main loop (WA = 3, round 4) on the 192x320 tile — 1 un-split convs, 2 split-K convs, 4 dense non-GEGLU,
     // 8 GEGLU (4 x 2 waves).  Same LDS footprint as the activations-ahead loop (three A stages + two W stages).
     static const int pp = getenv("AE_GEMM_PP") ? atoi(getenv("AE_GEMM_PP")) : AE_GEMM_PP_DEFAULT;
@@ -1266,7 +1259,6 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     if (conv && a.splitk > 1 && glds && make_plan(a.M, a.N, a.K, true).tile == 4) {  // split-K under the 192x320 tile (make_plan)
         const long t = (long)(a.M / 192) * (a.N / 320) * a.splitk;
         if ((pp & 2) && !a.ups) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); }
-        else if ((aa & 4) && !a.ups && (!AE_CONV_SPEC || a.kmajor)) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); }
         else rc = launch_kernel(gemm_kernel<192, 320, AMODE, 2, 4, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
         done = true;
     }
@@ -1287,15 +1279,8 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
             } else if (!conv && (pp & 4)) {
                 if constexpr (AMODE == A_DENSE) rc = launch_kernel(gemm_kernel<192, 320, A_DENSE, 2, 4, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
             } else if (cs_epi_ok && AMODE == A_CONV3) {
-                if constexpr (AMODE == A_CONV3) {
-                    if ((aa & 2) && !a.ups && (!AE_CONV_SPEC || a.kmajor)) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
-                    else rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
-                }
+                if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
                 cs_done = true;
-            } else if (conv && (aa & 2) && !a.ups && (!AE_CONV_SPEC || a.kmajor)) {
-                if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
-            } else if (!conv && (aa & 1)) {
-                if constexpr (AMODE == A_DENSE) rc = launch_kernel(gemm_kernel<192, 320, A_DENSE, 2, 4, true, 1, 2, false, 0, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
             }
 #ifdef AE_GEMM_ABLATE
             else if (conv && lab_abl == 1) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 1>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what); }

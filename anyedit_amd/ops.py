@@ -98,7 +98,7 @@ def pack_conv3x3(w, cin_pad=None, k_order=0):
     return wp.reshape(cout, 9 * cin_pad).contiguous()
 
 
-_CONV_KMAJOR = int(os.environ.get("AE_CONV_KMAJOR", "1"))  # tuning knob: 0 off, 1 un-split 192x320 plan, 2 + its split-K form, 3 every eligible conv, 4 un-split 192x320 and 128x128 plans
+_CONV_KMAJOR = int(os.environ.get("AE_CONV_KMAJOR", "2"))  # tuning knob: 0 off, 1 un-split 192x320 plan, 2 + its split-K form, 3 every eligible conv, 4 un-split 192x320 and 128x128 plans
 
 
 def conv_k_order(M, Cin, Cout, stride=1, upsample2x=False):
