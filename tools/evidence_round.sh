@@ -6,14 +6,16 @@ set -u
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
 R=$PWD; OUT=$R/gpurun_out; mkdir -p $OUT
 ( timeout 600 python -c "import __graft_entry__ as g; g.build(); g.smoke()" ) > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/smoke.log
-( timeout 900 python -m pytest tests -m gpu -q -s -p no:cacheprovider --durations=8 ) > $OUT/pytest_gpu_full.log 2>&1; echo "pytest rc=$?"
+# AE_TEST_EDIT_CONTROL=1: the 96x96 5-step edit test runs its bf16-storage control for real (+5 minutes of host time)
+( AE_TEST_EDIT_CONTROL=${AE_TEST_EDIT_CONTROL:-1} timeout 1800 python -m pytest tests -m gpu -q -s -p no:cacheprovider --durations=8 ) > $OUT/pytest_gpu_full.log 2>&1; echo "pytest rc=$?"
 grep -E "passed|failed|rel-L2|slowest|s call" $OUT/pytest_gpu_full.log | tail -20
 E2E=""; [ "${AE_EVIDENCE_CPU_E2E:-0}" = "1" ] && E2E="--cpu-e2e"
 # power / clock samples while the bench runs (the driver's own smi.*.json are not visible to the builder)
 ( rocm-smi --showmaxpower --showpower --showclocks 2>&1 | head -60 ) > $OUT/smi_idle.txt
 ( while true; do date +%s.%N; rocm-smi --showpower --showclocks --showuse --json 2>/dev/null; sleep 0.2; done ) > $OUT/smi_bench.jsonl &
 SMI=$!
-( timeout 900 python bench.py --steps 10 --warmup 2 --cpu-ops $E2E ) > $OUT/bench_full.json 2> $OUT/bench_full.err; echo "bench rc=$?"; cut -c1-400 $OUT/bench_full.json
+( timeout 1500 python bench.py --steps 10 --warmup 2 --cpu-ops $E2E ) > $OUT/bench_full.json 2> $OUT/bench_full.err; echo "bench rc=$?"; cut -c1-400 $OUT/bench_full.json
+( timeout 300 python bench.py ) > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "default bench rc=$?"; cut -c1-300 $OUT/bench_default.json
 kill $SMI 2>/dev/null; wait $SMI 2>/dev/null
 python - $OUT/smi_bench.jsonl $OUT/smi_during_bench.json <<'PY'
 import json, sys
