@@ -1271,7 +1271,9 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         if (fill >= 0.85) {
             if (a.epi == EPI_GEGLU && (pp & 8)) { if constexpr (AMODE == A_DENSE) rc = launch_kernel(gemm_kernel<192, 320, A_DENSE, 4, 2, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); }
             else if (a.epi == EPI_GEGLU) rc = launch_kernel(gemm_kernel<192, 320, AMODE, 4, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
-            else if (conv && (pp & 1) && !a.ups) {   // (the nearest-x2 gather's per-piece address arithmetic measured 283 vs 273 us under the first form of the ping-pong loop and is not instantiated)
+            else if (conv && (pp & 1) && !a.ups) {   // (the nearest-x2 gather: its per-piece address arithmetic measured 283 vs 273 us under the first form of the ping-pong loop; a second attempt with
+                                                     //  per-piece row / column offset tables — source pixel = virtual pixel >> 1 is not linear in the tap — measured 409 vs 330 us (hipcc kept the
+                                                     //  tables in scratch memory, profiles/r04_v23_ups_pp.txt).  Two launches per evaluation; they stay on the round-3 loop.)
                 if constexpr (AMODE == A_CONV3) {
                     if (cs_epi_ok) { rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); cs_done = true; }
                     else rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
