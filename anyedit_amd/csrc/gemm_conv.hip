@@ -66,6 +66,17 @@ struct GemmArgs {
                      // tiles, so that a block's activation window (~40 KB) is re-read from L2, not from the MALL (weights packed to match)
     int m_fast;      // tile order inside an XCD's run: 1 = M tiles fastest (tiles sharing a WEIGHT panel are neighbours: small-M layers whose
                      // weights outweigh the activations), 0 = N tiles fastest (tiles sharing an ACTIVATION panel are neighbours)
+    // LayerNorm folded into the GEMM that consumes it (round 4; attention.py:271-275's norm -> projection pairs of the 32x32 / 16x16 levels):
+    //   LN(x) W^T + b = rstd_m (x W'^T - mu_m s) + c   with  W' = W diag(gamma),  s[n] = sum_k W'[n][k],  c = W beta + b,
+    // so the consumer multiplies the UN-normalised rows and its epilogue applies two per-row scalars and two per-column vectors; the
+    // row sums come from the epilogue of the GEMM that PRODUCED x (proj_in, attn1.to_out, attn2.to_out), as one (sum, sum of squares)
+    // pair per row and 64-column slice (XE instantiations below) — the LayerNorm launch, its read of x and its write of LN(x) vanish.
+    int xe;                  // 0 none, 1 this launch EMITS the row statistics of its bf16 output, 2 this launch CONSUMES them (LayerNorm fold)
+    float* rowstats;         // xe 1: [M][N / 64][2] fp32 (sum, sum of squares) of the bf16-rounded output over each 64-column slice of a row
+    const float* ln_stats;   // xe 2: [M][ln_parts][2] fp32, the row statistics of A as its producer emitted them
+    const float* ln_colsum;  // xe 2: [N] fp32, s[n] = sum_k W'[n][k] over the bf16 values of W' (what the MFMA multiplies); `bias` holds c
+    int ln_parts;
+    float ln_eps;
 };
 
 // LDS-DMA: one wave moves 64 x 16 B from global straight into LDS at (wave-uniform dst) + lane*16.  The builtin exists only
@@ -122,8 +133,12 @@ constexpr int epilogue_passes(int FM, int bytes_per_frag_row, int lds_bytes) {
 // (activations two tiles ahead); counted vmcnt + raw s_barrier instead of the per-step drain, unrolled by six so that every stage index is a
 // constant.  See the comment at the loop, DESIGN.md §7a and profiles/r03_v30_weights_ahead.txt.
 // LAB (AE_GEMM_LAB builds only, tools/ubench): 1 = no DMA after the first tile, 2 = no LDS reads / MFMAs, 3 = MFMAs on stale registers (no LDS reads)
-template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false, int WAVES_K = 1, int STAGES = 2, bool CS = false, int LAB = 0, int WA = 0>
+// XE (round 4): 1 = the epilogue also emits per-row (sum, sum of squares) of its bf16 output per 64-column slice (GemmArgs::rowstats), 2 = the
+// epilogue applies the LayerNorm fold from such statistics of A (GemmArgs::ln_stats / ln_colsum).  XE = 0 instantiations are unchanged code.
+template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false, int WAVES_K = 1, int STAGES = 2, bool CS = false, int LAB = 0, int WA = 0, int XE = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(const GemmArgs p) {
+    static_assert(XE == 0 || (AMODE == A_DENSE && WAVES_K == 1 && !CS && GLDS), "row statistics / LayerNorm fold: dense LDS-DMA instantiations, one K group, no column statistics");
+    static_assert(XE != 1 || BN / WAVES_N == 64, "row statistics are emitted per 64-column slice = one wave tile's width");
     static_assert(STAGES == 2 || (GLDS && WAVES_K == 1), "the deep LDS ring exists only for the LDS-DMA loader");
     static_assert(!WA || (GLDS && STAGES == 2 && WAVES_K == 1), "operand-ahead is a variant of the two-stage LDS-DMA pipeline");
     static_assert(WA >= 0 && WA <= 3, "WA: 0 none, 1 weights two tiles ahead (three W stages), 2 activations two tiles ahead (three A stages), 3 ping-pong (two wave groups one barrier apart)");
@@ -342,6 +357,30 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // XE 2: rstd and -rstd * mean of this lane's row in each 16-row fragment, from the producer's per-slice sums.  Loaded HERE, in front of the main
+    // loop (two registers per fragment row live through it), so the epilogue does not start with a dependent L2 round trip.  The four lane groups
+    // of a row (lg) take every fourth slice and meet through two cross-lane adds: (s0 + s1) + (s2 + s3) in every lane, a fixed order.
+    float ln_r[XE == 2 ? FM : 1], ln_t[XE == 2 ? FM : 1];
+    if constexpr (XE == 2) {
+        const float inv_k = 1.0f / (float)p.K;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = min(m0 + wm * WM + i * 16 + l15, p.M - 1);
+            const f32x2* sp = reinterpret_cast<const f32x2*>(p.ln_stats) + (long)m * p.ln_parts;
+            float s = 0.f, q = 0.f;
+            for (int t = lg; t < p.ln_parts; t += 4) {
+                const f32x2 v = sp[t];
+                s += v[0]; q += v[1];
+            }
+            s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+            s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+            const float mu = s * inv_k;
+            const float r = rsqrtf(fmaxf(q * inv_k - mu * mu, 0.f) + p.ln_eps);
+            ln_r[i] = r;
+            ln_t[i] = -r * mu;
+        }
+    }
 
     auto compute_tile = [&](int cur, int curB = -1) __attribute__((always_inline)) {
         if (LAB == 2) return;
@@ -805,16 +844,42 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
             const bool av_v4 = (reinterpret_cast<uintptr_t>(p.addvec) & 15) == 0 && (p.ldav & 3) == 0;
             int ncol[FN];
             f32x4 bz[FN];
+            // XE 2: s of this lane's 4 columns per fragment (bz holds c; both 16-byte aligned: checked by the launcher).  The 192x320 tile has no
+            // registers for 2 x 40 of them beside its 120 accumulators (hipcc spilled 275): there the block's s and c sit in LDS, behind the
+            // staging area (which never reaches past STAGES * (BM + BN) * BK * 2 bytes = 128 KiB of the ping-pong loop's 152), and are read at their use.
+            constexpr bool SC_LDS = XE == 2 && WA == 3;
+            static_assert(!SC_LDS || (BN % 4 == 0 && (3 * BM + 2 * BN) * BK * 2 >= STAGES * (BM + BN) * BK * 2 + 2 * BN * 4), "s / c of the block must fit behind the staging area");
+            float* const sc_lds = reinterpret_cast<float*>(smem_raw + STAGES * (BM + BN) * BK * 2);   // [2][BN]: s, then c
+            f32x4 sz[(XE == 2 && !SC_LDS) ? FN : 1];
+            if constexpr (SC_LDS) {
+                for (int t = tid; t < BN / 4; t += NT) {
+                    const int n = min(n0 + 4 * t, p.N - 4);
+                    reinterpret_cast<f32x4*>(sc_lds)[t] = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
+                    reinterpret_cast<f32x4*>(sc_lds + BN)[t] = *reinterpret_cast<const f32x4*>(p.bias + n);
+                }
+                __syncthreads();
+            }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 if (geglu) ncol[j] = min(n0 + wn * WN + (j & ~1) * 16 + lg * 4, p.N - 20) + (j & 1) * 16;   // 'a' rows, gate rows at +16
                 else ncol[j] = min(n0 + wn * WN + j * 16 + lg * 4, p.N - 4);
                 bz[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (p.bias) {
+                if (!SC_LDS && p.bias) {
                     if (bias_v4) bz[j] = *reinterpret_cast<const f32x4*>(p.bias + ncol[j]);
                     else bz[j] = (f32x4){p.bias[ncol[j]], p.bias[ncol[j] + 1], p.bias[ncol[j] + 2], p.bias[ncol[j] + 3]};
                 }
+                if constexpr (XE == 2 && !SC_LDS) sz[j] = *reinterpret_cast<const f32x4*>(p.ln_colsum + ncol[j]);
             }
+            // XE 2: (s, c) of fragment j's four columns (local column wn * WN + 16 j + 4 lg in either packing: (j & ~1) * 16 + (j & 1) * 16 = 16 j)
+            auto ln_sc = [&](int j, f32x4& sj, f32x4& cj) __attribute__((always_inline)) {
+                if constexpr (SC_LDS) {
+                    const int col = wn * WN + j * 16 + lg * 4;
+                    sj = *reinterpret_cast<const f32x4*>(sc_lds + col);
+                    cj = *reinterpret_cast<const f32x4*>(sc_lds + BN + col);
+                } else if constexpr (XE == 2) {
+                    sj = sz[j]; cj = bz[j];
+                }
+            };
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) {
                 if (ps > 0) __syncthreads();
@@ -842,10 +907,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
 #pragma unroll
                                 for (int j = 0; j < FN; j += 2) {
                                     f32x4 o;
+                                    f32x4 sa, ca, sg, cg;
+                                    if constexpr (XE == 2) { ln_sc(j, sa, ca); ln_sc(j + 1, sg, cg); }
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) {
-                                        const float a = acc[i][j][r] + bz[j][r];
-                                        const float g = acc[i][j + 1][r] + bz[j + 1][r];
+                                        float a, g;
+                                        if constexpr (XE == 2) {   // LayerNorm fold: rstd (acc - mu s) + c
+                                            a = fmaf(acc[i][j][r], ln_r[i], fmaf(ln_t[i], sa[r], ca[r]));
+                                            g = fmaf(acc[i][j + 1][r], ln_r[i], fmaf(ln_t[i], sg[r], cg[r]));
+                                        } else {
+                                            a = acc[i][j][r] + bz[j][r];
+                                            g = acc[i][j + 1][r] + bz[j + 1][r];
+                                        }
                                         o[r] = a * gelu_erf_f(g);
                                     }
                                     const int ch = (j / 2) * 4 + lg;
@@ -856,9 +929,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
 #pragma unroll
                             for (int j = 0; j < FN; ++j) {
                                 f32x4 o;
+                                f32x4 sj, cj;
+                                if constexpr (XE == 2) ln_sc(j, sj, cj);
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
-                                    float v = acc[i][j][r] + bz[j][r];
+                                    float v;
+                                    if constexpr (XE == 2) v = fmaf(acc[i][j][r], ln_r[i], fmaf(ln_t[i], sj[r], cj[r]));   // LayerNorm fold: rstd (acc - mu s) + c
+                                    else v = acc[i][j][r] + bz[j][r];
                                     if constexpr (has_av) v += az[j][r];
                                     if constexpr (epi == EPI_SILU) v = silu_f(v);
                                     else if constexpr (epi == EPI_GELU) v = gelu_erf_f(v);
@@ -947,6 +1024,44 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                             *reinterpret_cast<f32x4*>(p.colstats + ((long)(mslab >> 5) * n_out + nc) * 2) = (f32x4){s0, q0, s1, q1};
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                } else if constexpr (XE == 1) {
+                    // ---- bf16 output + the row statistics of this wave's 64 columns (checked by the launcher: bf16 output, no GEGLU, N % 64 == 0).
+                    // Eight consecutive lanes hold one row's eight 8-column chunks; they meet through three cross-lane adds (every lane of the
+                    // wave takes part: the validity test guards the memory operations only), lane 0 of the eight writes the pair.
+                    static_assert(XE != 1 || (WMP * 8) % 64 == 0, "row statistics: whole 8-row groups per pass");
+                    const int nslice = p.N >> 6;
+#pragma unroll
+                    for (int it0 = 0; it0 < WMP * 8; it0 += 64) {
+                        const int it = it0 + lane;
+                        const int rl = it >> 3, oc = it & 7;
+                        const int m = m0 + wm * WM + ps * WMP + rl, n = nbase + oc * 8;
+                        const bool ok = m < p.M && n < n_out;
+                        float rs = 0.f, rq = 0.f;
+                        if (ok) {
+                            const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + rl * WN + (((2 * oc + rl) % NCH) << 2));
+                            const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + rl * WN + (((2 * oc + 1 + rl) % NCH) << 2));
+                            float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                            if (p.res) {
+                                const u32x4 rr = *reinterpret_cast<const u32x4*>(p.res + (long)m * p.ldr + n);
+                                o[0] += bf16lo(rr.x); o[1] += bf16hi(rr.x); o[2] += bf16lo(rr.y); o[3] += bf16hi(rr.y);
+                                o[4] += bf16lo(rr.z); o[5] += bf16hi(rr.z); o[6] += bf16lo(rr.w); o[7] += bf16hi(rr.w);
+                            }
+                            const u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) = pk;
+                            // statistics of the STORED (bf16-rounded) values: what the consuming GEMM multiplies
+                            const uint32_t w4[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float a = bf16lo(w4[e]), c = bf16hi(w4[e]);
+                                rs += a + c;
+                                rq += a * a + c * c;
+                            }
+                        }
+                        rs += __shfl_xor(rs, 1, 64); rq += __shfl_xor(rq, 1, 64);
+                        rs += __shfl_xor(rs, 2, 64); rq += __shfl_xor(rq, 2, 64);
+                        rs += __shfl_xor(rs, 4, 64); rq += __shfl_xor(rq, 4, 64);
+                        if (ok && oc == 0) *reinterpret_cast<f32x2*>(p.rowstats + ((long)m * nslice + (nbase >> 6)) * 2) = (f32x2){rs, rq};
+                    }
                 } else
                 for (int it = lane; it < (writer ? WMP * och : 0); it += 64) {
                     const int rl = it / och, oc = it - rl * och;
@@ -1163,8 +1278,13 @@ Plan make_plan(int M, int N, int K, bool can_split) {
 }
 
 // Launch one instantiation; kernels that need more than 64 KiB of dynamic LDS get the opt-in attribute once.
+// Plan query (ae_gemm_ln_plan): launch() runs its whole selection with g_plan_query set and launches nothing; the sites that hold a row-statistics /
+// LayerNorm-fold instantiation report through `xe_done` in launch().  One selection code path for the launch and for the question "would it be covered".
+thread_local int g_plan_query = 0;
+
 template <typename Kern>
 int launch_kernel(Kern kern, unsigned grid, int threads, size_t lds, hipStream_t stream, const GemmArgs& a, const char* what) {
+    if (g_plan_query) return 0;
     if (lds > 64 * 1024) {
         static const void* done[32];
         static int ndone = 0;
@@ -1245,6 +1365,7 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // (the same tile for the K = 320 dense GEMMs of the 64x64 level was A/B-ed too: N = 320 44.5 vs 34 us, N = 960 78 vs 63 us —
     // five K iterations do not amortise the big tile's prologue / epilogue.)
     bool done = false;
+    bool xe_done = false;   // a.xe: the selected instantiation carries the row-statistics / LayerNorm-fold epilogue
     // Column statistics for the consuming GroupNorm (GemmArgs::colstats): emitted by the epilogue where a CS instantiation exists (the
     // un-split 192x320 conv tile of the 64x64 level, the 8-wave 128x128 tile of the 32x32 level), by the stand-alone kernel otherwise.
     const bool cs_epi_ok = a.colstats && a.epi != EPI_GEGLU && !a.out_f32 && a.splitk <= 1 && a.N % 8 == 0 && a.ldc % 8 == 0 &&
@@ -1269,7 +1390,12 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         // 192x320 waves 2x4, or 4x2 for GEGLU (pairs of 16-column fragments must sit in one wave).  A 96x320 variant for the
         // 32x32 level (M = 12288) measured 9-13 % slower than the 128x128 tile there and was dropped.
         if (fill >= 0.85) {
-            if (a.epi == EPI_GEGLU && (pp & 8)) { if constexpr (AMODE == A_DENSE) rc = launch_kernel(gemm_kernel<192, 320, A_DENSE, 4, 2, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); }
+            if (a.epi == EPI_GEGLU && (pp & 8)) {
+                if constexpr (AMODE == A_DENSE) {
+                    if (a.xe == 2) { rc = launch_kernel(gemm_kernel<192, 320, A_DENSE, 4, 2, true, 1, 2, false, 0, 3, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); xe_done = true; }
+                    else rc = launch_kernel(gemm_kernel<192, 320, A_DENSE, 4, 2, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
+                }
+            }
             else if (a.epi == EPI_GEGLU) rc = launch_kernel(gemm_kernel<192, 320, AMODE, 4, 2, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
             else if (conv && (pp & 1) && !a.ups) {   // (the nearest-x2 gather: its per-piece address arithmetic measured 283 vs 273 us under the first form of the ping-pong loop; a second attempt with
                                                      //  per-piece row / column offset tables — source pixel = virtual pixel >> 1 is not linear in the tap — measured 409 vs 330 us (hipcc kept the
@@ -1313,6 +1439,13 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         const long t128 = (long)((a.M + 127) / 128) * (a.N / 128);
         const long t192 = (long)((a.M + 191) / 192) * (a.N / 128);
         if (t128 >= 128 && t128 <= 256) {
+            if (a.xe && AMODE == A_DENSE) {
+                if constexpr (AMODE == A_DENSE) {
+                    if (a.xe == 1) rc = launch_kernel(gemm_kernel<128, 128, A_DENSE, 4, 2, true, 1, 3, false, 0, 0, 1>, (unsigned)t128, 512, lds_of(128, 128, 3), stream, a, what);
+                    else rc = launch_kernel(gemm_kernel<128, 128, A_DENSE, 4, 2, true, 1, 3, false, 0, 0, 2>, (unsigned)t128, 512, lds_of(128, 128, 3), stream, a, what);
+                    xe_done = true;
+                }
+            } else
             rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 3>, (unsigned)t128, 512, lds_of(128, 128, 3), stream, a, what);
             done = true;
         } else if (t128 > 256 && t192 >= 128 && t192 <= 256 && a.K >= 2560) {
@@ -1346,6 +1479,13 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
             else rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, true>, grid, 512, lds_of(128, 128, 2), stream, a, what);
             cs_done = true;
         } else if (pick == 0 && w8 == 2 && glds && (wa & (conv ? 1 : 2)) && kt_block >= 3) {
+            if (a.xe && AMODE == A_DENSE) {
+                if constexpr (AMODE == A_DENSE) {
+                    if (a.xe == 1) rc = launch_kernel(gemm_kernel<128, 128, A_DENSE, 4, 2, true, 1, 2, false, 0, 1, 1>, grid, 512, lds_wa(128, 128), stream, a, what);
+                    else rc = launch_kernel(gemm_kernel<128, 128, A_DENSE, 4, 2, true, 1, 2, false, 0, 1, 2>, grid, 512, lds_wa(128, 128), stream, a, what);
+                    xe_done = true;
+                }
+            } else
             rc = launch_kernel(gemm_kernel<128, 128, AMODE, 4, 2, true, 1, 2, false, 0, 1>, grid, 512, lds_wa(128, 128), stream, a, what);
         }
 #ifdef AE_GEMM_ABLATE
@@ -1366,6 +1506,13 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
 #undef AE_LAUNCH
     }
     if (rc) return rc;
+    if (a.xe && !xe_done) {
+        // (ops.py asks ae_gemm_ln_plan first, so this is a caller error; whatever was launched above wrote a plain result)
+        ae_set_error("%s: no %s instantiation for M=%d N=%d K=%d epilogue %d (ae_gemm_ln_plan says which shapes are covered)", what,
+                     a.xe == 1 ? "row-statistics" : "LayerNorm-fold", a.M, a.N, a.K, a.epi);
+        return AE_ERR_UNSUPPORTED;
+    }
+    if (g_plan_query) return 0;
     if (a.splitk > 1) {
         long nb = ((long)a.M * a.N / 4 + 255) / 256;
         if (nb > 2048) nb = 2048;
@@ -1386,9 +1533,56 @@ int ae_launch_colstats(const bf16_t* x, long ld, int M, int N, float* out, hipSt
     return ae_check_launch("column statistics");
 }
 
+namespace {
+// the LayerNorm-fold extras of one launch (all null / zero: a plain ae_gemm_bf16)
+struct LnExtras {
+    float* rowstats_out = nullptr;
+    const float* ln_stats = nullptr;
+    const float* ln_colsum = nullptr;
+    int ln_parts = 0;
+    float ln_eps = 0.f;
+};
+int gemm_entry(const void* A, long lda, const void* A2, long lda2, int Ksplit, const void* W, long ldw,
+               void* C, long ldc, int M, int N, int K, const float* bias, const void* residual, long ldr,
+               const float* addvec, long addvec_ld, int rows_per_batch, int epilogue, int out_f32, float* colstats, const LnExtras& x, void* stream);
+}  // namespace
+
 extern "C" int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, int Ksplit, const void* W, long ldw,
                             void* C, long ldc, int M, int N, int K, const float* bias, const void* residual, long ldr,
                             const float* addvec, long addvec_ld, int rows_per_batch, int epilogue, int out_f32, float* colstats, void* stream) {
+    return gemm_entry(A, lda, A2, lda2, Ksplit, W, ldw, C, ldc, M, N, K, bias, residual, ldr, addvec, addvec_ld, rows_per_batch, epilogue, out_f32, colstats, LnExtras{}, stream);
+}
+
+extern "C" int ae_gemm_ln_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias,
+                               const void* residual, long ldr, int epilogue, float* rowstats_out, const float* ln_stats, int ln_parts,
+                               const float* ln_colsum, float ln_eps, void* stream) {
+    AE_REQUIRE((rowstats_out != nullptr) != (ln_stats != nullptr), "ae_gemm_ln_bf16: exactly one of rowstats_out (emit) and ln_stats (consume) must be given");
+    LnExtras x;
+    x.rowstats_out = rowstats_out; x.ln_stats = ln_stats; x.ln_colsum = ln_colsum; x.ln_parts = ln_parts; x.ln_eps = ln_eps;
+    return gemm_entry(A, lda, nullptr, 0, 0, W, ldw, C, ldc, M, N, K, bias, residual, ldr, nullptr, 0, 0, epilogue, 0, nullptr, x, stream);
+}
+
+extern "C" int ae_gemm_ln_plan(int M, int N, int K, int epilogue, int mode) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 8 || (mode != 1 && mode != 2) || epilogue < EPI_NONE || epilogue > EPI_RELU) return 0;
+    if (N % 64 || (mode == 1 && epilogue == EPI_GEGLU) || (mode == 2 && K % 64)) return 0;
+    if ((long)M * K * 2 >= (1L << 31) || (long)N * K * 2 >= (1L << 31)) return 0;
+    GemmArgs a{};
+    // (addresses are never dereferenced under g_plan_query: launch_kernel returns before the launch)
+    a.A = a.W = reinterpret_cast<const bf16_t*>(uintptr_t(256)); a.C = reinterpret_cast<void*>(uintptr_t(256));
+    a.M = M; a.N = N; a.K = K; a.Ksplit = K;
+    a.lda = K; a.ldw = K; a.ldc = epilogue == EPI_GEGLU ? N / 2 : N; a.ldav = N;
+    a.epi = epilogue; a.rows_per_batch = 1; a.splitk = 1; a.xe = mode;
+    a.a_bytes = (unsigned)((long)M * K * 2); a.w_bytes = (unsigned)((long)N * K * 2);
+    g_plan_query = 1;
+    const int rc = launch<A_DENSE>(a, nullptr);
+    g_plan_query = 0;
+    return rc == 0 ? 1 : 0;
+}
+
+namespace {
+int gemm_entry(const void* A, long lda, const void* A2, long lda2, int Ksplit, const void* W, long ldw,
+               void* C, long ldc, int M, int N, int K, const float* bias, const void* residual, long ldr,
+               const float* addvec, long addvec_ld, int rows_per_batch, int epilogue, int out_f32, float* colstats, const LnExtras& x, void* stream) {
     AE_REQUIRE(A && W && C, "ae_gemm_bf16: null pointer");
     if (colstats) AE_REQUIRE(!out_f32 && N % 8 == 0 && ldc % 8 == 0 && (reinterpret_cast<uintptr_t>(colstats) & 15) == 0, "ae_gemm_bf16: column statistics need a bf16 output with N %% 8 == 0 and 16-byte rows");
     AE_REQUIRE(M > 0 && N > 0 && K > 0, "ae_gemm_bf16: M,N,K must be positive (got %d,%d,%d)", M, N, K);
@@ -1418,8 +1612,23 @@ extern "C" int ae_gemm_bf16(const void* A, long lda, const void* A2, long lda2, 
     a.w_bytes = (unsigned)((((long)N - 1) * ldw + K) * 2);
     AE_REQUIRE(((long)M * lda * 2) < (1L << 31) && ((long)N * ldw * 2) < (1L << 31) && (!A2 || ((long)M * lda2 * 2) < (1L << 31)),
                "ae_gemm_bf16: operands must be smaller than 2 GiB");
+    if (x.rowstats_out || x.ln_stats) {
+        const int n_out = epilogue == EPI_GEGLU ? N / 2 : N;
+        // the staged (row-contiguous) epilogue is the one that carries both forms
+        AE_REQUIRE(N % 64 == 0 && n_out % 8 == 0 && ldc % 8 == 0 && (!residual || (ldr % 8 == 0 && aligned16(residual))),
+                   "ae_gemm_ln_bf16: N %% 64 == 0 and 16-byte aligned output / residual rows");
+        if (x.rowstats_out) {
+            AE_REQUIRE(epilogue != EPI_GEGLU && (reinterpret_cast<uintptr_t>(x.rowstats_out) & 7) == 0, "ae_gemm_ln_bf16: row statistics: no GEGLU, 8-byte aligned buffer");
+            a.xe = 1; a.rowstats = x.rowstats_out;
+        } else {
+            AE_REQUIRE(x.ln_colsum && bias && x.ln_parts > 0 && x.ln_parts <= 64 && x.ln_eps >= 0.f, "ae_gemm_ln_bf16: LayerNorm fold needs s (ln_colsum), c (bias), 1..64 statistics slices per row");
+            AE_REQUIRE(aligned16(x.ln_colsum) && aligned16(bias) && (reinterpret_cast<uintptr_t>(x.ln_stats) & 7) == 0, "ae_gemm_ln_bf16: s / c must be 16-byte aligned, the statistics 8-byte aligned");
+            a.xe = 2; a.ln_stats = x.ln_stats; a.ln_colsum = x.ln_colsum; a.ln_parts = x.ln_parts; a.ln_eps = x.ln_eps;
+        }
+    }
     return launch<A_DENSE>(a, (hipStream_t)stream);
 }
+}  // namespace
 
 extern "C" long ae_conv3x3_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride, int upsample2x) {
     const int Hv = upsample2x ? 2 * H : H, Wv = upsample2x ? 2 * W : W;

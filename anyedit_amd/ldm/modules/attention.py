@@ -58,8 +58,16 @@ class GEGLU(nn.Module):
 
     def repack(self):
         self._pk = None
+        self._pkln = None
 
-    def rows(self, x, norm=None):
+    def _packed_ln(self, norm):
+        """(W', s, c): the projection with `norm` folded in (ops.pack_ln_fold), rows interleaved like `_pk`."""
+        if ops.cache_stale(self, "_pkln", self.proj.weight, self.proj.bias, norm.weight, norm.bias):
+            self._pkln = ops.pack_ln_fold(self.proj.weight, self.proj.bias, norm.weight, norm.bias, geglu=True)
+        return self._pkln
+
+    def rows(self, x, norm=None, rowstats=None):
+        """rowstats: statistics of x from the GEMM that produced it — `norm` is then folded into the projection (no LayerNorm launch)."""
         if ops._TAPE is not None and ops._TAPE.active:
             if norm is not None:
                 x = norm.rows(x)
@@ -71,6 +79,9 @@ class GEGLU(nn.Module):
         if ops.cache_stale(self, "_pk", self.proj.weight, self.proj.bias):
             self._pk = ops.pack_geglu(self.proj.weight, self.proj.bias)
         w, b = self._pk
+        if norm is not None and rowstats is not None and ops.ln_fold_plan(x.shape[0], w.shape[0], x.shape[1], ops.EPI_GEGLU, 2):
+            wq, s, c = self._packed_ln(norm)
+            return ops.gemm_ln(x, rowstats, wq, s, c, norm.eps, epilogue=ops.EPI_GEGLU)
         if norm is not None:  # the block's norm3 fused in front of the projection (the caller passes the UN-normalised rows)
             g, be = norm._affine()
             return ops.ln_gemm(x, g, be, norm.eps, w, b, epilogue=ops.EPI_GEGLU)
@@ -93,8 +104,8 @@ class FeedForward(nn.Module):
         project_in = GEGLU(dim, inner_dim)
         self.net = nn.Sequential(project_in, nn.Dropout(dropout), Linear(inner_dim, dim_out))
 
-    def rows(self, x, residual=None, norm=None):
-        return self.net[2].rows(self.net[0].rows(x, norm=norm), residual=residual)
+    def rows(self, x, residual=None, norm=None, rowstats=None):
+        return self.net[2].rows(self.net[0].rows(x, norm=norm, rowstats=rowstats), residual=residual)
 
     def forward(self, x):
         shp = x.shape
@@ -121,6 +132,16 @@ class CrossAttention(nn.Module):
 
     def repack(self):
         self._pk = None
+        self._pkln_q = self._pkln_qkv = None
+
+    def _packed_ln(self, wname, norm):
+        """(W', s, c) of the query-side projection `wname` ('qkv' | 'q') with `norm` folded in (ops.pack_ln_fold)."""
+        attr = "_pkln_" + wname
+        mods = (self.to_q, self.to_k, self.to_v) if wname == "qkv" else (self.to_q,)
+        if ops.cache_stale(self, attr, *(m.weight for m in mods), norm.weight, norm.bias):
+            w = torch.cat([m.weight.detach().float() for m in mods], 0)
+            setattr(self, attr, ops.pack_ln_fold(w, None, norm.weight, norm.bias))
+        return getattr(self, attr)
 
     def _packed(self):
         if ops.cache_stale(self, "_pk", self.to_q.weight, self.to_k.weight, self.to_v.weight):
@@ -135,8 +156,11 @@ class CrossAttention(nn.Module):
         """K|V of a context [B*Nk, Dc] -> [B*Nk, 2*inner] (step-invariant for text conditioning: cache it)."""
         return ops.gemm(ctx_rows, self._packed()["kv"])
 
-    def rows(self, x, B, N, context_rows=None, Nk=None, kv=None, key_mask=None, residual=None, adapter=None, norm=None):
+    def rows(self, x, B, N, context_rows=None, Nk=None, kv=None, key_mask=None, residual=None, adapter=None, norm=None, rowstats=None,
+             out_rowstats=None):
         """x: [B*N, C] bf16 rows.  context_rows: [B*Nk, Dc] or None (self-attention).  Returns to_out(attn) (+residual).
+        rowstats: row statistics of x from the GEMM that produced it (`ops.rowstats_buffer`): `norm` is then folded into the query-side
+        projection; out_rowstats: buffer that receives the statistics of the result (to_out's epilogue) for the next block norm.
         adapter: optional (kv_ip [B*T, 2*inner] bf16, gate [B] fp32): decoupled expert attention added to the output,
         out = Attn(q,K,V) + gate_b * Attn(q,K_ip,V_ip)  (AnySD row A9, shape template ip_adapter/attention_processor.py:141-173)."""
         pk = self._packed()
@@ -146,6 +170,9 @@ class CrossAttention(nn.Module):
         def proj(wname):  # norm: the block's LayerNorm fused in front of the query-side projection (x = UN-normalised rows)
             if norm is None:
                 return ops.gemm(x, pk[wname])
+            if rowstats is not None and ops.ln_fold_plan(x.shape[0], pk[wname].shape[0], x.shape[1], ops.EPI_NONE, 2):
+                wq, s, c = self._packed_ln(wname, norm)
+                return ops.gemm_ln(x, rowstats, wq, s, c, norm.eps)
             g, be = norm._affine()
             return ops.ln_gemm(x, g, be, norm.eps, pk[wname])
 
@@ -176,7 +203,7 @@ class CrossAttention(nn.Module):
                     ks_ip = (T_ip * 2 * inner, d, 2 * inner)
                     ops.attention(q, kv_ip, kv_ip[:, inner:], B, h, N, T_ip, d, self.scale, qs, ks_ip, ks_ip, out=o,
                                   out_scale=gate, accumulate=True)
-        return self.to_out[0].rows(o.reshape(B * N, inner), residual=residual)
+        return self.to_out[0].rows(o.reshape(B * N, inner), residual=residual, rowstats=out_rowstats)
 
     def forward(self, x, context=None, mask=None):
         B, N, C = x.shape
@@ -220,16 +247,39 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = LayerNorm(dim)
         self.checkpoint = checkpoint
 
-    def rows(self, x, B, N, context_rows=None, kv_cache=None):
-        """x: [B*N, C] bf16.  kv_cache: optional dict id(attn)->projected K|V of the (step-invariant) context."""
+    def rows(self, x, B, N, context_rows=None, kv_cache=None, rowstats=None):
+        """x: [B*N, C] bf16.  kv_cache: optional dict id(attn)->projected K|V of the (step-invariant) context.
+        rowstats: row statistics of x from the GEMM that produced it (see `wants_rowstats`)."""
         tape = ops._TAPE
         if self.checkpoint and tape is not None and tape.active:  # attention.py:268: recompute this block in the backward pass
             return tape.checkpoint(lambda: self._rows(x, B, N, context_rows, kv_cache))
-        return self._rows(x, B, N, context_rows, kv_cache)
+        return self._rows(x, B, N, context_rows, kv_cache, rowstats)
 
-    def _rows(self, x, B, N, context_rows=None, kv_cache=None):
+    def _fold_plan(self, M, C):
+        """Which of the three norms can be folded into its projection at M rows: (norm1, norm2, norm3).  A norm folds when the GEMM behind it
+        carries the fold epilogue; norm2 / norm3 also need the to_out GEMM in front of them to emit the row statistics."""
+        key = (M, C, ops._LN_FOLD, ops._TAPE is not None and ops._TAPE.active)
+        if getattr(self, "_fold_key", None) != key:
+            inner1 = self.attn1.heads * self.attn1.dim_head
+            inner2 = self.attn2.heads * self.attn2.dim_head
+            n1 = inner1 if (self.disable_self_attn and not self.attn1.is_self) else 3 * inner1
+            f1 = ops.ln_fold_plan(M, n1, C, ops.EPI_NONE, 2)
+            f2 = ops.ln_fold_plan(M, inner2, C, ops.EPI_NONE, 2) and ops.ln_fold_plan(M, C, inner1, ops.EPI_NONE, 1)
+            f3 = ops.ln_fold_plan(M, self.ff.net[0].proj.weight.shape[0], C, ops.EPI_GEGLU, 2) and ops.ln_fold_plan(M, C, inner2, ops.EPI_NONE, 1)
+            self._fold_key, self._fold = key, (f1, f2, f3)
+        return self._fold
+
+    def wants_rowstats(self, M, C):
+        """True when norm1 would be folded into attn1's projection given the row statistics of the block's input."""
+        return self._fold_plan(M, C)[0]
+
+    def _rows(self, x, B, N, context_rows=None, kv_cache=None, rowstats=None):
         c1 = context_rows if self.disable_self_attn else None
-        x = self.attn1.rows(x, B, N, context_rows=c1, residual=x, norm=self.norm1)
+        M, C = x.shape
+        f1, f2, f3 = self._fold_plan(M, C)
+        st2 = ops.rowstats_buffer(M, C, x.device) if f2 else None
+        st3 = ops.rowstats_buffer(M, C, x.device) if f3 else None
+        x = self.attn1.rows(x, B, N, context_rows=c1, residual=x, norm=self.norm1, rowstats=rowstats if f1 else None, out_rowstats=st2)
         kv2, adapter = None, None
         if kv_cache is not None and context_rows is not None:
             key = id(self.attn2)
@@ -244,8 +294,8 @@ class BasicTransformerBlock(nn.Module):
             adapter = kv_cache.get(("adapter", key))  # installed by anysd.MoE.prepare_conditioning
             if callable(adapter):  # training: the expert K|V projection is recorded here, next to the attention that consumes it
                 adapter = adapter()
-        x = self.attn2.rows(x, B, N, context_rows=context_rows, kv=kv2, residual=x, adapter=adapter, norm=self.norm2)
-        x = self.ff.rows(x, residual=x, norm=self.norm3)
+        x = self.attn2.rows(x, B, N, context_rows=context_rows, kv=kv2, residual=x, adapter=adapter, norm=self.norm2, rowstats=st2, out_rowstats=st3)
+        x = self.ff.rows(x, residual=x, norm=self.norm3, rowstats=st3)
         return x
 
     def forward(self, x, context=None):
@@ -294,9 +344,14 @@ class SpatialTransformer(nn.Module):
         N = H * W
         h = self.norm.rows(x, B, N, colstats=colstats)
         pin = self.proj_in._packed()
-        h = ops.gemm(h, pin["w"], pin["b"])
+        # the first block's norm1 rides in its qkv projection where proj_in can emit the row statistics it needs (attention.py:271)
+        M, Ci = h.shape[0], pin["w"].shape[0]
+        st = None
+        if self.transformer_blocks[0].wants_rowstats(M, Ci) and ops.ln_fold_plan(M, Ci, h.shape[1], ops.EPI_NONE, 1):
+            st = ops.rowstats_buffer(M, Ci, h.device)
+        h = ops.gemm(h, pin["w"], pin["b"], rowstats=st)
         for i, blk in enumerate(self.transformer_blocks):
-            h = blk.rows(h, B, N, context_rows=ctxs[i], kv_cache=kv_cache)
+            h = blk.rows(h, B, N, context_rows=ctxs[i], kv_cache=kv_cache, rowstats=st if i == 0 else None)
         pout = self.proj_out._packed()
         return ops.gemm(h, pout["w"], pout["b"], residual=x, colstats=out_colstats)
 

@@ -109,8 +109,11 @@ class Linear(nn.Linear, _Packed):
     def _pack(self):
         return {"w": ops.pack_linear(self.weight), "b": None if self.bias is None else self.bias.detach().float().contiguous()}
 
-    def rows(self, x, residual=None, epilogue=ops.EPI_NONE, out_f32=False, a2=None):
+    def rows(self, x, residual=None, epilogue=ops.EPI_NONE, out_f32=False, a2=None, rowstats=None):
+        """rowstats: optional `ops.rowstats_buffer` that receives the row statistics of the result (for a LayerNorm folded into the next GEMM)."""
         pk = self._packed()
+        if rowstats is not None:
+            return ops.gemm(x, pk["w"], pk["b"], residual=residual, rowstats=rowstats)
         return ops.gemm(x, pk["w"], pk["b"], residual=residual, epilogue=epilogue, out_f32=out_f32, a2=a2)
 
     def forward(self, x):

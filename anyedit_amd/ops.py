@@ -143,9 +143,18 @@ def want_colstats(HW):
     return _GN_COLSTATS and HW > 256 and HW % 32 == 0 and not (_TAPE is not None and _TAPE.active)
 
 
-def gemm(a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue=EPI_NONE, out_f32=False, a2=None, out=None, colstats=None):
+def gemm(a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue=EPI_NONE, out_f32=False, a2=None, out=None, colstats=None,
+         rowstats=None):
     """out[M,N] = epi(cat([a, a2], 1) @ w^T).  a: [M,K1] bf16 (row stride free), w: [N,K] bf16.
-    colstats: optional `colstats_buffer(M, N)` that receives the per-channel slab statistics of the output."""
+    colstats: optional `colstats_buffer(M, N)` that receives the per-channel slab statistics of the output.
+    rowstats: optional `rowstats_buffer(M, N)` that receives the per-row statistics of the output for the LayerNorm folded into the
+    GEMM that consumes it (`gemm_ln`); only where `ln_fold_plan(M, N, K, EPI_NONE, 1)` says the tile plan carries that epilogue."""
+    if rowstats is not None:
+        if _TAPE is not None and _TAPE.active:
+            raise ValueError("gemm: row statistics are not recorded on the training tape (ln_fold_plan is False while it records)")
+        if addvec is not None or a2 is not None or out_f32 or colstats is not None or epilogue != EPI_NONE:
+            raise ValueError("gemm: rowstats goes with a plain bf16 GEMM (+bias, +residual) only")
+        return _gemm_ln(a, w, bias, residual, EPI_NONE, out, rowstats, None, None, 0.0)
     if _TAPE is not None and _TAPE.active:
         return _TAPE.gemm(a, w, bias=bias, residual=residual, addvec=addvec, rows_per_batch=rows_per_batch, epilogue=epilogue, out_f32=out_f32, a2=a2, out=out)
     _chk(a, BF16, "gemm.a", 2)
@@ -183,6 +192,91 @@ def gemm(a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue
                            addvec.stride(0) if addvec is not None else 0, rows_per_batch, epilogue,
                            1 if out_f32 else 0, _p(colstats), _s()), "ae_gemm_bf16")
     return out
+
+
+# --------------------------------------------------------------------------- LayerNorm folded into the consuming GEMM
+_LN_FOLD = os.environ.get("AE_LN_FOLD", "1") != "0"  # tuning knob (A/B): 0 = a LayerNorm launch in front of every K = 640 / 1280 projection
+_LN_PLAN = {}
+
+
+def ln_fold_plan(M, N, K, epilogue, mode):
+    """True where the tile plan `gemm` takes for [M, K] x [N, K]^T carries the row-statistics epilogue (mode 1: this GEMM PRODUCES the
+    rows a LayerNorm reads) or the LayerNorm-fold epilogue (mode 2: this GEMM CONSUMES the LayerNorm) — `ae_gemm_ln_plan`, cached per
+    shape.  Never while the training tape records (its LayerNorm keeps what the backward pass needs)."""
+    if not _LN_FOLD or (_TAPE is not None and _TAPE.active):
+        return False
+    key = (M, N, K, epilogue, mode)
+    r = _LN_PLAN.get(key)
+    if r is None:
+        # (shapes of the row-panel kernel — K = 320, the 64x64 level — keep it: its LayerNorm already rides in the GEMM's prologue)
+        r = _LN_PLAN[key] = not (_ROWPANEL and lib.ae_ln_gemm_supported(M, N, K, epilogue)) and bool(lib.ae_gemm_ln_plan(M, N, K, epilogue, mode))
+    return r
+
+
+def rowstats_buffer(M, N, device):
+    """fp32 [M, N / 64, 2]: (sum, sum of squares) of every row of a bf16 [M, N] activation over each 64-column slice — filled by the GEMM
+    that PRODUCES the activation (`gemm(..., rowstats=)`), consumed by `gemm_ln`."""
+    return torch.empty(M, N // 64, 2, dtype=torch.float32, device=device)
+
+
+def pack_ln_fold(w, bias, gamma, beta, geglu=False):
+    """Folds LayerNorm's affine part into the projection behind it (attention.py:271-275): LN(x) W^T + b = rstd (x W'^T - mu s) + c.
+    Returns (W' = W diag(gamma) as bf16 [N, K] (GEGLU: rows interleaved as `pack_geglu` does), s = row sums of the bf16 W' — exactly what
+    the MFMA multiplies —, c = W beta + b), s and c fp32 [N] in the packed row order.  Once per weight version (host side)."""
+    wf = w.detach().float().reshape(w.shape[0], -1).contiguous()
+    g, be = gamma.detach().float(), beta.detach().float()
+    c = linear_f32(be[None, :].contiguous(), wf, bias)[0]
+    wp = wf * g[None, :]
+    if geglu:
+        wq, c = pack_geglu(wp, c)
+    else:
+        wq = wp.to(BF16).contiguous()
+    s = linear_f32(torch.ones(1, wq.shape[1], dtype=torch.float32, device=wq.device), wq.float())[0]
+    return wq, s.contiguous(), c.contiguous()
+
+
+def _gemm_ln(a, w, bias, residual, epilogue, out, rowstats_out, ln_stats, ln_colsum, eps):
+    _chk(a, BF16, "gemm_ln.a", 2)
+    _chk(w, BF16, "gemm_ln.w", 2)
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K or a.stride(1) != 1 or w.stride(1) != 1:
+        raise ValueError(f"gemm_ln: a is [{M}, {K}], w is {tuple(w.shape)}; both need unit inner stride")
+    n_out = N // 2 if epilogue == EPI_GEGLU else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=BF16, device=a.device)
+    _chk(out, BF16, "gemm_ln.out", 2)
+    if bias is not None:
+        _chk(bias, torch.float32, "gemm_ln.bias", 1)
+    if residual is not None:
+        _chk(residual, BF16, "gemm_ln.residual", 2)
+    nparts = 0
+    if rowstats_out is not None:
+        if rowstats_out.dtype != torch.float32 or tuple(rowstats_out.shape) != (M, N // 64, 2) or not rowstats_out.is_contiguous():
+            raise ValueError(f"gemm: rowstats must be a contiguous fp32 [{M}, {N // 64}, 2] buffer (rowstats_buffer)")
+    else:
+        if ln_stats.dtype != torch.float32 or ln_stats.dim() != 3 or ln_stats.shape[0] != M or ln_stats.shape[2] != 2 or not ln_stats.is_contiguous() \
+                or ln_stats.shape[1] * 64 != K:
+            raise ValueError(f"gemm_ln: statistics must be the producer's contiguous fp32 [{M}, {K // 64}, 2] buffer, got {tuple(ln_stats.shape)}")
+        _chk(ln_colsum, torch.float32, "gemm_ln.s", 1)
+        if bias is None or bias.numel() != N or ln_colsum.numel() != N:
+            raise ValueError("gemm_ln: s and c must be fp32 [N]")
+        nparts = ln_stats.shape[1]
+    return _gemm_ln_launch(a, w, bias, residual, epilogue, out, M, N, K, rowstats_out, ln_stats, nparts, ln_colsum, float(eps))
+
+
+def _gemm_ln_launch(a, w, bias, residual, epilogue, out, M, N, K, rowstats_out, ln_stats, nparts, ln_colsum, eps):
+    check(lib.ae_gemm_ln_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), M, N, K, _p(bias), _p(residual),
+                              residual.stride(0) if residual is not None else 0, epilogue, _p(rowstats_out), _p(ln_stats), nparts,
+                              _p(ln_colsum), eps, _s()), "ae_gemm_ln_bf16")
+    return out
+
+
+def gemm_ln(x, rowstats, wq, s, c, eps, residual=None, epilogue=EPI_NONE, out=None):
+    """out = epi(LayerNorm(x) @ w^T + b (+ residual)) with the LayerNorm folded away: x are the UN-normalised rows, `rowstats` their
+    statistics from the GEMM that produced them, (wq, s, c) = `pack_ln_fold(w, b, gamma, beta)`.  Callers ask `ln_fold_plan(M, N, K,
+    epilogue, 2)` first and keep `ln_gemm` where it says no."""
+    return _gemm_ln(x, wq, c, residual, epilogue, out, None, rowstats, s, eps)
 
 
 _ROWPANEL = os.environ.get("AE_GEMM_ROWPANEL", "1") != "0"  # tuning knob: 0 = tiled kernel only (A/B)
@@ -1113,14 +1207,17 @@ def _wrap_profiled(fn, label_fn):
         e0.record()
         out = fn(*args, **kwargs)
         e1.record()
-        label, flops, nbytes = label_fn(out, *args, **kwargs)
-        _PROF.records.append((label, flops, nbytes, e0, e1))
+        lab = label_fn(out, *args, **kwargs)
+        if lab is not None:   # None: an inner wrapped launch already recorded this call
+            _PROF.records.append((lab[0], lab[1], lab[2], e0, e1))
         return out
     wrapped.__doc__ = fn.__doc__
     return wrapped
 
 
 def _gemm_label(_r, a, w, bias=None, residual=None, addvec=None, rows_per_batch=0, epilogue=EPI_NONE, out_f32=False, a2=None, **_):
+    if _.get("rowstats") is not None:
+        return None   # recorded by _gemm_ln_launch as "...,rowstats"
     M, (N, K) = a.shape[0], w.shape
     nb = 2 * (M * K + N * K) + _r.numel() * _r.element_size() + (2 * M * N if residual is not None else 0)
     if a2 is None and addvec is None and not out_f32 and _rowpanel_ok(a, w, _r, residual, M, N, K, epilogue):
@@ -1164,7 +1261,14 @@ def _ln_gemm_label(_r, x, w, bias, residual, gamma, beta, eps, epilogue, o, M, N
     return f"gemm_rowpanel_kernel<K=320,LN{',geglu' if epilogue == EPI_GEGLU else ''}>|M={M} N={N}", 2.0 * M * N * K, nb
 
 
+def _gemm_ln_label(_r, a, w, bias, residual, epilogue, out, M, N, K, rowstats_out, ln_stats, nparts, ln_colsum, eps):
+    nb = 2 * (M * K + N * K) + _r.numel() * 2 + (2 * M * N if residual is not None else 0)
+    tag = "rowstats" if rowstats_out is not None else "LNfold"
+    return f"gemm_kernel<{_tile_label(M, N, False, K, epilogue == EPI_GEGLU, True)},dense,{tag}>|M={M} N={N} K={K}", 2.0 * M * N * K, float(nb)
+
+
 _ln_gemm_fused = _wrap_profiled(_ln_gemm_launch, _ln_gemm_label)
+_gemm_ln_launch = _wrap_profiled(_gemm_ln_launch, _gemm_ln_label)
 gemm = _wrap_profiled(gemm, _gemm_label)
 attention_fp8 = _wrap_profiled(attention_fp8, _attn8_label)
 conv3x3 = _wrap_profiled(conv3x3, _conv_label)

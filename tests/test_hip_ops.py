@@ -137,6 +137,62 @@ def test_rowpanel_ln_gemm(ops, M, N, epi, ln, res, monkeypatch):
     check_close(out, out2.float().cpu(), rl2=6e-3, mabs=6e-2, what="rowpanel vs tiled")
 
 
+@pytest.mark.parametrize("M,C,N,epi", [(12288, 640, 1920, "none"), (12288, 640, 640, "none"), (12288, 640, 5120, "geglu"), (3072, 1280, 3840, "none"),
+                                       (3072, 1280, 1280, "none"), (3072, 1280, 10240, "geglu"), (12200, 640, 1920, "none"), (8192, 640, 5120, "geglu")])
+def test_layernorm_folded_into_gemm(ops, M, C, N, epi):
+    """attention.py:263-275 norm -> projection at the widths the row-panel kernel does not cover (C = 640 / 1280), with the LayerNorm folded
+    into the consuming GEMM (ae_gemm_ln_bf16): LN(x) W^T + b = rstd (x W'^T - mu s) + c.
+      1. the GEMM that produces x emits the row statistics beside an output that is BIT-IDENTICAL to the plain launch's;
+      2. the statistics are the per-row, per-64-column (sum, sum of squares) of the stored bf16 x (fp32, 1e-5 of sum |x| / sum x^2);
+      3. the folded GEMM against the fp32 LayerNorm + Linear of the same bf16 x and the fp32 master weights: within the operator tolerance
+         of this file, and no worse than the unfused HIP path (LayerNorm kernel, bf16 LN(x), plain GEMM) by more than 25 % + 5e-4 —
+         rows carry a mean of up to three standard deviations, the case the subtraction mu * s has to survive."""
+    E = ops.EPI_GEGLU if epi == "geglu" else ops.EPI_NONE
+    if not (ops.ln_fold_plan(M, C, C, ops.EPI_NONE, 1) and ops.ln_fold_plan(M, N, C, E, 2)):
+        pytest.skip("the tile plan of this shape carries no fold epilogue (AE_LN_FOLD / tile knobs)")
+    g = torch.Generator().manual_seed(M + C + N)
+    a = q(torch.randn(M, C, generator=g))
+    wp = q(torch.randn(C, C, generator=g) / C ** 0.5)
+    bp = 0.1 * torch.randn(C, generator=g)
+    r = q(torch.randn(M, C, generator=g) * 1.3 + torch.randn(M, 1, generator=g) * 3.0)
+    ad, wpd, bpd, rd = a.to(DEV, BF), wp.to(DEV, BF), bp.to(DEV), r.to(DEV, BF)
+    st = ops.rowstats_buffer(M, C, DEV)
+    st.fill_(float("nan"))
+    x = ops.gemm(ad, wpd, bpd, residual=rd, rowstats=st)
+    x_plain = ops.gemm(ad, wpd, bpd, residual=rd)
+    assert torch.equal(x, x_plain), "the statistics epilogue changed the GEMM's output"
+    check_close(x, a @ wp.t() + bp + r, what="producer")
+    xf = x.float().cpu()
+    xs = xf.reshape(M, C // 64, 64)
+    got = st.cpu()
+    assert torch.isfinite(got).all()
+    assert float((got[..., 0] - xs.sum(-1)).abs().max()) <= 1e-5 * float(xs.abs().sum(-1).max())
+    assert float((got[..., 1] - (xs * xs).sum(-1)).abs().max()) <= 1e-5 * float((xs * xs).sum(-1).max())
+    # consumer
+    w = torch.randn(N, C, generator=g) / C ** 0.5
+    b = 0.1 * torch.randn(N, generator=g)
+    gamma, beta = 1.0 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    z = (F.layer_norm(xf.double(), (C,), gamma.double(), beta.double(), 1e-5) @ w.double().t() + b.double()).float()
+    if epi == "geglu":
+        xx, gate = z.chunk(2, dim=-1)
+        ref = xx * F.gelu(gate)
+        wd, bd = ops.pack_geglu(w.to(DEV), b.to(DEV))
+    else:
+        ref = z
+        wd, bd = w.to(DEV, BF), b.to(DEV)
+    wq, s, c = ops.pack_ln_fold(w.to(DEV), b.to(DEV), gamma.to(DEV), beta.to(DEV), geglu=epi == "geglu")
+    assert wq.dtype == BF and wq.shape == (N, C) and s.shape == (N,) and c.shape == (N,)
+    y = ops.gemm_ln(x, st, wq, s, c, 1e-5, epilogue=E)
+    y_unfused = ops.ln_gemm(x, gamma.to(DEV), beta.to(DEV), 1e-5, wd, bd, epilogue=E)
+    e_fold, e_unf = rel_l2(y.float().cpu(), ref), rel_l2(y_unfused.float().cpu(), ref)
+    print(f"LN fold M={M} C={C} N={N} {epi}: rel-L2 folded {e_fold:.3e}, unfused {e_unf:.3e}")
+    check_close(y, ref, rl2=5e-3, mabs=3e-2, what=f"folded LayerNorm {M}x{C}->{N} {epi}")
+    assert e_fold <= 1.25 * e_unf + 5e-4, (e_fold, e_unf)
+    # a launch-side refusal, not a wrong answer, for a shape whose plan has no such epilogue
+    with pytest.raises(RuntimeError):
+        ops._gemm_ln(x[:64], wq, c, None, E, None, None, st[:64].contiguous(), s, 1e-5)
+
+
 def test_gemm_linearity_full_size(ops):
     """Size-independent property at a BASELINE-size shape: f(a1 + a2) == f(a1) + f(a2) up to rounding."""
     g = torch.Generator(device=DEV).manual_seed(1)

@@ -316,6 +316,37 @@ def test_python_plan_mirror_matches_the_library():
                 assert ops._conv_splitk(M, cout, 9 * cin_pad) == s_lib, (B, hw, cin, cout, s_lib)
 
 
+def test_layernorm_fold_plan_follows_the_tile_plan(monkeypatch):
+    """ops.ln_fold_plan / ae_gemm_ln_plan (host-only: the library runs its launch selection without launching): at the bench's UNet batch 12
+    every norm -> projection pair of the 32x32 and 16x16 levels folds (producer emits row statistics, consumer applies them); the 64x64
+    level stays on the row-panel kernel whose prologue already holds the LayerNorm; the 8x8 level and shapes whose producer runs another
+    tile fall back; nothing folds while the training tape records or under AE_LN_FOLD=0."""
+    from anyedit_amd import ops
+    from anyedit_amd._lib import lib
+    if not ops._LN_FOLD:
+        pytest.skip("AE_LN_FOLD=0")
+    E, G = ops.EPI_NONE, ops.EPI_GEGLU
+    for M, C in ((12 * 1024, 640), (12 * 256, 1280)):
+        assert ops.ln_fold_plan(M, C, C, E, 1), (M, C)                                     # proj_in / to_out emit
+        assert ops.ln_fold_plan(M, 3 * C, C, E, 2) and ops.ln_fold_plan(M, C, C, E, 2)     # qkv, q
+        assert ops.ln_fold_plan(M, 8 * C, C, G, 2)                                         # GEGLU projection
+    M = 12 * 4096
+    assert lib.ae_ln_gemm_supported(M, 960, 320, E) == 1
+    assert not ops.ln_fold_plan(M, 960, 320, E, 2) and not ops.ln_fold_plan(M, 320, 320, E, 1) and not ops.ln_fold_plan(M, 2560, 320, G, 2)
+    assert not ops.ln_fold_plan(12 * 64, 1280, 1280, E, 1)                                 # 8x8 level: 64x64 tiles, no statistics epilogue
+    assert lib.ae_gemm_ln_plan(M, 640, 640, G, 1) == 0 and lib.ae_gemm_ln_plan(M, 600, 640, E, 1) == 0 and lib.ae_gemm_ln_plan(M, 640, 640, E, 3) == 0
+    # a plan answer is a property of (M, N, K, epilogue): the same question twice, and the launch-side refusal for an uncovered shape
+    assert lib.ae_gemm_ln_plan(3072, 1280, 1280, E, 1) == lib.ae_gemm_ln_plan(3072, 1280, 1280, E, 1) == 1
+
+    class _Tape:
+        active = True
+    monkeypatch.setattr(ops, "_TAPE", _Tape())
+    assert not ops.ln_fold_plan(12 * 1024, 640, 640, E, 1)
+    monkeypatch.setattr(ops, "_TAPE", None)
+    monkeypatch.setattr(ops, "_LN_FOLD", False)
+    assert not ops.ln_fold_plan(12 * 1024, 640, 640, E, 1)
+
+
 def test_conv_k_order_follows_the_tile_plan():
     """ops.conv_k_order (which weight pack / K order a conv launch is given): chunk-major exactly where the un-split 192x320 plan runs — the
     64x64-level convs of a UNet batch >= 12 —, tap-major for every other grid, for upsampling convs and for channel counts that are not

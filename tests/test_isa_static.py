@@ -36,7 +36,7 @@ def test_operand_ahead_loops_keep_loads_in_flight(kernels):
     seen = 0
     for name, md, loop in kernels:
         a = _targs(name, "gemm_kernel")
-        if not a or a[-1] not in ("1", "2"):
+        if not a or a[10] not in ("1", "2"):      # WA is the eleventh template argument (XE, the LayerNorm-fold epilogue selector, follows it)
             continue
         seen += 1
         assert md["private_segment_fixed_size"] == "0" and md["vgpr_spill_count"] == "0", name
@@ -56,7 +56,7 @@ def test_ping_pong_loops_wait_by_count_and_alternate_phases(kernels):
     seen = 0
     for name, md, loop in kernels:
         a = _targs(name, "gemm_kernel")
-        if not a or a[-1] != "3":
+        if not a or a[10] != "3":
             continue
         seen += 1
         assert a[0] == "192" and a[1] == "320", name
@@ -65,7 +65,23 @@ def test_ping_pong_loops_wait_by_count_and_alternate_phases(kernels):
         assert n_mfma == 360, (name, n_mfma)
         assert n_scratch == 0 and n_gloads == 0 and n_dma >= 48, (name, loop)
         assert n_vmn >= 5 and n_vm0 <= 6, (name, loop)
-    assert seen >= 4, "ping-pong instantiations not found (conv with / without statistics, dense 2x4, GEGLU 4x2)"
+    assert seen >= 5, "ping-pong instantiations not found (conv with / without statistics, dense 2x4, GEGLU 4x2 without / with the LayerNorm fold)"
+
+
+def test_layernorm_fold_epilogues_leave_the_main_loops_alone(kernels):
+    """gemm_kernel<..., XE = 1 | 2> (round 4: row statistics out / LayerNorm fold in): five instantiations, none with scratch or spills (the
+    192x320 GEGLU form keeps the block's s and c vectors in LDS for that reason), and each one's hottest loop has the MFMA, DMA and wait
+    counts of its XE = 0 twin — the two row scalars per fragment row the fold carries through the loop cost it nothing."""
+    by_args = {tuple(_targs(name, "gemm_kernel")): (md, loop) for name, md, loop in kernels if _targs(name, "gemm_kernel")}
+    seen = 0
+    for a, (md, loop) in by_args.items():
+        if a[11] == "0":
+            continue
+        seen += 1
+        assert md["private_segment_fixed_size"] == "0" and md["vgpr_spill_count"] == "0", a
+        twin = by_args[a[:11] + ("0",)][1]
+        assert loop[:5] == twin[:5] and loop[6] == twin[6], (a, loop, twin)
+    assert seen == 5, seen
 
 
 def test_hot_loops_have_no_scratch_traffic(kernels):
