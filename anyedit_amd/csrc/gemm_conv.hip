@@ -141,8 +141,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
     static_assert(XE != 1 || BN / WAVES_N == 64, "row statistics are emitted per 64-column slice = one wave tile's width");
     static_assert(STAGES == 2 || (GLDS && WAVES_K == 1), "the deep LDS ring exists only for the LDS-DMA loader");
     static_assert(!WA || (GLDS && STAGES == 2 && WAVES_K == 1), "operand-ahead is a variant of the two-stage LDS-DMA pipeline");
-    static_assert(WA >= 0 && WA <= 3, "WA: 0 none, 1 weights two tiles ahead (three W stages), 2 activations two tiles ahead (three A stages), 3 ping-pong (two wave groups one barrier apart)");
-    static_assert(WA != 3 || 64 * WAVES_M * WAVES_N * WAVES_K == 512, "the ping-pong loop pairs wave w with wave w + 4 (one SIMD's two waves)");
+    static_assert(WA >= 0 && WA <= 4, "WA: 0 none, 1 weights two tiles ahead (three W stages), 2 activations two tiles ahead (three A stages), 3 ping-pong (two wave groups one barrier apart), 4 ping-pong over an activation slab per (channel chunk, ky)");
+    static_assert(WA < 3 || 64 * WAVES_M * WAVES_N * WAVES_K == 512, "the ping-pong loops pair wave w with wave w + 4 (one SIMD's two waves)");
+    static_assert(WA != 4 || (AMODE == A_CONV3 && GLDS && BM % 16 == 0), "the slab loop is a 3x3-convolution loop");
     static_assert(WAVES_K == 1 || WAVES_K == 2, "K groups: 1 or 2");
     constexpr int NT = 64 * WAVES_M * WAVES_N * WAVES_K;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // wave tile
@@ -526,7 +527,145 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
             }
         };
         auto dma_tile = [&](int kt, int buf) __attribute__((always_inline)) { dma_a(kt, buf); dma_w(kt, buf); };
-        if constexpr (WA == 3) {
+        if constexpr (WA == 4) {
+            // ---- Ping-pong over an activation SLAB (round 4, second half).  The ping-pong loop below sits at the LDS-DMA path's own rate
+            // (36.8 B/clk/CU: 64 KiB per K tile against 1920 MFMA cycles, profiles/r04_v4_pp_lab.txt), so this form moves fewer bytes: in the
+            // chunk-major K order the three taps (ky, 0..2) of a 64-channel chunk read the SAME input pixels one position apart.  The tile's
+            // BM output pixels are whole image rows (W | BM, checked by the launcher), so per (chunk, ky) the BM / W input rows y + ky - 1 are
+            // staged ONCE, as a slab with one ZERO row in front of every image row and one behind the last:
+            //     slab row  j (W + 1)          = zero                       (j = 0 .. BM / W)
+            //     slab row  j (W + 1) + 1 + x  = input pixel (y_j + ky - 1, x), zero when that row is outside the image
+            // and output pixel (row j, x) reads slab row j (W + 1) + x + kx for tap kx: x - 1 = -1 and x + 1 = W land on the zero rows, a row
+            // outside the image is zero as a whole — the conv's zero padding costs nothing in the loop (a first form that shifted through a
+            // contiguous pixel range and zeroed the wrapped rows in registers cost 48-72 VALU per K tile in the LOAD intervals).  Zero rows and
+            // out-of-image rows are lanes of the LDS-DMA pieces whose offset is out of the descriptor's range: the hardware writes zeros.
+            // 26 one-KiB pieces per slab (208 rows: W >= 16) instead of 3 x 24: DMA per chunk 3 x 32 + 9 x 40 = 456 KiB instead of 576 (waves without a
+            // piece in the last round repeat their previous one so that every wave's count is the same), activation reads from L2 a third.
+            // Split-K launches: a block's K range starts at a chunk boundary (kt_begin % 9 == 0, checked by the launcher).
+            // Fragment reads: 16 | W, so a 16-row fragment lies in one image row and its slab rows are consecutive; the XOR swizzle follows
+            // the slab row, hence one per-lane address per (fragment, kx, half) — 36 registers, no address arithmetic in the loop.
+            // Schedule: as in the loop below, with the A side in slab units.  Tile t = (chunk c, tap): L(t,0) reads half 0 and issues W(t + 1);
+            // L(t,1) reads half 1 and, when kx = 0, issues the NEXT slab (c, ky + 1) / (c + 1, 0) into the other of two slab stages — that
+            // stage held slab a - 1, last read in tile t - 1 by group 1's L(t - 1, 1), whose lgkmcnt(0) precedes the barrier that group 0
+            // passed before this interval.  Waits: after a slab issue vmcnt(S_CH) (W(t + 1) has landed, the slab flies on), otherwise
+            // vmcnt(0): by the end of the kx = 1 tile every wave has seen its slab pieces land, two barriers before their first reader.
+            // Unrolled by 18 = lcm(9 taps, 2 stages): tap, stage offsets and the issue decision are constants of each unrolled tile.
+            static_assert(BK * 2 == 128, "slab rows are 128 bytes");
+            constexpr int SLAB_P = (BM + BM / 16 + 1 + 7) / 8;          // 1-KiB pieces per slab stage (8 rows each): 26 for BM = 192, i.e. 208 rows >= BM + BM / W + 1 for W >= 16
+            constexpr int S_CH = (SLAB_P + NT / 64 - 1) / (NT / 64);    // pieces per wave; waves without a last-round piece repeat their previous one
+            constexpr int A_ST = SLAB_P * 1024, W_ST = BN * BK * 2;     // stage sizes in bytes
+            const int lds0 = (int)(uintptr_t)((__attribute__((address_space(3))) char*)smem_raw);
+            const int ldsW = lds0 + 2 * A_ST + wave * 1024;
+            const int grp = wave >> 2;
+            const int W1 = p.Wd + 1, nrow = BM / p.Wd;                  // slab row pitch, image rows per tile
+            const int y0 = (m0 / p.Wd) % p.H;                           // image row of the tile's first output row (m0 is a multiple of W)
+            int sl_off[S_CH], sl_dst[S_CH];
+            unsigned sl_ok[S_CH];                                       // bit ky: the slab row is an input pixel inside the image for that ky
+#pragma unroll
+            for (int j = 0; j < S_CH; ++j) {
+                int q = wave + (NT / 64) * j;
+                if (q >= SLAB_P) q -= NT / 64;
+                const int srow = 8 * q + (lane >> 3);                  // slab row of this lane; its LDS slot holds logical chunk (lane & 7) ^ (srow & 7)
+                const int jr = srow / W1, pos = srow - jr * W1;
+                const int m = m0 + jr * p.Wd + pos - 1;                 // output pixel above / below which the input pixel sits
+                // the tile's rows may cross into the next sample: (y0 + jr) mod H is the image row whatever the sample
+                int y = y0 + jr;
+                y -= (y >= p.H) ? p.H : 0;
+                unsigned ok = 0u;
+                if (pos > 0 && jr < nrow && m < p.M) {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+                        if ((unsigned)(y + ky - 1) < (unsigned)p.H) ok |= 1u << ky;
+                }
+                sl_ok[j] = ok;
+                sl_off[j] = m * p.Cin * 2 + (((lane & 7) ^ (lane >> 3)) << 4);
+                sl_dst[j] = lds0 + q * 1024;
+            }
+            const int ky_step = p.Wd * p.Cin * 2;
+            const int cbase = kt_begin / 9;                             // first channel chunk of this block's K range
+            auto pp_slab = [&](int c, int ky, int st) __attribute__((always_inline)) {
+                int off[S_CH];
+#pragma unroll
+                for (int j = 0; j < S_CH; ++j) off[j] = ((sl_ok[j] >> ky) & 1u) ? sl_off[j] + (ky - 1) * ky_step : OOB;   // zero rows / rows outside the image -> hardware zero
+#pragma unroll
+                for (int j = 0; j < S_CH; ++j) asm volatile("" : "+v"(off[j]));   // all offsets first, then the pieces back to back
+#pragma unroll
+                for (int j = 0; j < S_CH; ++j) ae_dma16(rsA, sl_dst[j] + st * A_ST, off[j], (cbase + c) * (BK * 2));
+            };
+            auto pp_w = [&](int kt, int st) __attribute__((always_inline)) {
+                const int k0 = (kt_begin + kt) * BK;
+#pragma unroll
+                for (int i = 0; i < B_CH; ++i) ae_dma16(rsW, ldsW + st * W_ST + i * (NT / 64) * 1024, fb_off[i], k0 * 2);
+            };
+            // LDS read offsets (bytes).  A fragment i of tap kx, half kk: slab row r0 + r0 / W + l15 + kx with r0 = wm WM + 16 i (the zero rows in
+            // front of its image row shift it), 16-byte chunk (4 kk + lg) ^ (row & 7).  W fragments as in the loop below.
+            int a_rd[FM][3][2];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int r0 = wm * WM + i * 16;
+                const int base = r0 + r0 / p.Wd + l15;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) a_rd[i][kx][kk] = (base + kx) * 128 + (((kk * 4 + lg) ^ ((base + kx) & 7)) << 4);
+            }
+            int w_rd[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) w_rd[kk] = 2 * A_ST + (wn * WN + l15) * 128 + (((kk * 4 + lg) ^ (l15 & 7)) << 4);
+            bf16x8_t af[FM], bfr[FN];
+            auto pp_read = [&](int kk, int kx, int sa, int sw) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i) af[i] = as_bf16x8(*reinterpret_cast<const u32x4*>(smem_raw + sa * A_ST + a_rd[i][kx][kk]));
+#pragma unroll
+                for (int j = 0; j < FN; ++j) bfr[j] = as_bf16x8(*reinterpret_cast<const u32x4*>(smem_raw + sw * W_ST + w_rd[kk] + j * 16 * 128));
+            };
+            auto pp_mfma = [&]() __attribute__((always_inline)) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (AE_PP_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                if (AE_PP_PRIO) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (KT > 0) { pp_w(0, 0); pp_slab(0, 0, 0); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (grp) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind
+            __builtin_amdgcn_sched_barrier(0);
+            for (int kt0 = 0; kt0 < KT; kt0 += 18) {
+                const int c0 = kt0 / 9;              // even: the slab stage of tile kt0 + u is ((u / 9) + ky) & 1
+#pragma unroll
+                for (int u = 0; u < 18; ++u) {
+                    const int kt = kt0 + u;
+                    if (kt >= KT) break;
+                    const int tap = u % 9, ky = tap / 3, kx = tap % 3;
+                    const int sa = ((u / 9) + ky) & 1, sw = u & 1;
+                    // L(t,0)
+                    pp_read(0, kx, sa, sw);
+                    if (kt + 1 < KT) pp_w(kt + 1, sw ^ 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    pp_mfma();   // M(t,0)
+                    // L(t,1)
+                    pp_read(1, kx, sa, sw);
+                    const bool slab_next = kx == 0 && kt + 3 < KT;
+                    if (slab_next) pp_slab(ky == 2 ? c0 + u / 9 + 1 : c0 + u / 9, ky == 2 ? 0 : ky + 1, sa ^ 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (slab_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S_CH) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    pp_mfma();   // M(t,1)
+                }
+            }
+            if (!grp) __builtin_amdgcn_s_barrier();  // group 0 waits for group 1's last MFMA interval
+            __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (WA == 3) {
             // ---- Ping-pong (round 4).  The eight waves form two groups — waves 0-3 and 4-7: wave w and w + 4 share a SIMD — that run the SAME
             // instruction stream one barrier apart.  A K tile is two phases (its two 32-deep halves), a phase is a LOAD interval (the half's
             // 11-13 fragment reads LDS -> registers, then this interval's LDS-DMA pieces, then the waits) and an MFMA interval (the half's
@@ -1352,7 +1491,8 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     auto lds_aa = [](int bm, int bn) { return (size_t)(3 * bm + 2 * bn) * BK * sizeof(bf16_t); };
 #endif
     // tuning knob (bit flags): the ping-pong main loop (WA = 3, round 4) on the 192x320 tile — 1 un-split convs, 2 split-K convs, 4 dense non-GEGLU,
-    // 8 GEGLU (4 x 2 waves).  Same LDS footprint as the activations-ahead loop (three A stages + two W stages).
+    // 8 GEGLU (4 x 2 waves).  Same LDS footprint as the activations-ahead loop (three A stages + two W stages).  16 / 32: the un-split / split-K
+    // convs on the activation-slab form of the loop (WA = 4; two slab stages + two W stages = 132 KiB).
     static const int pp = getenv("AE_GEMM_PP") ? atoi(getenv("AE_GEMM_PP")) : AE_GEMM_PP_DEFAULT;
     int rc = 0;
 
@@ -1377,9 +1517,15 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // (192x320 with FOUR waves of 96x160 — 0.27 LDS fragment reads per MFMA instead of 0.37, 240 accumulator registers per lane — was
     // instantiated and measured: hipcc places the accumulators in AGPRs and brackets the MFMAs with v_accvgpr moves, 166-206 TFLOP/s
     // against 911-1123 for the 8-wave form.  Bigger wave tiles need hand-scheduled AGPR code; not kept.)
+    // the slab form of the ping-pong loop (WA = 4): whole image rows per 192-row tile, 16-row fragments inside one image row, at most 208 slab rows,
+    // chunk-major K with every block's K range starting at a chunk boundary
+    const bool slab_ok = conv && a.kmajor && a.stride == 1 && !a.ups && a.Cin == a.CinPad && a.H == a.Ho && a.Wd == a.Wo && a.Wd % 16 == 0 && 192 % a.Wd == 0 &&
+                         (a.splitk <= 1 || kt_block % 9 == 0);
+    const size_t lds_slab = (size_t)2 * ((192 + 192 / 16 + 1 + 7) / 8) * 1024 + (size_t)2 * 320 * BK * sizeof(bf16_t);
     if (conv && a.splitk > 1 && glds && make_plan(a.M, a.N, a.K, true).tile == 4) {  // split-K under the 192x320 tile (make_plan)
         const long t = (long)(a.M / 192) * (a.N / 320) * a.splitk;
-        if ((pp & 2) && !a.ups) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); }
+        if ((pp & 32) && (pp & 2) && slab_ok) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 4>, (unsigned)t, 512, lds_slab, stream, a, what); }
+        else if ((pp & 2) && !a.ups) { if constexpr (AMODE == A_CONV3) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); }
         else rc = launch_kernel(gemm_kernel<192, 320, AMODE, 2, 4, true>, (unsigned)t, 512, lds_of(192, 320, 2), stream, a, what);
         done = true;
     }
@@ -1401,7 +1547,12 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
                                                      //  per-piece row / column offset tables — source pixel = virtual pixel >> 1 is not linear in the tap — measured 409 vs 330 us (hipcc kept the
                                                      //  tables in scratch memory, profiles/r04_v23_ups_pp.txt).  Two launches per evaluation; they stay on the round-3 loop.)
                 if constexpr (AMODE == A_CONV3) {
-                    if (cs_epi_ok) { rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); cs_done = true; }
+                    // flag 16: the slab form of the loop (WA = 4) where its preconditions hold — chunk-major K, stride 1, K range starting at tap 0
+                    // (whole image rows per tile, 16-row fragments inside one image row, at most 200 slab rows)
+                    const bool slab = (pp & 16) && slab_ok;
+                    if (slab && cs_epi_ok) { rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true, 0, 4>, (unsigned)t, 512, lds_slab, stream, a, what); cs_done = true; }
+                    else if (slab) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 4>, (unsigned)t, 512, lds_slab, stream, a, what);
+                    else if (cs_epi_ok) { rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); cs_done = true; }
                     else rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
                 }
             } else if (!conv && (pp & 4)) {

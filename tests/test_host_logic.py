@@ -347,6 +347,66 @@ def test_layernorm_fold_plan_follows_the_tile_plan(monkeypatch):
     assert not ops.ln_fold_plan(12 * 1024, 640, 640, E, 1)
 
 
+@pytest.mark.parametrize("B,H,W,Cin", [(2, 64, 64, 128), (12, 16, 16, 64), (3, 32, 32, 64), (1, 96, 96, 64)])
+def test_slab_layout_of_the_conv_loop_restated(B, H, W, Cin):
+    """The address arithmetic of gemm_conv.hip's slab loop (WA = 4), restated lane by lane in numpy: the LDS-DMA pieces of one (chunk, ky) slab
+    — zero row in front of every image row, rows outside the image zero, XOR swizzle on the source chunk — and the fragment reads of the three
+    kx taps, against the definition of a zero-padded 3x3 gather.  Covers tiles that cross a sample boundary, the ragged last tile and image
+    widths 16 .. 96 (the kernel's preconditions: 16 | W, W | 192).  No GPU: this pins the LAYOUT; tests/test_hip_* pin the kernel."""
+    import numpy as np
+    BM, NWAVE = 192, 8
+    SLAB_P = (BM + BM // 16 + 1 + 7) // 8
+    M = B * H * W
+    rng = np.random.default_rng(B + H + Cin)
+    x = rng.integers(1, 60000, size=(M, Cin), dtype=np.uint16)   # non-zero bf16 bit patterns
+    xb = x.view(np.uint8).reshape(-1)
+    W1, nrow, ntm = W + 1, BM // W, (M + BM - 1) // BM
+    assert W % 16 == 0 and BM % W == 0 and BM + nrow + 1 <= SLAB_P * 8
+    for tile in sorted({0, 1, ntm // 2, ntm - 1}):
+        m0 = tile * BM
+        y0 = (m0 // W) % H
+        c = (Cin // 64) - 1
+        for ky in range(3):
+            lds = np.full(SLAB_P * 1024, 0xAB, dtype=np.uint8)
+            for wave in range(NWAVE):
+                for j in range((SLAB_P + NWAVE - 1) // NWAVE):
+                    q = wave + NWAVE * j
+                    if q >= SLAB_P:
+                        q -= NWAVE                                   # the wave repeats its previous piece
+                    for lane in range(64):
+                        srow, lc = 8 * q + (lane >> 3), (lane & 7) ^ (lane >> 3)
+                        jr = srow // W1
+                        pos = srow - jr * W1
+                        m = m0 + jr * W + pos - 1
+                        y = y0 + jr - (H if y0 + jr >= H else 0)
+                        ok = pos > 0 and jr < nrow and m < M and 0 <= y + ky - 1 < H
+                        voff = m * Cin * 2 + lc * 16 + (ky - 1) * W * Cin * 2
+                        dst = q * 1024 + lane * 16
+                        if ok and 0 <= voff and voff + 16 <= xb.size:            # the descriptor's bounds check is on voffset alone
+                            lds[dst:dst + 16] = xb[voff + c * 128:voff + c * 128 + 16]
+                        else:
+                            lds[dst:dst + 16] = 0
+            for wm in range(2):
+                for i in range(6):
+                    r0 = wm * 96 + i * 16
+                    for l15 in range(16):
+                        base, m = r0 + r0 // W + l15, m0 + r0 + l15
+                        if m >= M:
+                            continue
+                        b, rem = divmod(m, H * W)
+                        oy, ox = divmod(rem, W)
+                        for kx in range(3):
+                            iy, ix = oy + ky - 1, ox + kx - 1
+                            for kk in range(2):
+                                for lg in range(4):
+                                    addr = (base + kx) * 128 + (((kk * 4 + lg) ^ ((base + kx) & 7)) << 4)
+                                    exp = np.zeros(16, np.uint8)
+                                    if 0 <= iy < H and 0 <= ix < W:
+                                        ch = c * 64 + (kk * 4 + lg) * 8
+                                        exp = x[(b * H + iy) * W + ix, ch:ch + 8].view(np.uint8)
+                                    assert np.array_equal(lds[addr:addr + 16], exp), (tile, ky, kx, wm, i, l15, kk, lg)
+
+
 def test_conv_k_order_follows_the_tile_plan():
     """ops.conv_k_order (which weight pack / K order a conv launch is given): chunk-major exactly where the un-split 192x320 plan runs — the
     64x64-level convs of a UNet batch >= 12 —, tap-major for every other grid, for upsampling convs and for channel counts that are not

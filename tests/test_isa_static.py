@@ -68,6 +68,24 @@ def test_ping_pong_loops_wait_by_count_and_alternate_phases(kernels):
     assert seen >= 5, "ping-pong instantiations not found (conv with / without statistics, dense 2x4, GEGLU 4x2 without / with the LayerNorm fold)"
 
 
+def test_slab_ping_pong_loop_structure(kernels):
+    """gemm_kernel<192, 320, conv, ..., WA = 4> (round 4: ping-pong over an activation slab per (chunk, ky)): 18 unrolled K tiles of 60 MFMAs, 18 x 5
+    weight pieces + 6 x 4 slab pieces per trip (a slab is issued on the kx = 0 tiles only), no scratch, no spills, and — the point of the
+    zero-row layout — next to no VALU in the loop (the conv's padding is not computed there)."""
+    seen = 0
+    for name, md, loop in kernels:
+        a = _targs(name, "gemm_kernel")
+        if not a or a[10] != "4":
+            continue
+        seen += 1
+        assert a[:3] == ["192", "320", "1"], name
+        assert md["private_segment_fixed_size"] == "0" and md["vgpr_spill_count"] == "0", name
+        n_mfma, n_vm0, n_scratch, n_dma, n_gloads, _, n_vmn, n_valu = loop[:8]
+        assert n_mfma == 18 * 60 and n_dma == 18 * 5 + 6 * 4, (name, loop)
+        assert n_scratch == 0 and n_gloads == 0 and n_vmn == 6 and n_valu <= 72, (name, loop)
+    assert seen == 2, "slab instantiations (with / without column statistics) not found"
+
+
 def test_layernorm_fold_epilogues_leave_the_main_loops_alone(kernels):
     """gemm_kernel<..., XE = 1 | 2> (round 4: row statistics out / LayerNorm fold in): five instantiations, none with scratch or spills (the
     192x320 GEGLU form keeps the block's s and c vectors in LDS for that reason), and each one's hottest loop has the MFMA, DMA and wait

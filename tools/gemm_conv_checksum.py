@@ -19,7 +19,8 @@ def show(tag, t):
 
 
 for B, H, Cin, Cout, ups, stride in ((12, 64, 320, 320, False, 1), (12, 32, 640, 640, False, 1), (12, 16, 1280, 1280, True, 1), (12, 64, 320, 320, False, 2),
-                                     (12, 8, 1280, 1280, False, 1), (2, 16, 2560, 1280, False, 1)):
+                                     (12, 8, 1280, 1280, False, 1), (2, 16, 2560, 1280, False, 1), (12, 64, 960, 320, False, 1), (12, 16, 1280, 1280, False, 1),
+                                     (12, 16, 2560, 1280, False, 1), (12, 16, 640, 1280, False, 1), (3, 64, 320, 320, False, 1)):
     x = (r(B * H * H, Cin) * 0.5).to(BF).to(dev)
     w = (r(Cout, Cin, 3, 3) * (9 * Cin) ** -0.5)
     bias, add = r(Cout).to(dev), r(B, Cout).to(dev)
