@@ -359,29 +359,71 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // XE 2: rstd and -rstd * mean of this lane's row in each 16-row fragment, from the producer's per-slice sums.  Loaded HERE, in front of the main
-    // loop (two registers per fragment row live through it), so the epilogue does not start with a dependent L2 round trip.  The four lane groups
-    // of a row (lg) take every fourth slice and meet through two cross-lane adds: (s0 + s1) + (s2 + s3) in every lane, a fixed order.
+    // XE 2: rstd and -rstd * mean of this lane's row in each 16-row fragment, from the producer's per-slice sums, and the block's s / c vectors.
+    // Everything the fold needs is LOADED here, in front of the main loop, and consumed in `xe_mid()`, which every loop variant calls right after
+    // its first DMA wait — a point where the wave has just waited for memory anyway — so neither the statistics nor s / c cost the block a
+    // round trip of their own (one block per CU on the 192x320 tile: nothing else would hide it; measured +7 .. +9 us per GEGLU launch when
+    // the epilogue started with these loads, profiles/r04_v25_lnfold_slab_ab.txt).
+    //  * statistics: the four lane groups of a row (lg) take every fourth slice and meet through two cross-lane adds: (s0 + s1) + (s2 + s3) in
+    //    every lane, a fixed order.  All loads of all fragment rows go out together (LNP = 5 per row: up to 20 slices, K <= 1280; slices past
+    //    ln_parts re-read the last one and count as zero): a first form looped over the slices and paid one L2 round trip per iteration and row.
+    //  * s / c: the 128x128 tiles keep this lane's 2 x FN x 4 values in registers through the loop; the 192x320 tile (254 registers) parks the
+    //    block's 2 x 320 values in the 8 KiB of LDS the ping-pong ring leaves free (behind its three A and two W stages).
     float ln_r[XE == 2 ? FM : 1], ln_t[XE == 2 ? FM : 1];
+    constexpr int LNP = 5;
+    constexpr bool SC_LDS = XE == 2 && WA == 3;
+    static_assert(!SC_LDS || (BN % 4 == 0 && (3 * BM + 2 * BN) * BK * 2 + 2 * BN * 4 <= 160 * 1024), "s / c of the block must fit behind the ping-pong ring");
+    float* const sc_lds = reinterpret_cast<float*>(smem_raw + (3 * BM + 2 * BN) * BK * 2);   // SC_LDS: [2][BN]: s, then c
+    f32x2 raw[XE == 2 ? FM : 1][LNP];
+    f32x4 szp[(XE == 2 && !SC_LDS) ? FN : 1], bzp[(XE == 2 && !SC_LDS) ? FN : 1], scv[2];
     if constexpr (XE == 2) {
-        const float inv_k = 1.0f / (float)p.K;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int m = min(m0 + wm * WM + i * 16 + l15, p.M - 1);
             const f32x2* sp = reinterpret_cast<const f32x2*>(p.ln_stats) + (long)m * p.ln_parts;
-            float s = 0.f, q = 0.f;
-            for (int t = lg; t < p.ln_parts; t += 4) {
-                const f32x2 v = sp[t];
-                s += v[0]; q += v[1];
+#pragma unroll
+            for (int u = 0; u < LNP; ++u) raw[i][u] = sp[min(lg + 4 * u, p.ln_parts - 1)];
+        }
+        if constexpr (SC_LDS) {
+            const int n = min(n0 + 4 * min(tid, BN / 4 - 1), p.N - 4);
+            scv[0] = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
+            scv[1] = *reinterpret_cast<const f32x4*>(p.bias + n);
+        } else {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {   // the epilogue's column of fragment j (GEGLU: 'a' rows, gate rows at +16)
+                const int nc = p.epi == EPI_GEGLU ? min(n0 + wn * WN + (j & ~1) * 16 + lg * 4, p.N - 20) + (j & 1) * 16 : min(n0 + wn * WN + j * 16 + lg * 4, p.N - 4);
+                szp[j] = *reinterpret_cast<const f32x4*>(p.ln_colsum + nc);
+                bzp[j] = *reinterpret_cast<const f32x4*>(p.bias + nc);
             }
-            s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
-            s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
-            const float mu = s * inv_k;
-            const float r = rsqrtf(fmaxf(q * inv_k - mu * mu, 0.f) + p.ln_eps);
-            ln_r[i] = r;
-            ln_t[i] = -r * mu;
         }
     }
+    auto xe_mid = [&]() __attribute__((always_inline)) {
+        if constexpr (XE == 2) {
+            const float inv_k = 1.0f / (float)p.K;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int u = 0; u < LNP; ++u) {
+                    const bool in = lg + 4 * u < p.ln_parts;
+                    s += in ? raw[i][u][0] : 0.f;
+                    q += in ? raw[i][u][1] : 0.f;
+                }
+                s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+                s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+                const float mu = s * inv_k;
+                const float r = rsqrtf(fmaxf(q * inv_k - mu * mu, 0.f) + p.ln_eps);
+                ln_r[i] = r;
+                ln_t[i] = -r * mu;
+            }
+            if constexpr (SC_LDS) {   // read by every wave in the epilogue, hundreds of barriers from here
+                if (tid < BN / 4) {
+                    reinterpret_cast<f32x4*>(sc_lds)[tid] = scv[0];
+                    reinterpret_cast<f32x4*>(sc_lds + BN)[tid] = scv[1];
+                }
+            }
+        }
+    };
 
     auto compute_tile = [&](int cur, int curB = -1) __attribute__((always_inline)) {
         if (LAB == 2) return;
@@ -775,6 +817,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
             pp_w(0, 0); pp_a(0, 0);
             if (KT > 1) { pp_a(1, 1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_CH) : "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            xe_mid();
             __builtin_amdgcn_s_barrier();
             if (grp) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind
             __builtin_amdgcn_sched_barrier(0);
@@ -847,6 +890,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
             else { dma_w(0, 0); dma_a(0, 0); if (KT > 1) dma_a(1, 1); }
             if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FAR) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            xe_mid();
             __builtin_amdgcn_s_barrier();
             for (int kt0 = 0; kt0 < KT; kt0 += 6) {
 #pragma unroll
@@ -895,6 +939,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
 #pragma unroll
             for (int t = 0; t < AHEAD; ++t)
                 if (t < KT) dma_tile(t, t);
+            xe_mid();
             int cur = 0, nxt = AHEAD % STAGES;
             for (int kt = 0; kt < KT; ++kt) {
                 const int younger = min(KT - 1 - kt, AHEAD - 1);  // tiles issued after tile kt and still allowed in flight
@@ -983,31 +1028,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
             const bool av_v4 = (reinterpret_cast<uintptr_t>(p.addvec) & 15) == 0 && (p.ldav & 3) == 0;
             int ncol[FN];
             f32x4 bz[FN];
-            // XE 2: s of this lane's 4 columns per fragment (bz holds c; both 16-byte aligned: checked by the launcher).  The 192x320 tile has no
-            // registers for 2 x 40 of them beside its 120 accumulators (hipcc spilled 275): there the block's s and c sit in LDS, behind the
-            // staging area (which never reaches past STAGES * (BM + BN) * BK * 2 bytes = 128 KiB of the ping-pong loop's 152), and are read at their use.
-            constexpr bool SC_LDS = XE == 2 && WA == 3;
-            static_assert(!SC_LDS || (BN % 4 == 0 && (3 * BM + 2 * BN) * BK * 2 >= STAGES * (BM + BN) * BK * 2 + 2 * BN * 4), "s / c of the block must fit behind the staging area");
-            float* const sc_lds = reinterpret_cast<float*>(smem_raw + STAGES * (BM + BN) * BK * 2);   // [2][BN]: s, then c
+            // XE 2: s of this lane's 4 columns per fragment (bz holds c; both 16-byte aligned: checked by the launcher), loaded in front of the main
+            // loop.  The 192x320 tile has no registers for 2 x 40 of them beside its 120 accumulators (hipcc spilled 275): there the block's s and
+            // c sit in LDS behind the ring and are read at their use.
             f32x4 sz[(XE == 2 && !SC_LDS) ? FN : 1];
-            if constexpr (SC_LDS) {
-                for (int t = tid; t < BN / 4; t += NT) {
-                    const int n = min(n0 + 4 * t, p.N - 4);
-                    reinterpret_cast<f32x4*>(sc_lds)[t] = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
-                    reinterpret_cast<f32x4*>(sc_lds + BN)[t] = *reinterpret_cast<const f32x4*>(p.bias + n);
-                }
-                __syncthreads();
-            }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 if (geglu) ncol[j] = min(n0 + wn * WN + (j & ~1) * 16 + lg * 4, p.N - 20) + (j & 1) * 16;   // 'a' rows, gate rows at +16
                 else ncol[j] = min(n0 + wn * WN + j * 16 + lg * 4, p.N - 4);
                 bz[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (!SC_LDS && p.bias) {
+                if constexpr (XE == 2) {
+                    if constexpr (!SC_LDS) { sz[j] = szp[j]; bz[j] = bzp[j]; }
+                } else if (p.bias) {
                     if (bias_v4) bz[j] = *reinterpret_cast<const f32x4*>(p.bias + ncol[j]);
                     else bz[j] = (f32x4){p.bias[ncol[j]], p.bias[ncol[j] + 1], p.bias[ncol[j] + 2], p.bias[ncol[j] + 3]};
                 }
-                if constexpr (XE == 2 && !SC_LDS) sz[j] = *reinterpret_cast<const f32x4*>(p.ln_colsum + ncol[j]);
             }
             // XE 2: (s, c) of fragment j's four columns (local column wn * WN + 16 j + 4 lg in either packing: (j & ~1) * 16 + (j & 1) * 16 = 16 j)
             auto ln_sc = [&](int j, f32x4& sj, f32x4& cj) __attribute__((always_inline)) {
@@ -1538,7 +1573,7 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         if (fill >= 0.85) {
             if (a.epi == EPI_GEGLU && (pp & 8)) {
                 if constexpr (AMODE == A_DENSE) {
-                    if (a.xe == 2) { rc = launch_kernel(gemm_kernel<192, 320, A_DENSE, 4, 2, true, 1, 2, false, 0, 3, 2>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what); xe_done = true; }
+                    if (a.xe == 2) { rc = launch_kernel(gemm_kernel<192, 320, A_DENSE, 4, 2, true, 1, 2, false, 0, 3, 2>, (unsigned)t, 512, lds_aa(192, 320) + 2 * 320 * sizeof(float), stream, a, what); xe_done = true; }
                     else rc = launch_kernel(gemm_kernel<192, 320, A_DENSE, 4, 2, true, 1, 2, false, 0, 3>, (unsigned)t, 512, lds_aa(192, 320), stream, a, what);
                 }
             }
@@ -1715,7 +1750,7 @@ extern "C" int ae_gemm_ln_bf16(const void* A, long lda, const void* W, long ldw,
 
 extern "C" int ae_gemm_ln_plan(int M, int N, int K, int epilogue, int mode) {
     if (M <= 0 || N <= 0 || K <= 0 || K % 8 || (mode != 1 && mode != 2) || epilogue < EPI_NONE || epilogue > EPI_RELU) return 0;
-    if (N % 64 || (mode == 1 && epilogue == EPI_GEGLU) || (mode == 2 && K % 64)) return 0;
+    if (N % 64 || (mode == 1 && (epilogue == EPI_GEGLU || N > 1280)) || (mode == 2 && (K % 64 || K > 1280))) return 0;   // the consumer sums up to 20 slices per row
     if ((long)M * K * 2 >= (1L << 31) || (long)N * K * 2 >= (1L << 31)) return 0;
     GemmArgs a{};
     // (addresses are never dereferenced under g_plan_query: launch_kernel returns before the launch)
@@ -1772,7 +1807,7 @@ int gemm_entry(const void* A, long lda, const void* A2, long lda2, int Ksplit, c
             AE_REQUIRE(epilogue != EPI_GEGLU && (reinterpret_cast<uintptr_t>(x.rowstats_out) & 7) == 0, "ae_gemm_ln_bf16: row statistics: no GEGLU, 8-byte aligned buffer");
             a.xe = 1; a.rowstats = x.rowstats_out;
         } else {
-            AE_REQUIRE(x.ln_colsum && bias && x.ln_parts > 0 && x.ln_parts <= 64 && x.ln_eps >= 0.f, "ae_gemm_ln_bf16: LayerNorm fold needs s (ln_colsum), c (bias), 1..64 statistics slices per row");
+            AE_REQUIRE(x.ln_colsum && bias && x.ln_parts > 0 && x.ln_parts <= 20 && x.ln_eps >= 0.f, "ae_gemm_ln_bf16: LayerNorm fold needs s (ln_colsum), c (bias), 1..20 statistics slices per row (K <= 1280)");
             AE_REQUIRE(aligned16(x.ln_colsum) && aligned16(bias) && (reinterpret_cast<uintptr_t>(x.ln_stats) & 7) == 0, "ae_gemm_ln_bf16: s / c must be 16-byte aligned, the statistics 8-byte aligned");
             a.xe = 2; a.ln_stats = x.ln_stats; a.ln_colsum = x.ln_colsum; a.ln_parts = x.ln_parts; a.ln_eps = x.ln_eps;
         }
