@@ -29,7 +29,8 @@ namespace {
 #define AE_GEMM_WA_DEFAULT 3
 #endif
 #ifndef AE_GEMM_PP_DEFAULT
-#define AE_GEMM_PP_DEFAULT 15
+#define AE_GEMM_PP_DEFAULT 63   // 15 + the slab form of the conv loop (16 un-split, 32 split-K): outputs bit-identical (56 checksums), every launch of the family 1-3 % faster
+                                // un-graphed, UNet step -0.02 ms over three alternating A/B rounds on two boxes (profiles/r04_v24..v26_lnfold_slab_ab.txt)
 #endif
 #ifndef AE_PP_LAB
 #define AE_PP_LAB 0         // lab builds only (tools/ubench/conv_lab.hip): 1 no DMA after the prologue, 2 DMA + barriers only (no LDS reads, no MFMAs), 3 MFMAs on stale registers (no LDS reads)
