@@ -1019,6 +1019,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
         static_assert(FM % PASSES == 0, "epilogue passes must divide the fragment rows");
         const bool geglu = p.epi == EPI_GEGLU;
         const int n_out = geglu ? p.N / 2 : p.N;
+        // Synchronisation inside the staged epilogue is WAVE-local: every wave stages and reads back only its own slice (`st` below), and a
+        // wave's LDS operations retire in order, so a later ds_read of the wave sees its earlier ds_write whatever lane issued it — what is needed
+        // is that hipcc keeps the order and, for tidiness, that the writes have left the queue.  The block-wide barriers that stood here (two per
+        // pass: six in a GEGLU epilogue of the 192x320 tile) made all eight waves wait for the slowest at every phase change and kept the two waves
+        // of a SIMD in the same phase — the VALU-heavy staging (bias, erf-GELU) of one could never run beside the LDS reads and global stores of
+        // the other.  Every main loop ends on a block barrier behind its last LDS read, so the first staging write is safe.  -DAE_EPI_BLOCK_SYNC=1
+        // restores the barriers (A/B builds).
+#ifndef AE_EPI_BLOCK_SYNC
+#define AE_EPI_BLOCK_SYNC 0
+#endif
+        auto epi_sync = [&]() __attribute__((always_inline)) {
+            if (AE_EPI_BLOCK_SYNC) __syncthreads();
+            else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
         const bool staged = (n_out % 8 == 0) && (p.ldc % 8 == 0) && (!p.res || (p.ldr % 8 == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0));
         if (staged) {
             float* st = reinterpret_cast<float*>(smem_raw) + wmn * (WMP * WN);
@@ -1057,7 +1074,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
             };
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) {
-                if (ps > 0) __syncthreads();
+                if (ps > 0) epi_sync();
                 // The staging loop is instantiated once per epilogue kind: inside it nothing depends on a runtime flag.  (Round 1 tested p.epi and
                 // the addvec pointer per VALUE: four scalar branches around every one of the 120 values a wave stages on the 192x320 tile.)
                 auto stage = [&](auto EPI_TAG, auto AV_TAG) {
@@ -1137,7 +1154,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                     else stage(std::integral_constant<int, EPI_RELU>{}, F{});
                 }
                 GL_T(6);
-                __syncthreads();
+                epi_sync();
                 const int ow = geglu ? WN / 2 : WN;      // output columns of this wave's tile
                 const int och = ow / 8;                  // 8-column output chunks per row
                 const int nbase = geglu ? (n0 + wn * WN) / 2 : n0 + wn * WN;

@@ -7,7 +7,9 @@ tag=$1; flt=$2; shift 2
 export TMPDIR=/tmp
 R=$PWD
 mkdir -p $R/gpurun_out
-cd /tmp && rm -rf pmc_$tag && timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$tag -o p -- python $R/tools/kbench.py "$flt" > $R/gpurun_out/pmc_$tag.log 2>&1
+# filter "@bench": the counters over the un-graphed UNet evaluations of bench.py (every kernel of the step in its place in the sequence) instead of kbench cases
+if [ "$flt" = "@bench" ]; then CMD="python $R/bench.py --no-graph --ddim-steps 2 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline"; else CMD="python $R/tools/kbench.py \"$flt\""; fi
+cd /tmp && rm -rf pmc_$tag && eval timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$tag -o p -- $CMD > $R/gpurun_out/pmc_$tag.log 2>&1
 echo "rocprofv3 rc=$?"
 python - /tmp/pmc_$tag "$R/gpurun_out/pmc_$tag.txt" <<'PY'
 import csv, sys, collections, glob, re
@@ -39,7 +41,7 @@ for r in csv.DictReader(open(cc[0])):
             pass
 with open(out, "w") as f:
     for k, dd in agg.items():
-        if not any(s in k for s in ("attn", "gemm", "gn_", "layernorm", "splitk")):
+        if not any(s in k for s in ("attn", "gemm", "gn_", "layernorm", "splitk", "colstats")):
             continue
         n = max(len(v) for v in dd.values())
         ns = sum(durs[k]) / len(durs[k]) if durs[k] else float("nan")
