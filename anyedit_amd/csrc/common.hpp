@@ -80,7 +80,33 @@ __device__ __forceinline__ float erf_as_f(float z) {
     const float r = __builtin_fmaf(-poly, e, 1.0f);
     return __builtin_copysignf(r, z);
 }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f)); }
+// GELU for the fused epilogues, written for instruction count (round 4: the epilogue is 25-40 % of the short-K GEGLU / GELU launches, and two thirds of
+// it is this arithmetic — profiles/r04_v31_epilogue_share.txt).  With w(x) = erf(|x| / sqrt 2) (the same 7.1.26 series, the 1 / sqrt 2 folded into its
+// two constants):   gelu(x) = 0.5 x (1 + sign(x) w) = 0.5 (x + |x| w)   — no copysign, no 1 + erf, |x| is a free source modifier: 13 VALU + rcp + exp2
+// instead of 16 + 2.  GEGLU's product a gelu(g) takes the 0.5 into a's bias add: (0.5 a) (g + |g| w) with 0.5 a = fma(acc, 0.5, 0.5 bias).
+__device__ __forceinline__ float gelu_w_f(float x) {
+    const float ax = __builtin_fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    poly = __builtin_fmaf(poly, t, 1.421413741f);
+    poly = __builtin_fmaf(poly, t, -0.284496736f);
+    poly = __builtin_fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f((-0.5f * 1.4426950408889634f) * ax * ax);   // exp(-x^2 / 2)
+    return __builtin_fmaf(-poly, e, 1.0f);
+}
+#ifndef AE_GELU_OLD
+#define AE_GELU_OLD 0   // 1: the round-1 form 0.5 x (1 + erf(x / sqrt 2)) through erf_as_f (A/B builds)
+#endif
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    if (AE_GELU_OLD) return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f));
+    return 0.5f * __builtin_fmaf(__builtin_fabsf(x), gelu_w_f(x), x);
+}
+// a_half * 2 gelu(g) = a gelu(g) for a_half = 0.5 a
+__device__ __forceinline__ float geglu_half_f(float a_half, float g) {
+    if (AE_GELU_OLD) return (a_half + a_half) * gelu_erf_f(g);
+    return a_half * __builtin_fmaf(__builtin_fabsf(g), gelu_w_f(g), g);
+}
 
 // XCD-aware, bijective block remap: hardware places block b on XCD b % 8.  Give every XCD a contiguous
 // run of logical tile ids so neighbouring tiles (which share operand panels) hit the same private L2.

@@ -419,8 +419,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
             }
             if constexpr (SC_LDS) {   // read by every wave in the epilogue, hundreds of barriers from here
                 if (tid < BN / 4) {
+                    // GEGLU: the packed columns interleave 16 'a' rows with their 16 gate rows; c of an 'a' column is stored halved (geglu_half_f)
+                    const float hc = (p.epi == EPI_GEGLU && ((4 * tid) & 16) == 0) ? 0.5f : 1.0f;
                     reinterpret_cast<f32x4*>(sc_lds)[tid] = scv[0];
-                    reinterpret_cast<f32x4*>(sc_lds + BN)[tid] = scv[1];
+                    reinterpret_cast<f32x4*>(sc_lds + BN)[tid] = (f32x4){scv[1][0] * hc, scv[1][1] * hc, scv[1][2] * hc, scv[1][3] * hc};
                 }
             }
         }
@@ -1061,6 +1063,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                     if (bias_v4) bz[j] = *reinterpret_cast<const f32x4*>(p.bias + ncol[j]);
                     else bz[j] = (f32x4){p.bias[ncol[j]], p.bias[ncol[j] + 1], p.bias[ncol[j] + 2], p.bias[ncol[j] + 3]};
                 }
+                if (geglu && (j & 1) == 0 && !SC_LDS) {   // GEGLU: fragment j is an 'a' fragment — its bias (XE 2: c) enters as 0.5 bias, see geglu_half_f
+                    bz[j][0] *= 0.5f; bz[j][1] *= 0.5f; bz[j][2] *= 0.5f; bz[j][3] *= 0.5f;
+                }
             }
             // XE 2: (s, c) of fragment j's four columns (local column wn * WN + 16 j + 4 lg in either packing: (j & ~1) * 16 + (j & 1) * 16 = 16 j)
             auto ln_sc = [&](int j, f32x4& sj, f32x4& cj) __attribute__((always_inline)) {
@@ -1103,15 +1108,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                                     if constexpr (XE == 2) { ln_sc(j, sa, ca); ln_sc(j + 1, sg, cg); }
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) {
-                                        float a, g;
+                                        float ah, g;   // ah = 0.5 a: the halves of the 'a' bias / c values were taken where they were loaded (bz, the LDS copy of c)
                                         if constexpr (XE == 2) {   // LayerNorm fold: rstd (acc - mu s) + c
-                                            a = fmaf(acc[i][j][r], ln_r[i], fmaf(ln_t[i], sa[r], ca[r]));
+                                            ah = fmaf(acc[i][j][r], 0.5f * ln_r[i], fmaf(0.5f * ln_t[i], sa[r], ca[r]));
                                             g = fmaf(acc[i][j + 1][r], ln_r[i], fmaf(ln_t[i], sg[r], cg[r]));
                                         } else {
-                                            a = acc[i][j][r] + bz[j][r];
+                                            ah = fmaf(acc[i][j][r], 0.5f, bz[j][r]);
                                             g = acc[i][j + 1][r] + bz[j + 1][r];
                                         }
-                                        o[r] = a * gelu_erf_f(g);
+                                        o[r] = geglu_half_f(ah, g);
                                     }
                                     const int ch = (j / 2) * 4 + lg;
                                     *reinterpret_cast<f32x4*>(st + rl * WN + (((ch + rl) % NCH) << 2)) = o;

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(64 * RP_NW, 2) void gemm_rowpanel_kernel(const RowP
             ae_dma16(rsA, lds0 + q * 1024, ((q / PIECES) * RP_BN + i) * (int)p.lda * 2 + ((pp & ~7) | ((pp ^ (i >> 1)) & 7)) * 16, soff);
         }
     }
-    for (int i = tid; i < p.N; i += 64 * RP_NW) sbias[i] = p.bias ? p.bias[i] : 0.f;
+    // (GEGLU: the packed columns interleave 16 'a' rows with their 16 gate rows; the bias of an 'a' column is kept halved: geglu_half_f)
+    for (int i = tid; i < p.N; i += 64 * RP_NW) sbias[i] = p.bias ? p.bias[i] * ((EPI == RP_EPI_GEGLU && (i & 16) == 0) ? 0.5f : 1.0f) : 0.f;
     if (LN) {
         for (int i = tid; i < K; i += 64 * RP_NW) { sln[i] = p.ln_g[i]; sln[K + i] = p.ln_b[i]; }
     }
@@ -268,10 +269,10 @@ __global__ __launch_bounds__(64 * RP_NW, 2) void gemm_rowpanel_kernel(const RowP
 #pragma unroll
             for (int f = 0; f < RP_MF; ++f) {
                 if (rok[f]) {
-                    const float o0 = (acc[f][0][0] + ba[0]) * gelu_erf_f(acc[f][1][0] + bg[0]);
-                    const float o1 = (acc[f][0][1] + ba[1]) * gelu_erf_f(acc[f][1][1] + bg[1]);
-                    const float o2 = (acc[f][0][2] + ba[2]) * gelu_erf_f(acc[f][1][2] + bg[2]);
-                    const float o3 = (acc[f][0][3] + ba[3]) * gelu_erf_f(acc[f][1][3] + bg[3]);
+                    const float o0 = geglu_half_f(fmaf(acc[f][0][0], 0.5f, ba[0]), acc[f][1][0] + bg[0]);   // ba holds 0.5 bias
+                    const float o1 = geglu_half_f(fmaf(acc[f][0][1], 0.5f, ba[1]), acc[f][1][1] + bg[1]);
+                    const float o2 = geglu_half_f(fmaf(acc[f][0][2], 0.5f, ba[2]), acc[f][1][2] + bg[2]);
+                    const float o3 = geglu_half_f(fmaf(acc[f][0][3], 0.5f, ba[3]), acc[f][1][3] + bg[3]);
                     *reinterpret_cast<u32x2*>(cb + coff[f]) = (u32x2){pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
                 }
             }
