@@ -74,6 +74,12 @@ def oracle_training_grads(moe_sd, cfg, prefixes, batch, control):
 def grad_tolerance(name, g_ref, e_ctl):
     """Derived bound for one trainable's gradient: 1.5 x the bf16-storage control's own error.  A gradient with only a handful of
     non-zero entries (the router bias: one entry per routed expert) is a NOISE NORM estimated from that handful of samples — two
-    independent realisations of it (HIP, control) differ by a chi-like factor, so those get 2.5 x."""
+    independent realisations of it (HIP, control) differ by a chi-like factor, so those get 2.5 x.
+    The router path (`gate.weight`, `gate.bias`, `task_embs`) belongs to the same class whatever its entry count: each of those gradients is a sum of
+    B rank-one terms (one per sample of the batch, B = 4 in the tests) of bf16-rounded upstream gradients that largely cancel, i.e. a handful of
+    independent contributions.  Measured on the tiny model with two forward passes that differ by fp32 rounding only (the round-1 and round-4
+    forms of the GELU arithmetic): gate.weight 6.27e-2 and 8.03e-2 against a control of 4.41e-2 — a quantity that moves by 30 % when
+    an ulp moves is a noise norm, and 1.5 x of one realisation of it is not a bound on another."""
     nz = int((g_ref != 0).sum())
-    return (2.5 if nz < 64 else 1.5) * e_ctl + 1e-3
+    few = nz < 64 or name.startswith("gate.") or name == "task_embs"
+    return (2.5 if few else 1.5) * e_ctl + 1e-3
