@@ -95,28 +95,6 @@ __device__ __forceinline__ float gelu_w_f(float x) {
     const float e = __builtin_amdgcn_exp2f((-0.5f * 1.4426950408889634f) * ax * ax);   // exp(-x^2 / 2)
     return __builtin_fmaf(-poly, e, 1.0f);
 }
-// Two values per instruction (v_pk_fma_f32 / v_pk_mul_f32) for epilogues that run with the matrix pipe idle: a packed op issues like a plain one and does
-// twice the work, which is the opposite of its price BESIDE MFMAs (MI355X_MICROARCH.md "price of one filler": the reason gemm_conv.hip is built with
-// -fno-slp-vectorize) — so the packing is written out here, only for the GEGLU staging loop of the 192x320 tile, whose four block rounds of VALU-bound
-// staging are a quarter of the launch.  rcp / exp2 stay per value (no packed transcendentals), |x| is two v_and (VOP3P has no abs modifier).
-__device__ __forceinline__ f32x2 gelu_w_pk(f32x2 x) {
-    const f32x2 ax = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
-    const f32x2 d = ax * (f32x2){0.3275911f * 0.70710678118654752440f, 0.3275911f * 0.70710678118654752440f} + (f32x2){1.0f, 1.0f};
-    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-    f32x2 poly = t * (f32x2){1.061405429f, 1.061405429f} + (f32x2){-1.453152027f, -1.453152027f};
-    poly = poly * t + (f32x2){1.421413741f, 1.421413741f};
-    poly = poly * t + (f32x2){-0.284496736f, -0.284496736f};
-    poly = poly * t + (f32x2){0.254829592f, 0.254829592f};
-    poly = poly * t;
-    const f32x2 u = (ax * ax) * (f32x2){-0.5f * 1.4426950408889634f, -0.5f * 1.4426950408889634f};
-    const f32x2 e = {__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};
-    return (f32x2){1.0f, 1.0f} - poly * e;
-}
-// (a_half, g) pairs -> a gelu(g), same arithmetic per value as geglu_half_f
-__device__ __forceinline__ f32x2 geglu_half_pk(f32x2 a_half, f32x2 g) {
-    const f32x2 ag = {__builtin_fabsf(g[0]), __builtin_fabsf(g[1])};
-    return a_half * (ag * gelu_w_pk(g) + g);
-}
 #ifndef AE_GELU_OLD
 #define AE_GELU_OLD 0   // 1: the round-1 form 0.5 x (1 + erf(x / sqrt 2)) through erf_as_f (A/B builds)
 #endif

@@ -32,9 +32,6 @@ namespace {
 #define AE_GEMM_PP_DEFAULT 63   // 15 + the slab form of the conv loop (16 un-split, 32 split-K): outputs bit-identical (56 checksums), every launch of the family 1-3 % faster
                                 // un-graphed, UNet step -0.02 ms over three alternating A/B rounds on two boxes (profiles/r04_v24..v26_lnfold_slab_ab.txt)
 #endif
-#ifndef AE_GEGLU_PK
-#define AE_GEGLU_PK 1       // packed fp32 VALU (v_pk_fma_f32) in the GEGLU staging loop of the 192x320 ping-pong tile (matrix pipe idle there); 0 = one value per instruction
-#endif
 #ifndef AE_PP_LAB
 #define AE_PP_LAB 0         // lab builds only (tools/ubench/conv_lab.hip): 1 no DMA after the prologue, 2 DMA + barriers only (no LDS reads, no MFMAs), 3 MFMAs on stale registers (no LDS reads)
 #endif
@@ -1109,24 +1106,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(
                                     f32x4 o;
                                     f32x4 sa, ca, sg, cg;
                                     if constexpr (XE == 2) { ln_sc(j, sa, ca); ln_sc(j + 1, sg, cg); }
-                                    if constexpr (AE_GEGLU_PK && WA == 3) {
-                                        // packed form (two values per VALU instruction: the matrix pipe is idle here, see gelu_w_pk); ah = 0.5 a as below
-#pragma unroll
-                                        for (int r = 0; r < 4; r += 2) {
-                                            const f32x2 xa = {acc[i][j][r], acc[i][j][r + 1]}, xg = {acc[i][j + 1][r], acc[i][j + 1][r + 1]};
-                                            f32x2 ah, g;
-                                            if constexpr (XE == 2) {
-                                                const f32x2 rh = {0.5f * ln_r[i], 0.5f * ln_r[i]}, th = {0.5f * ln_t[i], 0.5f * ln_t[i]}, r1 = {ln_r[i], ln_r[i]}, t1 = {ln_t[i], ln_t[i]};
-                                                ah = xa * rh + (th * (f32x2){sa[r], sa[r + 1]} + (f32x2){ca[r], ca[r + 1]});
-                                                g = xg * r1 + (t1 * (f32x2){sg[r], sg[r + 1]} + (f32x2){cg[r], cg[r + 1]});
-                                            } else {
-                                                ah = xa * (f32x2){0.5f, 0.5f} + (f32x2){bz[j][r], bz[j][r + 1]};
-                                                g = xg + (f32x2){bz[j + 1][r], bz[j + 1][r + 1]};
-                                            }
-                                            const f32x2 y = geglu_half_pk(ah, g);
-                                            o[r] = y[0]; o[r + 1] = y[1];
-                                        }
-                                    } else
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) {
                                         float ah, g;   // ah = 0.5 a: the halves of the 'a' bias / c values were taken where they were loaded (bz, the LDS copy of c)
