@@ -32,6 +32,9 @@ namespace {
 #define AE_GEMM_PP_DEFAULT 63   // 15 + the slab form of the conv loop (16 un-split, 32 split-K): outputs bit-identical (56 checksums), every launch of the family 1-3 % faster
                                 // un-graphed, UNet step -0.02 ms over three alternating A/B rounds on two boxes (profiles/r04_v24..v26_lnfold_slab_ab.txt)
 #endif
+#ifndef AE_XE_OCC
+#define AE_XE_OCC 4         // waves per SIMD the 128x128 LayerNorm-fold instantiations must leave room for (two 8-wave blocks per CU); 0 = unconstrained (A/B builds)
+#endif
 #ifndef AE_PP_LAB
 #define AE_PP_LAB 0         // lab builds only (tools/ubench/conv_lab.hip): 1 no DMA after the prologue, 2 DMA + barriers only (no LDS reads, no MFMAs), 3 MFMAs on stale registers (no LDS reads)
 #endif
@@ -136,8 +139,12 @@ constexpr int epilogue_passes(int FM, int bytes_per_frag_row, int lds_bytes) {
 // LAB (AE_GEMM_LAB builds only, tools/ubench): 1 = no DMA after the first tile, 2 = no LDS reads / MFMAs, 3 = MFMAs on stale registers (no LDS reads)
 // XE (round 4): 1 = the epilogue also emits per-row (sum, sum of squares) of its bf16 output per 64-column slice (GemmArgs::rowstats), 2 = the
 // epilogue applies the LayerNorm fold from such statistics of A (GemmArgs::ln_stats / ln_colsum).  XE = 0 instantiations are unchanged code.
+// (second launch bound = waves per SIMD the register allocation must leave room for; 0 = no constraint.  The LayerNorm-fold instantiations of the 8-wave
+// 128x128 tile carry 36 more live registers than their XE = 0 twins and sit AT the 128-register line that decides whether two blocks share a CU: an unrelated
+// edit moved them from 126 to 129 registers and the qkv / q launches from 38.2 to 47.3 us (profiles/r04_final2 / r04_final3_kernel_stats.csv) — so the
+// line is stated here, not left to the allocator's mood.)
 template <int BM, int BN, int AMODE, int WAVES_M = 2, int WAVES_N = 2, bool GLDS = false, int WAVES_K = 1, int STAGES = 2, bool CS = false, int LAB = 0, int WA = 0, int XE = 0>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, (XE == 2 && BM == 128 && BN == 128 && STAGES == 2) ? AE_XE_OCC : 0) void gemm_kernel(const GemmArgs p) {
     static_assert(XE == 0 || (AMODE == A_DENSE && WAVES_K == 1 && !CS && GLDS), "row statistics / LayerNorm fold: dense LDS-DMA instantiations, one K group, no column statistics");
     static_assert(XE != 1 || BN / WAVES_N == 64, "row statistics are emitted per 64-column slice = one wave tile's width");
     static_assert(STAGES == 2 || (GLDS && WAVES_K == 1), "the deep LDS ring exists only for the LDS-DMA loader");
