@@ -1723,7 +1723,7 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     }
     if (rc) return rc;
     if (a.xe && !xe_done) {
-        // (ops.py asks ae_gemm_ln_plan first, so this is a caller error; whatever was launched above wrote a plain result)
+        // (ops.py asks ae_gemm_ln_plan first, so this is a caller error; ae_gemm_ln_bf16 runs this selection as a query before it launches, so nothing was written)
         ae_set_error("%s: no %s instantiation for M=%d N=%d K=%d epilogue %d (ae_gemm_ln_plan says which shapes are covered)", what,
                      a.xe == 1 ? "row-statistics" : "LayerNorm-fold", a.M, a.N, a.K, a.epi);
         return AE_ERR_UNSUPPORTED;
@@ -1841,6 +1841,11 @@ int gemm_entry(const void* A, long lda, const void* A2, long lda2, int Ksplit, c
             AE_REQUIRE(aligned16(x.ln_colsum) && aligned16(bias) && (reinterpret_cast<uintptr_t>(x.ln_stats) & 7) == 0, "ae_gemm_ln_bf16: s / c must be 16-byte aligned, the statistics 8-byte aligned");
             a.xe = 2; a.ln_stats = x.ln_stats; a.ln_colsum = x.ln_colsum; a.ln_parts = x.ln_parts; a.ln_eps = x.ln_eps;
         }
+        // the selection runs once without launching: a shape whose plan has no such epilogue is refused before anything is written
+        g_plan_query = 1;
+        const int rc = launch<A_DENSE>(a, nullptr);
+        g_plan_query = 0;
+        if (rc) return rc;
     }
     return launch<A_DENSE>(a, (hipStream_t)stream);
 }

@@ -338,6 +338,15 @@ def test_layernorm_fold_plan_follows_the_tile_plan(monkeypatch):
     # a plan answer is a property of (M, N, K, epilogue): the same question twice, and the launch-side refusal for an uncovered shape
     assert lib.ae_gemm_ln_plan(3072, 1280, 1280, E, 1) == lib.ae_gemm_ln_plan(3072, 1280, 1280, E, 1) == 1
 
+    # ... and the launch side refuses such a shape BEFORE anything is launched (the selection runs once as a query): no GPU is touched here
+    import ctypes
+    buf = (ctypes.c_char * 4096)()
+    ptr = (ctypes.addressof(buf) + 255) // 256 * 256
+    rc = lib.ae_gemm_ln_bf16(ptr, 640, ptr, 640, ptr, 640, 64, 640, 640, ptr, None, 0, 0, ptr, None, 0, None, 0.0, None)
+    assert rc == -3 and b"no row-statistics instantiation" in lib.ae_last_error()
+    rc = lib.ae_gemm_ln_bf16(ptr, 640, ptr, 640, ptr, 640, 64, 640, 640, ptr, None, 0, 0, ptr, ptr, 10, ptr, 1e-5, None)
+    assert rc == -1 and b"exactly one of" in lib.ae_last_error()
+
     class _Tape:
         active = True
     monkeypatch.setattr(ops, "_TAPE", _Tape())
