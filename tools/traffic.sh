@@ -67,6 +67,11 @@ if ln:
     # per evaluation: 15 LN at [12288,640] + 15 at [3072,1280] (+ 3 at [768,1280]; the level-1 LayerNorms are fused into the row-panel
     # GEMM since round 2): expected mean
     exp = (15 * 12288 * 640 + 15 * 3072 * 1280 + 3 * 768 * 1280) * 2.0 / 33.0
+    # round 4: with the LayerNorm fold (AE_LN_FOLD, default on) only the three [768, 1280] LayerNorms of the 8x8 level are still launches — told apart
+    # by the launch count per evaluation (the d = 40 self-attention kernel runs five times per evaluation)
+    att = res["kernels"].get("attn_fast_kernel<D=40>")
+    if att and att["launches"] and ln["launches"] * 5.0 / att["launches"] < 8:
+        exp = 768 * 1280 * 2.0
     res["calibration"] = {"kernel": ln_name, "expected_bytes_each_way_approx": exp,
                           "fetch_over_expected": ln["fetch_bytes"] / exp if ln["fetch_bytes"] else None,
                           "write_over_expected": ln["write_bytes"] / exp if ln["write_bytes"] else None}
