@@ -69,6 +69,7 @@ SIGNATURES = {
     "ae_expert_kv_wgrad": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ae_transpose_last2": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ae_concat_channels_bf16": [c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_void_p],
+    "ae_im2col3x3_c8_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "ae_split_channels_bf16": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "ae_timestep_embedding": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "ae_ddim_step_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_float, c_float,

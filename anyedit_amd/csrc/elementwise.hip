@@ -53,6 +53,26 @@ __global__ void concat_kernel(const bf16_t* a, int Ca, const bf16_t* b, int Cb, 
     }
 }
 
+// im2col of a 3x3 / pad 1 / stride 1 convolution over an 8-channel channels-last map: row m of y holds the nine taps' 8 channels (k = 8 tap + c,
+// tap = 3 ky + kx; 16 bytes each, zeros outside the image) and seven zero chunks up to 128 columns — the UNet's stem conv (8 -> 320, openaimodel.py:536-542)
+// then runs as a dense K = 128 GEMM instead of an implicit GEMM whose nine K tiles are 7/8 zero padding (Cin = 8 padded to the 64-deep K tile).
+__global__ void im2col3x3_c8_kernel(const bf16_t* x, bf16_t* y, int B, int H, int W) {
+    const long total = (long)B * H * W * 16;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long m = i >> 4;
+        const int t = (int)(i & 15);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (t < 9) {
+            const int hw = H * W;
+            const int b = (int)(m / hw), rem = (int)(m - (long)b * hw);
+            const int oy = rem / W, ox = rem - oy * W;
+            const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *reinterpret_cast<const u32x4*>(x + (((long)b * H + iy) * W + ix) * 8);
+        }
+        *reinterpret_cast<u32x4*>(y + m * 128 + t * 8) = v;
+    }
+}
+
 // adjoint of concat_kernel: the two channel slices of dy go to da / db in one pass (written, or added to what is there)
 __global__ void split_kernel(const bf16_t* y, int Ca, int Cb, bf16_t* a, bf16_t* b, long rows, int acc_a, int acc_b) {
     const int C = Ca + Cb, ncc = C / 8;
@@ -473,6 +493,13 @@ extern "C" int ae_concat_channels_bf16(const void* a, int Ca, const void* b, int
     hipLaunchKernelGGL(concat_kernel, dim3(grid_for(rows * ((Ca + Cb) / 8))), dim3(NT), 0, (hipStream_t)stream,
                        (const bf16_t*)a, Ca, (const bf16_t*)b, Cb, (bf16_t*)y, rows);
     return ae_check_launch("ae_concat_channels_bf16");
+}
+
+extern "C" int ae_im2col3x3_c8_bf16(const void* x, void* y, int B, int H, int W, void* stream) {
+    AE_REQUIRE(x && y && B > 0 && H > 0 && W > 0, "ae_im2col3x3_c8_bf16: bad arguments");
+    AE_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "ae_im2col3x3_c8_bf16: 16-byte alignment");
+    hipLaunchKernelGGL(im2col3x3_c8_kernel, dim3(grid_for((long)B * H * W * 16)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, H, W);
+    return ae_check_launch("ae_im2col3x3_c8_bf16");
 }
 
 extern "C" int ae_split_channels_bf16(const void* y, int Ca, int Cb, void* a, void* b, long rows, int accumulate_a, int accumulate_b, void* stream) {

@@ -139,6 +139,11 @@ class Conv2d(nn.Conv2d, _Packed):
         pk = self._packed()
         if self.kernel_size[0] == 1:
             return ops.gemm(x, pk["w"], pk["b"], residual=residual, out_f32=out_f32, a2=a2, colstats=colstats), H, W
+        if addvec is None and residual is None and not out_f32 and a2 is None and ops.stem_im2col_ok(self.in_channels, self.stride[0], upsample2x):
+            # the 8-channel stem: nine taps x 8 channels are 72 real K columns — as im2col rows + a K = 128 dense GEMM instead of nine 64-deep K tiles of padding
+            if "w_taps" not in pk:
+                pk["w_taps"] = ops.pack_conv3x3_taps8(self.weight)
+            return ops.gemm(ops.im2col3x3_c8(x, B, H, W), pk["w_taps"], pk["b"], colstats=colstats), H, W
         Ho, Wo = self.out_hw(H, W, upsample2x)
         ko = ops.conv_k_order(B * Ho * Wo, self.in_channels, self.out_channels, self.stride[0], upsample2x)
         w = pk["w"]

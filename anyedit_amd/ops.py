@@ -98,6 +98,34 @@ def pack_conv3x3(w, cin_pad=None, k_order=0):
     return wp.reshape(cout, 9 * cin_pad).contiguous()
 
 
+def pack_conv3x3_taps8(w):
+    """[Cout, 8, 3, 3] -> bf16 [Cout, 128], column 8 * (3 ky + kx) + cin, zeros in columns 72..127: the stem conv as a dense GEMM over
+    `im2col3x3_c8` rows (same products as the implicit GEMM, a ninth of its K extent)."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert cin == 8 and tuple(w.shape[2:]) == (3, 3)
+    wp = torch.zeros(cout, 128, dtype=BF16, device=w.device)
+    wp[:, :72] = w.detach().permute(0, 2, 3, 1).reshape(cout, 72).to(BF16)
+    return wp.contiguous()
+
+
+_STEM_IM2COL = os.environ.get("AE_STEM_IM2COL", "1") != "0"  # tuning knob (A/B): 0 = the stem conv through the implicit-GEMM kernel (Cin = 8 padded to 64 per tap)
+
+
+def stem_im2col_ok(Cin, stride, upsample2x):
+    """True where a 3x3 conv runs as im2col + dense GEMM: the 8-channel stem (not under the training tape, whose conv node keeps the implicit-GEMM form)."""
+    return _STEM_IM2COL and Cin == 8 and stride == 1 and not upsample2x and not (_TAPE is not None and _TAPE.active)
+
+
+def im2col3x3_c8(x, B, H, W):
+    """x: [B*H*W, 8] bf16 channels-last -> [B*H*W, 128] bf16 (`pack_conv3x3_taps8` column order)."""
+    _chk(x, BF16, "im2col3x3_c8.x", 2)
+    if tuple(x.shape) != (B * H * W, 8) or not x.is_contiguous():
+        raise ValueError(f"im2col3x3_c8: x must be contiguous [{B * H * W}, 8], got {tuple(x.shape)}")
+    y = torch.empty(B * H * W, 128, dtype=BF16, device=x.device)
+    check(lib.ae_im2col3x3_c8_bf16(_p(x), _p(y), B, H, W, _s()), "ae_im2col3x3_c8_bf16")
+    return y
+
+
 _CONV_KMAJOR = int(os.environ.get("AE_CONV_KMAJOR", "2"))  # tuning knob: 0 off, 1 un-split 192x320 plan, 2 + its split-K form, 3 every eligible conv, 4 un-split 192x320 and 128x128 plans
 
 

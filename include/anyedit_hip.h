@@ -211,6 +211,10 @@ int ae_expert_kv_wgrad(const void* dy, const void* x, const int* experts, float*
 int ae_transpose_last2(const void* in, void* out, int B, int X, int Y, int Xpad, int in_bf16, int out_bf16, void* stream);
 /* th.cat([h, hs.pop()], dim=1) (openaimodel.py:780) on channels-last rows.                                                   */
 int ae_concat_channels_bf16(const void* a, int Ca, const void* b, int Cb, void* y, long rows, void* stream);
+/* im2col of the UNet's stem conv (3x3, pad 1, stride 1 over the 8-channel input, openaimodel.py:536-542): x [B,H,W,8] bf16 -> y [B*H*W, 128] bf16,
+ * column 8 tap + c (tap = 3 ky + kx), zeros outside the image and in columns 72..127; the conv is then ae_gemm_bf16 with the weight packed
+ * [Cout, 128] in the same column order — K = 128 instead of nine K tiles that are 7/8 zero padding.                                            */
+int ae_im2col3x3_c8_bf16(const void* x, void* y, int B, int H, int W, void* stream);
 /* Adjoint of the channel concat: a (+)= y[:, :Ca], b (+)= y[:, Ca:] in one pass; a or b may be NULL (that half is skipped).       */
 int ae_split_channels_bf16(const void* y, int Ca, int Cb, void* a, void* b, long rows, int accumulate_a, int accumulate_b, void* stream);
 /* timestep_embedding (util.py:154-174): [cos | sin], t given as int64 or fp32.                                               */

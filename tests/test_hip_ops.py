@@ -193,6 +193,35 @@ def test_layernorm_folded_into_gemm(ops, M, C, N, epi):
         ops._gemm_ln(x[:64], wq, c, None, E, None, None, st[:64].contiguous(), s, 1e-5)
 
 
+@pytest.mark.parametrize("B,H,W,Cout", [(2, 16, 16, 64), (1, 5, 7, 320), (12, 64, 64, 320)])
+def test_stem_conv_as_im2col_gemm(ops, B, H, W, Cout, monkeypatch):
+    """The UNet's 8-channel stem conv (openaimodel.py:536-542) as `im2col3x3_c8` + a K = 128 dense GEMM: the im2col rows bit-exact against the
+    definition of a zero-padded 3x3 gather, the conv against fp32 F.conv2d on the same bf16 operands and against the implicit-GEMM kernel."""
+    from anyedit_amd.ldm.modules.diffusionmodules.util import Conv2d
+    import anyedit_amd.ops as O
+    g = torch.Generator().manual_seed(B + H + Cout)
+    x = q(torch.randn(B, 8, H, W, generator=g))
+    rows = ops.nchw_to_rows(x.to(DEV))
+    col = ops.im2col3x3_c8(rows, B, H, W).cpu()
+    xp = F.pad(x, (1, 1, 1, 1))
+    ref = torch.zeros(B, H, W, 128)
+    for tap in range(9):
+        ref[..., 8 * tap:8 * tap + 8] = xp[:, :, tap // 3:tap // 3 + H, tap % 3:tap % 3 + W].permute(0, 2, 3, 1)
+    assert torch.equal(col.float().reshape(B, H, W, 128), ref), "im2col rows differ from the zero-padded gather"
+    conv = Conv2d(8, Cout, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(q(torch.randn(Cout, 8, 3, 3, generator=g) / 72 ** 0.5))
+        conv.bias.copy_(torch.randn(Cout, generator=g) * 0.1)
+    want = F.conv2d(x, conv.weight.detach(), conv.bias.detach(), padding=1)
+    conv = conv.to(DEV)
+    assert O.stem_im2col_ok(8, 1, False)
+    y, _, _ = conv.rows(rows, B, H, W)
+    check_close(ops.rows_to_nchw(y, B, H, W), want, what=f"stem conv via im2col [{B},8,{H},{W}] -> {Cout}")
+    monkeypatch.setattr(O, "_STEM_IM2COL", False)
+    y0, _, _ = conv.rows(rows, B, H, W)
+    check_close(y, y0.float().cpu(), rl2=3e-3, mabs=2e-2, what="im2col path vs implicit GEMM")
+
+
 def test_gemm_linearity_full_size(ops):
     """Size-independent property at a BASELINE-size shape: f(a1 + a2) == f(a1) + f(a2) up to rounding."""
     g = torch.Generator(device=DEV).manual_seed(1)

@@ -133,6 +133,12 @@ def test_weight_packing_layouts():
         assert torch.equal(wp[32 * j:32 * j + 16], wg[16 * j:16 * j + 16])
         assert torch.equal(wp[32 * j + 16:32 * j + 32], wg[inner + 16 * j:inner + 16 * j + 16])
         assert torch.equal(bp[32 * j + 16:32 * j + 32], bg[inner + 16 * j:inner + 16 * j + 16])
+    # the stem conv's tap-packed weight (im2col + dense GEMM): column 8 (3 ky + kx) + cin, zeros from column 72 on
+    ws = (torch.arange(5 * 8 * 9, dtype=torch.float32) % 61).reshape(5, 8, 3, 3)
+    wt = ops.pack_conv3x3_taps8(ws).float()
+    assert wt.shape == (5, 128) and float(wt[:, 72:].abs().max()) == 0.0
+    for tap in range(9):
+        assert torch.equal(wt[:, 8 * tap:8 * tap + 8], ws[:, :, tap // 3, tap % 3])
 
 
 def test_sam_key_schema_and_prompt_geometry():
