@@ -264,10 +264,17 @@ __global__ __launch_bounds__(64 * NWV, OCC) void attn_fast_kernel(const AttnArgs
     // by ds_read two instructions after its last MFMA).  The matrix pipe is in order and takes one MFMA at a time, so a fragment is safe once two
     // further MFMAs have been issued: the last two fragments stay live values in this ring until then.
     u32x4 srcring[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-    auto retire_src = [&](bf16x8_t frag) __attribute__((always_inline)) {
+    // Round 5: with ONE query group the plain use above is too weak — an input-only asm is not ordered against the MFMAs, and the
+    // listings of the head-dim 80 / 160 and SAM-window instantiations showed v_exp_f32 / address VALU writes into a K or V fragment one to four
+    // instructions behind the MFMA that reads it (tools/isa_audit.py).  There the retiring statement also takes `acc`, the RESULT of the MFMA that read
+    // `frag`, as a read-write operand: it can only sit behind that MFMA's issue, and the fragment of two MFMAs ago stays a live value until then.
+    // The two-query-group instantiation (clean listing, tuned schedule) keeps the plain form: its device code is unchanged.
+    auto retire_src = [&](bf16x8_t frag, f32x16& acc) __attribute__((always_inline)) {
         union { bf16x8_t b; u32x4 u; } cv;
         cv.b = frag;
-        asm volatile("" ::"v"(srcring[0]));
+        if constexpr (QG == 1 && D <= 96) asm volatile("" : "+v"(acc) : "v"(srcring[0]));
+        else if constexpr (QG == 1 && SEG2 && SKV) asm volatile("" : "+a"(acc) : "v"(srcring[0]));   // head dim 160: hipcc keeps S and O in the accumulator file, an "a" tie costs no copies
+        else asm volatile("" ::"v"(srcring[0]));
         srcring[0] = srcring[1];
         srcring[1] = cv.u;
     };
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(64 * NWV, OCC) void attn_fast_kernel(const AttnArgs
                         s[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, as_bf16x8(qf[gq][ks]), ks == 0 ? cinit[gq] : s[gq], 0, 0, 0);
                     }
                 }
-                retire_src(kf);
+                retire_src(kf, s[QG - 1]);
             }
             if (BIAS3) {
                 // (tile buffer index = kcur's buffer: the key row inside the resident image is buffer * 64 + B2 * 32 + l31)
@@ -327,12 +334,13 @@ __global__ __launch_bounds__(64 * NWV, OCC) void attn_fast_kernel(const AttnArgs
                     const bf16x8_t hf = as_bf16x8(*reinterpret_cast<const u32x4*>(skhot + (khot_row + B2 * 32) * 64 + hi * 16 + kb * 32));
 #pragma unroll
                     for (int gq = 0; gq < QG; ++gq) s[gq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hf, as_bf16x8(qrel[kb]), s[gq], 0, 0, 0);
-                    retire_src(hf);
+                    retire_src(hf, s[QG - 1]);
                 }
             }
             // the P registers of the previous block's last K-step (`hold`) are free from here on: six more MFMAs are in the pipe behind
             // the one that read them
-            if (AE_ATTN_FENCE_ALL || QG > 1) asm volatile("" ::"v"(hold[0]), "v"(hold[1]));
+            if constexpr (QG == 1 && D <= 96) { if (AE_ATTN_FENCE_ALL) asm volatile("" : "+v"(s[0]) : "v"(hold[0]), "v"(hold[1])); }   // behind the last logit MFMA's issue (see retire_src)
+            else asm volatile("" ::"v"(hold[0]), "v"(hold[1]));
         }
         if (ABL == 10 || ABL == 12) __builtin_amdgcn_s_setprio(0);
         if (ABL == 11) __builtin_amdgcn_s_setprio(1);
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(64 * NWV, OCC) void attn_fast_kernel(const AttnArgs
                     const bf16x8_t pb = as_bf16x8((u32x4){pk[gq][4 * kk], pk[gq][4 * kk + 1], pk[gq][4 * kk + 2], pk[gq][4 * kk + 3]});
                     o[gq][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[gq][db], 0, 0, 0);
                 }
-                retire_src(vf);
+                retire_src(vf, o[QG - 1][db]);
             }
         }
         if (AE_ATTN_FENCE_ALL || QG > 1) {
@@ -427,10 +435,14 @@ __global__ __launch_bounds__(64 * NWV, OCC) void attn_fast_kernel(const AttnArgs
             // different.  hipcc inserts no wait states for this write-after-read.  So every P register of the block stays a live
             // value until the block's last MFMA has been issued (these empty asm statements are uses), and the last K-step's until
             // the next block's QK^T MFMAs are out (`hold`).
+            if constexpr (QG == 1 && D <= 96) {
+                if (ABL != 3) asm volatile("" : "+v"(o[0][NDB - 1]) : "v"(pk[0][0]), "v"(pk[0][1]), "v"(pk[0][2]), "v"(pk[0][3]), "v"(pk[0][4]), "v"(pk[0][5]), "v"(pk[0][6]), "v"(pk[0][7]));   // behind the block's last MFMA's issue
+            } else {
 #pragma unroll
             for (int gq = 0; gq < QG; ++gq)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(pk[gq][j]));
+            }
             hold[0] = (u32x4){pk[0][4], pk[0][5], pk[0][6], pk[0][7]};
             hold[1] = (u32x4){pk[QG - 1][4], pk[QG - 1][5], pk[QG - 1][6], pk[QG - 1][7]};
         }
@@ -603,10 +615,16 @@ __global__ __launch_bounds__(64 * NWV, OCC) void attn_fast_kernel(const AttnArgs
             }
             seg_nk = p.Nk;
             for (int t = 0; t < nt0; ++t) tile(t, t);
+            // the same MFMA-source fences as behind the tiled loop below: park() / store_o() open with VALU work while the last PV MFMAs may
+            // still be reading their P / V fragment registers (tests/test_isa_static.py checks every instantiation's listing)
+            if (AE_ATTN_FENCE_ALL || QG > 1) asm volatile("" ::"v"(hold[0]), "v"(hold[1]));
+            asm volatile("" ::"v"(srcring[0]), "v"(srcring[1]));
             if (SEG2) {
                 park();
                 seg_nk = p.Nk2;
                 tile(0, 2);
+                if (AE_ATTN_FENCE_ALL || QG > 1) asm volatile("" ::"v"(hold[0]), "v"(hold[1]));
+                asm volatile("" ::"v"(srcring[0]), "v"(srcring[1]));
             }
             store_o();
         }

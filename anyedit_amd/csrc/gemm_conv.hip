@@ -7,15 +7,19 @@
 // (row A5) on channels-last activations, where conv3x3 is the same GEMM with an on-the-fly im2col gather
 // (M = B*Ho*Wo, K = 9*Cin ordered (ky,kx,cin)); stride-2 and nearest-x2 upsampling are folded into the gather.
 //
-// Structure (wave64, 256 threads = 2x2 waves):
-//   * block tile BM x BN x 64, double-buffered in LDS with a 16-byte-chunk XOR swizzle (conflict-free
-//     ds_read_b128 of MFMA fragments), register-staged global loads issued one K-tile ahead (issue-early /
-//     write-late), one barrier per K-tile;
-//   * v_mfma_f32_16x16x32_bf16 with the operands swapped (W fragment as the row operand) so each lane ends up
-//     with 4 consecutive output columns -> 8-byte bf16 stores;
-//   * fused epilogues: +bias, +per-(batch,channel) vector (time embedding), SiLU / exact-erf GELU / GEGLU gate,
-//     +residual, bf16 or fp32 output;
-//   * XCD-aware bijective tile remap so tiles sharing an A panel run on the same XCD's L2.
+// Structure (wave64; the instantiations and who launches which are listed at launch()):
+//   * block tile BM x BN x 64 in LDS, filled by LDS-DMA (`buffer_load_dwordx4 ... lds`: no staging registers, no ds_write) with the 16-byte-chunk
+//     XOR swizzle applied on the per-lane SOURCE side (conflict-free ds_read_b128 of MFMA fragments); a register-staged loader remains for
+//     tiles that need per-chunk decisions (K tails, padded channels);
+//   * main loops: 192x320 tile, 8 waves, one block per CU — the PING-PONG loop (two groups of four waves one barrier apart: LOAD interval ‖ MFMA
+//     interval, hand-placed counted vmcnt, asm DMA; WA = 3) and its activation-SLAB form for stride-1 convs (WA = 4);  128x128 tile, 8 waves, two
+//     blocks per CU — two-stage ring with the weights two K tiles ahead (WA = 1) or a three-stage ring where one block per CU runs anyway;
+//     128x64 / 64x64 tiles for small grids; split-K (fp32 partials + fixed-order reduce) for M <= 3072 convs;
+//   * v_mfma_f32_16x16x32_bf16 with the operands swapped (W fragment as the row operand) so each lane ends up with 4 consecutive output columns;
+//   * fused epilogues staged through LDS into 16-byte row-contiguous stores: +bias, +per-(batch,channel) vector (time embedding), SiLU / exact-erf
+//     GELU / GEGLU gate, +residual, bf16 or fp32 output, optional per-channel (CS) or per-row (XE 1) statistics of the stored values, optional
+//     LayerNorm fold (XE 2);
+//   * XCD-aware bijective tile remap so tiles sharing an operand panel run on the same XCD's L2.
 #include "common.hpp"
 #include <stdlib.h>
 #include <type_traits>
@@ -1585,6 +1589,7 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
     // the slab form of the ping-pong loop (WA = 4): whole image rows per 192-row tile, 16-row fragments inside one image row, at most 208 slab rows,
     // chunk-major K with every block's K range starting at a chunk boundary
     const bool slab_ok = conv && a.kmajor && a.stride == 1 && !a.ups && a.Cin == a.CinPad && a.H == a.Ho && a.Wd == a.Wo && a.Wd % 16 == 0 && 192 % a.Wd == 0 &&
+                         192 / a.Wd <= a.H + 1 &&   // the slab's image row is y0 + jr with ONE wrap into the next sample (a short-wide map would need a true modulo)
                          (a.splitk <= 1 || kt_block % 9 == 0);
     const size_t lds_slab = (size_t)2 * ((192 + 192 / 16 + 1 + 7) / 8) * 1024 + (size_t)2 * 320 * BK * sizeof(bf16_t);
     if (conv && a.splitk > 1 && glds && make_plan(a.M, a.N, a.K, true).tile == 4) {  // split-K under the 192x320 tile (make_plan)
@@ -1838,6 +1843,7 @@ int gemm_entry(const void* A, long lda, const void* A2, long lda2, int Ksplit, c
             a.xe = 1; a.rowstats = x.rowstats_out;
         } else {
             AE_REQUIRE(x.ln_colsum && bias && x.ln_parts > 0 && x.ln_parts <= 20 && x.ln_eps >= 0.f, "ae_gemm_ln_bf16: LayerNorm fold needs s (ln_colsum), c (bias), 1..20 statistics slices per row (K <= 1280)");
+            AE_REQUIRE(x.ln_parts * 64 == K, "ae_gemm_ln_bf16: the statistics must cover the row: ln_parts * 64 = %d, K = %d (the kernel divides the summed slices by K)", x.ln_parts * 64, K);
             AE_REQUIRE(aligned16(x.ln_colsum) && aligned16(bias) && (reinterpret_cast<uintptr_t>(x.ln_stats) & 7) == 0, "ae_gemm_ln_bf16: s / c must be 16-byte aligned, the statistics 8-byte aligned");
             a.xe = 2; a.ln_stats = x.ln_stats; a.ln_colsum = x.ln_colsum; a.ln_parts = x.ln_parts; a.ln_eps = x.ln_eps;
         }

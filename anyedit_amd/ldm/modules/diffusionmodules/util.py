@@ -113,7 +113,9 @@ class Linear(nn.Linear, _Packed):
         """rowstats: optional `ops.rowstats_buffer` that receives the row statistics of the result (for a LayerNorm folded into the next GEMM)."""
         pk = self._packed()
         if rowstats is not None:
-            return ops.gemm(x, pk["w"], pk["b"], residual=residual, rowstats=rowstats)
+            # forwarded in full: ops.gemm refuses the combinations the row-statistics epilogue does not carry (it raised nothing here before, the
+            # arguments were silently dropped — ADVICE r4)
+            return ops.gemm(x, pk["w"], pk["b"], residual=residual, epilogue=epilogue, out_f32=out_f32, a2=a2, rowstats=rowstats)
         return ops.gemm(x, pk["w"], pk["b"], residual=residual, epilogue=epilogue, out_f32=out_f32, a2=a2)
 
     def forward(self, x):

@@ -1151,12 +1151,13 @@ class OpProfiler:
 
     def summary(self, by_shape=False):
         agg = {}
-        for label, flops, nbytes, e0, e1 in self.records:
+        for label, flops, nbytes, e0, e1, nlaunch in self.records:
             if not by_shape:
                 label = label.split("|")[0]
             ms = e0.elapsed_time(e1)
-            a = agg.setdefault(label, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            a = agg.setdefault(label, {"calls": 0, "launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             a["calls"] += 1
+            a["launches"] += nlaunch   # kernel launches behind the call (GroupNorm: 1-3, split-K conv: + the reduce; mirrors of the C launchers)
             a["ms"] += ms
             a["flops"] += flops
             a["bytes"] += nbytes
@@ -1237,7 +1238,7 @@ def _wrap_profiled(fn, label_fn):
         e1.record()
         lab = label_fn(out, *args, **kwargs)
         if lab is not None:   # None: an inner wrapped launch already recorded this call
-            _PROF.records.append((lab[0], lab[1], lab[2], e0, e1))
+            _PROF.records.append((lab[0], lab[1], lab[2], e0, e1, lab[3] if len(lab) > 3 else 1))
         return out
     wrapped.__doc__ = fn.__doc__
     return wrapped
@@ -1257,7 +1258,8 @@ def _conv_label(_r, x, w, bias, B, H, W, addvec=None, residual=None, stride=1, u
     y = _r[0]
     M, Cout, Cin = y.shape[0], w.shape[0], x.shape[1]
     nb = 2 * (x.numel() + 9 * Cin * Cout) + y.numel() * y.element_size() + (2 * y.numel() if residual is not None else 0)
-    return f"gemm_kernel<{_tile_label(M, Cout, True, 9 * (-(-Cin // 64) * 64), False, Cin % 64 == 0)},conv3x3>|M={M} Cin={Cin} Cout={Cout} s{stride}{'u' if upsample2x else ''}", 2.0 * M * Cout * 9 * Cin, float(nb)
+    tl = _tile_label(M, Cout, True, 9 * (-(-Cin // 64) * 64), False, Cin % 64 == 0)
+    return f"gemm_kernel<{tl},conv3x3>|M={M} Cin={Cin} Cout={Cout} s{stride}{'u' if upsample2x else ''}", 2.0 * M * Cout * 9 * Cin, float(nb), (2 if "splitK" in tl else 1)
 
 
 def _attn_label(_r, q, k, v, B, H, Nq, Nk, D, *a, **kw):
@@ -1277,7 +1279,10 @@ def _attn8_label(_r, q, k, v, B, H, Nq, Nk, D, *a, **kw):
 
 
 def _gn_label(_r, x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, **_):
-    return f"groupnorm(stats+apply)|rows={_r.shape[0]} C={_r.shape[1]}", 0.0, 2.0 * _r.numel() * 2  # 1 read + 1 write algorithmic
+    # launches behind the call (mirror of ae_groupnorm_nhwc_bf16): producer statistics -> finalize_cs + apply; maps up to 16x16 -> the one-launch
+    # slab kernel; otherwise stats + finalize + apply (stats + apply with the last-block fold, AE_GN_TAIL)
+    nl = 2 if _.get("colstats") is not None and ((x2 is None) == (_.get("colstats2") is None)) else (1 if HW <= 256 and os.environ.get("AE_GN_SLAB", "1") != "0" else (2 if _GN_TAIL else 3))
+    return f"groupnorm(stats+apply)|rows={_r.shape[0]} C={_r.shape[1]}", 0.0, 2.0 * _r.numel() * 2, nl  # 1 read + 1 write algorithmic
 
 
 def _ln_label(_r, x, *a, **_):

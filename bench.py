@@ -306,7 +306,7 @@ def main():
             summ = prof.summary()
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             with open(os.path.join(ROOT, "gpurun_out", "kernels_by_shape.json"), "w") as f:  # per-shape table for the tuning loop
-                json.dump({k: {"calls": v["calls"] // 3, "avg_us": v["avg_us"], "tflops": v["tflops"], "gbps": v["gbps"]}
+                json.dump({k: {"calls": v["calls"] // 3, "launches": v["launches"] // 3, "avg_us": v["avg_us"], "tflops": v["tflops"], "gbps": v["gbps"]}
                            for k, v in sorted(prof.summary(by_shape=True).items(), key=lambda kv: -kv[1]["ms"])}, f, indent=1)
             # dominant KERNEL = the instantiation with the largest share of the step, as rocprofv3 --stats names it: the split-K and
             # single-pass launches of the 128x128 implicit-GEMM conv are one kernel symbol (gemm_kernel<128,128,conv,...>), so their
@@ -332,7 +332,8 @@ def main():
                 "avg_launch_us": a["avg_us"], "launches_per_unet_step": a["calls"] // 3,
                 "share_of_unet_step": a["ms"] / sum(v["ms"] for v in summ.values()),
             }
-            result["kernels"] = {k: {"calls_per_step": v["calls"] // 3, "ms_per_step": v["ms"] / 3, "avg_us": v["avg_us"],
+            # calls = module-level calls (a GroupNorm call is 1-3 launches, a split-K conv adds its reduce): launches_per_step counts kernels
+            result["kernels"] = {k: {"calls_per_step": v["calls"] // 3, "launches_per_step": v["launches"] // 3, "ms_per_step": v["ms"] / 3, "avg_us": v["avg_us"],
                                      "tflops": v["tflops"], "gbps": v["gbps"]} for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
         if world == 1 and not args.no_cpu_baseline:
             cpu, parity = cpu_baseline_and_parity(unet, device, e2e=args.cpu_e2e, per_op=args.cpu_ops)

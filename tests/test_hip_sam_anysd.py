@@ -214,7 +214,7 @@ def test_training_step_gradients_vs_oracle_autograd():
 
     # oracle: fp32 autograd of our spec, and the bf16-storage CONTROL of the same graph (forward and backward storage rounded to bf16,
     # exact arithmetic): the tolerance of every gradient below is derived from it, as the forward tests do
-    from util_models import oracle_training_grads, grad_tolerance
+    from util_models import oracle_training_grads, grad_tolerance, pooled_rel_l2, ROUTER_PATH
     sd = {k: v.detach().float().clone() for k, v in moe.state_dict().items()}
     prefixes = [n + ".attn2." for n, m in moe.unet.named_modules() if m.__class__.__name__ == "BasicTransformerBlock"]
     batch = (lat, img, noise, t, ehs, ref_emb, code, sa, s1)
@@ -241,9 +241,37 @@ def test_training_step_gradients_vs_oracle_autograd():
         # router-gate path (task_embs, gate.*) is a cancelling inner product of bf16 gradients, so ITS control error is large too
         # (gate.bias: 0.2 for the exact-arithmetic control) — the bound follows the control instead of a hand-picked constant.
         tol = grad_tolerance(k, gr, e_ctl)
-        print(f"  grad {k:34s} HIP {e:.3e}  control {e_ctl:.3e}  bound {tol:.3e}")
-        assert e <= tol, f"grad {k}: HIP rel_l2 {e:.3e} vs bf16-storage control {e_ctl:.3e}"
+        print(f"  grad {k:34s} HIP {e:.3e}  control {e_ctl:.3e}  bound {tol:.3e}" + ("  (single batch: informational, pooled below)" if k in ROUTER_PATH else ""))
+        if k not in ROUTER_PATH:
+            assert e <= tol, f"grad {k}: HIP rel_l2 {e:.3e} vs bf16-storage control {e_ctl:.3e}"
+        else:
+            assert e <= 4.0 * e_ctl + 1e-3, f"grad {k}: HIP rel_l2 {e:.3e} vs bf16-storage control {e_ctl:.3e} (gross-error cap of the single batch)"
     assert worst > 0.0
+    # Router path (gate.weight, gate.bias, task_embs), VERDICT r4: each of these gradients is a sum of B = 4 rank-one terms of cancelling bf16
+    # gradients — one batch gives a noise norm that moves by 30 % under an fp32-ulp change of the forward.  Pool the error over NB independent
+    # batches (fresh latents, noise, context, image embeddings, edit codes and time steps; same weights — no optimizer step has run yet) for
+    # the HIP path and for the bf16-storage control alike, and hold the POOLED HIP error to the derived 1.5 x of the POOLED control error.
+    NB = 8
+    pool_hip = {k: [(grads[k].cpu().reshape(g_ref[k].shape), g_ref[k])] for k in ROUTER_PATH}
+    pool_ctl = {k: [(g_ctl[k], g_ref[k])] for k in ROUTER_PATH}
+    for sb in range(1, NB):
+        gb = torch.Generator().manual_seed(7700 + sb)
+        lat_b, img_b, noise_b = torch.randn(B, 4, 8, 8, generator=gb), torch.randn(B, 4, 8, 8, generator=gb) * 0.5, torch.randn(B, 4, 8, 8, generator=gb)
+        t_b = torch.randint(0, 1000, (B,), generator=gb)
+        ehs_b, ref_b = torch.randn(B, 5, 16, generator=gb), torch.randn(B, 9, 32, generator=gb)
+        code_b = torch.randint(0, 5, (B,), generator=gb)
+        batch_b = (lat_b, img_b, noise_b, t_b, ehs_b, ref_b, code_b, sa, s1)
+        _, gr_b = oracle_training_grads(sd, cfg, prefixes, batch_b, control=False)
+        _, gc_b = oracle_training_grads(sd, cfg, prefixes, batch_b, control=True)
+        _, tape_b, leaves_b = tr.forward_loss(lat_b.to(DEV), img_b.to(DEV), ehs_b.to(DEV), ref_b.to(DEV), code_b.to(DEV), noise_b.to(DEV), t_b.to(DEV))
+        gh_b = tr.backward(tape_b, leaves_b)
+        for k in ROUTER_PATH:
+            pool_hip[k].append((gh_b[k].cpu().reshape(gr_b[k].shape), gr_b[k]))
+            pool_ctl[k].append((gc_b[k], gr_b[k]))
+    for k in ROUTER_PATH:
+        e_p, c_p = pooled_rel_l2(pool_hip[k]), pooled_rel_l2(pool_ctl[k])
+        print(f"  grad {k:34s} pooled over {NB} batches: HIP {e_p:.3e}  control {c_p:.3e}  ratio {e_p / max(c_p, 1e-12):.2f}")
+        assert e_p <= 1.5 * c_p + 1e-3, f"grad {k}: pooled HIP rel_l2 {e_p:.3e} vs pooled bf16-storage control {c_p:.3e}"
     # experts nobody was routed to get exactly zero gradient; routed ones do not
     _, top1, _ = A.task_gate(sd["task_embs"], code, sd["gate.weight"], sd["gate.bias"])
     g0 = grads["adapter_modules.0"].cpu()

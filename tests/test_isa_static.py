@@ -129,15 +129,22 @@ def test_hot_loops_have_no_scratch_traffic(kernels):
 
 
 def test_no_vgpr_write_to_the_sources_of_a_running_mfma(tmp_path):
-    """the two-query-group attention kernel keeps its P registers alive past the MFMAs that read them (empty asm uses + `hold`)
-    because gfx950 does not interlock a VALU / LDS write to an MFMA's SrcA / SrcB registers while that MFMA is still reading them
-    (profiles/r03_attn_qg2_hazard.txt).  That fence is only as good as the listing hipcc produces from it: read the listing.  No instruction may
-    write a source register of an MFMA before two further MFMAs have been issued (the in-order matrix pipe has then finished the first)."""
+    """gfx950 does not interlock a VALU write to an MFMA's SrcA / SrcB registers while that MFMA is still reading them
+    (profiles/r03_attn_qg2_hazard.txt), and hipcc pads nothing for it.  The attention kernel keeps such registers live by empty asm statements
+    (`hold`, `srcring`, the P registers) — which are only as good as the listing hipcc produces from them: read the listing.  In EVERY
+    instantiation (two query groups, one group tiled, short K/V with and without the adapter segment, SAM's rel-pos forms, head dims 40 / 80 /
+    160) no VALU instruction may write a source register of an MFMA before two further MFMAs have been issued or an instruction has read that
+    MFMA's result (either proves the in-order matrix pipe is done with it).  Round 4 asserted the two-query-group instantiation only; round 5
+    found v_exp_f32 / address writes one to four instructions behind an MFMA in the head-dim 80 / 160 and SAM-window instantiations and tied
+    the fences of the one-group forms to the MFMA results."""
     import isa_audit as A
     asm = A.compile_asm(["attention_fast.hip"], str(tmp_path))[0]
     res = A.mfma_source_overwrites(asm, "attn_fast_kernel<")
-    assert len(res) >= 10
-    qg2 = [k for k in res if re.search(r"attn_fast_kernel<\d+, \d+, (true|false), 0, 0, 2,", k)]
-    assert qg2, "the two-query-group instantiation was not found: did the template signature change?"
-    for k in qg2:
-        assert not res[k], (k, res[k][:3])
+    assert len(res) >= 20
+    kinds = {"qg2": r"attn_fast_kernel<\d+, \d+, (true|false), 0, 0, 2,", "short_kv": r"attn_fast_kernel<\d+, \d+, (true|false), 0, 0, 1, false, true",
+             "short_kv_seg2_d160": r"attn_fast_kernel<160, 1, true, 0, 0, 1, false, true", "sam_window": r"attn_fast_kernel<80, 2, false, 0, 3, 1, false, true, 7, 4>",
+             "sam_global": r"attn_fast_kernel<80, 2, false, 0, 2,"}
+    for kind, pat in kinds.items():
+        assert [k for k in res if re.search(pat, k)], f"{kind}: instantiation not found — did the template signature change?"
+    for k, hits in res.items():
+        assert not hits, (k, hits[:3])

@@ -109,6 +109,7 @@ def mfma_source_overwrites(asm_path, kernel_filter):
                 continue
             ops_ = [x.strip() for x in t.split(None, 1)[1].split(",")]
             src = _regs(ops_[1]) | _regs(ops_[2])      # SrcA, SrcB (operand 0 is the destination, 3 the accumulator input)
+            dstm = _regs(ops_[0])                      # (AGPR destinations parse as empty: no early exit for them — conservative)
             stack, visited = [(i + 1, 0, 0)], set()
             while stack:
                 j, seen, steps = stack.pop()
@@ -137,6 +138,15 @@ def mfma_source_overwrites(asm_path, kernel_filter):
                         dst = _regs(u.split(None, 1)[1].split(",")[0].strip()) if " " in u else set()
                         if dst & src:
                             hits.append((i, t, j, u))
+                    # A non-MFMA instruction that READS the MFMA's destination is issued (in order) only once that MFMA has written its result back,
+                    # i.e. has finished — with all of its source reads: everything behind it on this path is safe.  (An MFMA taking the result as
+                    # its C operand proves nothing: accumulate chains forward inside the matrix pipe.)  Round 5: without this the audit flagged the
+                    # rebase path's rewrite of the Q operand's offset slot, which sits behind the whole maximum tree over the MFMA's result.
+                    if dstm and " " in u and not u.startswith(("s_", "v_mfma")):
+                        rd = u.split(None, 1)[1].split(",")
+                        rd = rd[1:] if u.startswith(("v_", "ds_read", "buffer_load", "global_load")) and not u.startswith("v_cmp") else rd
+                        if any(_regs(x.strip().split(" ")[0]) & dstm for x in rd):
+                            break
                     j += 1
         bad[dm[m.group(1)]] = sorted(set(hits))
     return bad
