@@ -34,7 +34,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4v;
 
 constexpr int FKT = 64;  // keys per LDS tile
 #ifndef AE_ATTN_V_DEFAULT
-#define AE_ATTN_V_DEFAULT 3   // default variant of the plain long-sequence kernel (see launch_fast): decided by measurement
+#define AE_ATTN_V_DEFAULT 7   // default variant of the plain long-sequence kernel (see launch_fast): decided by measurement (round 5: + flag 4, the software-pipelined kernel)
 #endif
 #ifndef AE_ATTN_FENCE_ALL
 #define AE_ATTN_FENCE_ALL 1   // the MFMA-source fences (P registers, `hold`, `srcring`) in every instantiation, not only the two-query-group one
@@ -643,6 +643,327 @@ __global__ __launch_bounds__(64 * NWV, OCC) void attn_fast_kernel(const AttnArgs
     store_o();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the SOFTWARE-PIPELINED form of the long-sequence kernel (head dim 40, two query groups per wave, VSPLIT images).
+//
+// What round 4's counters said about attn_fast_kernel<40, ..., QG = 2> (profiles/r04_final3_pmc_attn.txt): the matrix pipe is busy 57 % of the
+// SIMD cycles, the VALU port ~60 %, and the sum of the two per 32-key block (7 x 32 MFMA cycles + ~186 VALU cycles per query group) IS the
+// measured block time — inside one wave the logit MFMAs, the maximum, exp2 / convert and the PV MFMAs of a block form one dependent chain, and
+// three such chains per SIMD interleave only by accident.  The structure below makes the overlap a property of the instruction stream of ONE
+// wave: while block i's probabilities are exponentiated (VALU), block i + 1's logits are multiplied (MFMA); while block i's PV products run
+// (MFMA), block i + 1's maximum is taken (VALU):
+//
+//     step(i):   S'(i+1) = K(i+1) Q^T          6 MFMAs   ||   P(i) = exp2(S'(i)), first halves             16 v_exp + 8 v_cvt_pk
+//                O += V(i) P(i), K-step 0      4 MFMAs   ||   P(i), second halves                            16 v_exp + 8 v_cvt_pk
+//                O += V(i) P(i), K-step 1      4 MFMAs   ||   maximum of S'(i+1), the rebase decision        16 v_max3 + compare
+//
+// Every number the wave computes is the one attn_fast_kernel computes, in the same order per accumulator (the rebase of block i + 1 still sees an O
+// that holds the PV products up to block i, S'(i+1) is still corrected by the same exact step, the offset still rides in Q's free slot):
+// the outputs are BIT-IDENTICAL to the QG = 2 kernel's (tests/test_hip_ops.py::test_attention_pipelined_equals_two_group_kernel).
+// Cost: two logit blocks live at once (64 registers instead of 32) -> 2 waves per SIMD instead of 3; three tile buffers instead of two, so that
+// the logits of the NEXT tile's first block can be multiplied while the current tile's second block is still being reduced (one barrier per
+// 64-key tile as before: tile t + 2 is issued into the buffer of tile t - 1 behind the barrier that proves every wave has left tile t - 1).
+// Envelope: head dim 40, Nk a multiple of 64 and >= 128, no bias / mask / second segment (everything else: attn_fast_kernel).
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
+    static_assert(D == 40, "pipelined kernel: head dim 40 (K steps 3 with a free slot, two 32-row output blocks)");
+    constexpr int QG = 2;
+    constexpr int KS = (D + 15) / 16;
+    constexpr int NDB = D / 32 + 1, LDB = D / 32, LREG = 4 * ((D % 32) / 8);
+    constexpr int ROWB = 2 * D, CH = D / 8, TILEB = FKT * ROWB, BUFB = 2 * TILEB, NTB = 3;
+    constexpr int ONES_OFF = NTB * BUFB;
+    constexpr int NFULL = D / 32, REM = D % 32, RS = REM * 2 > 16 ? REM * 2 : 16, RC = REM / 8;
+    constexpr int VONES_OFF = ONES_OFF + TILEB + 64;
+    constexpr int LDSB = VONES_OFF + 64 * RS;
+    constexpr int NPIECE = 2 * CH, NWV = 4, MAXP = (NPIECE + NWV - 1) / NWV;
+    __shared__ __attribute__((aligned(16))) char smem[LDSB];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5, l15 = lane & 15, g = lane >> 4;
+    constexpr int QB = 32 * NWV * QG;
+    const int nqb = (p.Nq + QB - 1) / QB;
+    const int vb = xcd_remap(blockIdx.x, nqb * p.B * p.H);
+    const int bh = vb / nqb, qb = vb - bh * nqb;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qb * QB + wave * 32 * QG;
+
+    if (tid < FKT) *reinterpret_cast<u32x4*>(smem + ONES_OFF + tid * ROWB) = (u32x4){0x00003F80u, 0u, 0u, 0u};
+    if (tid < FKT) *reinterpret_cast<u32x4*>(smem + VONES_OFF + tid * RS) = (u32x4){0x00003F80u, 0u, 0u, 0u};
+
+    // Q^T operand: lane (q = l31, hi) holds c Q[q][16 ks + 8 hi .. + 8], zero beyond head_dim (slot D carries -m~ later)
+    const bf16_t* qp = p.q + (long)b * p.q_sb + (long)h * p.q_sh;
+    const float c = p.scale * FLOG2E;
+    u32x4 qf[QG][KS];
+#pragma unroll
+    for (int gq = 0; gq < QG; ++gq) {
+        const int qrow = min(q0 + 32 * gq + l31, p.Nq - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = 16 * ks + 8 * hi;
+            u32x4 t = *reinterpret_cast<const u32x4*>(qp + (long)qrow * p.q_sn + (d0 < D ? d0 : 0));
+            if (d0 >= D) t = (u32x4){0u, 0u, 0u, 0u};
+            qf[gq][ks].x = pack_bf16x2(bf16lo(t.x) * c, bf16hi(t.x) * c);
+            qf[gq][ks].y = pack_bf16x2(bf16lo(t.y) * c, bf16hi(t.y) * c);
+            qf[gq][ks].z = pack_bf16x2(bf16lo(t.z) * c, bf16hi(t.z) * c);
+            qf[gq][ks].w = pack_bf16x2(bf16lo(t.w) * c, bf16hi(t.w) * c);
+        }
+    }
+
+    // per-lane LDS addresses relative to a tile buffer (see attn_fast_kernel: same images, same fragment maps)
+    const int kaddr = l31 * ROWB + hi * 16;
+    const int klast0 = hi ? ONES_OFF + l31 * ROWB : kaddr + (KS - 1) * 32;   // K step 2: the lanes of the padding columns read the ones tile (column D = 1.0)
+    const int kl_mask = hi ? 0 : -1;                                          // ... which does not move with the tile buffer
+    const int vrow = 4 * hi + (l15 >> 2);
+    const int vaddr = TILEB + vrow * 64 + (16 * (g & 1) + 4 * (l15 & 3)) * 2;
+    const int vcol = 32 * LDB + 16 * (g & 1) + 4 * (l15 & 3);
+    const bool ones_lane = vcol == D, zero_lane = vcol > D;
+    const int vlast0 = ones_lane ? VONES_OFF + vrow * RS : (zero_lane ? VONES_OFF + vrow * RS + 8 : TILEB + NFULL * 4096 + vrow * RS + (16 * (g & 1) + 4 * (l15 & 3)) * 2);
+    const int vl_mask = (ones_lane || zero_lane) ? 0 : -1;
+
+    float mt[QG];
+    f32x16 o[QG][NDB];
+#pragma unroll
+    for (int gq = 0; gq < QG; ++gq) {
+        mt[gq] = 0.f;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[gq][db][r] = 0.f;
+    }
+
+    // ---- LDS-DMA plan (as attn_fast_kernel, VSPLIT): piece j of a tile (K pieces 0..CH-1, V pieces CH..2CH-1) is issued by wave j % 4
+    const bf16_t* kp = p.k + (long)b * p.k_sb + (long)h * p.k_sh;
+    const bf16_t* vp = p.v + (long)b * p.v_sb + (long)h * p.v_sh;
+    const int ksn2 = (int)p.k_sn * 2, vsn2 = (int)p.v_sn * 2;
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kp), 0, (p.Nk - 1) * ksn2 + D * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vp), 0, (p.Nk - 1) * vsn2 + D * 2, 0x00020000);
+    int voff[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int j = wave + NWV * i;
+        const bool isK = j < CH;
+        const int cidx = (isK ? j : j - CH) * 64 + lane;
+        int row = cidx / CH, cc = cidx - row * CH;
+        if (!isK) {
+            if (cidx < NFULL * 256) { row = (cidx & 255) >> 2; cc = (cidx >> 8) * 4 + (cidx & 3); }
+            else { const int c2 = cidx - NFULL * 256; row = c2 / (RC > 0 ? RC : 1); cc = NFULL * 4 + (c2 - row * (RC > 0 ? RC : 1)); }
+        }
+        voff[i] = row * (isK ? ksn2 : vsn2) + cc * 16;
+    }
+    const int lds0 = (int)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    auto issue = [&](int t, int boff) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int j = wave + NWV * i;
+            if (j < NPIECE) {
+                if (j < CH) dma16(rsK, lds0 + boff + j * 1024, voff[i] + t * FKT * ksn2);
+                else dma16(rsV, lds0 + boff + TILEB + (j - CH) * 1024, voff[i] + t * FKT * vsn2);
+            }
+        }
+    };
+
+    // ---- the pieces of a step ------------------------------------------------------------------------------------------------------------------------
+    // Source lifetimes.  gfx950 does not interlock a VALU write to a register an issued MFMA still reads as SrcA / SrcB (attn_fast_kernel, round 3), and
+    // in a stream this dense hipcc reuses a fragment's registers for exp2 results right behind the MFMA (186 such writes in the first listing of
+    // this kernel, tools/isa_audit.py).  Here it is excluded BY CONSTRUCTION: the 14 MFMAs of a step are chained into one program order by empty asm
+    // statements that take the result of MFMA k as an input and the accumulator of MFMA k + 1 as a read-write operand (no instruction, no wait: the
+    // statement can only sit between the two issues), and each statement also names, as inputs, the fragments whose last reader was issued two
+    // MFMAs earlier — they stay live values exactly until the in-order matrix pipe is done with them.  The sources of a step's last two MFMAs are
+    // carried into the next step (`hv`, `hp`) and retired behind its first two.  tests/test_isa_static.py reads the listing.
+    // (device pass only: on the host pass the x86 meaning of the "v" constraint rejects 512-bit operands, and clang then drops the kernel's host stub
+    // without a diagnostic — the library linked and failed to load with an undefined __device_stub__ symbol)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AE_TIE0(nxt, prev) asm volatile("" : "+v"(nxt) : "v"(prev))
+#define AE_TIE1(nxt, prev, a) asm volatile("" : "+v"(nxt) : "v"(prev), "v"(a))
+#define AE_TIE2(nxt, prev, a, b) asm volatile("" : "+v"(nxt) : "v"(prev), "v"(a), "v"(b))
+#else
+#define AE_TIE0(nxt, prev)
+#define AE_TIE1(nxt, prev, a)
+#define AE_TIE2(nxt, prev, a, b)
+#endif
+    u32x4 hv = {0u, 0u, 0u, 0u}, hp[QG] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};   // V fragment / P registers of the previous step's last two MFMAs
+    auto rdK = [&](int byte) __attribute__((always_inline)) { return *reinterpret_cast<const u32x4*>(smem + byte); };
+    // block maximum of both groups and the (rare) rebase: m~ moves up by an exact bf16-representable step, S' and O follow (see attn_fast_kernel).
+    // `k1`, `k2`: the K fragments of the last logit MFMAs — live until the maximum has READ the logits (an instruction reading an MFMA's result
+    // is issued only when that MFMA, and with the in-order pipe every earlier one, has finished).
+    auto decide = [&](f32x16 (&sn)[QG], bool first, u32x4 k1, u32x4 k2) __attribute__((always_inline)) {
+        float mx[QG];
+#pragma unroll
+        for (int gq = 0; gq < QG; ++gq) {
+            mx[gq] = fmaxf(fmaxf(sn[gq][0], sn[gq][1]), sn[gq][2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx[gq] = fmaxf(fmaxf(mx[gq], sn[gq][r]), sn[gq][r + 1]);
+            mx[gq] = fmaxf(mx[gq], sn[gq][15]);
+        }
+        asm volatile("" : "+v"(mx[0]), "+v"(mx[1]) : "v"(k1), "v"(k2));
+        if (__builtin_expect(first || __any(fmaxf(mx[0], mx[QG - 1]) > RESCALE_THR), 0)) {
+#pragma unroll
+            for (int gq = 0; gq < QG; ++gq) {
+                const float m2 = fmaxf(mx[gq], __shfl_xor(mx[gq], 32, 64));
+                float tgt = (first || m2 > 0.f) ? mt[gq] + __builtin_ceilf(m2) : mt[gq];
+                tgt = fmaxf(tgt, -1.0e4f);
+                uint32_t tb = __float_as_uint(tgt);
+                tb = (tgt > 0.f) ? ((tb + 0xFFFFu) & 0xFFFF0000u) : (tb & 0xFFFF0000u);
+                const float mnew = __uint_as_float(tb);
+                const float d = mnew - mt[gq];
+                mt[gq] = mnew;
+                if (hi) qf[gq][KS - 1].x = (qf[gq][KS - 1].x & 0xFFFF0000u) | ((tb >> 16) ^ 0x8000u);
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sn[gq][r] -= d;
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[gq][db][r] *= alpha;
+            }
+        }
+    };
+    // One pipeline step.  The block (tile buffer `boff`, half B2) whose final logits are `sc` is exponentiated and multiplied into O (CUR) while the
+    // logits of the block (buffer `nboff`, half NB2) are produced into `sn`, reduced and (rarely) rebased (NEXT).  The prologue runs NEXT alone.
+    auto step = [&](auto blk_tag, auto next_tag, auto has_cur_tag, auto has_next_tag, int boff, int nboff, f32x16 (&sc)[QG], f32x16 (&sn)[QG], bool first) __attribute__((always_inline)) {
+        constexpr int B2 = decltype(blk_tag)::value, NB2 = decltype(next_tag)::value;
+        constexpr bool CUR = decltype(has_cur_tag)::value, NEXT = decltype(has_next_tag)::value;
+        static_assert(NDB == 2 && KS == 3, "the MFMA order below is written out for head dim 40");
+        u32x4 kf[KS];
+        if constexpr (NEXT) {
+            constexpr int BO = NB2 * 32 * ROWB;
+            const int kc = kaddr + nboff, kl = klast0 + (nboff & kl_mask);
+            kf[0] = rdK(kc + BO); kf[1] = rdK(kc + BO + 32); kf[2] = rdK(kl + BO);
+            // MFMA 1, 2: K step 0 of both groups (C = 0); ordered behind the previous step's last MFMA through the Q operand
+            AE_TIE1(qf[0][0], o[QG - 1][NDB - 1], hp[0]);
+            {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf[0]), as_bf16x8(qf[0][0]), z, 0, 0, 0);
+                AE_TIE2(qf[1][0], sn[0], hv, hp[1]);
+                sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf[0]), as_bf16x8(qf[1][0]), z, 0, 0, 0);
+            }
+            AE_TIE0(sn[0], sn[1]);
+            sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf[1]), as_bf16x8(qf[0][1]), sn[0], 0, 0, 0);     // 3
+            AE_TIE0(sn[1], sn[0]);
+            sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf[1]), as_bf16x8(qf[1][1]), sn[1], 0, 0, 0);     // 4
+            AE_TIE1(sn[0], sn[1], kf[0]);
+            sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf[2]), as_bf16x8(qf[0][2]), sn[0], 0, 0, 0);     // 5
+            AE_TIE0(sn[1], sn[0]);
+            sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf[2]), as_bf16x8(qf[1][2]), sn[1], 0, 0, 0);     // 6
+        }
+        if constexpr (CUR) {
+            const int vc = vaddr + boff, vl = vlast0 + (boff & vl_mask);
+            u32x4 vf[2][NDB];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    const int va = (db == LDB) ? vl + B2 * 32 * RS + kk * 16 * RS : vc + db * 4096 + B2 * 32 * 64 + kk * 16 * 64;
+                    const int vstep = (db == LDB) ? 8 * RS : 8 * 64;
+                    union { bf16x8_t b; u32x4 u; } cv;
+                    cv.b = cat_tr(lds_tr16(smem + va), lds_tr16(smem + va + vstep));
+                    vf[kk][db] = cv.u;
+                }
+            u32x4 pk[QG][2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int gq = 0; gq < QG; ++gq) {
+                    uint32_t w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = pack_bf16x2(__builtin_amdgcn_exp2f(sc[gq][8 * kk + 2 * j]), __builtin_amdgcn_exp2f(sc[gq][8 * kk + 2 * j + 1]));
+                    pk[gq][kk] = (u32x4){w[0], w[1], w[2], w[3]};
+                }
+            if constexpr (NEXT) AE_TIE1(o[0][0], sn[1], kf[1]);                    // behind MFMA 6: K step 1's fragment (read by 3, 4) is free
+            else AE_TIE0(o[0][0], o[QG - 1][NDB - 1]);                             // (no logit MFMAs in this step: 7 follows the previous step's 14 ...
+            o[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vf[0][0]), as_bf16x8(pk[0][0]), o[0][0], 0, 0, 0);   // 7
+            if constexpr (NEXT) AE_TIE0(o[1][0], o[0][0]);
+            else AE_TIE1(o[1][0], o[0][0], hp[0]);                                 //  ... and the carried sources retire behind 7 and 8 instead of 1 and 2)
+            o[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vf[0][0]), as_bf16x8(pk[1][0]), o[1][0], 0, 0, 0);   // 8
+            if constexpr (NEXT) AE_TIE1(o[0][1], o[1][0], kf[2]);
+            else AE_TIE2(o[0][1], o[1][0], hv, hp[1]);
+            o[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vf[0][1]), as_bf16x8(pk[0][0]), o[0][1], 0, 0, 0);   // 9
+            AE_TIE0(o[1][1], o[0][1]);
+            o[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vf[0][1]), as_bf16x8(pk[1][0]), o[1][1], 0, 0, 0);   // 10
+            AE_TIE1(o[0][0], o[1][1], vf[0][0]);
+            o[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vf[1][0]), as_bf16x8(pk[0][1]), o[0][0], 0, 0, 0);   // 11
+            AE_TIE1(o[1][0], o[0][0], pk[0][0]);
+            o[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vf[1][0]), as_bf16x8(pk[1][1]), o[1][0], 0, 0, 0);   // 12
+            AE_TIE2(o[0][1], o[1][0], vf[0][1], pk[1][0]);
+            o[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vf[1][1]), as_bf16x8(pk[0][1]), o[0][1], 0, 0, 0);   // 13
+            AE_TIE0(o[1][1], o[0][1]);
+            o[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vf[1][1]), as_bf16x8(pk[1][1]), o[1][1], 0, 0, 0);   // 14
+            asm volatile("" : "+v"(o[1][1]) : "v"(vf[1][0]));                      // behind MFMA 14: the fragment read by 11, 12 is free
+            hv = vf[1][1]; hp[0] = pk[0][1]; hp[1] = pk[1][1];                     // sources of 13, 14: retired behind the next step's first two MFMAs
+        }
+        if constexpr (NEXT) decide(sn, first, CUR ? kf[2] : kf[1], kf[2]);
+    };
+
+    const int ntiles = p.Nk / FKT;   // launcher: Nk % 64 == 0, ntiles >= 2
+    f32x16 sA[QG], sB[QG];
+    issue(0, 0);
+    issue(1, BUFB);
+    dma_wait_all_and_barrier();      // tiles 0 and 1 (and the ones tiles) are in LDS
+    if (ntiles > 2) issue(2, 2 * BUFB);
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+    using YES = std::true_type;
+    using NO = std::false_type;
+    step(T0{}, T0{}, NO{}, YES{}, 0, 0, sB, sA, true);   // prologue: logits of block (0, 0), the first offset
+    int boff = 0, nboff = BUFB, iboff = 0;   // buffers of tile t, tile t + 1, and (after the rotation below) the one tile t + 2 lands in
+    for (int t = 0; t + 1 < ntiles; ++t) {
+        // block (t, 0); next = (t, 1), same tile
+        step(T0{}, T1{}, YES{}, YES{}, boff, boff, sA, sB, false);
+        // block (t, 1); next = (t + 1, 0): tile t + 1 must be visible to every wave.  Its pieces were issued a whole tile ago; the barrier also proves
+        // that every wave has left tile t - 1 (it has finished step (t, 0), which follows its last read of tile t - 1): tile t + 2 goes there.
+        if (t > 0) {
+            dma_wait_all_and_barrier();
+            if (t + 2 < ntiles) issue(t + 2, iboff);
+        }
+        step(T1{}, T0{}, YES{}, YES{}, boff, nboff, sB, sA, false);
+        iboff = boff; boff = nboff; nboff = (nboff == 2 * BUFB) ? 0 : nboff + BUFB;
+    }
+    // last tile: its second block has no successor
+    step(T0{}, T1{}, YES{}, YES{}, boff, boff, sA, sB, false);
+    step(T1{}, T0{}, YES{}, NO{}, boff, boff, sB, sA, false);
+#undef AE_TIE0
+#undef AE_TIE1
+#undef AE_TIE2
+
+    // ---- normalise and store (as attn_fast_kernel::store_o without a second segment)
+    bf16_t* op = p.o + (long)b * p.o_sb + (long)h * p.o_sh;
+    // (the Q operand is dead behind the last logit MFMA: keep it a live value until here — asm volatile statements keep their order, and the last
+    // step's ties sit eight MFMAs behind that MFMA)
+    asm volatile("" ::"v"(qf[0][0]), "v"(qf[0][1]), "v"(qf[0][2]), "v"(qf[1][0]), "v"(qf[1][1]), "v"(qf[1][2]));
+    float lsum_g[QG];
+#pragma unroll
+    for (int gq = QG - 1; gq >= 0; --gq) lsum_g[gq] = __shfl(o[gq][LDB][LREG], l31, 64);   // group 1 first: it reads the result of the LAST MFMA issued ...
+    asm volatile("" : "+v"(lsum_g[QG - 1]) : "v"(hv), "v"(hp[0]), "v"(hp[1]));              // ... whose sources (and the one before's) stay live until that read is out
+#pragma unroll
+    for (int gq = 0; gq < QG; ++gq) {
+        const float lsum = lsum_g[gq];
+        const float inv = (p.out_scale ? p.out_scale[b] : 1.0f) / lsum;
+        const int qrow = q0 + 32 * gq + l31;
+        if (p.lse && hi == 0 && qrow < p.Nq) p.lse[((long)b * p.H + h) * p.Nq + qrow] = mt[gq] + __builtin_amdgcn_logf(lsum);
+        if (qrow < p.Nq) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int d = 32 * db + 8 * r4 + 4 * hi;
+                    if (d < D) {
+                        float r0 = o[gq][db][4 * r4] * inv, r1 = o[gq][db][4 * r4 + 1] * inv, r2 = o[gq][db][4 * r4 + 2] * inv, r3 = o[gq][db][4 * r4 + 3] * inv;
+                        u32x2* dst = reinterpret_cast<u32x2*>(op + (long)qrow * p.o_sn + d);
+                        if (p.accum) {
+                            const u32x2 prev = *dst;
+                            r0 += bf16lo(prev.x); r1 += bf16hi(prev.x); r2 += bf16lo(prev.y); r3 += bf16hi(prev.y);
+                        }
+                        *dst = (u32x2){pack_bf16x2(r0, r1), pack_bf16x2(r2, r3)};
+                    }
+                }
+        }
+    }
+}
+
 template <int D>
 int launch_fast(const AttnArgs& a, hipStream_t stream) {
     const long blocks = (long)((a.Nq + 127) / 128) * a.B * a.H;
@@ -702,6 +1023,14 @@ int launch_fast(const AttnArgs& a, hipStream_t stream) {
         return ae_check_launch("ae_attn_fwd_bf16(fast)");
     }
     static const int var_env = getenv("AE_ATTN_V") ? atoi(getenv("AE_ATTN_V")) : AE_ATTN_V_DEFAULT;
+    // flag 4 (round 5): the software-pipelined kernel where the two-query-group kernel would run and the key count is whole tiles
+    if constexpr (D == 40) {
+        if ((var_env & 4) && (long)((a.Nq + 255) / 256) * a.B * a.H >= 512 && a.Nk % FKT == 0 && a.Nk >= 2 * FKT && !a.lse2) {
+            dim3 grid2((unsigned)((long)((a.Nq + 255) / 256) * a.B * a.H));
+            hipLaunchKernelGGL((attn_pipe_kernel<D>), grid2, block, 0, stream, a);
+            return ae_check_launch("ae_attn_fwd_bf16(fast, pipelined)");
+        }
+    }
     const bool qg2 = (var_env & 2) && D <= 48 && (long)((a.Nq + 255) / 256) * a.B * a.H >= 1024;   // head_dim 80 would spill with two groups
     if (qg2) {
         if constexpr (D <= 48) {

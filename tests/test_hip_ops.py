@@ -640,6 +640,22 @@ def test_attention_two_query_groups_vs_oracle(ops):
     check_close(out2[:, 3840:], out[:, 3840:Nq], rl2=4e-3, mabs=2e-2, what="attention QG=2 ragged tail block")
 
 
+def test_attention_pipelined_equals_two_group_kernel():
+    """Round 5: the software-pipelined long-sequence kernel (attn_pipe_kernel, AE_ATTN_V flag 4: the default) issues the same MFMAs on the same
+    operands in the same per-accumulator order as the two-query-group kernel (AE_ATTN_V = 3) and takes the same rebase decisions, so the two must
+    agree BIT FOR BIT: the UNet shape with late logit spikes, a ragged query count, the fused-qkv strided layout, two / three / sixteen key tiles at
+    the usual and at a hot logit scale (frequent rebases), and the log-sum-exp / output-scale / accumulate options.  The launcher reads its variant
+    knob once per process, so tools/attn_pipe_check.py runs one child per variant and compares what they wrote; it also checks both against an fp32
+    torch statement and for run-to-run equality."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_pipe_check.py"), "3", "7"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "bit-identical on all" in r.stdout and "FAIL" not in r.stdout and "bit-identical: False" not in r.stdout
+
+
 def test_conv3x3_linearity_and_groupnorm_scale_invariance_full_size(ops):
     """BASELINE-size layer ([12, 320, 64, 64] -> 320): conv(x1 + x2) = conv(x1) + conv(x2) - bias; GroupNorm(c x) = GroupNorm(x)."""
     g = torch.Generator(device=DEV).manual_seed(22)

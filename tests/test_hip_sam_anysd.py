@@ -263,11 +263,13 @@ def test_training_step_gradients_vs_oracle_autograd():
         batch_b = (lat_b, img_b, noise_b, t_b, ehs_b, ref_b, code_b, sa, s1)
         _, gr_b = oracle_training_grads(sd, cfg, prefixes, batch_b, control=False)
         _, gc_b = oracle_training_grads(sd, cfg, prefixes, batch_b, control=True)
+        tr.zero_grad()   # `backward` ACCUMULATES across calls until an optimizer step (micro-batches): every batch of the pool starts a fresh accumulation
         _, tape_b, leaves_b = tr.forward_loss(lat_b.to(DEV), img_b.to(DEV), ehs_b.to(DEV), ref_b.to(DEV), code_b.to(DEV), noise_b.to(DEV), t_b.to(DEV))
         gh_b = tr.backward(tape_b, leaves_b)
         for k in ROUTER_PATH:
             pool_hip[k].append((gh_b[k].cpu().reshape(gr_b[k].shape), gr_b[k]))
             pool_ctl[k].append((gc_b[k], gr_b[k]))
+    tr.zero_grad()       # (the step below is taken with the first batch's gradients, passed explicitly)
     for k in ROUTER_PATH:
         e_p, c_p = pooled_rel_l2(pool_hip[k]), pooled_rel_l2(pool_ctl[k])
         print(f"  grad {k:34s} pooled over {NB} batches: HIP {e_p:.3e}  control {c_p:.3e}  ratio {e_p / max(c_p, 1e-12):.2f}")

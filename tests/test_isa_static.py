@@ -148,3 +148,15 @@ def test_no_vgpr_write_to_the_sources_of_a_running_mfma(tmp_path):
         assert [k for k in res if re.search(pat, k)], f"{kind}: instantiation not found — did the template signature change?"
     for k, hits in res.items():
         assert not hits, (k, hits[:3])
+    # round 5: the software-pipelined kernel — its 14 MFMAs per step are chained into one program order and every fragment is tied to the MFMA two
+    # positions behind its last reader (the first listing of that kernel, without the ties, had 186 such writes)
+    pipe = A.mfma_source_overwrites(asm, "attn_pipe_kernel<")
+    assert len(pipe) == 1
+    for k, hits in pipe.items():
+        assert not hits, (k, hits[:3])
+    rows = [(n, md, loop) for n, md, loop in A.audit_named(asm) if "attn_pipe_kernel<" in n]
+    assert len(rows) == 1
+    _, md, loop = rows[0]
+    assert md["vgpr_spill_count"] == "0" and md["private_segment_fixed_size"] == "0" and int(md["vgpr_count"]) <= 256, md   # two waves per SIMD
+    assert loop[0] == 28 and loop[2] == 0, loop     # one 64-key tile per loop trip: 2 steps x 14 MFMAs, no scratch traffic
+    assert loop[7] <= 160, loop                     # VALU per trip (148 at the time of writing: 64 exp2, 32 converts, 34 max3, addresses): register copies would show here

@@ -34,7 +34,7 @@ static void timed(const char* tag, double flops, F&& launch) {
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_dbg), zero, sizeof(zero)));
 #endif
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const int iters = 20;
+    const int iters = getenv("AE_LAB_ITERS") ? atoi(getenv("AE_LAB_ITERS")) : 20;   // AE_LAB_ITERS=20000: a multi-second run of one shape for tools/throttle_probe.py
     CK(hipEventRecord(e0));
     for (int i = 0; i < iters; ++i) launch();
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
