@@ -25,6 +25,7 @@ SIGNATURES = {
     "ae_conv3x3_workspace_floats": [c_int, c_int, c_int, c_int, c_int, c_int, c_int],
     "ae_conv3x3_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                         c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "ae_conv3x3_up2_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "ae_groupnorm_rows_per_chunk": [c_int, c_int],
     "ae_groupnorm_workspace_floats": [c_int, c_int, c_int, c_int],
     "ae_groupnorm_nhwc_bf16": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,

@@ -85,6 +85,13 @@ struct GemmArgs {
     const float* ln_colsum;  // xe 2: [N] fp32, s[n] = sum_k W'[n][k] over the bf16 values of W' (what the MFMA multiplies); `bias` holds c
     int ln_parts;
     float ln_eps;
+    // Nearest-x2 upsample + 3x3 conv as FOUR 2x2 convs on the low-resolution input (round 5; openaimodel.py:108-118).  Output pixel (2y + py, 2x + px)
+    // of conv3x3(upsample2(X)) reads X at rows {y - 1, y} (py = 0) or {y, y + 1} (py = 1) and likewise in x: per output parity (py, px) a 2 x 2 window
+    // of the 3x3 frame, with the weights of the taps that fall on the same source pixel SUMMED at pack time (ops.pack_conv3x3_up2) — 4 / 9 of the
+    // multiply-adds of the gather form, no upsampling arithmetic in the loader.  sub2 = 1: the grid holds four copies of the tile grid, copy `par`
+    // (the split-K index of a launch that does not split) multiplies against weight set `par` ([N, 4 CinPad] each, K ordered (tap, channel) with tap =
+    // 2 i + j over the window rows / columns) and scatters its rows to the parity's pixels of the [B, 2H, 2W] output.
+    int sub2;
 };
 
 // LDS-DMA: one wave moves 64 x 16 B from global straight into LDS at (wave-uniform dst) + lane*16.  The builtin exists only
@@ -193,7 +200,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, (XE == 2 && BM ==
     const int l15 = lane & 15, lg = lane >> 4;
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
     const int ntiles = ntm * ntn;
-    const int split = blockIdx.x / ntiles;
+    const int split = blockIdx.x / ntiles;       // split-K index; sub2: the output parity 2 py + px
+    const int py = (AMODE == A_CONV3 && p.sub2) ? split >> 1 : 0, px = (AMODE == A_CONV3 && p.sub2) ? split & 1 : 0;
     const int tile = xcd_remap(blockIdx.x % ntiles, ntiles);
     const int m0 = (p.m_fast ? tile % ntm : tile / ntn) * BM, n0 = (p.m_fast ? tile / ntm : tile % ntn) * BN;
 
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, (XE == 2 && BM ==
     // ~10 VALU per MFMA, profiles/r01_pmc_conv128x64.txt).  Tiles that need per-chunk decisions fall back to the generic loader.
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : 0u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W), 0, (int)p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W) + ((AMODE == A_CONV3 && p.sub2) ? (long)split * p.N * p.ldw : 0L), 0, (int)p.w_bytes, 0x00020000);   // (sub2: w_bytes is ONE parity's weight set)
     constexpr int OOB = (int)0x80000000;  // any offset >= 2 GiB is out of range for every tensor on this path
     int fa_off[A_CH], fa2_off[A_CH], fb_off[B_CH];
     unsigned fa_mask[A_CH];
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, (XE == 2 && BM ==
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     const int KT_all = (p.K + BK - 1) / BK;
     const int kt_per = (KT_all + p.splitk - 1) / p.splitk;
-    const int kt_begin = split * kt_per;
+    const int kt_begin = (AMODE == A_CONV3 && p.sub2) ? 0 : split * kt_per;
     const int KT = max(min(KT_all - kt_begin, kt_per), 0);  // K tiles of this block
     const int klast = p.K - 8;
     // conv: tap / channel offset of the NEXT tile to load
@@ -545,7 +553,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, (XE == 2 && BM ==
                         cur_ci = (lin - cur_tap * conv_per) * BK;
                     } else { const int per = p.CinPad / BK; cur_tap = lin / per; cur_ci = (lin - cur_tap * per) * BK; }
                 }
-                const int ky = cur_tap / 3, kx = cur_tap - ky * 3;
+                // sub2: cur_tap counts the 2 x 2 window's taps; (ky, kx) is the tap's place in the 3 x 3 frame the masks and offsets are laid out for
+                const int ky = (!KM1 && p.sub2) ? py + (cur_tap >> 1) : cur_tap / 3, kx = (!KM1 && p.sub2) ? px + (cur_tap & 1) : cur_tap - ky * 3;
+                const int mbit = (!KM1 && p.sub2) ? ky * 3 + kx : cur_tap;
                 if (cur_ci == 0 || kt == 0 || KM1 || p.kmajor || WA == 2) {  // a new tap: the per-lane part (halo mask, upsample source pixel) changes only here
 #pragma unroll
                     for (int i = 0; i < A_CH; ++i) {
@@ -554,7 +564,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, (XE == 2 && BM ==
                             const int cc = ((tid + i * NT) & 7) ^ (((tid + i * NT) >> 3) & 7);
                             src = (int)((a_base[i] + (long)(max(a_iy[i] + ky, 0) >> 1) * p.Wd + (max(a_ix[i] + kx, 0) >> 1)) * p.Cin + cc * 8) * 2;
                         }
-                        fa_cur[fs][i] = ((fa_mask[i] >> cur_tap) & 1u) ? src : OOB;
+                        fa_cur[fs][i] = ((fa_mask[i] >> mbit) & 1u) ? src : OOB;
                     }
                 }
                 const int tap_off = cur_ci * 2;  // wave-uniform -> SGPR offset
@@ -755,21 +765,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, (XE == 2 && BM ==
             // No upsampling gather here: the launcher keeps those three convs on the round-3 loop.
             int cs_tap = 0, cs_kx = 0, cs_base = 0, cs_ci = 0;   // tap index 0..8, its kx, ((ky * W + kx) * Cin) * 2, channel offset (elements)
             const int cs_cin2 = p.Cin * 2, cs_row2 = (p.Wd - 3) * p.Cin * 2;
+            // sub2 (tap-major only): the window's taps in the order (py, px), (py, px + 1), (py + 1, px), (py + 1, px + 1); cs_tap stays the 3 x 3-frame index
             auto cs_set = [&](int kt) __attribute__((always_inline)) {   // stateless (prologue only)
                 const int lin = kt_begin + kt;
                 if (p.kmajor) { cs_tap = lin % 9; cs_ci = (lin / 9) * BK; }
                 else { cs_tap = conv_per == 1 ? lin : (int)__umulhi((unsigned)lin, pp_magic); cs_ci = (lin - cs_tap * conv_per) * BK; }
-                const int ky = cs_tap / 3;
+                int ky = cs_tap / 3;
                 cs_kx = cs_tap - ky * 3;
+                if (p.sub2) { ky = py + (cs_tap >> 1); cs_kx = px + (cs_tap & 1); cs_tap = ky * 3 + cs_kx; }
                 cs_base = ((ky * p.Wd + cs_kx) * p.Cin) * 2;
             };
             auto cs_next = [&]() __attribute__((always_inline)) {
                 bool tap_step = true;
                 if (!p.kmajor) { cs_ci += BK; tap_step = cs_ci >= p.CinPad; cs_ci = tap_step ? 0 : cs_ci; }
                 if (tap_step) {
+                    if (p.sub2) {
+                        if (cs_kx == px) { ++cs_tap; ++cs_kx; cs_base += cs_cin2; }
+                        else { cs_tap += 2; cs_kx = px; cs_base += cs_row2 + 2 * cs_cin2; }   // one row down, one column back: (W - 1) pixels on
+                    } else {
                     ++cs_tap; ++cs_kx; cs_base += cs_cin2;
                     if (cs_kx == 3) { cs_kx = 0; cs_base += cs_row2; }
                     if (cs_tap == 9) { cs_tap = 0; cs_base = 0; cs_ci += BK; }   // (chunk-major order only: in the tap-major order the loop ends with tap 8)
+                    }
                 }
             };
             auto pp_a = [&](int kt, int st) __attribute__((always_inline)) {
@@ -1049,6 +1066,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, (XE == 2 && BM ==
                 __builtin_amdgcn_wave_barrier();
             }
         };
+        // sub2: GEMM row m = low-resolution pixel (b, y, x) -> output pixel (b, 2 y + py, 2 x + px) of the [B, 2H, 2W] map (whole rows of N channels move)
+        auto orow = [&](int m) __attribute__((always_inline)) -> long {
+            if (!(AMODE == A_CONV3 && p.sub2)) return (long)m;
+            const int hw = p.H * p.Wd;
+            const int b = m / hw, rem = m - b * hw;
+            const int y = rem / p.Wd, x = rem - y * p.Wd;
+            return ((long)(b * 2 * p.H + 2 * y + py) * (2 * p.Wd) + 2 * x + px);
+        };
         const bool staged = (n_out % 8 == 0) && (p.ldc % 8 == 0) && (!p.res || (p.ldr % 8 == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0));
         if (staged) {
             float* st = reinterpret_cast<float*>(smem_raw) + wmn * (WMP * WN);
@@ -1196,7 +1221,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, (XE == 2 && BM ==
                                 o[4] += bf16lo(rr4.z); o[5] += bf16hi(rr4.z); o[6] += bf16lo(rr4.w); o[7] += bf16hi(rr4.w);
                             }
                             const u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
-                            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) = pk;
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + orow(m) * p.ldc + n) = pk;
                             // statistics of the STORED (bf16-rounded) values: what the consuming GroupNorm reads
                             const uint32_t w4[4] = {pk.x, pk.y, pk.z, pk.w};
 #pragma unroll
@@ -1228,8 +1253,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, (XE == 2 && BM ==
                             const f32x2 c = *reinterpret_cast<const f32x2*>(st + (r * 2 + 1) * WN + 2 * c2);
                             s0 += a[0]; s1 += a[1]; q0 += c[0]; q1 += c[1];
                         }
+                        // sub2: the statistics buffer is laid out for the OUTPUT map, sample-major: sample b owns 4 hw / 32 slabs, parity `split` of them the
+                        // run [split hw / 32, (split + 1) hw / 32) — which 32 rows of a sample a slab sums is immaterial to the GroupNorm's per-sample fold
+                        long slab = mslab >> 5;
+                        if (AMODE == A_CONV3 && p.sub2) {
+                            const int spp = (p.H * p.Wd) >> 5;
+                            const int bs = (int)slab / spp;
+                            slab = (long)bs * 4 * spp + (long)split * spp + ((int)slab - bs * spp);
+                        }
                         if (mslab < p.M && nc < n_out)
-                            *reinterpret_cast<f32x4*>(p.colstats + ((long)(mslab >> 5) * n_out + nc) * 2) = (f32x4){s0, q0, s1, q1};
+                            *reinterpret_cast<f32x4*>(p.colstats + (slab * n_out + nc) * 2) = (f32x4){s0, q0, s1, q1};
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 } else if constexpr (XE == 1) {
@@ -1284,11 +1317,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K, (XE == 2 && BM ==
                         o[4] += bf16lo(rr.z); o[5] += bf16hi(rr.z); o[6] += bf16lo(rr.w); o[7] += bf16hi(rr.w);
                     }
                     if (p.out_f32) {
-                        float* dst = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+                        float* dst = reinterpret_cast<float*>(p.C) + orow(m) * p.ldc + n;
                         *reinterpret_cast<f32x4*>(dst) = (f32x4){o[0], o[1], o[2], o[3]};
                         *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){o[4], o[5], o[6], o[7]};
                     } else {
-                        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) =
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + orow(m) * p.ldc + n) =
                             (u32x4){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
                     }
                 }
@@ -1856,6 +1889,49 @@ int gemm_entry(const void* A, long lda, const void* A2, long lda2, int Ksplit, c
     return launch<A_DENSE>(a, (hipStream_t)stream);
 }
 }  // namespace
+
+namespace {
+// nearest-x2 upsample + 3x3 conv as four 2x2 convs (GemmArgs::sub2): the 192x320 ping-pong tile where the four parity copies of its tile grid fill whole
+// rounds of the chip (UNet batch 12: the 32x32 -> 64x64 and 16x16 -> 32x32 up-convs), the 8-wave 128x128 weights-ahead tile otherwise.  Both are the
+// instantiations the stride-1 convs of those levels already run (with / without the column statistics for the consuming GroupNorm).
+int launch_sub2(GemmArgs a, hipStream_t stream) {
+    const char* what = "ae_conv3x3_up2_bf16";
+    a.m_fast = (9L * a.N >= 8L * a.M) ? 1 : 0;
+    const bool cs = a.colstats != nullptr;
+    int rc;
+    const long t192 = (a.M % 192 == 0 && a.N % 320 == 0) ? (long)(a.M / 192) * (a.N / 320) * 4 : 0;
+    if (t192 > 0 && (double)t192 / (double)(((t192 + 255) / 256) * 256) >= 0.85) {
+        const size_t lds = (size_t)(3 * 192 + 2 * 320) * BK * sizeof(bf16_t);
+        if (cs) rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, true, 0, 3>, (unsigned)t192, 512, lds, stream, a, what);
+        else rc = launch_kernel(gemm_kernel<192, 320, A_CONV3, 2, 4, true, 1, 2, false, 0, 3>, (unsigned)t192, 512, lds, stream, a, what);
+    } else {
+        const unsigned grid = (unsigned)((long)((a.M + 127) / 128) * ((a.N + 127) / 128) * 4);
+        const size_t lds = (size_t)(2 * 128 + 3 * 128) * BK * sizeof(bf16_t);
+        if (cs) rc = launch_kernel(gemm_kernel<128, 128, A_CONV3, 4, 2, true, 1, 2, true, 0, 1>, grid, 512, lds, stream, a, what);
+        else rc = launch_kernel(gemm_kernel<128, 128, A_CONV3, 4, 2, true, 1, 2, false, 0, 1>, grid, 512, lds, stream, a, what);
+    }
+    return rc;
+}
+}  // namespace
+
+extern "C" int ae_conv3x3_up2_bf16(const void* x, const void* w4, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, float* colstats, void* stream) {
+    AE_REQUIRE(x && w4 && y, "ae_conv3x3_up2_bf16: null pointer");
+    AE_REQUIRE(B > 0 && H > 0 && W > 0, "ae_conv3x3_up2_bf16: bad shape B=%d H=%d W=%d", B, H, W);
+    AE_REQUIRE(Cin % 64 == 0 && Cout % 8 == 0, "ae_conv3x3_up2_bf16: Cin %% 64 == 0 (whole K tiles per tap) and Cout %% 8 == 0 (row-contiguous stores), got %d -> %d", Cin, Cout);
+    AE_REQUIRE(aligned16(x) && aligned16(w4) && aligned16(y), "ae_conv3x3_up2_bf16: pointers must be 16-byte aligned");
+    if (colstats) AE_REQUIRE((H * W) % 32 == 0 && (reinterpret_cast<uintptr_t>(colstats) & 15) == 0, "ae_conv3x3_up2_bf16: column statistics are kept per 32-row slab of a sample and parity: H * W = %d must be a multiple of 32", H * W);
+    AE_REQUIRE((long)B * H * W * Cin * 2 < (1L << 31) && (long)Cout * 4 * Cin * 2 < (1L << 31) && (long)B * 4 * H * W < (1L << 31), "ae_conv3x3_up2_bf16: operands must be smaller than 2 GiB");
+    GemmArgs a{};
+    a.A = (const bf16_t*)x; a.A2 = nullptr; a.W = (const bf16_t*)w4; a.C = y;
+    a.bias = bias; a.res = nullptr; a.addvec = nullptr;
+    a.M = B * H * W; a.N = Cout; a.K = 4 * Cin; a.Ksplit = a.K;
+    a.lda = 0; a.lda2 = 0; a.ldw = 4L * Cin; a.ldc = Cout; a.ldr = Cout; a.ldav = Cout;
+    a.epi = EPI_NONE; a.out_f32 = 0; a.rows_per_batch = H * W;
+    a.H = H; a.Wd = W; a.Cin = Cin; a.CinPad = Cin; a.Ho = H; a.Wo = W; a.stride = 1; a.ups = 0;
+    a.a_bytes = (unsigned)((long)B * H * W * Cin * 2); a.a2_bytes = 0u; a.w_bytes = (unsigned)((long)Cout * 4 * Cin * 2);
+    a.splitk = 1; a.partial = nullptr; a.colstats = colstats; a.kmajor = 0; a.sub2 = 1;
+    return launch_sub2(a, (hipStream_t)stream);
+}
 
 extern "C" long ae_conv3x3_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride, int upsample2x) {
     const int Hv = upsample2x ? 2 * H : H, Wv = upsample2x ? 2 * W : W;

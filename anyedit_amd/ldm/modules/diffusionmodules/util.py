@@ -146,6 +146,12 @@ class Conv2d(nn.Conv2d, _Packed):
             if "w_taps" not in pk:
                 pk["w_taps"] = ops.pack_conv3x3_taps8(self.weight)
             return ops.gemm(ops.im2col3x3_c8(x, B, H, W), pk["w_taps"], pk["b"], colstats=colstats), H, W
+        if upsample2x and addvec is None and residual is None and not out_f32 and a2 is None and \
+                ops.up2_subpixel_ok(self.in_channels, self.out_channels, H, W, colstats is not None) and self.stride[0] == 1:
+            # Upsample (openaimodel.py:108-118): nearest x2 + conv3x3 = four 2x2 convs on the low-resolution map with summed taps — 4/9 of the multiply-adds
+            if "w_up2" not in pk:
+                pk["w_up2"] = ops.pack_conv3x3_up2(self.weight)
+            return ops.conv3x3_up2(x, pk["w_up2"], pk["b"], B, H, W, colstats=colstats)
         Ho, Wo = self.out_hw(H, W, upsample2x)
         ko = ops.conv_k_order(B * Ho * Wo, self.in_channels, self.out_channels, self.stride[0], upsample2x)
         w = pk["w"]

@@ -108,6 +108,62 @@ def pack_conv3x3_taps8(w):
     return wp.contiguous()
 
 
+def pack_conv3x3_up2(w):
+    """[Cout, Cin, 3, 3] (fp32 master) -> bf16 [4, Cout, 4*Cin]: the weights of `conv3x3_up2` — nearest-x2 upsampling followed by the 3x3 conv equals, per
+    output parity (py, px), a 2x2 conv on the low-resolution input whose taps are SUMS of the 3x3 taps that land on the same input pixel
+    (row pairs: py = 0 -> {w[0]}, {w[1] + w[2]}; py = 1 -> {w[0] + w[1]}, {w[2]}; columns likewise).  Summed in fp32, rounded to bf16 once."""
+    cout, cin = w.shape[0], w.shape[1]
+    assert tuple(w.shape[2:]) == (3, 3) and cin % 64 == 0
+    return up2_weight_sums(w).reshape(4, cout, 4 * cin).to(BF16).contiguous()
+
+
+def up2_weight_sums(w):
+    """fp32 [4, Cout, 4, Cin]: set 2 py + px, tap 2 i + j of `pack_conv3x3_up2` before the rounding (tests/test_host_logic.py restates the identity on CPU)."""
+    cout, cin = w.shape[0], w.shape[1]
+    w32 = w.detach().float()
+    sets = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}
+    out = torch.empty(4, cout, 4, cin, dtype=torch.float32, device=w.device)
+    for py in range(2):
+        for px in range(2):
+            for i in range(2):
+                for j in range(2):
+                    acc = torch.zeros(cout, cin, dtype=torch.float32, device=w.device)
+                    for ky in sets[(py, i)]:
+                        for kx in sets[(px, j)]:
+                            acc = acc + w32[:, :, ky, kx]
+                    out[2 * py + px, :, 2 * i + j] = acc
+    return out
+
+
+_UP2_SUBPIXEL = os.environ.get("AE_UP2_SUBPIXEL", "1") != "0"  # tuning knob (A/B): 0 = the up-convs through the upsampling gather of ae_conv3x3_bf16 (9 taps per output pixel)
+
+
+def up2_subpixel_ok(Cin, Cout, H, W, want_stats):
+    """True where `Upsample`'s nearest-x2 + conv runs as four 2x2 convs on the low-resolution map (not under the training tape: its conv node and
+    adjoint keep the gather form)."""
+    return _UP2_SUBPIXEL and Cin % 64 == 0 and Cout % 8 == 0 and (not want_stats or (H * W) % 32 == 0) and not (_TAPE is not None and _TAPE.active)
+
+
+def conv3x3_up2(x, w4, bias, B, H, W, out=None, colstats=None):
+    """conv3x3(nearest_upsample_x2(x)) on channels-last rows: x [B*H*W, Cin] bf16, w4 = `pack_conv3x3_up2(weight)` -> ([B*2H*2W, Cout], 2H, 2W).
+    colstats: optional `colstats_buffer(B*4*H*W, Cout)` for the consuming GroupNorm."""
+    _chk(x, BF16, "conv3x3_up2.x", 2)
+    _chk(w4, BF16, "conv3x3_up2.w4", 3)
+    Cin, Cout = x.shape[1], w4.shape[1]
+    if x.shape[0] != B * H * W or not x.is_contiguous():
+        raise ValueError(f"conv3x3_up2: x must be contiguous [B*H*W, Cin] = [{B * H * W}, Cin], got {tuple(x.shape)}")
+    if tuple(w4.shape) != (4, Cout, 4 * Cin) or not w4.is_contiguous():
+        raise ValueError(f"conv3x3_up2: packed weight must be a contiguous [4, Cout, {4 * Cin}] tensor, got {tuple(w4.shape)}")
+    if out is None:
+        out = torch.empty(B * 4 * H * W, Cout, dtype=BF16, device=x.device)
+    if colstats is not None:
+        _chk(colstats, torch.float32, "conv3x3_up2.colstats", 3)
+        if tuple(colstats.shape) != (B * 4 * H * W // 32, Cout, 2) or not colstats.is_contiguous() or (H * W) % 32:
+            raise ValueError(f"conv3x3_up2: colstats must be a contiguous [{B * 4 * H * W // 32}, {Cout}, 2] fp32 buffer (H * W % 32 == 0)")
+    check(lib.ae_conv3x3_up2_bf16(_p(x), _p(w4), _p(bias), _p(out), B, H, W, Cin, Cout, _p(colstats), _s()), "ae_conv3x3_up2_bf16")
+    return out, 2 * H, 2 * W
+
+
 _STEM_IM2COL = os.environ.get("AE_STEM_IM2COL", "1") != "0"  # tuning knob (A/B): 0 = the stem conv through the implicit-GEMM kernel (Cin = 8 padded to 64 per tap)
 
 
@@ -1300,6 +1356,17 @@ def _gemm_ln_label(_r, a, w, bias, residual, epilogue, out, M, N, K, rowstats_ou
     return f"gemm_kernel<{_tile_label(M, N, False, K, epilogue == EPI_GEGLU, True)},dense,{tag}>|M={M} N={N} K={K}", 2.0 * M * N * K, float(nb)
 
 
+def _up2_label(_r, x, w4, bias, B, H, W, **_):
+    y = _r[0]
+    M, Cout, Cin = x.shape[0], w4.shape[1], x.shape[1]
+    t192 = (M // 192) * (Cout // 320) * 4 if (M % 192 == 0 and Cout % 320 == 0) else 0
+    tl = "192x320" if t192 and t192 / (-(-t192 // 256) * 256) >= 0.85 else "128x128"
+    nb = 2 * (x.numel() + 16 * Cin * Cout) + 2 * y.numel()
+    # FLOP: the 2x2 form's own count (4 taps per output pixel); the gather form it replaces spends 9/4 of it for the same function
+    return f"gemm_kernel<{tl},conv3x3,up2x2>|M={y.shape[0]} Cin={Cin} Cout={Cout}", 2.0 * y.shape[0] * Cout * 4 * Cin, float(nb)
+
+
+conv3x3_up2 = _wrap_profiled(conv3x3_up2, _up2_label)
 _ln_gemm_fused = _wrap_profiled(_ln_gemm_launch, _ln_gemm_label)
 _gemm_ln_launch = _wrap_profiled(_gemm_ln_launch, _gemm_ln_label)
 gemm = _wrap_profiled(gemm, _gemm_label)

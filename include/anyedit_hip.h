@@ -91,6 +91,18 @@ int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float
                     void* y, int B, int H, int W, int Cin, int Cout, int stride, int upsample2x, int out_f32, float* workspace,
                     float* colstats /* as for ae_gemm_bf16 (M = B*Ho*Wo, N = Cout); NULL = none */, int k_order, void* stream);
 
+/* Upsample (openaimodel.py:108-118: F.interpolate(scale_factor=2, mode="nearest") followed by the 3x3 conv) as FOUR 2x2 convolutions on the
+ * low-resolution input: output pixel (2y+py, 2x+px) reads input rows {y-1, y} (py = 0) or {y, y+1} (py = 1), columns likewise, and the 3x3
+ * taps that land on the same input pixel are summed at pack time — 4/9 of the multiply-adds of ae_conv3x3_bf16(..., upsample2x = 1), the same
+ * function up to the rounding of the summed bf16 weights.
+ *   x [B,H,W,Cin] bf16 channels-last (Cin % 64 == 0); y [B,2H,2W,Cout] bf16 (Cout % 8 == 0); bias fp32 [Cout] or NULL;
+ *   w4 [4][Cout][4*Cin] bf16: set p = 2*py + px, K ordered (tap t = 2*i + j, cin) with
+ *       w4[p][co][t*Cin + ci] = sum_{ky in S(py,i)} sum_{kx in S(px,j)} w[co][ci][ky][kx],   S(0,0)={0} S(0,1)={1,2} S(1,0)={0,1} S(1,1)={2}
+ *   (summed in fp32 from the fp32 master weights, then rounded to bf16 once);
+ *   colstats: as for ae_conv3x3_bf16, for the OUTPUT map ([B*4*H*W/32][Cout][2]; needs H*W % 32 == 0), or NULL.                       */
+int ae_conv3x3_up2_bf16(const void* x, const void* w4, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                        float* colstats, void* stream);
+
 /* GroupNorm32 (+SiLU) (util.py:217-219 eps 1e-5; attention.py:88-89 eps 1e-6); input may be the channel-concat [x | x2].
  * workspace: fp32, ae_groupnorm_workspace_floats(B,HW,C,groups) elements.  act: 0 none, 1 SiLU.
  * counters: optional int32[B], ZERO on entry and zero again on exit, not shared with a launch running concurrently on another

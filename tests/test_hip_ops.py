@@ -337,6 +337,49 @@ def test_conv3x3(ops, B, H, W, Cin, Cout, stride, ups):
     check_close(ops.rows_to_nchw(y, B, Ho, Wo), ref, what="conv3x3")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stats", [(12, 32, 32, 640, 640, True),      # UNet 32x32 -> 64x64: 192x320 ping-pong tile, 4 x 128 tiles, statistics from the epilogue
+                                                  (12, 32, 32, 640, 640, False),
+                                                  (12, 16, 16, 1280, 1280, True),    # 16x16 -> 32x32: 4 x 64 tiles = one round of the chip
+                                                  (12, 8, 8, 1280, 1280, False),     # 8x8 -> 16x16: 128x128 weights-ahead tile (240 blocks)
+                                                  (3, 16, 16, 64, 320, True),        # small grid on the 128x128 tile, one K tile per tap
+                                                  (2, 6, 10, 128, 72, False),        # ragged: M = 120 (tile tail rows), N = 72 (column tail), W not a power of two
+                                                  (1, 8, 8, 64, 64, True)])
+def test_conv3x3_up2_as_four_2x2_convs(ops, B, H, W, Cin, Cout, stats):
+    """Round 5 — Upsample (openaimodel.py:108-118) as four 2x2 convs on the low-resolution map (`ae_conv3x3_up2_bf16`): against torch's
+    interpolate + conv2d on the bf16-rounded input and ORIGINAL weights (the summed weights are rounded once more: the same 4e-3 operator bound must
+    hold), against the gather form of `ae_conv3x3_bf16(upsample2x = 1)` it replaces, and — where asked — the producer statistics of the stored map."""
+    g = torch.Generator().manual_seed(B + H * 3 + Cin + Cout + 500)
+    x = q(torch.randn(B, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), q(w), bias, padding=1)
+    rows = ops.nchw_to_rows(x.to(DEV))
+    w4 = ops.pack_conv3x3_up2(w.to(DEV))
+    cs = None
+    if stats:
+        cs = ops.colstats_buffer(B * 4 * H * W, Cout, DEV)
+        cs.fill_(float("nan"))
+    y, Ho, Wo = ops.conv3x3_up2(rows, w4, bias.to(DEV), B, H, W, colstats=cs)
+    assert (Ho, Wo) == (2 * H, 2 * W) and tuple(y.shape) == (B * 4 * H * W, Cout)
+    check_close(ops.rows_to_nchw(y, B, Ho, Wo), ref, what="conv3x3_up2")
+    y_old, _, _ = ops.conv3x3(rows, ops.pack_conv3x3(w.to(DEV)), bias.to(DEV), B, H, W, upsample2x=True)
+    assert rel_l2(y.float().cpu(), y_old.float().cpu()) < 4e-3
+    assert torch.equal(ops.conv3x3_up2(rows, w4, bias.to(DEV), B, H, W)[0], y), "asking for statistics must not change the output; launches must repeat bit for bit"
+    if stats:
+        # the GroupNorm that consumes them folds every slab of a SAMPLE: per-sample sums are what must match (which 32 rows a slab holds is the producer's choice)
+        got = cs.cpu().double()
+        assert torch.isfinite(got).all()
+        yf = y.float().cpu().double().reshape(B, 4 * H * W, Cout)
+        ref_s = torch.stack([yf.sum(1), (yf * yf).sum(1)], -1)
+        got_s = got.reshape(B, 4 * H * W // 32, Cout, 2).sum(1)
+        assert float((got_s - ref_s).abs().max()) <= 2e-4 * float(ref_s.abs().max())
+        gamma, beta = torch.randn(Cout, generator=g).to(DEV), torch.randn(Cout, generator=g).to(DEV)
+        if Cout % 32 == 0 and 4 * H * W > 256:
+            n_own = ops.groupnorm(y, gamma, beta, B, 4 * H * W, 1e-5, silu=True)
+            n_cs = ops.groupnorm(y, gamma, beta, B, 4 * H * W, 1e-5, silu=True, colstats=cs)
+            assert rel_l2(n_cs.float().cpu(), n_own.float().cpu()) < 2e-3
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(2, 8, 8, 64, 64, 1), (1, 7, 9, 64, 64, 2), (3, 5, 6, 128, 72, 1), (1, 64, 64, 320, 320, 1),
                                                    (12, 16, 16, 256, 1280, 1), (12, 16, 16, 320, 640, 1), (12, 8, 8, 1280, 1280, 1)])
 def test_conv3x3_chunk_major_k_order(ops, B, H, W, Cin, Cout, stride):

@@ -458,6 +458,35 @@ def test_conv_k_order_follows_the_tile_plan(monkeypatch):
     assert ops.conv_k_order(12 * 64 * 64, 320, 320) == 0                               # the chunk-major order exists in the LDS-DMA loader only
 
 
+def test_upsample_conv_as_four_2x2_convs_identity():
+    """Round 5 (openaimodel.py:108-118): conv3x3(nearest_upsample_x2(X), pad 1) restated as four 2x2 convs on X with summed taps — the identity behind
+    `ops.pack_conv3x3_up2` / `ae_conv3x3_up2_bf16`, checked in fp32 on the CPU against torch's interpolate + conv2d, including the image border (the
+    zero padding of the upsampled map is the zero padding of the low-resolution map) and the tap order / parity layout the kernel assumes:
+    set p = 2 py + px, tap t = 2 i + j reads input pixel (y + py - 1 + i, x + px - 1 + j) and writes output pixel (2 y + py, 2 x + px)."""
+    import torch.nn.functional as F
+    from anyedit_amd import ops
+    g = torch.Generator().manual_seed(31)
+    B, C, Co, H, W = 2, 64, 8, 5, 7
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, padding=1)
+    ws = ops.up2_weight_sums(w)                                  # [4, Co, 4, C]
+    xp = F.pad(x, (1, 1, 1, 1))                                  # zero border of the LOW-resolution map
+    out = torch.zeros(B, Co, 2 * H, 2 * W)
+    for py in range(2):
+        for px in range(2):
+            acc = torch.zeros(B, Co, H, W)
+            for i in range(2):
+                for j in range(2):
+                    win = xp[:, :, py + i:py + i + H, px + j:px + j + W]     # input pixel (y + py - 1 + i, x + px - 1 + j)
+                    acc += torch.einsum("bchw,oc->bohw", win, ws[2 * py + px, :, 2 * i + j])
+            out[:, :, py::2, px::2] = acc
+    assert float((out - ref).abs().max()) < 2e-4 * float(ref.abs().max())
+    packed = ops.pack_conv3x3_up2(w)
+    assert tuple(packed.shape) == (4, Co, 4 * C) and packed.dtype == torch.bfloat16
+    assert torch.equal(packed.reshape(4, Co, 4, C), ws.to(torch.bfloat16))
+
+
 def test_mask_tool_box_logic_on_cpu():
     """tools/tool.py:184-222 (no GPU involved): box conversion and the phrase-based target filter, including its fallbacks and the
     list form of `target_object`."""
