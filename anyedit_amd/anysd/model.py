@@ -107,9 +107,10 @@ class MoE(nn.Module):
         return context_rows, kv_cache
 
     @torch.no_grad()
-    def denoise(self, x, timesteps, context_rows, kv_cache):
-        """One UNet evaluation with the prepared conditioning (the per-step call of the DDIM loop)."""
-        return self.unet.forward_rows(x, timesteps, context_rows, kv_cache=kv_cache)
+    def denoise(self, x, timesteps, context_rows, kv_cache, emb_pack=None):
+        """One UNet evaluation with the prepared conditioning (the per-step call of the DDIM loop).  emb_pack: the step's time-embedding rows when the
+        sampler computed them ahead for its whole schedule (`UNetModel.time_embedding_rows`)."""
+        return self.unet.forward_rows(x, timesteps, context_rows, kv_cache=kv_cache, emb_pack=emb_pack)
 
     def forward(self, noisy_latents, timesteps, encoder_hidden_states, image_embeds, edit_code):
         """train.py:694-695 call contract."""

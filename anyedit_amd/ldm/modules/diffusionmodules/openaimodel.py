@@ -372,21 +372,36 @@ class UNetModel(nn.Module):
         wp[:, 0] = w[:, 0]
         return ops.linear_f32(yp, wp, b)
 
-    def forward_rows(self, x, timesteps, context_rows, kv_cache=None, y=None):
+    def time_embedding_rows(self, timesteps):
+        """The whole time-embedding chain of openaimodel.py:762-763 + every ResBlock's emb_layers (:262-263) for a VECTOR of time steps, one row each:
+        timestep_embedding -> Linear + SiLU -> Linear -> SiLU -> the batched emb_layers projection.  It depends on t alone (not on x, the context or the
+        sample), so a sampler that knows its schedule computes it ONCE for all steps (EditPipeline.edit: one M = 50 pass instead of fifty M = 3B ones)
+        and hands row i, broadcast over the batch, to `forward_rows(..., emb_pack=)`.  Returns an EmbPack whose `.all` is fp32 [len(timesteps), sum Cout]."""
+        assert self.num_classes is None, "class-conditional models add label_emb(y) per sample: use forward_rows(y=...)"
+        t_emb = ops.timestep_embedding(timesteps, self.model_channels)
+        emb = self.time_embed[0].rows(t_emb, epilogue=ops.EPI_SILU)
+        return self._emb_pack(self.time_embed[2].rows(emb, epilogue=ops.EPI_SILU))
+
+    def forward_rows(self, x, timesteps, context_rows, kv_cache=None, y=None, emb_pack=None):
         """x: [B, Cin, H, W] fp32/bf16 NCHW; context_rows: bf16 [B*L, Dc]; y: class labels [B] of a class-conditional model
-        (openaimodel.py:764-772).  Returns eps [B, Cout, H, W] fp32."""
+        (openaimodel.py:764-772).  emb_pack: optional EmbPack with `.all` = fp32 [B, sum Cout] from `time_embedding_rows` (then `timesteps` is not
+        read).  Returns eps [B, Cout, H, W] fp32."""
         B, C, H, W = x.shape
         assert (y is not None) == (self.num_classes is not None), "must specify y if and only if the model is class-conditional"
-        t_emb = ops.timestep_embedding(timesteps, self.model_channels)                 # bf16 [B, mc]
-        emb = self.time_embed[0].rows(t_emb, epilogue=ops.EPI_SILU)                   # Linear + SiLU fused
-        if y is None:
-            emb_silu = self.time_embed[2].rows(emb, epilogue=ops.EPI_SILU)            # SiLU(emb): what every ResBlock consumes
-        else:  # emb + label_emb(y) in fp32, then the SiLU every ResBlock starts with
-            assert y.shape[0] == B
-            e32 = self.time_embed[2].rows(emb, out_f32=True)
-            lab = self._label_rows(y, e32.device)
-            emb_silu = ops.silu_to_bf16(ops.lincomb([(e32, 1.0), (lab, 1.0)]))
-        emb_silu = self._emb_pack(emb_silu)
+        if emb_pack is not None:
+            assert y is None and emb_pack.all is not None and emb_pack.all.shape[0] == B and emb_pack.all.is_contiguous()
+            emb_silu = emb_pack
+        else:
+            t_emb = ops.timestep_embedding(timesteps, self.model_channels)                 # bf16 [B, mc]
+            emb = self.time_embed[0].rows(t_emb, epilogue=ops.EPI_SILU)                   # Linear + SiLU fused
+            if y is None:
+                emb_silu = self.time_embed[2].rows(emb, epilogue=ops.EPI_SILU)            # SiLU(emb): what every ResBlock consumes
+            else:  # emb + label_emb(y) in fp32, then the SiLU every ResBlock starts with
+                assert y.shape[0] == B
+                e32 = self.time_embed[2].rows(emb, out_f32=True)
+                lab = self._label_rows(y, e32.device)
+                emb_silu = ops.silu_to_bf16(ops.lincomb([(e32, 1.0), (lab, 1.0)]))
+            emb_silu = self._emb_pack(emb_silu)
         f = Feat(ops.nchw_to_rows(x, (C + 7) // 8 * 8), B, H, W)
         hs = []
         for module in self.input_blocks:
