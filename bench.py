@@ -32,6 +32,11 @@ SD15 = dict(image_size=64, in_channels=8, model_channels=320, out_channels=4, nu
 GFLOP_PER_UNET_SAMPLE = 803.4  # BASELINE.md §2 (64x64 latent)
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBPS = 8000.0
+# What the matrix pipes SUSTAIN on this part under its 1400 W package-power limit with random bf16 operands, measured by a pure-MFMA loop on every SIMD
+# while the firmware reported the PPT limiter active in every sample (tools/ubench/mfma_burn.hip + tools/throttle_probe.py, profiles/r05_throttle_mfma*.json):
+# v_mfma_f32_16x16x32_bf16 (the GEMM / conv kernels' shape) 1645 TFLOP/s at ~2.05 GHz, v_mfma_f32_32x32x16_bf16 (attention) 1873 TFLOP/s at ~1.85 GHz; with all-zero
+# operands the same loop draws 840 W and holds 2.39 GHz.  Quoted NEXT TO the datasheet fraction, never instead of it.
+SUSTAINED_BF16_TFLOPS = {"16x16x32": 1645.0, "32x32x16": 1873.0}
 
 
 def build_model(device, seed=0):
@@ -328,6 +333,8 @@ def main():
                 "achieved": a["tflops"] if mfma else a["gbps"], "peak": PEAK_BF16_TFLOPS if mfma else PEAK_HBM_GBPS,
                 "unit": "TFLOP/s" if mfma else "GB/s",
                 "frac": (a["tflops"] / PEAK_BF16_TFLOPS) if mfma else (a["gbps"] / PEAK_HBM_GBPS),
+                "frac_of_sustained_mfma_rate": (a["tflops"] / SUSTAINED_BF16_TFLOPS["32x32x16" if "attn" in name else "16x16x32"]) if mfma else None,
+                "sustained_mfma_rate_tflops": (SUSTAINED_BF16_TFLOPS["32x32x16" if "attn" in name else "16x16x32"]) if mfma else None,
                 "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": m["bytes"] / m["calls"] if m["calls"] else None,
                 "avg_launch_us": a["avg_us"], "launches_per_unet_step": a["calls"] // 3,
                 "share_of_unet_step": a["ms"] / sum(v["ms"] for v in summ.values()),
