@@ -23,7 +23,7 @@ def label(name):
     if m:  # same family names as bench.py's folded profiler labels; the three-stage-ring instantiations are their own symbols
         ring = ",ring3" if m.group(4) == "3" else ""
         return f"gemm_kernel<{m.group(1)}x{m.group(2)}{ring},{'conv3x3' if m.group(3) == '1' else 'dense'}>"
-    m = re.search(r"attn_fast_kernel<(\d+)", name)
+    m = re.search(r"attn_(?:fast|pipe)_kernel<(\d+)", name)   # (round 5: the pipelined long-sequence kernel keeps the family label of bench.py's profiler)
     if m:
         return f"attn_fast_kernel<D={m.group(1)}>"
     m = re.search(r"gemm_rowpanel_kernel<(\d+), (\d+), (\w+)>", name)
