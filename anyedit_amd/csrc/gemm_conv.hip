@@ -1638,7 +1638,18 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         const double fill = (double)t / (double)(((t + 255) / 256) * 256) * ((double)a.M / (double)(((a.M + 191) / 192) * 192));
         // 192x320 waves 2x4, or 4x2 for GEGLU (pairs of 16-column fragments must sit in one wave).  A 96x320 variant for the
         // 32x32 level (M = 12288) measured 9-13 % slower than the 128x128 tile there and was dropped.
-        if (fill >= 0.85) {
+        // Round 5: a LayerNorm-fold launch whose 128x128 grid would leave a bad tail ALSO takes this tile at a three-quarter-full single round —
+        // qkv of the 16x16 level, M = 3072 x N = 3840 x K = 1280: 720 tiles of 128x128 on 512 block slots = 1.41 rounds (42.7 us, the library 29.7:
+        // profiles/r05_ev1_gemm_vs_library.txt) against 192 tiles of 192x320 in one round of the ping-pong loop.  It runs the 4x2-wave LayerNorm-fold
+        // instantiation the GEGLU launches use (its epilogue kind is a run-time argument): no new device code.  AE_GEMM_T320_XE=0 turns the rule off (A/B).
+        static const int t320_xe = getenv("AE_GEMM_T320_XE") ? atoi(getenv("AE_GEMM_T320_XE")) : 1;
+        const long t128x = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+        const bool xe_tail = t320_xe && !conv && a.xe == 2 && a.epi != EPI_GEGLU && (pp & 8) && fill >= 0.74 && fill < 0.85 &&
+                             (double)t128x / (double)(((t128x + 511) / 512) * 512) <= 0.72;
+        if (fill >= 0.85 || xe_tail) {
+            if (xe_tail) {
+                if constexpr (AMODE == A_DENSE) { rc = launch_kernel(gemm_kernel<192, 320, A_DENSE, 4, 2, true, 1, 2, false, 0, 3, 2>, (unsigned)t, 512, lds_aa(192, 320) + 2 * 320 * sizeof(float), stream, a, what); xe_done = true; }
+            } else
             if (a.epi == EPI_GEGLU && (pp & 8)) {
                 if constexpr (AMODE == A_DENSE) {
                     if (a.xe == 2) { rc = launch_kernel(gemm_kernel<192, 320, A_DENSE, 4, 2, true, 1, 2, false, 0, 3, 2>, (unsigned)t, 512, lds_aa(192, 320) + 2 * 320 * sizeof(float), stream, a, what); xe_done = true; }

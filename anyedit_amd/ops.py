@@ -1227,15 +1227,19 @@ class OpProfiler:
 _PROF = None
 
 
-def _tile_label(M, N, conv=False, K=0, geglu=False, dma_ok=True):
+def _tile_label(M, N, conv=False, K=0, geglu=False, dma_ok=True, xe2=False):
     """Mirror of the tile choice in csrc/gemm_conv.hip::launch / make_plan (for labelling only)."""
     if conv and dma_ok and _conv_t320_split(M, N, K):
         return "192x320,splitK"
     if dma_ok and N % 320 == 0 and (conv or K >= 640):   # convs, GEGLU GEMMs with K >= 640 and (round 3) the other dense GEMMs with K >= 640
         tm = -(-M // 192)
         t = tm * (N // 320)
-        if t / (-(-t // 256) * 256) * (M / (tm * 192)) >= 0.85 and not (conv and _conv_splitk(M, N, K) > 1):
+        fill = t / (-(-t // 256) * 256) * (M / (tm * 192))
+        if fill >= 0.85 and not (conv and _conv_splitk(M, N, K) > 1):
             return "192x320"
+        t128 = -(-M // 128) * -(-N // 128)
+        if xe2 and not conv and not geglu and 0.74 <= fill < 0.85 and t128 / (-(-t128 // 512) * 512) <= 0.72 and os.environ.get("AE_GEMM_T320_XE", "1") != "0":
+            return "192x320"   # round 5: a LayerNorm-fold launch whose 128x128 grid leaves a bad tail (qkv of the 16x16 level)
     if conv and _conv_splitk(M, N, K) > 1:  # small grids: one block per CU under the three-stage ring (a different kernel symbol)
         return "128x128,ring3,splitK" if dma_ok and _CONV_DEEP and -(-M // 128) * -(-N // 128) * _conv_splitk(M, N, K) <= 256 else "128x128,splitK"
     if conv and N % 160 == 0 and N % 128 != 0 and -(-M // 128) * (N // 160) >= 256:
@@ -1353,7 +1357,7 @@ def _ln_gemm_label(_r, x, w, bias, residual, gamma, beta, eps, epilogue, o, M, N
 def _gemm_ln_label(_r, a, w, bias, residual, epilogue, out, M, N, K, rowstats_out, ln_stats, nparts, ln_colsum, eps):
     nb = 2 * (M * K + N * K) + _r.numel() * 2 + (2 * M * N if residual is not None else 0)
     tag = "rowstats" if rowstats_out is not None else "LNfold"
-    return f"gemm_kernel<{_tile_label(M, N, False, K, epilogue == EPI_GEGLU, True)},dense,{tag}>|M={M} N={N} K={K}", 2.0 * M * N * K, float(nb)
+    return f"gemm_kernel<{_tile_label(M, N, False, K, epilogue == EPI_GEGLU, True, xe2=rowstats_out is None)},dense,{tag}>|M={M} N={N} K={K}", 2.0 * M * N * K, float(nb)
 
 
 def _up2_label(_r, x, w4, bias, B, H, W, **_):
