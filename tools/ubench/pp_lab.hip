@@ -110,6 +110,14 @@ int main(int argc, char** argv) {
         conv(12, 64, 960, 320, 1, "conv L1 960->320 @64 kmajor");
         return 0;
     }
+    if (argc > 1 && argv[1][0] == 'p') {   // one short-K dense launch only (round 5: is this family power-limited? tools/throttle_probe.py beside AE_LAB_ITERS=200000)
+        dense(12288, 640, 640, EPI_NONE, "gemm proj L2 12288x640x640");
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'g') {   // one GEGLU launch only
+        dense(12288, 5120, 640, EPI_GEGLU, "gemm ff1 L2 geglu 12288x5120x640");
+        return 0;
+    }
     conv(12, 64, 320, 320, 1, "conv L1 320->320 @64 kmajor");
     conv(12, 64, 960, 320, 1, "conv L1 960->320 @64 kmajor");
     conv(12, 16, 1280, 1280, 0, "conv L3 1280->1280 @16 splitK");
