@@ -1491,7 +1491,10 @@ Plan make_plan(int M, int N, int K, bool can_split) {
     // incl. the reduce); in situ 15.35 -> 15.10 ms per UNet step (two runs each way).  Extending the rule to the 32x32 level's 128-tile
     // grids (split 2) gains on the K = 17280 convs in isolation (272 -> 241 us) and is neutral-to-negative inside the UNet: knob value 1
     // (3: only for >= 180 K tiles).  0 = round-1 plans.  tile id 4.
-    static const int t320_split = getenv("AE_CONV_T320_SPLITK") ? atoi(getenv("AE_CONV_T320_SPLITK")) : 2;
+    // Round 5, re-measured under the ping-pong / slab loop: value 3 (the 32x32-level convs with >= 180 K tiles — 1920 -> 640 and 1280 -> 640 at UNet batch 12 — cut two ways onto
+    // 256 blocks of the 192x320 tile instead of 480 blocks of 128x128) 12.828 / 12.792 -> 12.756 / 12.751 ms per UNet step in two alternating rounds, value 1 (every 128-tile
+    // grid) 12.766 / 12.757 (profiles/r05_v11_t320_splitk_ab.txt).  Default 3.
+    static const int t320_split = getenv("AE_CONV_T320_SPLITK") ? atoi(getenv("AE_CONV_T320_SPLITK")) : 3;
     if (t320_split && can_split && N % 320 == 0 && M % 192 == 0 && force_s <= 0) {
         const long t192 = (long)(M / 192) * (N / 320);
         if (t192 >= 32 && t192 <= (t320_split == 2 ? 64 : (t320_split == 3 && kt < 180 ? 64 : 128))) {

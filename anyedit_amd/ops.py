@@ -1265,7 +1265,9 @@ _CONV_DEEP = os.environ.get("AE_CONV_DEEP", "0") != "0"  # mirror of the library
 def _conv_t320_split(M, N, K):
     """split count of the 192x320 split-K plan (16x16-level convs), 0 when it does not apply (make_plan, tile id 4)."""
     kt = -(-K // 64)
-    if N % 320 == 0 and M % 192 == 0 and 32 <= (M // 192) * (N // 320) <= 64:
+    knob = int(os.environ.get("AE_CONV_T320_SPLITK", "3"))   # mirror of make_plan's knob: 2 = grids of 32..64 tiles, 3 (default, round 5) = + 65..128 tiles with >= 180 K tiles, 1 = every grid up to 128
+    hi = 64 if (knob == 2 or (knob == 3 and kt < 180)) else 128
+    if knob and N % 320 == 0 and M % 192 == 0 and 32 <= (M // 192) * (N // 320) <= hi:
         s_ = min(256 // ((M // 192) * (N // 320)), 8)
         while s_ > 1 and kt // s_ < 16:
             s_ -= 1

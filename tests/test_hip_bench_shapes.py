@@ -70,6 +70,44 @@ def test_conv3x3_bench_plan_vs_conv2d(B, H, W, Cin, Cout, ups):
         assert e1 <= 4e-3 and float((got1 - ref).abs().max()) / float(ref.abs().max()) <= 2e-2
 
 
+@pytest.mark.parametrize("Cin", [1280, 1920])
+def test_conv3x3_long_k_32x32_level_takes_the_split_192x320_plan(Cin):
+    """Round 5 plan change (AE_CONV_T320_SPLITK default 3): the decoder convs of the 32x32 level with >= 180 K tiles (1280 -> 640, 1920 -> 640 at UNet
+    batch 12: 128 tiles of 192x320) are cut two ways onto 256 blocks of the ping-pong tile, in the chunk-major K order (slab form: 90 / 135 K tiles per
+    block are whole 9-tap chunks), with the fixed-order reduce and the stand-alone statistics pass behind them.  Against fp32 conv2d on the bf16-rounded
+    operands, both K orders, bit-repeatable, statistics = those of the stored tensor."""
+    from anyedit_amd import ops
+    _threads()
+    B, H, W, Cout = 12, 32, 32, 640
+    g = torch.Generator().manual_seed(Cin + 77)
+    x = (torch.randn(B, Cin, H, W, generator=g)).to(BF).float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(BF).float()
+    bias = torch.randn(Cout, generator=g)
+    emb = torch.randn(B, Cout, generator=g)
+    M = B * H * W
+    assert ops._tile_label(M, Cout, True, 9 * Cin, False, True) == "192x320,splitK" and ops._conv_t320_split(M, Cout, 9 * Cin) == 2
+    assert ops.lib.ae_conv3x3_workspace_floats(B, H, W, Cin, Cout, 1, 0) == 2 * M * Cout
+    assert ops.conv_k_order(M, Cin, Cout) == 1
+    ref = F.conv2d(x, w, bias, padding=1) + emb[:, :, None, None]
+    rows = ops.nchw_to_rows(x.to(DEV))
+    outs = []
+    for ko in (0, 1):
+        cs = ops.colstats_buffer(M, Cout, DEV)
+        cs.fill_(float("nan"))
+        y, _, _ = ops.conv3x3(rows, ops.pack_conv3x3(w.to(DEV), k_order=ko), bias.to(DEV), B, H, W, addvec=emb.to(DEV), colstats=cs, k_order=ko)
+        got = ops.rows_to_nchw(y, B, H, W).cpu()
+        e = rel_l2(got, ref)
+        print(f"\nconv3x3 [12,{Cin},32,32] -> 640 split-K 192x320, k_order {ko}: rel-L2 {e:.3e}")
+        assert e <= 4e-3 and float((got - ref).abs().max()) / float(ref.abs().max()) <= 2e-2
+        yf = y.float().cpu().double().reshape(-1, 32, Cout)
+        ref_s = torch.stack([yf.sum(1), (yf * yf).sum(1)], -1)
+        assert float((cs.cpu().double() - ref_s).abs().max()) <= 2e-4 * float(ref_s.abs().max())
+        y2, _, _ = ops.conv3x3(rows, ops.pack_conv3x3(w.to(DEV), k_order=ko), bias.to(DEV), B, H, W, addvec=emb.to(DEV), k_order=ko)
+        assert torch.equal(y, y2)
+        outs.append(got)
+    assert rel_l2(outs[1], outs[0]) < 2e-3    # two summation orders of the same products, each rounded to bf16 once
+
+
 # ------------------------------------------------------------------------------------------------- UNet batch 12 / 24
 _ORACLE = {}
 

@@ -453,7 +453,15 @@ def test_conv_k_order_follows_the_tile_plan(monkeypatch):
             sp = ops._conv_t320_split(12 * 16 * 16, 1280, 9 * cin)
             kt = 9 * cin // 64
             assert sp == 4 and ((-(-kt // sp)) % 9 == 0) == slab, (cin, sp)
+    # round 5: the split plan also takes the 32x32-level convs with >= 180 K tiles (AE_CONV_T320_SPLITK default 3), in the chunk-major order; not the shorter ones
     monkeypatch.setattr(ops, "_CONV_KMAJOR", 2)
+    monkeypatch.delenv("AE_CONV_T320_SPLITK", raising=False)
+    assert ops._conv_t320_split(12 * 32 * 32, 640, 9 * 1920) == 2 and ops._conv_t320_split(12 * 32 * 32, 640, 9 * 1280) == 2
+    assert ops.conv_k_order(12 * 32 * 32, 1920, 640) == 1 and ops.conv_k_order(12 * 32 * 32, 1280, 640) == 1
+    assert ops._conv_t320_split(12 * 32 * 32, 640, 9 * 960) == 0 and ops.conv_k_order(12 * 32 * 32, 960, 640) == 0 and ops.conv_k_order(12 * 32 * 32, 640, 640) == 0
+    monkeypatch.setenv("AE_CONV_T320_SPLITK", "2")
+    assert ops._conv_t320_split(12 * 32 * 32, 640, 9 * 1920) == 0 and ops.conv_k_order(12 * 32 * 32, 1920, 640) == 0
+    monkeypatch.delenv("AE_CONV_T320_SPLITK", raising=False)
     monkeypatch.setenv("AE_GEMM_GLDS", "0")
     assert ops.conv_k_order(12 * 64 * 64, 320, 320) == 0                               # the chunk-major order exists in the LDS-DMA loader only
 
