@@ -23,6 +23,11 @@ int ae_check_launch(const char* what);
 // statistics a producing kernel hands to the GroupNorm that consumes its output; N % 8 == 0, rows 16-byte aligned
 int ae_launch_colstats(const uint16_t* x, long ld, int M, int N, float* out, hipStream_t stream);
 
+// LayerNorm fold on the row-panel kernel (gemm_rowpanel.hip; K = 320 shapes of ae_gemm_ln_bf16 / ae_gemm_ln_plan, forwarded from gemm_conv.hip)
+int ae_rowpanel_fold_covers(int M, int N, int K, int epilogue, int mode);
+int ae_rowpanel_fold_launch(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias, const void* residual,
+                            long ldr, int epilogue, float* rowstats_out, const float* ln_stats, int ln_parts, const float* ln_colsum, float ln_eps, void* stream);
+
 #define AE_REQUIRE(cond, ...)                 \
     do {                                      \
         if (!(cond)) {                        \

@@ -1825,6 +1825,11 @@ extern "C" int ae_gemm_ln_bf16(const void* A, long lda, const void* W, long ldw,
                                const void* residual, long ldr, int epilogue, float* rowstats_out, const float* ln_stats, int ln_parts,
                                const float* ln_colsum, float ln_eps, void* stream) {
     AE_REQUIRE((rowstats_out != nullptr) != (ln_stats != nullptr), "ae_gemm_ln_bf16: exactly one of rowstats_out (emit) and ln_stats (consume) must be given");
+    AE_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "ae_gemm_ln_bf16: null pointer or empty shape");
+    {   // K = 320 (the 64x64 UNet level): the row-panel kernel's fold forms (round 5); AE_ERR_UNSUPPORTED = outside its envelope, the tiled plan decides
+        const int rc = ae_rowpanel_fold_launch(A, lda, W, ldw, C, ldc, M, N, K, bias, residual, ldr, epilogue, rowstats_out, ln_stats, ln_parts, ln_colsum, ln_eps, stream);
+        if (rc != AE_ERR_UNSUPPORTED) return rc;
+    }
     LnExtras x;
     x.rowstats_out = rowstats_out; x.ln_stats = ln_stats; x.ln_colsum = ln_colsum; x.ln_parts = ln_parts; x.ln_eps = ln_eps;
     return gemm_entry(A, lda, nullptr, 0, 0, W, ldw, C, ldc, M, N, K, bias, residual, ldr, nullptr, 0, 0, epilogue, 0, nullptr, x, stream);
@@ -1832,6 +1837,7 @@ extern "C" int ae_gemm_ln_bf16(const void* A, long lda, const void* W, long ldw,
 
 extern "C" int ae_gemm_ln_plan(int M, int N, int K, int epilogue, int mode) {
     if (M <= 0 || N <= 0 || K <= 0 || K % 8 || (mode != 1 && mode != 2) || epilogue < EPI_NONE || epilogue > EPI_RELU) return 0;
+    if (ae_rowpanel_fold_covers(M, N, K, epilogue, mode)) return 1;   // the row-panel kernel's fold forms (K = 320)
     if (N % 64 || (mode == 1 && (epilogue == EPI_GEGLU || N > 1280)) || (mode == 2 && (K % 64 || K > 1280))) return 0;   // the consumer sums up to 20 slices per row
     if ((long)M * K * 2 >= (1L << 31) || (long)N * K * 2 >= (1L << 31)) return 0;
     GemmArgs a{};

@@ -31,6 +31,11 @@ struct RowPanelArgs {
     const float* ln_g; const float* ln_b; float ln_eps;
     int M, N;
     long lda, ldw, ldc, ldr;
+    // LayerNorm FOLD (round 5; the form the tiled kernel has had since round 4, gemm_conv.hip `XE`):  LN(x) W^T + b = rstd (x W'^T - mu s) + c.
+    float* rowstats;          // RS instantiation: [M][N / 64][2] fp32 (sum, sum of squares) of the STORED bf16 output per row and 64-column slice
+    const float* ln_stats;    // LNM 2: [M][ln_parts][2], the row statistics of A as its producer emitted them
+    const float* ln_colsum;   // LNM 2: [N] s[n] = sum_k W'[n][k] over the bf16 values of W' (packed row order); `bias` holds c
+    int ln_parts;
 };
 
 constexpr int RP_MF = 3;     // 16-row fragments per wave
@@ -74,16 +79,25 @@ __device__ __forceinline__ int rp_wrow(int i) {
     return EPI == RP_EPI_GEGLU ? i : 8 * ((i & 15) >> 2) + 4 * (i >> 4) + (i & 3);
 }
 
-template <int KS, int EPI, bool LN>
+// LNM: 0 plain, 1 LayerNorm on the A registers in the prologue (rounds 2-4), 2 LayerNorm FOLDED into the epilogue from the producer's row statistics
+// (round 5: the prologue form costs every wave ~2300 VALU instructions — statistics in two passes and the re-packing of its 240 operand values — and
+// the two waves of a row group both do it for the same 48 rows: ~8 us of a 32-54 us launch; the fold multiplies the RAW rows and spends two FMAs per
+// output instead).  RS: the epilogue also emits the row statistics of its output for the NEXT LayerNorm (EPI_NONE only).
+template <int KS, int EPI, int LNM, bool RS = false>
 __global__ __launch_bounds__(64 * RP_NW, 2) void gemm_rowpanel_kernel(const RowPanelArgs p) {
+    constexpr bool LN = LNM == 1, FOLD = LNM == 2;
+    static_assert(!RS || (EPI == RP_EPI_NONE && LNM == 0), "row statistics: plain GEMM (+bias, +residual) only");
     constexpr int K = 32 * KS, ROWB = 2 * K, CHUNKB = RP_BN * ROWB, PIECES = CHUNKB / 1024;
     constexpr int PPW = 2 * PIECES / RP_NW;        // DMA pieces per wave per chunk PAIR
     constexpr int APW = 6 * PIECES / RP_NW;        // ... for the A panel (six chunks)
     static_assert((2 * PIECES) % RP_NW == 0 && (6 * PIECES) % RP_NW == 0 && KS % 2 == 0, "pieces must split evenly over the waves; K % 64 == 0");
     static_assert(RP_BM == 6 * RP_BN && RP_PAIRS == 3, "the A panel is staged through the six chunk slots of the ring");
-    __shared__ __attribute__((aligned(16))) char smem[2 * RP_PAIRS * CHUNKB + RP_MAXN * 4];
+    __shared__ __attribute__((aligned(16))) char smem[2 * RP_PAIRS * CHUNKB + RP_MAXN * 4 * (FOLD ? 2 : 1)];
     float* const sbias = reinterpret_cast<float*>(smem + 2 * RP_PAIRS * CHUNKB);
+    float* const ssum = sbias + (FOLD ? RP_MAXN : 0);                     // FOLD: s[n] behind c[n]
     __shared__ __attribute__((aligned(16))) float sln[LN ? 2 * K : 4];  // gamma | beta
+    // RS: (sum, sum of squares) of a wave's 32-column chunk per row, parked for the pair's other half: [pair parity][half][row group][fragment][row]
+    __shared__ __attribute__((aligned(8))) f32x2 sred[RS ? 2 : 1][2][RP_RG][RP_MF][16];
 
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef AE_RP_LAB
@@ -133,6 +147,9 @@ __global__ __launch_bounds__(64 * RP_NW, 2) void gemm_rowpanel_kernel(const RowP
     }
     // (GEGLU: the packed columns interleave 16 'a' rows with their 16 gate rows; the bias of an 'a' column is kept halved: geglu_half_f)
     for (int i = tid; i < p.N; i += 64 * RP_NW) sbias[i] = p.bias ? p.bias[i] * ((EPI == RP_EPI_GEGLU && (i & 16) == 0) ? 0.5f : 1.0f) : 0.f;
+    if (FOLD) {
+        for (int i = tid; i < p.N; i += 64 * RP_NW) ssum[i] = p.ln_colsum[i];
+    }
     if (LN) {
         for (int i = tid; i < K; i += 64 * RP_NW) { sln[i] = p.ln_g[i]; sln[K + i] = p.ln_b[i]; }
     }
@@ -204,6 +221,25 @@ __global__ __launch_bounds__(64 * RP_NW, 2) void gemm_rowpanel_kernel(const RowP
         }
     }
 
+    // FOLD: rstd and -rstd * mean of this lane's row in each fragment, from the producer's per-slice sums (lane group g takes slices g, g + 4, ...;
+    // two cross-lane adds: (s0 + s1) + (s2 + s3) in every lane, a fixed order).  Ordinary loads, issued and consumed in front of the chunk loop.
+    float ln_r[FOLD ? RP_MF : 1], ln_t[FOLD ? RP_MF : 1];
+    if (FOLD) {
+#pragma unroll
+        for (int f = 0; f < RP_MF; ++f) {
+            const int row = min(m0 + 16 * f + l15, p.M - 1);
+            const f32x2* sp = reinterpret_cast<const f32x2*>(p.ln_stats) + (long)row * p.ln_parts;
+            float sm = 0.f, sq = 0.f;
+            for (int u = g; u < p.ln_parts; u += 4) { const f32x2 v = sp[u]; sm += v[0]; sq += v[1]; }
+            sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
+            sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+            const float mu = sm * (1.0f / K);
+            const float r = __builtin_amdgcn_rsqf(fmaxf(sq * (1.0f / K) - mu * mu, 0.f) + p.ln_eps);
+            ln_r[f] = r;
+            ln_t[f] = -r * mu;
+        }
+    }
+
     // W fragment (A operand: lane (i = l15 (+16), g) holds image row i, k = 32 ks + 8 g .. +8) addresses inside a chunk slot
     int woff[KS];
 #pragma unroll
@@ -236,6 +272,13 @@ __global__ __launch_bounds__(64 * RP_NW, 2) void gemm_rowpanel_kernel(const RowP
         const int c = 2 * pi + half;
         const int n0 = c * RP_BN;
         if (pi + RP_PAIRS - 1 < npairs) issue(pi + RP_PAIRS - 1);  // refills the slot of pair pi - 1
+        if (RS && pi > 0 && half == 0 && g == 0) {   // pair pi - 1 = output columns [64 (pi - 1), 64 pi): both halves parked their 32-column sums before this pair's barrier
+#pragma unroll
+            for (int f = 0; f < RP_MF; ++f) {
+                const f32x2 a0 = sred[(pi - 1) & 1][0][rg][f][l15], a1 = sred[(pi - 1) & 1][1][rg][f][l15];
+                if (rok[f]) *reinterpret_cast<f32x2*>(p.rowstats + ((long)(m0 + 16 * f + l15) * (p.N >> 6) + (pi - 1)) * 2) = (f32x2){a0[0] + a1[0], a0[1] + a1[1]};
+            }
+        }
         u32x4 rres[RP_MF];
         if (EPI == RP_EPI_NONE && p.res) {  // residual rows of this chunk, in flight under the MFMAs
 #pragma unroll
@@ -269,11 +312,18 @@ __global__ __launch_bounds__(64 * RP_NW, 2) void gemm_rowpanel_kernel(const RowP
 #pragma unroll
             for (int f = 0; f < RP_MF; ++f) {
                 if (rok[f]) {
-                    const float o0 = geglu_half_f(fmaf(acc[f][0][0], 0.5f, ba[0]), acc[f][1][0] + bg[0]);   // ba holds 0.5 bias
-                    const float o1 = geglu_half_f(fmaf(acc[f][0][1], 0.5f, ba[1]), acc[f][1][1] + bg[1]);
-                    const float o2 = geglu_half_f(fmaf(acc[f][0][2], 0.5f, ba[2]), acc[f][1][2] + bg[2]);
-                    const float o3 = geglu_half_f(fmaf(acc[f][0][3], 0.5f, ba[3]), acc[f][1][3] + bg[3]);
-                    *reinterpret_cast<u32x2*>(cb + coff[f]) = (u32x2){pack_bf16x2(o0, o1), pack_bf16x2(o2, o3)};
+                    float o[4];
+                    if (FOLD) {   // a half = 0.5 (rstd (acc - mu s) + c), gate = rstd (acc - mu s) + c; ba holds 0.5 c, the s values are un-halved
+                        const f32x4 sa = *reinterpret_cast<const f32x4*>(ssum + n0 + 4 * g), sg = *reinterpret_cast<const f32x4*>(ssum + n0 + 16 + 4 * g);
+                        const float rh = 0.5f * ln_r[f], th = 0.5f * ln_t[f];
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4)
+                            o[r4] = geglu_half_f(fmaf(acc[f][0][r4], rh, fmaf(th, sa[r4], ba[r4])), fmaf(acc[f][1][r4], ln_r[f], fmaf(ln_t[f], sg[r4], bg[r4])));
+                    } else {
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) o[r4] = geglu_half_f(fmaf(acc[f][0][r4], 0.5f, ba[r4]), acc[f][1][r4] + bg[r4]);   // ba holds 0.5 bias
+                    }
+                    *reinterpret_cast<u32x2*>(cb + coff[f]) = (u32x2){pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
                 }
             }
         } else {  // columns n0 + 8 g .. + 7: fragment 0 holds the first four, fragment 1 the next four (rp_wrow)
@@ -281,32 +331,67 @@ __global__ __launch_bounds__(64 * RP_NW, 2) void gemm_rowpanel_kernel(const RowP
             bf16_t* const cb = p.C + n0;
 #pragma unroll
             for (int f = 0; f < RP_MF; ++f) {
-                if (rok[f]) {
-                    float o0 = acc[f][0][0] + b0[0], o1 = acc[f][0][1] + b0[1], o2 = acc[f][0][2] + b0[2], o3 = acc[f][0][3] + b0[3];
-                    float o4 = acc[f][1][0] + b1[0], o5 = acc[f][1][1] + b1[1], o6 = acc[f][1][2] + b1[2], o7 = acc[f][1][3] + b1[3];
-                    if (p.res) {
-                        const u32x4 r = rres[f];
-                        o0 += bf16lo(r.x); o1 += bf16hi(r.x); o2 += bf16lo(r.y); o3 += bf16hi(r.y);
-                        o4 += bf16lo(r.z); o5 += bf16hi(r.z); o6 += bf16lo(r.w); o7 += bf16hi(r.w);
+                float o0, o1, o2, o3, o4, o5, o6, o7;
+                if (FOLD) {   // rstd (acc - mu s) + c
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(ssum + n0 + 8 * g), s1 = *reinterpret_cast<const f32x4*>(ssum + n0 + 8 * g + 4);
+                    const float r = ln_r[f], t = ln_t[f];
+                    o0 = fmaf(acc[f][0][0], r, fmaf(t, s0[0], b0[0])); o1 = fmaf(acc[f][0][1], r, fmaf(t, s0[1], b0[1]));
+                    o2 = fmaf(acc[f][0][2], r, fmaf(t, s0[2], b0[2])); o3 = fmaf(acc[f][0][3], r, fmaf(t, s0[3], b0[3]));
+                    o4 = fmaf(acc[f][1][0], r, fmaf(t, s1[0], b1[0])); o5 = fmaf(acc[f][1][1], r, fmaf(t, s1[1], b1[1]));
+                    o6 = fmaf(acc[f][1][2], r, fmaf(t, s1[2], b1[2])); o7 = fmaf(acc[f][1][3], r, fmaf(t, s1[3], b1[3]));
+                } else {
+                    o0 = acc[f][0][0] + b0[0]; o1 = acc[f][0][1] + b0[1]; o2 = acc[f][0][2] + b0[2]; o3 = acc[f][0][3] + b0[3];
+                    o4 = acc[f][1][0] + b1[0]; o5 = acc[f][1][1] + b1[1]; o6 = acc[f][1][2] + b1[2]; o7 = acc[f][1][3] + b1[3];
+                }
+                if (p.res) {
+                    const u32x4 r = rres[f];
+                    o0 += bf16lo(r.x); o1 += bf16hi(r.x); o2 += bf16lo(r.y); o3 += bf16hi(r.y);
+                    o4 += bf16lo(r.z); o5 += bf16hi(r.z); o6 += bf16lo(r.w); o7 += bf16hi(r.w);
+                }
+                const u32x4 pk = {pack_bf16x2(o0, o1), pack_bf16x2(o2, o3), pack_bf16x2(o4, o5), pack_bf16x2(o6, o7)};
+                if (rok[f]) *reinterpret_cast<u32x4*>(cb + coff[f]) = pk;
+                if (RS) {   // statistics of the STORED values: this lane's 8 columns, then the row's four lane groups (every lane of the wave takes part)
+                    const uint32_t w4[4] = {pk.x, pk.y, pk.z, pk.w};
+                    float ps = 0.f, pq = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = bf16lo(w4[e]), c2 = bf16hi(w4[e]);
+                        ps += a + c2;
+                        pq += a * a + c2 * c2;
                     }
-                    *reinterpret_cast<u32x4*>(cb + coff[f]) = (u32x4){pack_bf16x2(o0, o1), pack_bf16x2(o2, o3), pack_bf16x2(o4, o5), pack_bf16x2(o6, o7)};
+                    ps += __shfl_xor(ps, 16, 64); pq += __shfl_xor(pq, 16, 64);
+                    ps += __shfl_xor(ps, 32, 64); pq += __shfl_xor(pq, 32, 64);
+                    if (g == 0) sred[pi & 1][half][rg][f][l15] = (f32x2){ps, pq};
                 }
             }
         }
         RP_T(4);  // epilogue
+    }
+    if (RS) {   // the last pair's statistics: every wave has parked its sums once the block passes this barrier
+        __syncthreads();
+        if (half == 0 && g == 0) {
+#pragma unroll
+            for (int f = 0; f < RP_MF; ++f) {
+                const f32x2 a0 = sred[(npairs - 1) & 1][0][rg][f][l15], a1 = sred[(npairs - 1) & 1][1][rg][f][l15];
+                if (rok[f]) *reinterpret_cast<f32x2*>(p.rowstats + ((long)(m0 + 16 * f + l15) * (p.N >> 6) + (npairs - 1)) * 2) = (f32x2){a0[0] + a1[0], a0[1] + a1[1]};
+            }
+        }
     }
 }
 
 template <int KS>
 int launch_rowpanel(const RowPanelArgs& a, int epi, hipStream_t stream) {
     const unsigned grid = (unsigned)((a.M + RP_BM - 1) / RP_BM);
-    const bool ln = a.ln_g != nullptr;
+    const bool ln = a.ln_g != nullptr, fold = a.ln_stats != nullptr;
     if (epi == RP_EPI_GEGLU) {
-        if (ln) hipLaunchKernelGGL((gemm_rowpanel_kernel<KS, RP_EPI_GEGLU, true>), dim3(grid), dim3(64 * RP_NW), 0, stream, a);
-        else hipLaunchKernelGGL((gemm_rowpanel_kernel<KS, RP_EPI_GEGLU, false>), dim3(grid), dim3(64 * RP_NW), 0, stream, a);
+        if (fold) hipLaunchKernelGGL((gemm_rowpanel_kernel<KS, RP_EPI_GEGLU, 2>), dim3(grid), dim3(64 * RP_NW), 0, stream, a);
+        else if (ln) hipLaunchKernelGGL((gemm_rowpanel_kernel<KS, RP_EPI_GEGLU, 1>), dim3(grid), dim3(64 * RP_NW), 0, stream, a);
+        else hipLaunchKernelGGL((gemm_rowpanel_kernel<KS, RP_EPI_GEGLU, 0>), dim3(grid), dim3(64 * RP_NW), 0, stream, a);
     } else {
-        if (ln) hipLaunchKernelGGL((gemm_rowpanel_kernel<KS, RP_EPI_NONE, true>), dim3(grid), dim3(64 * RP_NW), 0, stream, a);
-        else hipLaunchKernelGGL((gemm_rowpanel_kernel<KS, RP_EPI_NONE, false>), dim3(grid), dim3(64 * RP_NW), 0, stream, a);
+        if (fold) hipLaunchKernelGGL((gemm_rowpanel_kernel<KS, RP_EPI_NONE, 2>), dim3(grid), dim3(64 * RP_NW), 0, stream, a);
+        else if (a.rowstats) hipLaunchKernelGGL((gemm_rowpanel_kernel<KS, RP_EPI_NONE, 0, true>), dim3(grid), dim3(64 * RP_NW), 0, stream, a);
+        else if (ln) hipLaunchKernelGGL((gemm_rowpanel_kernel<KS, RP_EPI_NONE, 1>), dim3(grid), dim3(64 * RP_NW), 0, stream, a);
+        else hipLaunchKernelGGL((gemm_rowpanel_kernel<KS, RP_EPI_NONE, 0>), dim3(grid), dim3(64 * RP_NW), 0, stream, a);
     }
     return ae_check_launch("ae_ln_gemm_bf16");
 }
@@ -320,6 +405,32 @@ extern "C" int ae_ln_gemm_supported(int M, int N, int K, int epilogue) {
     static const int any_m = getenv("AE_ROWPANEL_ANY_M") ? atoi(getenv("AE_ROWPANEL_ANY_M")) : 0;
     if (!any_m && (M + RP_BM - 1) / RP_BM < 192) return 0;
     return (K == 320 && N % (2 * RP_BN) == 0 && N <= RP_MAXN && M >= RP_BM && (epilogue == RP_EPI_NONE || epilogue == RP_EPI_GEGLU)) ? 1 : 0;
+}
+
+// LayerNorm fold on the row-panel kernel (round 5): the K = 320 shapes of ae_gemm_ln_bf16 (gemm_conv.hip forwards them here).  Returns AE_ERR_UNSUPPORTED
+// when the shape / alignment is outside this kernel's envelope (the caller then takes the tiled kernel's plan).  AE_RP_FOLD=0 turns it off (A/B).
+int ae_rowpanel_fold_covers(int M, int N, int K, int epilogue, int mode) {
+    static const int on = getenv("AE_RP_FOLD") ? atoi(getenv("AE_RP_FOLD")) : 1;
+    if (!on || !ae_ln_gemm_supported(M, N, K, epilogue)) return 0;
+    return mode == 2 || (mode == 1 && epilogue == RP_EPI_NONE);
+}
+int ae_rowpanel_fold_launch(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias, const void* residual,
+                            long ldr, int epilogue, float* rowstats_out, const float* ln_stats, int ln_parts, const float* ln_colsum, float ln_eps, void* stream) {
+    if (!ae_rowpanel_fold_covers(M, N, K, epilogue, rowstats_out ? 1 : 2)) return AE_ERR_UNSUPPORTED;
+    if (lda % 8 || ldw % 8 || ldc % 8 || (residual && ldr % 8) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 15) || ((uintptr_t)residual & 15)) return AE_ERR_UNSUPPORTED;
+    const long ldmax = lda > ldc ? (lda > ldr ? lda : ldr) : (ldc > ldr ? ldc : ldr);
+    if ((long)N * ldw * 2 >= (1L << 31) || ((long)M + RP_BM) * ldmax * 2 >= (1L << 31)) return AE_ERR_UNSUPPORTED;
+    if (ln_stats) {
+        AE_REQUIRE(ln_colsum && bias && ln_parts > 0 && ln_parts * 64 == K && ln_eps >= 0.f, "ae_gemm_ln_bf16 (row panel): LayerNorm fold needs s, c and K / 64 = %d statistics slices per row (got %d)", K / 64, ln_parts);
+        AE_REQUIRE(!(epilogue == RP_EPI_GEGLU && residual), "ae_gemm_ln_bf16 (row panel): GEGLU has no residual");
+    } else {
+        AE_REQUIRE(epilogue == RP_EPI_NONE && ((uintptr_t)rowstats_out & 7) == 0, "ae_gemm_ln_bf16 (row panel): row statistics go with a plain GEMM (+bias, +residual)");
+    }
+    RowPanelArgs a{};
+    a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.bias = bias; a.res = (const bf16_t*)residual;
+    a.ln_g = nullptr; a.ln_b = nullptr; a.ln_eps = ln_eps; a.M = M; a.N = N; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr;
+    a.rowstats = rowstats_out; a.ln_stats = ln_stats; a.ln_colsum = ln_colsum; a.ln_parts = ln_parts;
+    return launch_rowpanel<10>(a, epilogue, (hipStream_t)stream);
 }
 
 extern "C" int ae_ln_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias,

@@ -292,8 +292,10 @@ def ln_fold_plan(M, N, K, epilogue, mode):
     key = (M, N, K, epilogue, mode)
     r = _LN_PLAN.get(key)
     if r is None:
-        # (shapes of the row-panel kernel — K = 320, the 64x64 level — keep it: its LayerNorm already rides in the GEMM's prologue)
-        r = _LN_PLAN[key] = not (_ROWPANEL and lib.ae_ln_gemm_supported(M, N, K, epilogue)) and bool(lib.ae_gemm_ln_plan(M, N, K, epilogue, mode))
+        # shapes of the row-panel kernel (K = 320, the 64x64 level): round 5 gave that kernel the fold forms too (AE_RP_FOLD, read by the library: its
+        # plan query says yes for them); with the row-panel kernel switched off (AE_GEMM_ROWPANEL=0, A/B) the tiled plan answers
+        r = _LN_PLAN[key] = bool(lib.ae_gemm_ln_plan(M, N, K, epilogue, mode)) and \
+            (_ROWPANEL or not lib.ae_ln_gemm_supported(M, N, K, epilogue) or os.environ.get("AE_RP_FOLD", "1") == "0")
     return r
 
 
@@ -1359,6 +1361,9 @@ def _ln_gemm_label(_r, x, w, bias, residual, gamma, beta, eps, epilogue, o, M, N
 def _gemm_ln_label(_r, a, w, bias, residual, epilogue, out, M, N, K, rowstats_out, ln_stats, nparts, ln_colsum, eps):
     nb = 2 * (M * K + N * K) + _r.numel() * 2 + (2 * M * N if residual is not None else 0)
     tag = "rowstats" if rowstats_out is not None else "LNfold"
+    if _ROWPANEL and os.environ.get("AE_RP_FOLD", "1") != "0" and lib.ae_ln_gemm_supported(M, N, K, epilogue) and (rowstats_out is None or epilogue == EPI_NONE):
+        # round 5: the K = 320 shapes run the row-panel kernel's fold forms (ae_gemm_ln_bf16 forwards them)
+        return f"gemm_rowpanel_kernel<K=320,{tag}{',geglu' if epilogue == EPI_GEGLU else ''}>|M={M} N={N}", 2.0 * M * N * K, nb
     return f"gemm_kernel<{_tile_label(M, N, False, K, epilogue == EPI_GEGLU, True, xe2=rowstats_out is None)},dense,{tag}>|M={M} N={N} K={K}", 2.0 * M * N * K, float(nb)
 
 

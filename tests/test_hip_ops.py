@@ -138,7 +138,10 @@ def test_rowpanel_ln_gemm(ops, M, N, epi, ln, res, monkeypatch):
 
 
 @pytest.mark.parametrize("M,C,N,epi", [(12288, 640, 1920, "none"), (12288, 640, 640, "none"), (12288, 640, 5120, "geglu"), (3072, 1280, 3840, "none"),
-                                       (3072, 1280, 1280, "none"), (3072, 1280, 10240, "geglu"), (12200, 640, 1920, "none"), (8192, 640, 5120, "geglu")])
+                                       (3072, 1280, 1280, "none"), (3072, 1280, 10240, "geglu"), (12200, 640, 1920, "none"), (8192, 640, 5120, "geglu"),
+                                       # round 5: the 64x64 level (K = 320) — the row-panel kernel's fold forms (producer: statistics from its chunk epilogue,
+                                       # the two halves of a row group combined through LDS; consumers: qkv, q, GEGLU without the LayerNorm prologue)
+                                       (49152, 320, 960, "none"), (49152, 320, 320, "none"), (49152, 320, 2560, "geglu"), (49000, 320, 960, "none")])
 def test_layernorm_folded_into_gemm(ops, M, C, N, epi):
     """attention.py:263-275 norm -> projection at the widths the row-panel kernel does not cover (C = 640 / 1280), with the LayerNorm folded
     into the consuming GEMM (ae_gemm_ln_bf16): LN(x) W^T + b = rstd (x W'^T - mu s) + c.
