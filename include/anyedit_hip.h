@@ -62,7 +62,8 @@ int ae_ln_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, l
                     float* colstats /* as for ae_gemm_bf16; NULL = none */, void* stream);
 
 /* LayerNorm folded into the projection that consumes it (BasicTransformerBlock, attention.py:263-265, 271-275: norm1 -> to_q|k|v,
- * norm2 -> to_q, norm3 -> GEGLU projection) for the channel widths the row-panel kernel above does not cover (640 / 1280):
+ * norm2 -> to_q, norm3 -> GEGLU projection) — at every channel width since round 5: 640 / 1280 on the tiled kernel's fold epilogues, 320 (the
+ * shapes ae_ln_gemm_supported() covers) on the row-panel kernel's own fold forms, which replace its LayerNorm prologue (AE_RP_FOLD=0: off):
  *   LN(x) W^T + b = rstd_m (x W'^T - mu_m s) + c,   W' = W diag(gamma),  s[n] = sum_k W'[n][k] (over the bf16 values of W'),  c = W beta + b.
  * The GEMM that PRODUCES x (proj_in :296-318, attn1 / attn2 to_out :159-161) emits, next to its bf16 output, one (sum, sum of squares)
  * pair per row and 64-column slice (rowstats_out: fp32 [M][N / 64][2], statistics of the stored bf16 values); the GEMM that consumes
@@ -70,7 +71,7 @@ int ae_ln_gemm_bf16(const void* A, long lda, const void* W, long ldw, void* C, l
  * (ln_stats = the producer's rowstats_out with ln_parts = its N / 64 slices per row; ln_colsum = s; bias = c; the normalised width is K).
  * No LayerNorm launch, no read of x and write of LN(x) for it.  Exactly one of rowstats_out / ln_stats is non-NULL.  epilogue: AE_EPI_NONE
  * (+ residual) when emitting; AE_EPI_NONE or AE_EPI_GEGLU when consuming.  bf16 output, N % 64 == 0, 16-byte aligned rows.
- * ae_gemm_ln_plan(M, N, K, epilogue, mode) tells whether the tile plan ae_gemm_bf16 would take for this shape carries the epilogue
+ * ae_gemm_ln_plan(M, N, K, epilogue, mode) tells whether the kernel ae_gemm_ln_bf16 would run for this shape carries the epilogue
  * (mode 1 emit, 2 consume): 1 yes, 0 no — callers keep ae_layernorm_bf16 + ae_gemm_bf16 otherwise.                                    */
 int ae_gemm_ln_plan(int M, int N, int K, int epilogue, int mode);
 int ae_gemm_ln_bf16(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias,
