@@ -324,9 +324,9 @@ def test_python_plan_mirror_matches_the_library():
 
 def test_layernorm_fold_plan_follows_the_tile_plan(monkeypatch):
     """ops.ln_fold_plan / ae_gemm_ln_plan (host-only: the library runs its launch selection without launching): at the bench's UNet batch 12
-    every norm -> projection pair of the 32x32 and 16x16 levels folds (producer emits row statistics, consumer applies them); the 64x64
-    level stays on the row-panel kernel whose prologue already holds the LayerNorm; the 8x8 level and shapes whose producer runs another
-    tile fall back; nothing folds while the training tape records or under AE_LN_FOLD=0."""
+    every norm -> projection pair of the 32x32 and 16x16 levels folds (producer emits row statistics, consumer applies them); since round 5 the
+    64x64 level folds too — on the row-panel kernel's own fold forms (AE_RP_FOLD=0 restores its LayerNorm prologue: then the plan says no there);
+    the 8x8 level and shapes whose producer runs another tile fall back; nothing folds while the training tape records or under AE_LN_FOLD=0."""
     from anyedit_amd import ops
     from anyedit_amd._lib import lib
     if not ops._LN_FOLD:
@@ -338,7 +338,11 @@ def test_layernorm_fold_plan_follows_the_tile_plan(monkeypatch):
         assert ops.ln_fold_plan(M, 8 * C, C, G, 2)                                         # GEGLU projection
     M = 12 * 4096
     assert lib.ae_ln_gemm_supported(M, 960, 320, E) == 1
-    assert not ops.ln_fold_plan(M, 960, 320, E, 2) and not ops.ln_fold_plan(M, 320, 320, E, 1) and not ops.ln_fold_plan(M, 2560, 320, G, 2)
+    if __import__("os").environ.get("AE_RP_FOLD", "1") != "0":
+        assert ops.ln_fold_plan(M, 960, 320, E, 2) and ops.ln_fold_plan(M, 320, 320, E, 2) and ops.ln_fold_plan(M, 320, 320, E, 1) and ops.ln_fold_plan(M, 2560, 320, G, 2)
+        assert lib.ae_gemm_ln_plan(M, 2560, 320, G, 1) == 0                                # statistics go with a plain GEMM (+bias, +residual), not with GEGLU
+    else:
+        assert not ops.ln_fold_plan(M, 960, 320, E, 2) and not ops.ln_fold_plan(M, 320, 320, E, 1) and not ops.ln_fold_plan(M, 2560, 320, G, 2)
     assert not ops.ln_fold_plan(12 * 64, 1280, 1280, E, 1)                                 # 8x8 level: 64x64 tiles, no statistics epilogue
     assert lib.ae_gemm_ln_plan(M, 640, 640, G, 1) == 0 and lib.ae_gemm_ln_plan(M, 600, 640, E, 1) == 0 and lib.ae_gemm_ln_plan(M, 640, 640, E, 3) == 0
     # a plan answer is a property of (M, N, K, epilogue): the same question twice, and the launch-side refusal for an uncovered shape
