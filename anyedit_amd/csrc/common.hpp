@@ -89,7 +89,31 @@ __device__ __forceinline__ float erf_as_f(float z) {
 // it is this arithmetic — profiles/r04_v31_epilogue_share.txt).  With w(x) = erf(|x| / sqrt 2) (the same 7.1.26 series, the 1 / sqrt 2 folded into its
 // two constants):   gelu(x) = 0.5 x (1 + sign(x) w) = 0.5 (x + |x| w)   — no copysign, no 1 + erf, |x| is a free source modifier: 13 VALU + rcp + exp2
 // instead of 16 + 2.  GEGLU's product a gelu(g) takes the 0.5 into a's bias add: (0.5 a) (g + |g| w) with 0.5 a = fma(acc, 0.5, 0.5 bias).
+#ifndef AE_GELU_POLY
+#define AE_GELU_POLY 0   // round 5, measured and NOT taken: 1 = w(x) by a polynomial alone (no v_rcp_f32 / v_exp_f32), 1.7e-5 absolute instead of 1.5e-7: UNet step 12.676 -> 12.636 ms in three
+                         // alternating pairs (profiles/r05_v14_gelu_poly_ab.txt) — 0.3 % is not worth two orders of erf accuracy.  The form stays for A/B builds.
+#endif
+// Round 5: the K = 320 GEGLU launches are bound by this arithmetic, not by the matrix pipe (row-panel kernel: the chunk epilogue of a wave is ~2 250 cycles against
+// 960 of MFMAs, profiles/r02_gemm_rowpanel_lab.txt), and a transcendental issues at ~1.8 x a plain VALU operation.  w(x) = erf(|x| / sqrt 2) for |x| <= 4.25 as
+// |x| P(x^2), P of degree 8 (near-minimax fit, Horner in t = 2 x^2 / 4.25^2 - 1 so that fp32 evaluation is well conditioned), |x| clamped to 4.25 beyond
+// (erf(4.25 / sqrt 2) = 1 - 2.1e-5): max |w - erf| = 1.7e-5 over the whole line INCLUDING fp32 evaluation error (tools: the fit and the check are in DESIGN.md §7.00),
+// i.e. |delta gelu(x)| <= 0.5 |x| 1.7e-5 — a hundredth of the bf16 rounding of the stored result for x > 0; w stays below 1 (no sign flip of the tail).
+// 12 VALU, no transcendental, against 13 + 2.
+__device__ __forceinline__ float gelu_w_poly_f(float x) {
+    const float ax = __builtin_fminf(__builtin_fabsf(x), 4.25f);
+    const float t = __builtin_fmaf(ax * ax, 0.11072664707899094f, -1.0f);
+    float p = __builtin_fmaf(0.004925727378576994f, t, -0.012811211869120598f);
+    p = __builtin_fmaf(p, t, 0.017165469005703926f);
+    p = __builtin_fmaf(p, t, -0.02821926586329937f);
+    p = __builtin_fmaf(p, t, 0.05118509382009506f);
+    p = __builtin_fmaf(p, t, -0.07870230078697205f);
+    p = __builtin_fmaf(p, t, 0.11140184104442596f);
+    p = __builtin_fmaf(p, t, -0.1615230143070221f);
+    p = __builtin_fmaf(p, t, 0.33187076449394226f);
+    return ax * p;
+}
 __device__ __forceinline__ float gelu_w_f(float x) {
+    if (AE_GELU_POLY) return gelu_w_poly_f(x);
     const float ax = __builtin_fabsf(x);
     const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
     float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
