@@ -10,6 +10,8 @@
 #include <random>
 #include <stdarg.h>
 
+int ae_rowpanel_fold_covers(int, int, int, int, int) { return 0; }
+int ae_rowpanel_fold_launch(const void*, long, const void*, long, void*, long, int, int, int, const float*, const void*, long, int, float*, const float*, int, const float*, float, void*) { return AE_ERR_UNSUPPORTED; }
 void ae_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 int ae_check_launch(const char* what) { hipError_t e = hipGetLastError(); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); return AE_ERR_LAUNCH; } return AE_OK; }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
