@@ -36,7 +36,8 @@ SIGNATURES = {
                          c_float, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
                          c_void_p, c_void_p, c_int, c_long, c_long, c_long, c_long, c_long, c_long, c_void_p, c_void_p, c_void_p,
                          c_void_p],
-    "ae_attn_bwd_bf16": [c_void_p] * 10 + [c_int] * 5 + [c_long] * 21 + [c_float, c_void_p, c_int, c_void_p],
+    "ae_attn_bwd_bf16": [c_void_p] * 10 + [c_int] * 5 + [c_long] * 21 + [c_float, c_void_p, c_int, c_void_p, c_void_p],
+    "ae_attn_bwd_workspace_floats": [c_int] * 5,
     "ae_groupnorm_bwd_workspace_floats": [c_int, c_int, c_int, c_int],
     "ae_groupnorm_bwd_nhwc_bf16": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -105,7 +106,7 @@ SIGNATURES = {
     "ae_task_gate": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
 }
 _RESTYPES = {"ae_last_error": ctypes.c_char_p, "ae_groupnorm_workspace_floats": c_long, "ae_conv3x3_workspace_floats": c_long,
-             "ae_groupnorm_bwd_workspace_floats": c_long, "ae_attn_fp8_workspace_bytes": c_long}
+             "ae_groupnorm_bwd_workspace_floats": c_long, "ae_attn_fp8_workspace_bytes": c_long, "ae_attn_bwd_workspace_floats": c_long}
 
 
 class AnyEditHipError(RuntimeError):

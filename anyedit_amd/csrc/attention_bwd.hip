@@ -37,6 +37,11 @@ struct BwdArgs {
     long dq_sb, dq_sh, dq_sn, dk_sb, dk_sh, dk_sn, dv_sb, dv_sh, dv_sn;
     float scale;
     int accum_dq;  // dq += (second segment sharing the same queries)
+    // MODE_DKV with few key rows (cross-attention: 78 text / 16 adapter tokens against 4096 queries is B H blocks of 64 query tiles each): the query
+    // tiles are cut `nsplit` ways, every block writes its fp32 partial (dK, dV) to `part` [nsplit][B H][Nk][2][DVP] and attn_bwd_reduce_kernel sums
+    // them in split order (fixed order: deterministic) and rounds once.  nsplit <= 1: the block owns every query tile and writes bf16 itself.
+    float* part;
+    int nsplit;
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4v;
@@ -105,7 +110,9 @@ __global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const 
     const int l15 = lane & 15, lg = lane >> 4;
     const int nfixed = MODE == MODE_DQ ? p.Nq : p.Nk, nstream = MODE == MODE_DQ ? p.Nk : p.Nq;
     const int nfb = (nfixed + FB - 1) / FB;
-    const int vb = xcd_remap(blockIdx.x, nfb * p.B * p.H);
+    const int nsp = MODE == MODE_DKV ? max(p.nsplit, 1) : 1;
+    const int vbs = xcd_remap(blockIdx.x, nfb * p.B * p.H * nsp);
+    const int sp = vbs % nsp, vb = vbs / nsp;
     const int bh = vb / nfb, fb = vb % nfb;
     const int b = bh / p.H, h = bh % p.H;
     const int f0 = fb * FB + wave * 16 * QF;
@@ -163,6 +170,8 @@ __global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const 
         for (int df = 0; df < NDF; ++df) acc0[a][df] = acc1[a][df] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int ntiles = (nstream + ST - 1) / ST;
+    const int tpb = (ntiles + nsp - 1) / nsp;                       // streamed tiles of this block: [tb, te)
+    const int tb = sp * tpb, te = min(ntiles, tb + tpb);
     // Software pipeline: the global loads of tile t + 1 are issued into registers before tile t is multiplied out of LDS and written
     // to the other stage after it — one barrier per tile, load latency under the MFMAs.
     constexpr int ITEMS = (ST / 2) * DCH;              // (pair of streamed rows) x (16-byte chunk)
@@ -207,17 +216,17 @@ __global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const 
             sStat[stage * 2 * ST + ST + tid] = pst[1];
         }
     };
-    load_tile(0);
+    load_tile(tb);
     __syncthreads();  // pad columns zeroed
     store_tile(0);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = tb; t < te; ++t) {
         const int t0 = t * ST;
-        const int cur = t & 1;
+        const int cur = (t - tb) & 1;
         const bf16_t* const sX = sImg + cur * STAGE;
         const bf16_t* const sY = sX + IMG;
         const float* const sSt = sStat + cur * 2 * ST;
-        if (t + 1 < ntiles) load_tile(t + 1);
+        if (t + 1 < te) load_tile(t + 1);
 
         // ---- S_T = X_s X_f^T and dP_T = Y_s Y_f^T : lane holds [streamed row 16 f + 4 lg + r][fixed row l15] -----------------
         f32x4 s[QF][4], dp[QF][4];
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const 
                 }
             }
         }
-        if (t + 1 < ntiles) store_tile(cur ^ 1);  // the other stage was last read before the previous barrier
+        if (t + 1 < te) store_tile(cur ^ 1);  // the other stage was last read before the previous barrier
         __syncthreads();
     }
 
@@ -354,9 +363,19 @@ __global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const 
             }
         } else {
             if (row >= p.Nk) continue;
+            const float gs = g * p.scale;
+            if (nsp > 1) {  // fp32 partial of this block's query range
+                float* const pr = p.part + (((long)sp * p.B * p.H + bh) * p.Nk + row) * (2 * NDF * 16);
+#pragma unroll
+                for (int df = 0; df < NDF; ++df) {
+                    const int d = df * 16 + lg * 4;
+                    *reinterpret_cast<f32x4*>(pr + d) = (f32x4){gs * acc0[a][df][0], gs * acc0[a][df][1], gs * acc0[a][df][2], gs * acc0[a][df][3]};
+                    *reinterpret_cast<f32x4*>(pr + NDF * 16 + d) = (f32x4){g * acc1[a][df][0], g * acc1[a][df][1], g * acc1[a][df][2], g * acc1[a][df][3]};
+                }
+                continue;
+            }
             bf16_t* dkd = p.dk + (long)b * p.dk_sb + (long)h * p.dk_sh + (long)row * p.dk_sn;
             bf16_t* dvd = p.dv + (long)b * p.dv_sb + (long)h * p.dv_sh + (long)row * p.dv_sn;
-            const float gs = g * p.scale;
 #pragma unroll
             for (int df = 0; df < NDF; ++df) {
                 const int d = df * 16 + lg * 4;
@@ -368,6 +387,45 @@ __global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const 
     }
 }
 
+// Sum of the query-range partials of a split dK / dV pass, in split order; one thread per (b h, key row, dK | dV, 4 head-dim columns).
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(const BwdArgs p) {
+    constexpr int DVP = (D + 15) / 16 * 16;
+    const long n = (long)p.B * p.H * p.Nk * 2 * (DVP / 4);
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int d = (int)(i % (DVP / 4)) * 4;
+    const int which = (int)((i / (DVP / 4)) % 2);
+    const long br = i / (2 * (DVP / 4));               // (b h) * Nk + row
+    const int row = (int)(br % p.Nk);
+    const int bh = (int)(br / p.Nk);
+    if (d >= D) return;
+    const long stride = (long)p.B * p.H * p.Nk * 2 * DVP;
+    const float* src = p.part + br * (2 * DVP) + which * DVP + d;
+    f32x4 s = *reinterpret_cast<const f32x4*>(src);
+    for (int k = 1; k < p.nsplit; ++k) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + k * stride);
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+    const int b = bh / p.H, h = bh % p.H;
+    bf16_t* dst = which == 0 ? p.dk + (long)b * p.dk_sb + (long)h * p.dk_sh + (long)row * p.dk_sn : p.dv + (long)b * p.dv_sb + (long)h * p.dv_sh + (long)row * p.dv_sn;
+    *reinterpret_cast<u32x2*>(dst + d) = (u32x2){pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3])};
+}
+
+// Query-range split of the dK / dV pass (see BwdArgs::part).  Only grids that leave most of the chip idle and stream at least 8 query tiles are cut: the
+// UNet's cross-attention layers at training batch 4 (B H = 32 blocks of 64 / 16 tiles: 102 / 41 us per pass before).  AE_ATTN_BWD_SPLIT=0 turns it off.
+int bwd_nsplit(int B, int H, int Nq, int Nk, int QF) {
+    static const int on = getenv("AE_ATTN_BWD_SPLIT") ? atoi(getenv("AE_ATTN_BWD_SPLIT")) : 1;
+    const int FB = 4 * 16 * QF;
+    const long blocks0 = (long)((Nk + FB - 1) / FB) * B * H;
+    const int ntiles = (Nq + ST - 1) / ST;
+    if (!on || blocks0 >= 128 || ntiles < 8) return 1;
+    long s = (512 + blocks0 - 1) / blocks0;
+    if (s > ntiles / 2) s = ntiles / 2;
+    if (s > 32) s = 32;
+    return (int)s;
+}
+
 template <int D, int QF, int MODE, bool PRE = false>
 int launch_bwd(const BwdArgs& a, hipStream_t stream) {
     constexpr int NC = D / 32;
@@ -376,7 +434,7 @@ int launch_bwd(const BwdArgs& a, hipStream_t stream) {
     constexpr size_t lds = (size_t)(4 * ST * (DQK + 8)) * sizeof(bf16_t) + 4 * ST * sizeof(float);  // two stages of (X, Y) + (L2, delta)
     constexpr int FB = 4 * 16 * QF;
     const int nfixed = MODE == MODE_DQ ? a.Nq : a.Nk;
-    const long blocks = (long)((nfixed + FB - 1) / FB) * a.B * a.H;
+    const long blocks = (long)((nfixed + FB - 1) / FB) * a.B * a.H * (MODE == MODE_DKV && a.nsplit > 1 ? a.nsplit : 1);
     if (lds > 64 * 1024) {
         static bool done = false;
         if (!done) {
@@ -388,11 +446,18 @@ int launch_bwd(const BwdArgs& a, hipStream_t stream) {
         }
     }
     hipLaunchKernelGGL((attn_bwd_kernel<D, QF, MODE, PRE>), dim3((unsigned)blocks), dim3(256), lds, stream, a);
-    return ae_check_launch(MODE == MODE_DQ ? "ae_attn_bwd_bf16(dQ)" : "ae_attn_bwd_bf16(dK,dV)");
+    int rc = ae_check_launch(MODE == MODE_DQ ? "ae_attn_bwd_bf16(dQ)" : "ae_attn_bwd_bf16(dK,dV)");
+    if (rc || MODE != MODE_DKV || a.nsplit <= 1) return rc;
+    const long n = (long)a.B * a.H * a.Nk * 2 * (DV / 4);
+    hipLaunchKernelGGL((attn_bwd_reduce_kernel<D>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+    return ae_check_launch("ae_attn_bwd_bf16(dK,dV reduce)");
 }
 
 template <int D, int QF>
-int launch_both(const BwdArgs& a, const bf16_t* out, hipStream_t stream) {
+int launch_both(const BwdArgs& a_in, const bf16_t* out, float* workspace, hipStream_t stream) {
+    BwdArgs a = a_in;
+    a.nsplit = (workspace && a.dk) ? bwd_nsplit(a.B, a.H, a.Nq, a.Nk, QF) : 1;
+    a.part = a.nsplit > 1 ? workspace : nullptr;
     int rc;
     if (out) {  // single-segment attention whose own output is known: delta = rowsum(dO o O) up front, one accumulator set in the dQ pass
         const long n = (long)a.B * a.Nq * a.H;
@@ -411,6 +476,14 @@ int launch_both(const BwdArgs& a, const bf16_t* out, hipStream_t stream) {
 
 }  // namespace
 
+// fp32 elements of the optional workspace of ae_attn_bwd_bf16 (0: this shape's dK / dV pass is not split).
+extern "C" long ae_attn_bwd_workspace_floats(int B, int H, int Nq, int Nk, int D) {
+    if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || D <= 0) return 0;
+    const int QF = D >= 96 ? 1 : 2;
+    const int ns = bwd_nsplit(B, H, Nq, Nk, QF);
+    return ns > 1 ? (long)ns * B * H * Nk * 2 * ((D + 15) / 16 * 16) : 0;
+}
+
 // Gradients of ae_attn_fwd_bf16 for one key/value segment.  `lse` is the forward's log2-domain log-sum-exp for THIS segment;
 // `delta` ([B,H,Nq] fp32) is an output (rowsum(P o dP) with the UN-scaled dO: summed over heads and rows it is the gradient of
 // the segment's out_scale).  dk / dv may both be NULL when only dQ is needed.  dq is overwritten, or accumulated if accumulate_dq.
@@ -419,8 +492,9 @@ extern "C" int ae_attn_bwd_bf16(const void* q, const void* k, const void* v, con
                                 long q_sb, long q_sh, long q_sn, long k_sb, long k_sh, long k_sn, long v_sb, long v_sh, long v_sn,
                                 long o_sb, long o_sh, long o_sn, long dq_sb, long dq_sh, long dq_sn, long dk_sb, long dk_sh, long dk_sn,
                                 long dv_sb, long dv_sh, long dv_sn, float scale, const float* out_scale, int accumulate_dq,
-                                void* stream) {
+                                float* workspace, void* stream) {
     AE_REQUIRE(q && k && v && dout && lse && delta && dq, "ae_attn_bwd_bf16: null pointer");
+    AE_REQUIRE(((uintptr_t)workspace & 15) == 0, "ae_attn_bwd_bf16: workspace must be 16-byte aligned");
     AE_REQUIRE((dk == nullptr) == (dv == nullptr), "ae_attn_bwd_bf16: dk and dv go together");
     AE_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0, "ae_attn_bwd_bf16: bad sizes B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
     AE_REQUIRE((q_sb | q_sh | q_sn | k_sb | k_sh | k_sn | v_sb | v_sh | v_sn | o_sb | o_sh | o_sn) % 8 == 0,
@@ -444,16 +518,16 @@ extern "C" int ae_attn_bwd_bf16(const void* q, const void* k, const void* v, con
     AE_REQUIRE(!out || (((uintptr_t)out & 15) == 0), "ae_attn_bwd_bf16: out must be 16-byte aligned");
     const bf16_t* o_own = (out && !out_scale && !accumulate_dq) ? (const bf16_t*)out : nullptr;
     switch (D) {
-        case 8: return launch_both<8, 2>(a, o_own, s);
-        case 16: return launch_both<16, 2>(a, o_own, s);
-        case 32: return launch_both<32, 2>(a, o_own, s);
-        case 40: return launch_both<40, 2>(a, o_own, s);
-        case 48: return launch_both<48, 2>(a, o_own, s);
-        case 64: return launch_both<64, 2>(a, o_own, s);
-        case 80: return launch_both<80, 2>(a, o_own, s);
-        case 96: return launch_both<96, 1>(a, o_own, s);
-        case 128: return launch_both<128, 1>(a, o_own, s);
-        case 160: return launch_both<160, 1>(a, o_own, s);
+        case 8: return launch_both<8, 2>(a, o_own, workspace, s);
+        case 16: return launch_both<16, 2>(a, o_own, workspace, s);
+        case 32: return launch_both<32, 2>(a, o_own, workspace, s);
+        case 40: return launch_both<40, 2>(a, o_own, workspace, s);
+        case 48: return launch_both<48, 2>(a, o_own, workspace, s);
+        case 64: return launch_both<64, 2>(a, o_own, workspace, s);
+        case 80: return launch_both<80, 2>(a, o_own, workspace, s);
+        case 96: return launch_both<96, 1>(a, o_own, workspace, s);
+        case 128: return launch_both<128, 1>(a, o_own, workspace, s);
+        case 160: return launch_both<160, 1>(a, o_own, workspace, s);
         default:
             ae_set_error("ae_attn_bwd_bf16: unsupported head_dim %d (supported: 8,16,32,40,48,64,80,96,128,160)", D);
             return AE_ERR_UNSUPPORTED;

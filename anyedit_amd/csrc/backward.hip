@@ -149,7 +149,22 @@ __global__ __launch_bounds__(NT) void rowsum_kernel(const float* x, float* out, 
     __shared__ float red[NT];
     const float* src = x + (long)blockIdx.x * n;
     float s = 0.f;
-    for (long i = threadIdx.x; i < n; i += NT) s += src[i];
+    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        // 16-byte loads, four independent chains per thread (a row of 32 768 values was 128 dependent 4-byte loads per thread: 14 us per launch)
+        const f32x4* v = reinterpret_cast<const f32x4*>(src);
+        const long nv = n >> 2;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        long i = threadIdx.x;
+        for (; i + 3 * NT < nv; i += 4 * NT) {
+            const f32x4 v0 = v[i], v1 = v[i + NT], v2 = v[i + 2 * NT], v3 = v[i + 3 * NT];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; i < nv; i += NT) a0 += v[i];
+        const f32x4 t = (a0 + a1) + (a2 + a3);
+        s = (t[0] + t[1]) + (t[2] + t[3]);
+    } else {
+        for (long i = threadIdx.x; i < n; i += NT) s += src[i];
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = NT / 2; o > 0; o >>= 1) {

@@ -554,16 +554,21 @@ def attention_fp8(q, k, v, B, H, Nq, Nk, D, scale, q_strides, k_strides, v_strid
 
 
 def attention_bwd(q, k, v, dout, lse, B, H, Nq, Nk, D, scale, q_strides, k_strides, v_strides, dq, dk, dv, dq_strides,
-                  dk_strides, dv_strides, out_scale=None, accumulate_dq=False, out=None):
+                  dk_strides, dv_strides, out_scale=None, accumulate_dq=False, out=None, split_dkv=True):
     """Gradients of one attention segment (ae_attn_bwd_bf16).  dq/dk/dv: bf16 tensors written through the given element strides
     (dk = dv = None when the key/value side needs no gradient).  out: the forward output [B, Nq, H*D] when it is this segment's alone
     (lets the kernel take delta = rowsum(dout o out) up front).  Returns delta [B, H, Nq] fp32."""
     delta = torch.empty(B, H, Nq, dtype=torch.float32, device=q.device)
     o_strides = (Nq * H * D, D, H * D)
     zero3 = (0, 0, 0)
+    ws = None
+    if dk is not None and split_dkv:   # few-key segments (cross-attention): the dK / dV pass cuts its query tiles across blocks through fp32 partials
+        nws = lib.ae_attn_bwd_workspace_floats(B, H, Nq, Nk, D)
+        if nws > 0:
+            ws = torch.empty(nws, dtype=torch.float32, device=q.device)
     check(lib.ae_attn_bwd_bf16(_p(q), _p(k), _p(v), _p(dout), _p(out), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, Nq, Nk, D,
                                *q_strides, *k_strides, *v_strides, *o_strides, *dq_strides, *(dk_strides if dk is not None else zero3),
-                               *(dv_strides if dv is not None else zero3), scale, _p(out_scale), 1 if accumulate_dq else 0, _s()),
+                               *(dv_strides if dv is not None else zero3), scale, _p(out_scale), 1 if accumulate_dq else 0, _p(ws), _s()),
           "ae_attn_bwd_bf16")
     return delta
 

@@ -159,12 +159,17 @@ int ae_attn_fwd_fp8(const void* q, const void* k, const void* v, void* out, int 
  * Attention backward for one key/value segment (autograd of attention.py:171-193): delta [B,H,Nq] fp32 is an OUTPUT
  * (rowsum(P o dP) with the un-scaled dout; its sum over heads and rows is d/d out_scale[b]).  dk, dv may both be NULL.
  * out (optional, layout of dout): the forward output of THIS segment alone (no second segment, no out_scale folded in): delta is
- * then rowsum(dout o out), computed up front, and the dQ pass keeps one accumulator set instead of two.                        */
+ * then rowsum(dout o out), computed up front, and the dQ pass keeps one accumulator set instead of two.
+ * workspace (optional): NULL or ae_attn_bwd_workspace_floats(...) fp32 elements, 16-byte aligned (0 = not needed): lets the dK / dV
+ * pass of a FEW-key segment (cross-attention: 78 text or 16 adapter tokens against 4096 queries is only B H blocks) cut its query
+ * tiles across blocks — fp32 partials, summed in split order by a second launch (deterministic).  Without it every shape runs
+ * the one-block-per-128-keys pass.                                                                                             */
+long ae_attn_bwd_workspace_floats(int B, int H, int Nq, int Nk, int D);
 int ae_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* dout, const void* out, const float* lse, float* delta, void* dq,
                      void* dk, void* dv, int B, int H, int Nq, int Nk, int D, long q_sb, long q_sh, long q_sn, long k_sb,
                      long k_sh, long k_sn, long v_sb, long v_sh, long v_sn, long o_sb, long o_sh, long o_sn, long dq_sb,
                      long dq_sh, long dq_sn, long dk_sb, long dk_sh, long dk_sn, long dv_sb, long dv_sh, long dv_sn,
-                     float scale, const float* out_scale, int accumulate_dq, void* stream);
+                     float scale, const float* out_scale, int accumulate_dq, float* workspace, void* stream);
 /* GroupNorm(+SiLU) backward w.r.t. the input(s) (autograd of util.py:217-219 + nn.SiLU); dx2 receives channels [C1, C).
  * counters: as for ae_groupnorm_nhwc_bf16.  stat_in: optional (mean, rstd) saved by the forward launch — the statistics pass over
  * x is skipped (three launches instead of five) and the gradient uses exactly the statistics the forward normalised with.      */

@@ -98,7 +98,9 @@ def test_geglu_forward_backward(ops):
 
 # ------------------------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("BH,Nq,Nk,D", [(2, 64, 64, 40), (2, 200, 77, 80), (2, 128, 4, 40), (1, 144, 272, 160), (2, 130, 200, 16),
-                                        (1, 1024, 1024, 40), (2, 256, 256, 80), (2, 70, 129, 64), (1, 33, 65, 48)])
+                                        (1, 1024, 1024, 40), (2, 256, 256, 80), (2, 70, 129, 64), (1, 33, 65, 48),
+                                        # few keys against many queries (cross-attention): the dK / dV pass cuts its query tiles across blocks
+                                        (8, 1024, 78, 40), (4, 600, 16, 80), (3, 520, 130, 160)])
 def test_attention_backward(ops, BH, Nq, Nk, D):
     from oracle import ldm_ref as L
     g = torch.Generator().manual_seed(BH + Nq + Nk + D)
@@ -127,6 +129,35 @@ def test_attention_backward(ops, BH, Nq, Nk, D):
     check_close(dv2, vr.grad, rl2=1e-2, what=f"dV' {BH}x{Nq}x{Nk}x{D}")
     check_close(dk2, kr.grad, rl2=1.5e-2, mabs=5e-2, what=f"dK' {BH}x{Nq}x{Nk}x{D}")
     check_close(dq2, qr.grad, rl2=1.5e-2, mabs=5e-2, what=f"dQ' {BH}x{Nq}x{Nk}x{D}")
+
+
+@pytest.mark.parametrize("BH,Nq,Nk,D,nsplit", [(32, 4096, 78, 40, 16), (32, 1024, 78, 80, 8), (32, 4096, 16, 40, 16), (3, 520, 130, 160, 4), (32, 256, 78, 160, 0),
+                                               (128, 4096, 78, 40, 0)])
+def test_attention_backward_query_split_of_the_key_pass(ops, BH, Nq, Nk, D, nsplit):
+    """ae_attn_bwd_bf16 with the workspace (query tiles of the dK / dV pass cut `nsplit` ways, fp32 partials, fixed-order reduce) against the same call
+    without it (one block per 128 keys streams every query tile): equal to the order of an fp32 sum; run-to-run bit-identical.  The training step's
+    cross-attention shapes at batch 4 (B H = 32), a shape with an EMPTY last split (9 tiles cut 4 ways), and shapes the rule leaves alone."""
+    from anyedit_amd._lib import lib
+    assert lib.ae_attn_bwd_workspace_floats(BH, 1, Nq, Nk, D) == nsplit * BH * Nk * 2 * ((D + 15) // 16 * 16)
+    g = torch.Generator().manual_seed(Nq + Nk + D)
+    qd, kd, vd = (q(torch.randn(BH, n, D, generator=g)).to(DEV, BF) for n in (Nq, Nk, Nk))
+    dod = q(torch.randn(BH, Nq, D, generator=g)).to(DEV, BF)
+    lse = torch.empty(BH, 1, Nq, dtype=torch.float32, device=DEV)
+    sq, sk = (Nq * D, 0, D), (Nk * D, 0, D)
+    ops.attention(qd, kd, vd, BH, 1, Nq, Nk, D, D ** -0.5, sq, sk, sk, lse=lse)
+    res = []
+    for split in (False, True, True):
+        dq, dk, dv = torch.empty_like(qd), torch.full_like(kd, float("nan")), torch.full_like(vd, float("nan"))
+        ops.attention_bwd(qd, kd, vd, dod, lse, BH, 1, Nq, Nk, D, D ** -0.5, sq, sk, sk, dq, dk, dv, sq, sk, sk, split_dkv=split)
+        res.append((dq, dk, dv))
+    assert all(torch.equal(a, b) for a, b in zip(res[1], res[2])), "split pass is not run-to-run identical"
+    assert torch.equal(res[0][0], res[1][0])   # dQ does not depend on the split
+    for name, a, b in (("dK", res[0][1], res[1][1]), ("dV", res[0][2], res[1][2])):
+        assert torch.isfinite(b.float()).all()
+        if nsplit == 0:
+            assert torch.equal(a, b)
+        else:
+            check_close(b, a.float().cpu(), rl2=2e-3, mabs=8e-3, what=f"{name} split {nsplit} vs one block, {BH}x{Nq}x{Nk}x{D}")
 
 
 def test_fuzz_attention_and_norm_backward_shapes(ops):
@@ -260,6 +291,9 @@ def test_sumpool_add_mse_grad_rowsum(ops):
     check_close(ops.mse_grad(p.to(DEV), t.to(DEV)), pr.grad, rl2=1e-6, mabs=1e-6, what="mse grad")
     r = torch.randn(3, 5000, generator=g)
     check_close(ops.rowsum_f32(r.to(DEV)), r.sum(1), rl2=1e-5, mabs=1e-5, what="rowsum")
+    for n in (32768, 4100, 1027, 3):   # the gate-gradient rows of the 64x64 level (16-byte-load path, four chains + a tail), a ragged vector count, scalar paths
+        r = torch.randn(4, n, generator=g)
+        check_close(ops.rowsum_f32(r.to(DEV)), r.double().sum(1).float(), rl2=1e-5, mabs=1e-5, what=f"rowsum n={n}")
 
 
 def test_adamw_matches_torch(ops):
