@@ -40,8 +40,8 @@ SIGNATURES = {
     "ae_attn_bwd_workspace_floats": [c_int] * 5,
     "ae_groupnorm_bwd_workspace_floats": [c_int, c_int, c_int, c_int],
     "ae_groupnorm_bwd_nhwc_bf16": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                   c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
-    "ae_layernorm_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+                                   c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "ae_layernorm_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p],
     "ae_layernorm_param_grad_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "ae_add_bf16": [c_void_p, c_void_p, c_void_p, c_long, c_void_p],
     "ae_axpy_bf16": [c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p],

@@ -16,6 +16,7 @@ Activation gradients are bf16 (the reference trains under bf16/fp16 autocast, tr
 Only tensors that (transitively) depend on a trainable leaf get a gradient: layers upstream of the first adapter are skipped.
 """
 import contextlib
+import os
 
 import torch
 
@@ -33,6 +34,8 @@ def _base(t):
 # NOT cached.
 _FROZEN_WT = {}
 _FROZEN_WROT = {}
+# AE_TAPE_FUSE_ADD=0: every fan-out gradient goes through ae_add_bf16 again (A/B knob; round 5: 134 add launches per training step -> 30)
+FUSE_ACCUMULATE = os.environ.get("AE_TAPE_FUSE_ADD", "1") != "0"
 
 
 class Tape:
@@ -95,6 +98,20 @@ class Tape:
             self.grads[id(b)] = g if g.is_contiguous() else g.contiguous()
         else:
             ops.add(cur, g, out=cur)
+
+    def into(self, t, *not_aliasing):
+        """The gradient buffer `t` already has (viewed in t's shape), for backward kernels that can ADD their result to it in place instead of
+        producing a tensor for `accumulate` (one ae_add_bf16 launch and one pass over the gradient less per fan-out); None when t has no gradient
+        yet, is a partial view, or the buffer is one of `not_aliasing` (the kernel's own inputs)."""
+        if t is None or not FUSE_ACCUMULATE:
+            return None
+        b = _base(t)
+        cur = self.grads.get(id(b))
+        if cur is None or t.numel() != b.numel() or cur.dtype != BF16 or not cur.is_contiguous() or not t.is_contiguous():
+            return None
+        if any(o is not None and o.data_ptr() == cur.data_ptr() for o in not_aliasing):
+            return None
+        return cur.view(t.shape)
 
     def add_param_grad(self, name, g):
         cur = self.param_grads.get(name)
@@ -225,7 +242,11 @@ class Tape:
             if self.needs(a) or self.needs(a2):
                 wt = self.transposed(w)  # [K, N]
                 if self.needs(a):
-                    self.accumulate(a, ops.gemm(dy, wt[:K1]))
+                    cur = self.into(a, dy)
+                    if cur is not None and cur.dim() == 2:
+                        ops.gemm(dy, wt[:K1], residual=cur, out=cur)   # dX added to the gradient a already has, in the GEMM's epilogue
+                    else:
+                        self.accumulate(a, ops.gemm(dy, wt[:K1]))
                 if a2 is not None and self.needs(a2):
                     self.accumulate(a2, ops.gemm(dy, wt[K1:]))
             if wname is not None:  # dW[N, K] = dY^T A  (rows padded to a multiple of 8 for the K-contiguous operand layout)
@@ -289,10 +310,14 @@ class Tape:
             dy = self.grad(y)
             if dy is None:
                 return
-            dx, dx2 = ops.groupnorm_bwd(x, gamma, beta, dy, B, HW, eps, silu=silu, groups=groups, x2=x2, stat=stat)
-            if self.needs(x):
+            tx = self.into(x, dy) if self.needs(x) else None
+            tx2 = self.into(x2, dy) if (x2 is not None and self.needs(x2)) else None
+            if tx is not None and tx2 is not None and tx.data_ptr() == tx2.data_ptr():
+                tx2 = None
+            dx, dx2 = ops.groupnorm_bwd(x, gamma, beta, dy, B, HW, eps, silu=silu, groups=groups, x2=x2, stat=stat, dx_into=tx, dx2_into=tx2)
+            if self.needs(x) and tx is None:
                 self.accumulate(x, dx)
-            if x2 is not None and self.needs(x2):
+            if x2 is not None and self.needs(x2) and tx2 is None:
                 self.accumulate(x2, dx2)
 
         self._record([y], [x, x2], bwd)
@@ -307,8 +332,9 @@ class Tape:
             dy = self.grad(y)
             if dy is None:
                 return
-            dx, dg, db = ops.layernorm_bwd(x, gamma, dy, eps, want_param_grads=gname is not None or bname is not None)
-            if self.needs(x):
+            tx = self.into(x, dy) if self.needs(x) else None
+            dx, dg, db = ops.layernorm_bwd(x, gamma, dy, eps, want_param_grads=gname is not None or bname is not None, dx_into=tx)
+            if self.needs(x) and tx is None:
                 self.accumulate(x, dx)
             if gname is not None:
                 self.add_param_grad(gname, dg)

@@ -34,6 +34,7 @@ struct GNArgs {
     int* counters; // optional [B], zero on entry and on exit: the LAST partial-sum block of a sample runs the finalize fold itself
     const float* cs1; const float* cs2;  // optional per-channel (sum, sumsq) over 32-row slabs of x / x2, written by their PRODUCERS
                                          // ([B*HW/32][C1][2], [B*HW/32][C-C1][2]): replaces the statistics pass over the activation
+    int accum;     // backward: bit 0 dx += (the tensor already holds a gradient from another consumer of x), bit 1 dx2 +=
 };
 
 // Fold of the per-chunk partials of sample b by the calling block (any block size): 16 slices x 64 group lanes, slice i takes chunks
@@ -574,16 +575,18 @@ __global__ void gnb_apply_kernel(const GNArgs p) {
         const u32x4 dv = *reinterpret_cast<const u32x4*>(p.dy + row * p.C + ch);
         const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
         uint32_t o[4];
+        bf16_t* const dst = ch < p.C1 ? p.dx + row * p.C1 + ch : p.dx2 + row * (p.C - p.C1) + (ch - p.C1);
+        u32x4 old = {0u, 0u, 0u, 0u};
+        if (p.accum & (ch < p.C1 ? 1 : 2)) old = *reinterpret_cast<const u32x4*>(dst);   // fp32 add of the gradient already there, one rounding
+        const uint32_t ow[4] = {old.x, old.y, old.z, old.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float x0 = bf16lo(xw[e]), x1 = bf16hi(xw[e]);
             const float z0 = x0 * sc[2 * e] + sh[2 * e], z1 = x1 * sc[2 * e + 1] + sh[2 * e + 1];
             const float d0 = bf16lo(dw[e]) * act_grad(z0, p.act), d1 = bf16hi(dw[e]) * act_grad(z1, p.act);
-            o[e] = pack_bf16x2(d0 * sc[2 * e] + x0 * ka[2 * e] + kb[2 * e], d1 * sc[2 * e + 1] + x1 * ka[2 * e + 1] + kb[2 * e + 1]);
+            o[e] = pack_bf16x2(d0 * sc[2 * e] + x0 * ka[2 * e] + kb[2 * e] + bf16lo(ow[e]), d1 * sc[2 * e + 1] + x1 * ka[2 * e + 1] + kb[2 * e + 1] + bf16hi(ow[e]));
         }
-        const u32x4 ov = {o[0], o[1], o[2], o[3]};
-        if (ch < p.C1) *reinterpret_cast<u32x4*>(p.dx + row * p.C1 + ch) = ov;
-        else *reinterpret_cast<u32x4*>(p.dx2 + row * (p.C - p.C1) + (ch - p.C1)) = ov;
+        *reinterpret_cast<u32x4*>(dst) = (u32x4){o[0], o[1], o[2], o[3]};
     }
 }
 
@@ -591,7 +594,7 @@ __global__ void gnb_apply_kernel(const GNArgs p) {
 // Optionally writes (mean, rstd) per row for the parameter-gradient kernel.
 template <int MAXCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* x, const float* gamma, const bf16_t* dy, bf16_t* dx,
-                                                            float* row_stat, int M, int C, float eps) {
+                                                            float* row_stat, int M, int C, float eps, int accum) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long row = (long)blockIdx.x * 4 + wave;
     if (row >= M) return;
@@ -636,10 +639,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* x, con
         const int cc = lane + i * 64;
         if (cc < ncc) {
             uint32_t o[4];
+            u32x4 old = {0u, 0u, 0u, 0u};
+            if (accum) old = *reinterpret_cast<const u32x4*>(dx + row * C + cc * 8);   // dx += : fp32 add of the gradient already there, one rounding
+            const uint32_t ow[4] = {old.x, old.y, old.z, old.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float h0 = (xv[i][2 * e] - mu) * rstd, h1 = (xv[i][2 * e + 1] - mu) * rstd;
-                o[e] = pack_bf16x2(rstd * (tv[i][2 * e] - m1 - h0 * m2), rstd * (tv[i][2 * e + 1] - m1 - h1 * m2));
+                o[e] = pack_bf16x2(rstd * (tv[i][2 * e] - m1 - h0 * m2) + bf16lo(ow[e]), rstd * (tv[i][2 * e + 1] - m1 - h1 * m2) + bf16hi(ow[e]));
             }
             *reinterpret_cast<u32x4*>(dx + row * C + cc * 8) = (u32x4){o[0], o[1], o[2], o[3]};
         }
@@ -970,8 +976,9 @@ extern "C" long ae_groupnorm_bwd_workspace_floats(int B, int HW, int C, int grou
 
 extern "C" int ae_groupnorm_bwd_nhwc_bf16(const void* x, const void* x2, int C1, const float* gamma, const float* beta, const void* dy,
                                           void* dx, void* dx2, int B, int HW, int C, int groups, float eps, int act,
-                                          float* workspace, int* counters, const float* stat_in, void* stream) {
+                                          float* workspace, int* counters, const float* stat_in, int accumulate, void* stream) {
     AE_REQUIRE(x && gamma && beta && dy && dx && workspace, "ae_groupnorm_bwd_nhwc_bf16: null pointer");
+    AE_REQUIRE(accumulate >= 0 && accumulate <= 3 && (x2 || !(accumulate & 2)), "ae_groupnorm_bwd_nhwc_bf16: accumulate %d (bit 0: dx +=, bit 1: dx2 +=)", accumulate);
     AE_REQUIRE(B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, "ae_groupnorm_bwd_nhwc_bf16: bad shape C=%d groups=%d", C, groups);
     AE_REQUIRE(C % 8 == 0 && C <= 8192 && groups <= 64 && B <= 65535, "ae_groupnorm_bwd_nhwc_bf16: unsupported size");
     AE_REQUIRE(act == 0 || act == 1, "ae_groupnorm_bwd_nhwc_bf16: act must be 0 (none) or 1 (SiLU)");
@@ -982,7 +989,7 @@ extern "C" int ae_groupnorm_bwd_nhwc_bf16(const void* x, const void* x2, int C1,
     GNArgs p{};
     p.x = (const bf16_t*)x; p.x2 = (const bf16_t*)x2; p.C1 = x2 ? C1 : C;
     p.gamma = gamma; p.beta = beta; p.y = nullptr;
-    p.dy = (const bf16_t*)dy; p.dx = (bf16_t*)dx; p.dx2 = (bf16_t*)dx2;
+    p.dy = (const bf16_t*)dy; p.dx = (bf16_t*)dx; p.dx2 = (bf16_t*)dx2; p.accum = accumulate;
     p.B = B; p.HW = HW; p.C = C; p.groups = groups; p.act = act; p.eps = eps;
     p.rows_per_chunk = ae_groupnorm_rows_per_chunk(HW, C);
     p.nchunk = (HW + p.rows_per_chunk - 1) / p.rows_per_chunk;
@@ -1040,16 +1047,16 @@ extern "C" int ae_layernorm_act_bf16(const void* x, const float* gamma, const fl
 }
 
 extern "C" int ae_layernorm_bwd_bf16(const void* x, const float* gamma, const void* dy, void* dx, float* row_stat, int M, int C,
-                                     float eps, void* stream) {
+                                     float eps, int accumulate, void* stream) {
     AE_REQUIRE(x && gamma && dy && dx, "ae_layernorm_bwd_bf16: null pointer");
     AE_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "ae_layernorm_bwd_bf16: C=%d must be a multiple of 8 and <= 2048", C);
     AE_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0, "ae_layernorm_bwd_bf16: 16-byte alignment");
     dim3 grid((M + 3) / 4), block(256);
     const int ncc = C / 8;
     hipStream_t s = (hipStream_t)stream;
-    if (ncc <= 64) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, s, (const bf16_t*)x, gamma, (const bf16_t*)dy, (bf16_t*)dx, row_stat, M, C, eps);
-    else if (ncc <= 128) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, s, (const bf16_t*)x, gamma, (const bf16_t*)dy, (bf16_t*)dx, row_stat, M, C, eps);
-    else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, s, (const bf16_t*)x, gamma, (const bf16_t*)dy, (bf16_t*)dx, row_stat, M, C, eps);
+    if (ncc <= 64) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, s, (const bf16_t*)x, gamma, (const bf16_t*)dy, (bf16_t*)dx, row_stat, M, C, eps, accumulate);
+    else if (ncc <= 128) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, s, (const bf16_t*)x, gamma, (const bf16_t*)dy, (bf16_t*)dx, row_stat, M, C, eps, accumulate);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, s, (const bf16_t*)x, gamma, (const bf16_t*)dy, (bf16_t*)dx, row_stat, M, C, eps, accumulate);
     return ae_check_launch("ae_layernorm_bwd_bf16");
 }
 

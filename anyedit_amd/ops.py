@@ -1053,23 +1053,33 @@ def geglu_bwd(h, dy):
     return dh
 
 
-def groupnorm_bwd(x, gamma, beta, dy, B, HW, eps, silu=False, groups=32, x2=None, stat=None):
+def _grad_target(t, into):
+    """`into`: a contiguous bf16 tensor of t's shape that already holds a gradient of t (the kernel then adds to it in place), or None."""
+    if into is None:
+        return torch.empty_like(t), 0
+    if into.dtype != BF16 or into.shape != t.shape or not into.is_contiguous():
+        raise ValueError("gradient accumulation target must be a contiguous bf16 tensor of the input's shape")
+    return into, 1
+
+
+def groupnorm_bwd(x, gamma, beta, dy, B, HW, eps, silu=False, groups=32, x2=None, stat=None, dx_into=None, dx2_into=None):
+    """dx_into / dx2_into: tensors that already hold a gradient of x / x2 — the kernel adds to them in place (no separate add launch) and they are returned."""
     C1 = x.shape[1]
     C = C1 + (x2.shape[1] if x2 is not None else 0)
-    dx = torch.empty_like(x)
-    dx2 = torch.empty_like(x2) if x2 is not None else None
+    dx, acc1 = _grad_target(x, dx_into)
+    dx2, acc2 = _grad_target(x2, dx2_into) if x2 is not None else (None, 0)
     ws = torch.empty(lib.ae_groupnorm_bwd_workspace_floats(B, HW, C, groups), dtype=torch.float32, device=x.device)
     check(lib.ae_groupnorm_bwd_nhwc_bf16(_p(x), _p(x2), C1, _p(gamma), _p(beta), _p(_tmp(dy.contiguous())), _p(dx), _p(dx2), B, HW, C, groups,
-                                         eps, 1 if silu else 0, _p(ws), _p(_gn_counters(x.device, B)), _p(stat), _s()), "ae_groupnorm_bwd_nhwc_bf16")
+                                         eps, 1 if silu else 0, _p(ws), _p(_gn_counters(x.device, B)), _p(stat), acc1 | (acc2 << 1), _s()), "ae_groupnorm_bwd_nhwc_bf16")
     return dx, dx2
 
 
-def layernorm_bwd(x, gamma, dy, eps=1e-5, want_param_grads=False):
+def layernorm_bwd(x, gamma, dy, eps=1e-5, want_param_grads=False, dx_into=None):
     M, C = x.shape
-    dx = torch.empty_like(x)
+    dx, acc = _grad_target(x, dx_into)
     stat = torch.empty(M, 2, dtype=torch.float32, device=x.device) if want_param_grads else None
     dy = dy.contiguous()
-    check(lib.ae_layernorm_bwd_bf16(_p(x), _p(gamma), _p(dy), _p(dx), _p(stat), M, C, eps, _s()), "ae_layernorm_bwd_bf16")
+    check(lib.ae_layernorm_bwd_bf16(_p(x), _p(gamma), _p(dy), _p(dx), _p(stat), M, C, eps, acc, _s()), "ae_layernorm_bwd_bf16")
     if not want_param_grads:
         return dx, None, None
     dg = torch.empty(C, dtype=torch.float32, device=x.device)

@@ -176,10 +176,12 @@ int ae_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* do
 long ae_groupnorm_bwd_workspace_floats(int B, int HW, int C, int groups);
 int ae_groupnorm_bwd_nhwc_bf16(const void* x, const void* x2, int C1, const float* gamma, const float* beta, const void* dy,
                                void* dx, void* dx2, int B, int HW, int C, int groups, float eps, int act, float* workspace,
-                               int* counters, const float* stat_in, void* stream);
-/* LayerNorm backward w.r.t. the input; row_stat (optional fp32 [M,2]) receives (mean, rstd) for the parameter gradients.    */
+                               int* counters, const float* stat_in, int accumulate, void* stream);
+/* accumulate (GroupNorm: bit 0 -> dx, bit 1 -> dx2; LayerNorm: 0 / 1): the gradient is ADDED to what the output tensor already
+ * holds (fp32 add, one rounding) — a tensor with several consumers collects its gradient without a separate ae_add_bf16 launch.
+ * LayerNorm backward w.r.t. the input; row_stat (optional fp32 [M,2]) receives (mean, rstd) for the parameter gradients.    */
 int ae_layernorm_bwd_bf16(const void* x, const float* gamma, const void* dy, void* dx, float* row_stat, int M, int C, float eps,
-                          void* stream);
+                          int accumulate, void* stream);
 int ae_layernorm_param_grad_f32(const void* x, const void* dy, const float* row_stat, float* dgamma, float* dbeta, int M, int C,
                                 void* stream);
 /* y = a + b (gradient accumulation where a layer's input fans out).                                                          */

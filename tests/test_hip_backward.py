@@ -83,6 +83,62 @@ def test_layernorm_backward(ops, M, C):
     check_close(db, br.grad, rl2=2e-3, mabs=1e-2, what="layernorm dbeta")
 
 
+@pytest.mark.parametrize("B,HW,C,C1,silu", [(2, 256, 320, None, True), (3, 100, 640, 320, True), (1, 64, 1280, 640, False), (4, 4096, 320, None, True)])
+def test_groupnorm_backward_adds_into_an_existing_gradient(ops, B, HW, C, C1, silu):
+    """accumulate flags of ae_groupnorm_bwd_nhwc_bf16: dx (+)= / dx2 (+)= in the apply kernel against the separate kernel + ae_add_bf16 route the tape
+    used before (fp32 add of an existing bf16 gradient, one rounding: at least as close to the fp32 sum as the two-rounding route)."""
+    g = torch.Generator().manual_seed(B + HW + C)
+    rows = q(torch.randn(B * HW, C, generator=g) * 2 + 0.5).to(DEV, BF)
+    w, b = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV), (0.2 * torch.randn(C, generator=g)).to(DEV)
+    dy = q(torch.randn(B * HW, C, generator=g)).to(DEV, BF)
+    old = q(torch.randn(B * HW, C, generator=g)).to(DEV, BF)
+    x1, x2 = (rows, None) if C1 is None else (rows[:, :C1].contiguous(), rows[:, C1:].contiguous())
+    o1, o2 = (old, None) if C1 is None else (old[:, :C1].contiguous(), old[:, C1:].contiguous())
+    dx, dx2 = ops.groupnorm_bwd(x1, w, b, dy, B, HW, 1e-5, silu=silu, x2=x2)
+    for mask in ((1, 2, 3) if C1 is not None else (1,)):
+        t1 = o1.clone() if mask & 1 else None
+        t2 = o2.clone() if (mask & 2) else None
+        r1, r2 = ops.groupnorm_bwd(x1, w, b, dy, B, HW, 1e-5, silu=silu, x2=x2, dx_into=t1, dx2_into=t2)
+        for name, got, into, plain, prev in (("dx", r1, t1, dx, o1), ("dx2", r2, t2, dx2, o2)):
+            if plain is None:
+                continue
+            if into is None:
+                assert torch.equal(got, plain), f"{name}: un-accumulated half changed (mask {mask})"
+            else:
+                assert got.data_ptr() == into.data_ptr()
+                ref = plain.float() + prev.float()   # plain is bf16-rounded: the fused result is within one more rounding of this
+                check_close(got, ref, rl2=4e-3, mabs=8e-3, what=f"groupnorm {name} += (mask {mask})")
+
+
+@pytest.mark.parametrize("M,C", [(300, 320), (130, 640), (77, 1280), (16384, 320)])
+def test_layernorm_backward_adds_into_an_existing_gradient(ops, M, C):
+    g = torch.Generator().manual_seed(M + C)
+    x = q(torch.randn(M, C, generator=g) * 3 + 1).to(DEV, BF)
+    w = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV)
+    dy = q(torch.randn(M, C, generator=g)).to(DEV, BF)
+    old = q(torch.randn(M, C, generator=g)).to(DEV, BF)
+    dx, _, _ = ops.layernorm_bwd(x, w, dy, 1e-5)
+    into = old.clone()
+    got, _, _ = ops.layernorm_bwd(x, w, dy, 1e-5, dx_into=into)
+    assert got.data_ptr() == into.data_ptr()
+    check_close(got, dx.float() + old.float(), rl2=4e-3, mabs=8e-3, what="layernorm dx +=")
+
+
+@pytest.mark.parametrize("M,N,K", [(312, 768, 640), (312, 768, 1280), (4096, 640, 640), (16384, 320, 320), (1024, 1280, 1280), (1024, 1280, 5120), (16384, 320, 1280),
+                                   (4096, 640, 2560), (256, 1280, 1280), (49152, 320, 320), (12288, 640, 640), (3072, 1280, 5120)])
+def test_gemm_output_may_alias_its_residual(ops, M, N, K):
+    """The tape adds a data gradient to the one its input already has through the GEMM's residual, in place (out is residual): every tile plan, the split-K
+    reduce and the row-panel kernel read a residual element in the thread that writes the same output element, so the result is bit-identical to the out-of-place call."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = q(torch.randn(M, K, generator=g)).to(DEV, BF)
+    w = q(torch.randn(N, K, generator=g) * K ** -0.5).to(DEV, BF)
+    r = q(torch.randn(M, N, generator=g)).to(DEV, BF)
+    ref = ops.gemm(a, w, residual=r)
+    buf = r.clone()
+    out = ops.gemm(a, w, residual=buf, out=buf)
+    assert out.data_ptr() == buf.data_ptr() and torch.equal(out, ref)
+
+
 def test_geglu_forward_backward(ops):
     g = torch.Generator().manual_seed(5)
     M, Fd = 300, 1280
