@@ -50,6 +50,7 @@ struct BwdArgs {
     // them in split order (fixed order: deterministic) and rounds once.  nsplit <= 1: the block owns every query tile and writes bf16 itself.
     float* part;
     int nsplit;
+    int abl;   // lab build only (-DAE_BWD_LAB, env AE_BWD_ABL): bit 0 skip the second product, 1 skip the exp2 / P block, 2 skip the first product, 3 no barrier / restage, 4 no global loads
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4v;
@@ -62,6 +63,7 @@ __device__ __forceinline__ s16x4v lds_tr16(const bf16_t* p) {
     return s16x4v{};
 #endif
 }
+__device__ __forceinline__ float lab_f(bf16x8_t v) { union { bf16x8_t b; float f[4]; } u; u.b = v; return u.f[0]; }   // lab ablations: keeps an operand alive
 __device__ __forceinline__ bf16x8_t cat_tr(s16x4v lo, s16x4v hi) {
     union { struct { s16x4v a, b; } s; bf16x8_t v; } u;
     u.s.a = lo; u.s.b = hi;
@@ -115,6 +117,11 @@ __global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
+#ifdef AE_BWD_LAB
+    const int abl = p.abl;
+#else
+    constexpr int abl = 0;
+#endif
     const int nfixed = MODE == MODE_DQ ? p.Nq : p.Nk, nstream = MODE == MODE_DQ ? p.Nk : p.Nq;
     const int nfb = (nfixed + FB - 1) / FB;
     const int nsp = MODE == MODE_DKV ? max(p.nsplit, 1) : 1;
@@ -179,24 +186,51 @@ __global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const 
     constexpr int NIT = (ITEMS + NT - 1) / NT;
     u32x4 px[NIT][4];                                  // x(row 2pr), x(row 2pr+1), y(row 2pr), y(row 2pr+1)
     float pst[2] = {0.f, 0.f};
+    // per-thread source addresses of tile 0 (row pair 2 pr, 16-byte chunk c), advanced by ST rows per tile: a full tile (every tile but a ragged last one) is
+    // 4 NIT loads at pointer + constant, no per-tile multiplies and no per-row predicates (round 5: ~40 of the loop's ~200 VALU instructions and nine
+    // exec-mask branches per tile were address arithmetic and bounds checks of this staging)
+    const bf16_t* bx[NIT]; const bf16_t* by[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = min(tid + it * NT, ITEMS - 1);
+        const int pr = i / DCH, c = i - pr * DCH;
+        bx[it] = xs_p + (long)(2 * pr) * xs_sn + c * 8;
+        by[it] = ys_p + (long)(2 * pr) * ys_sn + c * 8;
+    }
+    const float* const lse_bh = p.lse + ((long)b * p.H + h) * p.Nq;
+    const float* const dlt_bh = p.delta + ((long)b * p.H + h) * p.Nq;
     auto load_tile = [&](int t) {
         const int t0 = t * ST;
+        const long ox = (long)t0 * xs_sn, oy = (long)t0 * ys_sn;
+        if (t0 + ST <= nstream) {   // uniform: whole tile in range
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                px[it][0] = *reinterpret_cast<const u32x4*>(bx[it] + ox);
+                px[it][1] = *reinterpret_cast<const u32x4*>(bx[it] + ox + xs_sn);
+                px[it][2] = *reinterpret_cast<const u32x4*>(by[it] + oy);
+                px[it][3] = *reinterpret_cast<const u32x4*>(by[it] + oy + ys_sn);
+            }
+            if (MODE == MODE_DKV && tid < ST) {
+                pst[0] = lse_bh[t0 + tid];
+                pst[1] = dlt_bh[t0 + tid];
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * NT;
-            const int pr = min(i, ITEMS - 1) / DCH, c = min(i, ITEMS - 1) - pr * DCH;
+            const int pr = min(i, ITEMS - 1) / DCH;
             const int r0 = t0 + 2 * pr, r1 = r0 + 1;
             const u32x4 z4 = {0u, 0u, 0u, 0u};
-            px[it][0] = r0 < nstream ? *reinterpret_cast<const u32x4*>(xs_p + (long)r0 * xs_sn + c * 8) : z4;
-            px[it][1] = r1 < nstream ? *reinterpret_cast<const u32x4*>(xs_p + (long)r1 * xs_sn + c * 8) : z4;
-            px[it][2] = r0 < nstream ? *reinterpret_cast<const u32x4*>(ys_p + (long)r0 * ys_sn + c * 8) : z4;
-            px[it][3] = r1 < nstream ? *reinterpret_cast<const u32x4*>(ys_p + (long)r1 * ys_sn + c * 8) : z4;
+            px[it][0] = r0 < nstream ? *reinterpret_cast<const u32x4*>(bx[it] + ox) : z4;
+            px[it][1] = r1 < nstream ? *reinterpret_cast<const u32x4*>(bx[it] + ox + xs_sn) : z4;
+            px[it][2] = r0 < nstream ? *reinterpret_cast<const u32x4*>(by[it] + oy) : z4;
+            px[it][3] = r1 < nstream ? *reinterpret_cast<const u32x4*>(by[it] + oy + ys_sn) : z4;
         }
         if (MODE == MODE_DKV && tid < ST) {
             const int qrow = t0 + tid;
-            const long si = ((long)b * p.H + h) * p.Nq + min(qrow, p.Nq - 1);
-            pst[0] = qrow < p.Nq ? p.lse[si] : 1.0e30f;  // padding queries: P = 2^(s - 1e30) = 0
-            pst[1] = qrow < p.Nq ? p.delta[si] : 0.f;
+            pst[0] = qrow < p.Nq ? lse_bh[qrow] : 1.0e30f;  // padding queries: P = 2^(s - 1e30) = 0
+            pst[1] = qrow < p.Nq ? dlt_bh[qrow] : 0.f;
         }
     };
     auto store_tile = [&](int stage) {
@@ -227,93 +261,137 @@ __global__ __launch_bounds__(256, (D <= 48 ? 2 : 1)) void attn_bwd_kernel(const 
         const bf16_t* const sX = sImg + cur * STAGE;
         const bf16_t* const sY = sX + IMG;
         const float* const sSt = sStat + cur * 2 * ST;
-        if (t + 1 < te) load_tile(t + 1);
+        if (t + 1 < te && !(abl & 16)) load_tile(t + 1);
 
         // ---- S_T = X_s X_f^T and dP_T = Y_s Y_f^T : lane holds [streamed row 16 f + 4 lg + r][fixed row l15] -----------------
+        // Every LDS operand of this iteration is read ONE STEP AHEAD of the MFMAs / VALU block that consumes it (fragment f + 1 while fragment f is multiplied,
+        // the statistics of fragment f + 1 under the exp2 block of fragment f, the transposed operands of product (df, j) + 1 under the MFMAs of (df, j)), with a
+        // scheduling barrier after each issue so that hipcc keeps the distance: round 5's PMC + listing showed 28 s_waitcnt per tile, most of them directly
+        // between a ds_read and its first use — with two waves per SIMD the pass was LDS-LATENCY-bound (halving the VALU work or removing the bank
+        // conflicts did not move it; matrix pipe 37 % busy).
         f32x4 s[QF][4], dp[QF][4];
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-#pragma unroll
-            for (int a = 0; a < QF; ++a) s[a][f] = dp[a][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8_t xk[2][NC], yk[2][NC];
+        auto ld1 = [&](int f, int buf) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const bf16x8_t xk = as_bf16x8(*reinterpret_cast<const u32x4*>(sX + (f * 16 + l15) * ROW + c * 32 + lg * 8));
-                const bf16x8_t yk = as_bf16x8(*reinterpret_cast<const u32x4*>(sY + (f * 16 + l15) * ROW + c * 32 + lg * 8));
+                xk[buf][c] = as_bf16x8(*reinterpret_cast<const u32x4*>(sX + (f * 16 + l15) * ROW + c * 32 + lg * 8));
+                yk[buf][c] = as_bf16x8(*reinterpret_cast<const u32x4*>(sY + (f * 16 + l15) * ROW + c * 32 + lg * 8));
+            }
+        };
+        f32x4 lrow[2], drow[2];
+        auto ldst = [&](int f, int buf) {
+            if (MODE == MODE_DKV) {
+                lrow[buf] = *reinterpret_cast<const f32x4*>(sSt + f * 16 + lg * 4);
+                drow[buf] = *reinterpret_cast<const f32x4*>(sSt + ST + f * 16 + lg * 4);
+            }
+        };
+        ld1(0, 0);
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            if (f + 1 < 4) ld1(f + 1, (f + 1) & 1);
+            else ldst(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < QF; ++a) s[a][f] = dp[a][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!(abl & 4))
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
 #pragma unroll
                 for (int a = 0; a < QF; ++a) {
-                    s[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xk, xf[a][c], s[a][f], 0, 0, 0);
-                    dp[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yk, yf[a][c], dp[a][f], 0, 0, 0);
+                    s[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xk[f & 1][c], xf[a][c], s[a][f], 0, 0, 0);
+                    dp[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yk[f & 1][c], yf[a][c], dp[a][f], 0, 0, 0);
                 }
             }
         }
 
         // ---- P and the second-product operands --------------------------------------------------------------------------------
         bf16x8_t rb0[QF][2], rb1[QF][2];  // DQ: (P o dP, P) ; DKV: (dS, P)
+        const int trow = l15 >> 2, tcol = 4 * (l15 & 3);
+        bf16x8_t z0[2], z1[2];
+        // contraction slot (group lg, e) of half j = streamed row 16 (2j + e / 4) + 4 lg + e % 4 (the accumulator order of rb): two
+        // transposing reads of 4 consecutive rows each deliver this lane's 8 values of head-dim column 16 df + l15
+        auto ldz = [&](int idx, int buf) {
+            const int df = idx >> 1, j = idx & 1;
+            const int a0 = (32 * j + 4 * lg + trow) * ROW + df * 16 + tcol;
+            z0[buf] = cat_tr(lds_tr16(sX + a0), lds_tr16(sX + a0 + 16 * ROW));
+            if (MODE == MODE_DKV) z1[buf] = cat_tr(lds_tr16(sY + a0), lds_tr16(sY + a0 + 16 * ROW));   // DQ: both products use K^T ; DKV: dV uses dO^T
+        };
+        float r0v[QF][2][4], r1v[QF][2][4];   // the two fragments of the current half j
+        const f32x2 c2v = {c2, c2};
 #pragma unroll
-        for (int a = 0; a < QF; ++a) {
-            float r0v[4][4], r1v[4][4];
+        for (int f = 0; f < 4; ++f) {
+            if (f + 1 < 4) ldst(f + 1, (f + 1) & 1);
+            else ldz(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (abl & 2) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                f32x4 lrow = {0.f, 0.f, 0.f, 0.f}, drow = {0.f, 0.f, 0.f, 0.f};
-                if (MODE == MODE_DKV) {
-                    lrow = *reinterpret_cast<const f32x4*>(sSt + f * 16 + lg * 4);
-                    drow = *reinterpret_cast<const f32x4*>(sSt + ST + f * 16 + lg * 4);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float pv;
-                    if (MODE == MODE_DQ) {
-                        pv = __builtin_amdgcn_exp2f(fmaf(s[a][f][r], c2, -l2f[a]));
-                        if (t0 + f * 16 + lg * 4 + r >= p.Nk) pv = 0.f;  // padding keys
-                        if (PRE) {
-                            r0v[f][r] = pv * (dp[a][f][r] - dlt[a]);
-                            r1v[f][r] = 0.f;
-                        } else {
-                            const float w = pv * dp[a][f][r];
-                            dlt[a] += w;
-                            r0v[f][r] = w;
-                            r1v[f][r] = pv;
-                        }
-                    } else {
-                        pv = __builtin_amdgcn_exp2f(fmaf(s[a][f][r], c2, -lrow[r]));
-                        r0v[f][r] = pv * (dp[a][f][r] - drow[r]);
-                        r1v[f][r] = pv;
-                    }
-                }
+                for (int a = 0; a < QF; ++a) { rb0[a][f >> 1] = as_bf16x8((u32x4){__float_as_uint(s[a][f][0]), 0u, 0u, 0u}); rb1[a][f >> 1] = as_bf16x8((u32x4){__float_as_uint(dp[a][f][0]), 0u, 0u, 0u}); }
+                continue;
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                u32x4 w0, w1;
-                w0.x = pack_bf16x2(r0v[2 * j][0], r0v[2 * j][1]); w0.y = pack_bf16x2(r0v[2 * j][2], r0v[2 * j][3]);
-                w0.z = pack_bf16x2(r0v[2 * j + 1][0], r0v[2 * j + 1][1]); w0.w = pack_bf16x2(r0v[2 * j + 1][2], r0v[2 * j + 1][3]);
-                rb0[a][j] = as_bf16x8(w0);
-                if (!PRE) {
-                    w1.x = pack_bf16x2(r1v[2 * j][0], r1v[2 * j][1]); w1.y = pack_bf16x2(r1v[2 * j][2], r1v[2 * j][3]);
-                    w1.z = pack_bf16x2(r1v[2 * j + 1][0], r1v[2 * j + 1][1]); w1.w = pack_bf16x2(r1v[2 * j + 1][2], r1v[2 * j + 1][3]);
-                    rb1[a][j] = as_bf16x8(w1);
+            for (int a = 0; a < QF; ++a) {
+                // two elements per instruction (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32): the logit rebase, dP - delta and the product are packed fp32 math,
+                // only the exp2 is per element
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const f32x2 sv = {s[a][f][2 * hh], s[a][f][2 * hh + 1]}, dpv = {dp[a][f][2 * hh], dp[a][f][2 * hh + 1]};
+                    const f32x2 lv = MODE == MODE_DQ ? (f32x2){l2f[a], l2f[a]} : (f32x2){lrow[f & 1][2 * hh], lrow[f & 1][2 * hh + 1]};
+                    const f32x2 tv = __builtin_elementwise_fma(sv, c2v, -lv);
+                    f32x2 pv = {__builtin_amdgcn_exp2f(tv.x), __builtin_amdgcn_exp2f(tv.y)};
+                    f32x2 r0, r1;
+                    if (MODE == MODE_DQ) {
+                        const int k0 = t0 + f * 16 + lg * 4 + 2 * hh;
+                        if (k0 >= p.Nk) pv.x = 0.f;          // padding keys
+                        if (k0 + 1 >= p.Nk) pv.y = 0.f;
+                        if (PRE) {
+                            r0 = pv * (dpv - (f32x2){dlt[a], dlt[a]});
+                            r1 = (f32x2){0.f, 0.f};
+                        } else {
+                            r0 = pv * dpv;
+                            dlt[a] += r0.x;
+                            dlt[a] += r0.y;
+                            r1 = pv;
+                        }
+                    } else {
+                        r0 = pv * (dpv - (f32x2){drow[f & 1][2 * hh], drow[f & 1][2 * hh + 1]});
+                        r1 = pv;
+                    }
+                    r0v[a][f & 1][2 * hh] = r0.x; r0v[a][f & 1][2 * hh + 1] = r0.y;
+                    r1v[a][f & 1][2 * hh] = r1.x; r1v[a][f & 1][2 * hh + 1] = r1.y;
+                }
+                if (f & 1) {
+                    const int j = f >> 1;
+                    u32x4 w0, w1;
+                    w0.x = pack_bf16x2(r0v[a][0][0], r0v[a][0][1]); w0.y = pack_bf16x2(r0v[a][0][2], r0v[a][0][3]);
+                    w0.z = pack_bf16x2(r0v[a][1][0], r0v[a][1][1]); w0.w = pack_bf16x2(r0v[a][1][2], r0v[a][1][3]);
+                    rb0[a][j] = as_bf16x8(w0);
+                    if (!PRE) {
+                        w1.x = pack_bf16x2(r1v[a][0][0], r1v[a][0][1]); w1.y = pack_bf16x2(r1v[a][0][2], r1v[a][0][3]);
+                        w1.z = pack_bf16x2(r1v[a][1][0], r1v[a][1][1]); w1.w = pack_bf16x2(r1v[a][1][2], r1v[a][1][3]);
+                        rb1[a][j] = as_bf16x8(w1);
+                    }
                 }
             }
         }
 
         // ---- acc^T[d][fixed] += Z^T[d][streamed] R[streamed][fixed] -------------------------------------------------------------
-        // contraction slot (group lg, e) of half j = streamed row 16 (2j + e / 4) + 4 lg + e % 4 (the accumulator order of rb): two
-        // transposing reads of 4 consecutive rows each deliver this lane's 8 values of head-dim column 16 df + l15
-        const int trow = l15 >> 2, tcol = 4 * (l15 & 3);
 #pragma unroll
-        for (int df = 0; df < NDF; ++df) {
+        for (int idx = 0; idx < 2 * NDF; ++idx) {
+            if (idx + 1 < 2 * NDF) ldz(idx + 1, (idx + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int df = idx >> 1, j = idx & 1;
+            if (abl & 1) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int a0 = (32 * j + 4 * lg + trow) * ROW + df * 16 + tcol;
-                const bf16x8_t z0 = cat_tr(lds_tr16(sX + a0), lds_tr16(sX + a0 + 16 * ROW));
-                bf16x8_t z1 = z0;  // DQ: both products use K^T ; DKV: dV uses dO^T
-                if (MODE == MODE_DKV) z1 = cat_tr(lds_tr16(sY + a0), lds_tr16(sY + a0 + 16 * ROW));
+                for (int a = 0; a < QF; ++a) { acc0[a][df][0] += lab_f(z0[idx & 1]) + lab_f(rb0[a][j]); if (!PRE) acc1[a][df][0] += lab_f(rb1[a][j]); }
+                continue;
+            }
 #pragma unroll
-                for (int a = 0; a < QF; ++a) {
-                    acc0[a][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z0, rb0[a][j], acc0[a][df], 0, 0, 0);
-                    if (!PRE) acc1[a][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z1, rb1[a][j], acc1[a][df], 0, 0, 0);
-                }
+            for (int a = 0; a < QF; ++a) {
+                acc0[a][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z0[idx & 1], rb0[a][j], acc0[a][df], 0, 0, 0);
+                if (!PRE) acc1[a][df] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(MODE == MODE_DKV ? z1[idx & 1] : z0[idx & 1], rb1[a][j], acc1[a][df], 0, 0, 0);
             }
         }
+        if (abl & 8) continue;
         if (t + 1 < te) store_tile(cur ^ 1);  // the other stage was last read before the previous barrier
         __syncthreads();
     }
@@ -496,6 +574,9 @@ extern "C" int ae_attn_bwd_bf16(const void* q, const void* k, const void* v, con
     a.dq_sb = dq_sb; a.dq_sh = dq_sh; a.dq_sn = dq_sn; a.dk_sb = dk_sb; a.dk_sh = dk_sh; a.dk_sn = dk_sn;
     a.dv_sb = dv_sb; a.dv_sh = dv_sh; a.dv_sn = dv_sn;
     a.scale = scale; a.accum_dq = accumulate_dq;
+#ifdef AE_BWD_LAB
+    a.abl = getenv("AE_BWD_ABL") ? atoi(getenv("AE_BWD_ABL")) : 0;
+#endif
     hipStream_t s = (hipStream_t)stream;
     // `out` (optional): THIS segment's own forward output, same layout as dout.  Only usable when nothing else was folded into it.
     AE_REQUIRE(!out || (((uintptr_t)out & 15) == 0), "ae_attn_bwd_bf16: out must be 16-byte aligned");
@@ -504,7 +585,7 @@ extern "C" int ae_attn_bwd_bf16(const void* q, const void* k, const void* v, con
         case 8: return launch_both<8, 2>(a, o_own, workspace, s);
         case 16: return launch_both<16, 2>(a, o_own, workspace, s);
         case 32: return launch_both<32, 2>(a, o_own, workspace, s);
-        case 40: return launch_both<40, 2>(a, o_own, workspace, s);
+        case 40: return launch_both<40, 2>(a, o_own, workspace, s);   // (64 fixed rows per block, three blocks per CU: 646 vs 552 us for the two passes at N = 4096 — operand reuse beats occupancy here)
         case 48: return launch_both<48, 2>(a, o_own, workspace, s);
         case 64: return launch_both<64, 2>(a, o_own, workspace, s);
         case 80: return launch_both<80, 2>(a, o_own, workspace, s);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5, visit 21: attention backward with whole K = 32 steps and the conflict-free LDS row stride (32 k + 16 elements) against the previous layout
+# Round 5, visit 21 (re-used for 21b: staging addresses hoisted + packed fp32 math in the P computation, against the commit before):
 # (variant library bwdold = the commit before): tests, the lab shape, PMC conflict counter, training step.
 set -u
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
