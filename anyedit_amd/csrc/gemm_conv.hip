@@ -1514,7 +1514,8 @@ Plan make_plan(int M, int N, int K, bool can_split) {
     if (waste128 <= 1.10 && t128 < 256) {
         int s = force_s > 0 ? force_s : (int)((480 + t128 - 1) / t128);
         if (conv_deep && force_s <= 0 && t128 <= 128) s = (int)(256 / t128);   // grid <= 256: every block alone on its CU, latency hidden by the ring
-        if (s > 8) s = 8;
+        static const int smax = getenv("AE_CONV_SPLIT_MAX") ? atoi(getenv("AE_CONV_SPLIT_MAX")) : 8;   // A/B knob (round 5: 16 for the M = 256 convs of a training batch)
+        if (s > smax) s = smax;
         if (s > kt / 8) s = kt / 8;
         if (s >= 2) return {0, s};
     }

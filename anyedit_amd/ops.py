@@ -1302,7 +1302,7 @@ def _conv_splitk(M, N, K):
     if kt < 32 or picked_big or is160:
         return 1
     if -(-N // 128) * 128 / N <= 1.10 and t128 < 256:
-        s_ = min((256 // t128) if (t128 <= 128 and _CONV_DEEP) else -(-480 // t128), 8, kt // 8)
+        s_ = min((256 // t128) if (t128 <= 128 and _CONV_DEEP) else -(-480 // t128), int(os.environ.get("AE_CONV_SPLIT_MAX", "8")), kt // 8)
         return s_ if s_ >= 2 else 1
     return 1
 
