@@ -110,6 +110,38 @@ def test_groupnorm_backward_adds_into_an_existing_gradient(ops, B, HW, C, C1, si
                 check_close(got, ref, rl2=4e-3, mabs=8e-3, what=f"groupnorm {name} += (mask {mask})")
 
 
+@pytest.mark.parametrize("B,HW,C,C1,silu", [(4, 256, 1280, None, True), (4, 256, 2560, 1280, True), (4, 256, 1920, 1280, True), (4, 64, 2560, 1280, True), (4, 256, 640, None, True),
+                                            (4, 64, 1280, None, False), (2, 200, 320, None, True), (1, 9, 960, 320, True)])
+def test_groupnorm_backward_single_launch_on_small_maps(ops, B, HW, C, C1, silu):
+    """gnb_slab_kernel (HW <= 256 with the forward's (mean, rstd)): one launch instead of partial / finalize / apply.  Against fp32 autograd of the oracle
+    expression, against the three-launch path (no saved statistics), and with both accumulate flags; the training step's 16x16 / 8x8 shapes at batch 4."""
+    from oracle import ldm_ref as L
+    g = torch.Generator().manual_seed(B + HW + C)
+    x = q(torch.randn(B, HW, C, generator=g) * 2 + 0.5)
+    w, b = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    dy = q(torch.randn(B, HW, C, generator=g))
+    xr = x.clone().requires_grad_(True)
+    y = L.group_norm32(xr.permute(0, 2, 1).reshape(B, C, HW, 1), w, b, 1e-5).reshape(B, C, HW).permute(0, 2, 1)
+    (F.silu(y) if silu else y).backward(dy)
+    rows, dyd = x.reshape(B * HW, C).to(DEV, BF), dy.reshape(B * HW, C).to(DEV, BF)
+    x1, x2 = (rows, None) if C1 is None else (rows[:, :C1].contiguous(), rows[:, C1:].contiguous())
+    wd, bd = w.to(DEV), b.to(DEV)
+    stat = torch.empty(B, 32, 2, dtype=torch.float32, device=DEV)
+    ops.groupnorm(x1, wd, bd, B, HW, 1e-5, silu=silu, x2=x2, stat_out=stat)
+    d3, d3b = ops.groupnorm_bwd(x1, wd, bd, dyd, B, HW, 1e-5, silu=silu, x2=x2)                 # three launches (own statistics pass)
+    d1, d1b = ops.groupnorm_bwd(x1, wd, bd, dyd, B, HW, 1e-5, silu=silu, x2=x2, stat=stat)      # one launch
+    cat = (lambda a, c: a if c is None else torch.cat([a, c], 1))
+    check_close(cat(d1, d1b).reshape(B, HW, C), xr.grad, what="groupnorm dx (single launch)")
+    check_close(cat(d1, d1b), cat(d3, d3b).float().cpu(), rl2=3e-3, mabs=1.5e-2, what="single launch vs three launches")
+    again = ops.groupnorm_bwd(x1, wd, bd, dyd, B, HW, 1e-5, silu=silu, x2=x2, stat=stat)
+    assert torch.equal(again[0], d1) and (d1b is None or torch.equal(again[1], d1b))
+    old = q(torch.randn(B * HW, C, generator=g)).to(DEV, BF)
+    o1, o2 = (old, None) if C1 is None else (old[:, :C1].contiguous(), old[:, C1:].contiguous())
+    t1, t2 = o1.clone(), (o2.clone() if o2 is not None else None)
+    r1, r2 = ops.groupnorm_bwd(x1, wd, bd, dyd, B, HW, 1e-5, silu=silu, x2=x2, stat=stat, dx_into=t1, dx2_into=t2)
+    check_close(cat(r1, r2), cat(d1, d1b).float().cpu() + old.float().cpu(), rl2=4e-3, mabs=8e-3, what="single launch, dx += / dx2 +=")
+
+
 @pytest.mark.parametrize("M,C", [(300, 320), (130, 640), (77, 1280), (16384, 320)])
 def test_layernorm_backward_adds_into_an_existing_gradient(ops, M, C):
     g = torch.Generator().manual_seed(M + C)
