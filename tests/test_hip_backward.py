@@ -248,6 +248,30 @@ def test_attention_backward_query_split_of_the_key_pass(ops, BH, Nq, Nk, D, nspl
             check_close(b, a.float().cpu(), rl2=2e-3, mabs=8e-3, what=f"{name} split {nsplit} vs one block, {BH}x{Nq}x{Nk}x{D}")
 
 
+@pytest.mark.parametrize("BH,N,Nk,D,gated", [(32, 4096, 4096, 40, False), (32, 1024, 1024, 80, False), (32, 1024, 78, 80, True), (32, 256, 256, 160, False), (8, 4096, 16, 40, True)])
+def test_attention_backward_run_to_run_determinism(ops, BH, N, Nk, D, gated):
+    """30 launches of the backward passes on identical inputs, bit for bit (dQ, dK, dV, delta): the training step's shapes, with and without the per-batch
+    gate (the two-accumulator dQ pass).  Guards the MFMA-operand hazard of DESIGN 7.00h / tests/test_isa_static.py on the hardware, not only in the listing."""
+    g = torch.Generator().manual_seed(N + Nk + D)
+    qd, kd, vd = (q(torch.randn(BH, n, D, generator=g)).to(DEV, BF) for n in (N, Nk, Nk))
+    dod = q(torch.randn(BH, N, D, generator=g)).to(DEV, BF)
+    lse = torch.empty(BH, 1, N, dtype=torch.float32, device=DEV)
+    sq, sk = (N * D, 0, D), (Nk * D, 0, D)
+    ops.attention(qd, kd, vd, BH, 1, N, Nk, D, D ** -0.5, sq, sk, sk, lse=lse)
+    gate = torch.linspace(0.5, 1.5, BH, device=DEV) if gated else None
+    first = None
+    for i in range(30):
+        dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+        delta = ops.attention_bwd(qd, kd, vd, dod, lse, BH, 1, N, Nk, D, D ** -0.5, sq, sk, sk, dq, dk, dv, sq, sk, sk, out_scale=gate)
+        cur = (dq, dk, dv, delta)
+        if first is None:
+            first = cur
+            assert all(torch.isfinite(t.float()).all() for t in cur)
+        else:
+            for name, a, b in zip(("dQ", "dK", "dV", "delta"), first, cur):
+                assert torch.equal(a, b), f"launch {i}: {name} differs from launch 0 in {int((a != b).sum())} elements"
+
+
 def test_fuzz_attention_and_norm_backward_shapes(ops):
     """Seeded random ragged shapes through the backward kernels (attention dQ/dK/dV, GroupNorm(+SiLU), LayerNorm) against autograd
     of the fp32 oracle expressions."""

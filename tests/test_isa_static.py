@@ -160,3 +160,24 @@ def test_no_vgpr_write_to_the_sources_of_a_running_mfma(tmp_path):
     assert md["vgpr_spill_count"] == "0" and md["private_segment_fixed_size"] == "0" and int(md["vgpr_count"]) <= 256, md   # two waves per SIMD
     assert loop[0] == 28 and loop[2] == 0, loop     # one 64-key tile per loop trip: 2 steps x 14 MFMAs, no scratch traffic
     assert loop[7] <= 160, loop                     # VALU per trip (148 at the time of writing: 64 exp2, 32 converts, 34 max3, addresses): register copies would show here
+
+
+def test_attention_backward_keeps_valu_writes_behind_its_mfma_phases(tmp_path):
+    """Round 5: the same listing check on EVERY instantiation of attn_bwd_kernel (training step).  The passes are phase-structured — first-product MFMAs,
+    the exp2 / P block, second-product MFMAs — and hipcc re-uses the operand registers of a phase's last MFMAs for the first VALU results of the next (the
+    first audit of this file: 904 such writes; e.g. `v_exp_f32 v184, ...` six instructions behind `v_mfma ... v[184:187]`).  Each phase now ends in a fence
+    that READS the results of its last MFMA group (in-order matrix pipe: everything before is finished), and the two-accumulator dQ pass at head dims 64 / 80
+    runs one query fragment per wave (at two it needs 328 registers and hipcc shuffled accumulators through AGPRs between the MFMAs)."""
+    import isa_audit as A
+    asm = A.compile_asm(["attention_bwd.hip"], str(tmp_path))[0]
+    res = A.mfma_source_overwrites(asm, "attn_bwd_kernel<")
+    assert len(res) >= 27, sorted(res)
+    for want in ("attn_bwd_kernel<40, 2, 0, true>", "attn_bwd_kernel<40, 2, 0, false>", "attn_bwd_kernel<40, 2, 1, false>", "attn_bwd_kernel<80, 1, 0, false>",
+                 "attn_bwd_kernel<80, 2, 1, false>", "attn_bwd_kernel<160, 1, 1, false>"):
+        assert [k for k in res if want in k], f"{want}: instantiation not found"
+    assert not [k for k in res if "attn_bwd_kernel<80, 2, 0, false>" in k or "attn_bwd_kernel<64, 2, 0, false>" in k]
+    for k, hits in res.items():
+        assert not hits, (k, hits[:3])
+    for n, md, loop in A.audit_named(asm):
+        if "attn_bwd_kernel<" in n:
+            assert md["private_segment_fixed_size"] == "0" and md["vgpr_spill_count"] == "0", (n, md)

@@ -69,12 +69,14 @@ def audit(asm_path):
 
 
 def _regs(tok):
-    """'v[18:33]' / 'v7' -> set of VGPR numbers; anything else -> empty set."""
-    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    """'v[18:33]' / 'v7' -> set of VGPR numbers; 'a[0:3]' / 'a5' -> AGPR numbers offset by 1000 (a separate file: an MFMA's AGPR destination read back by
+    v_accvgpr_read is a read of its result like any other); anything else -> empty set."""
+    m = re.fullmatch(r"([va])\[(\d+):(\d+)\]", tok)
     if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    m = re.fullmatch(r"v(\d+)", tok)
-    return {int(m.group(1))} if m else set()
+        off = 1000 if m.group(1) == "a" else 0
+        return set(range(off + int(m.group(2)), off + int(m.group(3)) + 1))
+    m = re.fullmatch(r"([va])(\d+)", tok)
+    return {(1000 if m.group(1) == "a" else 0) + int(m.group(2))} if m else set()
 
 
 def mfma_source_overwrites(asm_path, kernel_filter):
@@ -109,10 +111,11 @@ def mfma_source_overwrites(asm_path, kernel_filter):
                 continue
             ops_ = [x.strip() for x in t.split(None, 1)[1].split(",")]
             src = _regs(ops_[1]) | _regs(ops_[2])      # SrcA, SrcB (operand 0 is the destination, 3 the accumulator input)
-            dstm = _regs(ops_[0])                      # (AGPR destinations parse as empty: no early exit for them — conservative)
-            stack, visited = [(i + 1, 0, 0)], set()
+            dstm0 = _regs(ops_[0])                     # (AGPR destinations parse as empty: no early exit for them — conservative)
+            stack, visited = [(i + 1, 0, 0, frozenset(dstm0))], set()
             while stack:
-                j, seen, steps = stack.pop()
+                j, seen, steps, dstm = stack.pop()
+                dstm = set(dstm)
                 while j < len(ins) and steps < 48 and seen < 2:
                     if (j, seen) in visited:
                         break
@@ -121,6 +124,8 @@ def mfma_source_overwrites(asm_path, kernel_filter):
                     steps += 1
                     if u.startswith("v_mfma"):
                         seen += 1
+                        # the matrix pipe is in order: a later reader of THIS MFMA's result also proves the flagged one finished (round 5)
+                        dstm |= _regs([x.strip() for x in u.split(None, 1)[1].split(",")][0])
                         j += 1
                         continue
                     bm = re.match(r"^s_branch\s+(\.LBB\d+_\d+)", u)
@@ -129,24 +134,25 @@ def mfma_source_overwrites(asm_path, kernel_filter):
                         continue
                     cm = re.match(r"^s_cbranch_\w+\s+(\.LBB\d+_\d+)", u)
                     if cm:
-                        stack.append((label.get(cm.group(1), len(ins)), seen, steps))
+                        stack.append((label.get(cm.group(1), len(ins)), seen, steps, frozenset(dstm)))
                         j += 1
                         continue
+                    # A non-MFMA instruction that READS the MFMA's destination (or that of a later MFMA: the pipe is in order) is issued only once that
+                    # MFMA has written its result back, i.e. has finished — with all of its source reads: it, and everything behind it on this path, is
+                    # safe.  (An MFMA taking the result as its C operand proves nothing: accumulate chains forward inside the matrix pipe.)  Round 5: without
+                    # this the audit flagged the rebase path's rewrite of the Q operand's offset slot, which sits behind the whole maximum tree over the
+                    # MFMA's result; AGPR results read back by v_accvgpr_read count the same way.
+                    if dstm and " " in u and not u.startswith(("s_", "v_mfma")):
+                        rd = u.split(None, 1)[1].split(",")
+                        rd = rd[1:] if u.startswith(("v_", "ds_read", "buffer_load", "global_load")) and not u.startswith("v_cmp") else rd
+                        if any(_regs(x.strip().split(" ")[0]) & dstm for x in rd):
+                            break
                     # VALU writes only: an LDS / VMEM load returns its data 64+ cycles after issue (the reload of a fragment register right behind
                     # its last MFMA is what hipcc emits in every GEMM loop), a VALU result lands a few cycles after issue
                     if u.startswith("v_") and not u.startswith(("v_cmp", "v_nop", "v_readfirstlane", "v_readlane", "v_mfma")):
                         dst = _regs(u.split(None, 1)[1].split(",")[0].strip()) if " " in u else set()
                         if dst & src:
                             hits.append((i, t, j, u))
-                    # A non-MFMA instruction that READS the MFMA's destination is issued (in order) only once that MFMA has written its result back,
-                    # i.e. has finished — with all of its source reads: everything behind it on this path is safe.  (An MFMA taking the result as
-                    # its C operand proves nothing: accumulate chains forward inside the matrix pipe.)  Round 5: without this the audit flagged the
-                    # rebase path's rewrite of the Q operand's offset slot, which sits behind the whole maximum tree over the MFMA's result.
-                    if dstm and " " in u and not u.startswith(("s_", "v_mfma")):
-                        rd = u.split(None, 1)[1].split(",")
-                        rd = rd[1:] if u.startswith(("v_", "ds_read", "buffer_load", "global_load")) and not u.startswith("v_cmp") else rd
-                        if any(_regs(x.strip().split(" ")[0]) & dstm for x in rd):
-                            break
                     j += 1
         bad[dm[m.group(1)]] = sorted(set(hits))
     return bad
