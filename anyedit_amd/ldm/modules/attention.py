@@ -104,7 +104,22 @@ class FeedForward(nn.Module):
         project_in = GEGLU(dim, inner_dim)
         self.net = nn.Sequential(project_in, nn.Dropout(dropout), Linear(inner_dim, dim_out))
 
+    def repack(self):
+        self._pkf = None
+
+    def fused_ok(self, M, C):
+        """True where norm3 -> GEGLU -> ff2 (+ residual) runs as ONE launch (`ops.ff_fused`: the 64x64 UNet level at bench batch sizes)."""
+        return ops.ff_fused_ok(M, C, self.net[2].weight.shape[1])
+
     def rows(self, x, residual=None, norm=None, rowstats=None):
+        if norm is not None and self.fused_ok(x.shape[0], x.shape[1]):
+            proj, ff2 = self.net[0].proj, self.net[2]
+            if ops.cache_stale(self, "_pkf", proj.weight, proj.bias, ff2.weight, ff2.bias):
+                w1, b1 = ops.pack_geglu(proj.weight, proj.bias)
+                self._pkf = (w1, b1, ops.pack_ff2_fused(ff2.weight), None if ff2.bias is None else ff2.bias.detach().float().contiguous())
+            w1, b1, w2img, b2 = self._pkf
+            g, be = norm._affine()
+            return ops.ff_fused(x, g, be, norm.eps, w1, b1, w2img, b2, residual=residual)
         return self.net[2].rows(self.net[0].rows(x, norm=norm, rowstats=rowstats), residual=residual)
 
     def forward(self, x):
@@ -265,7 +280,9 @@ class BasicTransformerBlock(nn.Module):
             n1 = inner1 if (self.disable_self_attn and not self.attn1.is_self) else 3 * inner1
             f1 = ops.ln_fold_plan(M, n1, C, ops.EPI_NONE, 2)
             f2 = ops.ln_fold_plan(M, inner2, C, ops.EPI_NONE, 2) and ops.ln_fold_plan(M, C, inner1, ops.EPI_NONE, 1)
-            f3 = ops.ln_fold_plan(M, self.ff.net[0].proj.weight.shape[0], C, ops.EPI_GEGLU, 2) and ops.ln_fold_plan(M, C, inner2, ops.EPI_NONE, 1)
+            # (where the feed-forward runs as one fused launch it normalises its rows itself: attn2's to_out need not emit statistics)
+            f3 = not self.ff.fused_ok(M, C) and ops.ln_fold_plan(M, self.ff.net[0].proj.weight.shape[0], C, ops.EPI_GEGLU, 2) \
+                and ops.ln_fold_plan(M, C, inner2, ops.EPI_NONE, 1)
             self._fold_key, self._fold = key, (f1, f2, f3)
         return self._fold
 

@@ -209,6 +209,60 @@ def pack_geglu(w, b):
     return wp.detach().to(BF16).contiguous(), bp.detach().float().contiguous()
 
 
+def pack_ff2_fused(w2):
+    """ff2 weight [C = 320, H] -> the LDS images of `ae_ff_fused_bf16` (csrc/ff_fused.hip), bf16 [H / 32, C, 32], once per weight version.
+    Image row i of a 32-hidden-unit chunk holds output column 32 (i >> 5) + 8 ((i & 15) >> 2) + 4 ((i & 31) >> 4) + (i & 3) (a lane's two result
+    fragments are eight consecutive columns: 16-byte stores).  Its 64 bytes are four 16-byte pieces; logical piece g, element e, is hidden unit
+    32 s + 16 (e >> 2) + 4 g + (e & 3) — the order the gated values of chunks 2 s, 2 s + 1 sit in the P1 result registers of lane group g —
+    stored at position (g + 2 ((i & 15) >> 2)) & 3 (conflict-free ds_read_b128 lane groups)."""
+    C, H = w2.shape
+    assert C == 320 and H % 32 == 0
+    dev = w2.device
+    i = torch.arange(C, device=dev)
+    i5 = i & 31
+    col = 32 * (i >> 5) + 8 * ((i5 & 15) >> 2) + 4 * (i5 >> 4) + (i5 & 3)
+    pos = torch.arange(4, device=dev)
+    e = torch.arange(8, device=dev)
+    gp = (pos[None, :] - 2 * ((i[:, None] & 15) >> 2)) & 3                                         # [C, 4]: the logical piece stored at (row, position)
+    u = 16 * (e >> 2)[None, None, :] + 4 * gp[:, :, None] + (e & 3)[None, None, :]                  # [C, 4, 8] hidden unit inside the chunk
+    wf = w2.detach().float()[col]                                                                  # rows in image order
+    img = wf.reshape(C, H // 32, 32).permute(1, 0, 2)                                              # [S, C, 32]
+    idx = u.reshape(1, C, 32).expand(H // 32, C, 32)
+    return torch.gather(img, 2, idx).to(BF16).contiguous()
+
+
+def ff_fused_ok(M, C, H):
+    """True where `ff_fused` covers the feed-forward shape (never while the training tape records: its backward needs the pre-activations)."""
+    return not (_TAPE is not None and _TAPE.active) and bool(lib.ae_ff_fused_supported(M, C, H))
+
+
+def ff_fused(x, gamma, beta, eps, w1, b1, w2img, b2, residual=None, out=None):
+    """out = FF(LayerNorm(x)) (+ residual) in ONE launch (attention.py:49-76 behind norm3, :271-275): x [M, 320] bf16 rows, (w1, b1) = `pack_geglu`,
+    w2img = `pack_ff2_fused`.  Callers ask `ff_fused_ok` first."""
+    _chk(x, BF16, "ff_fused.x", 2)
+    _chk(w1, BF16, "ff_fused.w1", 2)
+    _chk(w2img, BF16, "ff_fused.w2img", 3)
+    _chk(gamma, torch.float32, "ff_fused.gamma", 1)
+    _chk(beta, torch.float32, "ff_fused.beta", 1)
+    _chk(b1, torch.float32, "ff_fused.b1", 1)
+    M, C = x.shape
+    H = w1.shape[0] // 2
+    if w1.shape[1] != C or tuple(w2img.shape) != (H // 32, C, 32) or not w2img.is_contiguous() or x.stride(1) != 1 or w1.stride(1) != 1:
+        raise ValueError(f"ff_fused: x {tuple(x.shape)}, w1 {tuple(w1.shape)}, w2img {tuple(w2img.shape)} do not fit together")
+    if b1.numel() != 2 * H or gamma.numel() != C or beta.numel() != C:
+        raise ValueError("ff_fused: b1 / gamma / beta sizes")
+    if b2 is not None:
+        _chk(b2, torch.float32, "ff_fused.b2", 1)
+    if residual is not None:
+        _chk(residual, BF16, "ff_fused.residual", 2)
+    if out is None:
+        out = torch.empty(M, C, dtype=BF16, device=x.device)
+    _chk(out, BF16, "ff_fused.out", 2)
+    check(lib.ae_ff_fused_bf16(_p(x), x.stride(0), _p(gamma), _p(beta), float(eps), _p(w1), w1.stride(0), _p(b1), _p(w2img), _p(b2), _p(residual),
+                               residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), M, C, H, _s()), "ae_ff_fused_bf16")
+    return out
+
+
 # --------------------------------------------------------------------------- GEMM / conv
 def colstats_buffer(M, N, device):
     """fp32 [ceil(M/32), N, 2]: per-channel (sum, sum of squares) over each 32-row slab of a bf16 [M, N] activation — filled by the kernel
@@ -1393,6 +1447,9 @@ def _up2_label(_r, x, w4, bias, B, H, W, **_):
 
 
 conv3x3_up2 = _wrap_profiled(conv3x3_up2, _up2_label)
+ff_fused = _wrap_profiled(ff_fused, lambda _r, x, gamma, beta, eps, w1, b1, w2img, b2, residual=None, out=None: (
+    f"ff_fused_kernel<C=320>|M={x.shape[0]} H={w1.shape[0] // 2}", 2.0 * x.shape[0] * x.shape[1] * 3 * (w1.shape[0] // 2),
+    float(2 * (x.numel() * (3 if residual is not None else 2) + w1.numel() + w2img.numel()))))
 _ln_gemm_fused = _wrap_profiled(_ln_gemm_launch, _ln_gemm_label)
 _gemm_ln_launch = _wrap_profiled(_gemm_ln_launch, _gemm_ln_label)
 gemm = _wrap_profiled(gemm, _gemm_label)

@@ -196,6 +196,40 @@ def test_layernorm_folded_into_gemm(ops, M, C, N, epi):
         ops._gemm_ln(x[:64], wq, c, None, E, None, None, st[:64].contiguous(), s, 1e-5)
 
 
+@pytest.mark.parametrize("M,H,res", [(192, 1280, True), (500, 1280, True), (777, 64, False), (1000, 256, True), (49152, 1280, True), (49000, 1280, True)])
+def test_feed_forward_fused_one_launch(ops, M, H, res):
+    """attention.py:49-76 behind norm3 (:271-275) as ONE launch (ae_ff_fused_bf16, round 6): LayerNorm -> GEGLU projection -> exact-erf gate -> ff2
+    + bias + residual with the gated hidden activation kept in registers.
+      1. against the fp64 module arithmetic on the same bf16 inputs and fp32 master weights (operator tolerance of this file);
+      2. no worse than the two-launch HIP path it replaces (row-panel LayerNorm + GEGLU projection, then ff2) by more than 25 % + 5e-4;
+      3. run-to-run bit-equal (fixed summation order); ragged last block; H down to two 32-unit steps."""
+    C = 320
+    assert ops.lib.ae_ff_fused_supported(M, C, H) == 1, "AE_ROWPANEL_ANY_M lets the small cases reach the kernel"
+    g = torch.Generator().manual_seed(M + H)
+    x = q(torch.randn(M, C, generator=g) * 1.3 + torch.randn(M, 1, generator=g) * 2.0)
+    w1 = torch.randn(2 * H, C, generator=g) / C ** 0.5
+    b1 = 0.1 * torch.randn(2 * H, generator=g)
+    w2 = torch.randn(C, H, generator=g) / H ** 0.5
+    b2 = 0.1 * torch.randn(C, generator=g)
+    gamma, beta = 1.0 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    z = F.layer_norm(x.double(), (C,), gamma.double(), beta.double(), 1e-5) @ q(w1).double().t() + b1.double()
+    a, gate = z.chunk(2, dim=-1)
+    ref = ((a * F.gelu(gate)) @ q(w2).double().t() + b2.double() + (x.double() if res else 0.0)).float()
+    xd = x.to(DEV, BF)
+    w1p, b1p = ops.pack_geglu(w1.to(DEV), b1.to(DEV))
+    w2img = ops.pack_ff2_fused(w2.to(DEV))
+    assert w2img.shape == (H // 32, C, 32) and w2img.dtype == BF
+    y = ops.ff_fused(xd, gamma.to(DEV), beta.to(DEV), 1e-5, w1p, b1p, w2img, b2.to(DEV), residual=xd if res else None)
+    h = ops.ln_gemm(xd, gamma.to(DEV), beta.to(DEV), 1e-5, w1p, b1p, epilogue=ops.EPI_GEGLU)
+    y2 = ops.gemm(h, w2.to(DEV, BF), bias=b2.to(DEV), residual=xd if res else None)
+    e1, e2 = rel_l2(y.float().cpu(), ref), rel_l2(y2.float().cpu(), ref)
+    print(f"fused feed-forward M={M} H={H}: rel-L2 fused {e1:.3e}, two launches {e2:.3e}")
+    check_close(y, ref, rl2=5e-3, mabs=3e-2, what=f"fused feed-forward {M}x{H}")
+    assert e1 <= 1.25 * e2 + 5e-4, (e1, e2)
+    y3 = ops.ff_fused(xd, gamma.to(DEV), beta.to(DEV), 1e-5, w1p, b1p, w2img, b2.to(DEV), residual=xd if res else None)
+    assert torch.equal(y, y3), "the fused feed-forward is not run-to-run bit-equal"
+
+
 @pytest.mark.parametrize("B,H,W,Cout", [(2, 16, 16, 64), (1, 5, 7, 320), (12, 64, 64, 320)])
 def test_stem_conv_as_im2col_gemm(ops, B, H, W, Cout, monkeypatch):
     """The UNet's 8-channel stem conv (openaimodel.py:536-542) as `im2col3x3_c8` + a K = 128 dense GEMM: the im2col rows bit-exact against the

@@ -499,6 +499,39 @@ def test_upsample_conv_as_four_2x2_convs_identity():
     assert torch.equal(packed.reshape(4, Co, 4, C), ws.to(torch.bfloat16))
 
 
+def test_fused_feed_forward_weight_image_index_map():
+    """Round 6 (attention.py:49-76): `ops.pack_ff2_fused` against the data flow of csrc/ff_fused.hip restated with index arithmetic on the CPU.  The gated
+    values of hidden chunks 2 s, 2 s + 1 leave P1 in lane (row n = lane & 15, g = lane >> 4) as elements e = 4 j + r <-> unit 32 s + 16 j + 4 g + r and are fed
+    to the next MFMA as its B operand as they are; lane (i = lane & 15, g) reads 16 bytes of image row 16 cf + i at position (g + 2 (i >> 2)) & 3 as the A
+    operand; D[i][n] = sum over (g, e); result row i = 4 g' + r of fragment cf is output column 32 (cf >> 1) + 8 g' + 4 (cf & 1) + r."""
+    from anyedit_amd import ops
+    g_ = torch.Generator().manual_seed(5)
+    C, H, R = 320, 128, 16
+    w2 = torch.randn(C, H, generator=g_)
+    hval = torch.randn(R, H, generator=g_).to(torch.bfloat16).float()
+    img = ops.pack_ff2_fused(w2).float()                       # [H / 32, C, 32]
+    assert tuple(img.shape) == (H // 32, C, 32)
+    out = torch.zeros(R, C)
+    for s in range(H // 32):
+        for cf in range(20):
+            D = torch.zeros(16, R)
+            for i in range(16):
+                for gg in range(4):
+                    pos = (gg + 2 * (i >> 2)) & 3
+                    a = img[s, 16 * cf + i, 8 * pos:8 * pos + 8]                                               # lane (i, gg)'s A fragment
+                    units = torch.tensor([32 * s + 16 * (e >> 2) + 4 * gg + (e & 3) for e in range(8)])
+                    D[i] += hval[:, units] @ a                                                                 # B fragment of lane (n, gg) = hval[n, units]
+            for gp in range(4):
+                for r in range(4):
+                    out[:, 32 * (cf >> 1) + 8 * gp + 4 * (cf & 1) + r] += D[4 * gp + r]
+    ref = hval @ w2.to(torch.bfloat16).float().t()
+    assert float((out - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    # conflict-free: the 16 lanes of a ds_read_b128 group ({0-3, 12-15, 20-27}) touch 16 different 16-byte slots of the 256-byte bank row
+    for grp in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]):
+        slots = {((lane & 15) * 64 + (((lane >> 4) + 2 * ((lane & 15) >> 2)) & 3) * 16) % 256 // 16 for lane in grp}
+        assert len(slots) == 16
+
+
 def test_mask_tool_box_logic_on_cpu():
     """tools/tool.py:184-222 (no GPU involved): box conversion and the phrase-based target filter, including its fallbacks and the
     list form of `target_object`."""
