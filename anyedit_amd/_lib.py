@@ -62,8 +62,8 @@ SIGNATURES = {
                         c_float, c_int, c_void_p, c_void_p],
     "ae_gemm_ln_plan": [c_int, c_int, c_int, c_int, c_int],
     "ae_ff_fused_supported": [c_int, c_int, c_int],
-    "ae_ff_fused_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long,
-                         c_int, c_int, c_int, c_void_p],
+    "ae_ff_fused_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long,
+                         c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p],
     "ae_gemm_ln_bf16": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_long, c_int, c_void_p,
                         c_void_p, c_int, c_void_p, c_float, c_void_p],
     "ae_task_gate_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],

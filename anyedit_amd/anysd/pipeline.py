@@ -50,6 +50,16 @@ class EditPipeline:
             self._graph = None   # the graph reads this buffer: recapture
         return pack.all
 
+    def set_step(self, t, temb_row=None):
+        """Points the static buffers the UNet evaluation (and its captured graph) reads at DDIM timestep `t`: the timestep vector AND — when the
+        time-embedding chain is hoisted — the embedding rows, which is what the evaluation actually consumes then (callers that only filled
+        `_t` evaluated the last step's embedding).  temb_row: the row of `_hoist_time_embedding`'s table for this step; None recomputes it."""
+        self._t.fill_(int(t))
+        if self._emb_pack is not None:
+            if temb_row is None:
+                temb_row = self.moe.unet.time_embedding_rows(torch.full((1,), int(t), dtype=torch.long, device=self._t.device)).all[0]
+            self._emb_pack.all.copy_(temb_row.unsqueeze(0).expand_as(self._emb_pack.all))
+
     def _ensure_graph(self, key):
         if self._graph is not None and self._graph_key == key:
             return
@@ -132,9 +142,7 @@ class EditPipeline:
         for i, step in enumerate(np.flip(timesteps)):
             index = total - i - 1                                                            # ddim.py:151 bookkeeping
             x_view.copy_(img.unsqueeze(0))
-            self._t.fill_(int(step))
-            if temb is not None:
-                self._emb_pack.all.copy_(temb[i].unsqueeze(0).expand_as(self._emb_pack.all))
+            self.set_step(step, temb[i] if temb is not None else None)
             if self.use_graph:
                 self._graph.replay()
                 eps = self._eps

@@ -31,6 +31,9 @@ struct FFArgs {
     float ln_eps;
     int M, H;
     long ldx, ldw1, ldy, ldr;
+    // PROJ (SpatialTransformer.proj_out behind the block, attention.py:337-340): Y = (feed-forward result, bf16) W3^T + b3 + res3
+    const bf16_t* W3; const float* b3; const bf16_t* res3;
+    long ldw3, ldr3;
 };
 
 constexpr int FF_KS = 10, FF_K = 320, FF_ROWB = 640, FF_CHUNKB = 32 * FF_ROWB, FF_MF = 3, FF_BM = 192, FF_NW = 4, FF_NCF = 20;
@@ -98,11 +101,13 @@ __device__ __forceinline__ void ff_wait_dma() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <bool PROJ>
 __global__ __launch_bounds__(64 * FF_NW, 1) void ff_fused_kernel(const FFArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[FF_NSLOT * FF_SLOTB + FF_MAXH2 * 4 + 3 * FF_K * 4];
+    __shared__ __attribute__((aligned(16))) char smem[FF_NSLOT * FF_SLOTB + FF_MAXH2 * 4 + 4 * FF_K * 4];
     float* const sc1 = reinterpret_cast<float*>(smem + FF_NSLOT * FF_SLOTB);   // b1 in the packed column order, 'a' columns halved
     float* const sb2 = sc1 + FF_MAXH2;
     float* const sln = sb2 + FF_K;                                             // gamma | beta
+    float* const sb3 = sln + 2 * FF_K;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(64 * FF_NW, 1) void ff_fused_kernel(const FFArgs p)
         }
     }
     for (int i = tid; i < H2; i += 64 * FF_NW) sc1[i] = p.b1[i] * ((i & 16) == 0 ? 0.5f : 1.0f);   // the bias of an 'a' column is kept halved (geglu_half_f)
-    for (int i = tid; i < FF_K; i += 64 * FF_NW) { sb2[i] = p.b2 ? p.b2[i] : 0.f; sln[i] = p.ln_g[i]; sln[FF_K + i] = p.ln_b[i]; }
+    for (int i = tid; i < FF_K; i += 64 * FF_NW) { sb2[i] = p.b2 ? p.b2[i] : 0.f; sln[i] = p.ln_g[i]; sln[FF_K + i] = p.ln_b[i]; sb3[i] = (PROJ && p.b3) ? p.b3[i] : 0.f; }
     ff_wait_dma<0>();
     __syncthreads();
     u32x4 af[FF_MF][FF_KS];
@@ -359,27 +364,104 @@ __global__ __launch_bounds__(64 * FF_NW, 1) void ff_fused_kernel(const FFArgs p)
 #pragma unroll
         for (int cf = 0; cf < FF_NCF; ++cf) asm volatile("" : "+a"(acc2[f][cf]));
 
-    // ---- epilogue: + b2 + residual, 16-byte stores (a lane's fragments 2 j / 2 j + 1 are eight consecutive columns 32 j + 8 g .. + 7: the W2 image's row order)
+    // ---- epilogue of the feed-forward: + b2 + residual.  A lane's fragments 2 j / 2 j + 1 are eight consecutive columns 32 j + 8 g .. + 7 (the W2 image's row
+    // order): a 16-byte store — or, PROJ, exactly the B operand fragment of k step j of the next product: the rounded result replaces the X fragments in `af`.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    [[maybe_unused]] int dma3[5], dmaR[3];
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rsW3 = rsW1, rsR3 = rsW1;
+    if constexpr (PROJ) {
+        // Phase 3 streams ten items [W3 chunk image (32 output columns, 20 KiB, the row-panel kernel's image and row order) | the 192 x 32 piece of the residual
+        // (12 KiB: rows of 64 bytes, the 16-byte part of lane group g at position (g + 2 (row >> 2)) & 3)] through the same four slots.  The ring must be quiet
+        // first: the tail phases' refills (items past the end: zeros) were drained by the wait above; this barrier says every wave has left the last slot.
+        __builtin_amdgcn_s_barrier();
+        rsW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.W3), 0, (int)((long)FF_K * p.ldw3 * 2), 0x00020000);
+        rsR3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.res3), 0, (int)((long)p.M * p.ldr3 * 2), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int o = (wave + FF_NW * j) * 1024 + lane * 16;
+            const int i = o / FF_ROWB, pp = (o - i * FF_ROWB) >> 4;
+            const int wrow = 8 * ((i & 15) >> 2) + 4 * (i >> 4) + (i & 3);   // image row i holds W3 row n0 + wrow: a lane's two fragments are eight consecutive output columns
+            dma3[j] = wrow * (int)p.ldw3 * 2 + ((pp & ~7) | ((pp ^ (i >> 1)) & 7)) * 16;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int row = 16 * (wave + FF_NW * j) + (lane >> 2), part = ((lane & 3) - 2 * (row >> 2)) & 3;
+            dmaR[j] = row * (int)p.ldr3 * 2 + part * 16 + (blockIdx.x * FF_BM + row < p.M ? 0 : FF_OOB);
+        }
+    }
+    auto issue_item3 = [&](int c) {   // item c of phase 3 into slot c & 3; c >= 10 reads zeros
+        if constexpr (PROJ) {
+            const int slot = lds0 + (c & (FF_NSLOT - 1)) * FF_SLOTB, ob = c < FF_K / 32 ? 0 : FF_OOB, cc = c < FF_K / 32 ? c : 0;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) ae_dma16(rsW3, slot + (wave + FF_NW * j) * 1024, dma3[j] + ob, cc * 32 * (int)p.ldw3 * 2);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ae_dma16(rsR3, slot + FF_CHUNKB + (wave + FF_NW * j) * 1024, dmaR[j] + ob, blockIdx.x * FF_BM * (int)p.ldr3 * 2 + cc * 64);
+        }
+    };
+    if constexpr (PROJ) { issue_item3(0); issue_item3(1); issue_item3(2); }
 #pragma unroll
     for (int f = 0; f < FF_MF; ++f) {
         const int row = m0 + 16 * f + l15;
-        if (row < p.M) {
-            bf16_t* const yrow = p.Y + (long)row * p.ldy + 8 * g;
-            const bf16_t* const rrow = p.res ? p.res + (long)row * p.ldr + 8 * g : nullptr;
+        const bool rok = row < p.M;
+        bf16_t* const yrow = p.Y + (long)min(row, p.M - 1) * p.ldy + 8 * g;
+        const bf16_t* const rrow = p.res ? p.res + (long)min(row, p.M - 1) * p.ldr + 8 * g : nullptr;
 #pragma unroll
-            for (int j = 0; j < FF_NCF / 2; ++j) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(sb2 + 32 * j + 8 * g), b1 = *reinterpret_cast<const f32x4*>(sb2 + 32 * j + 8 * g + 4);
-                float o0 = acc2[f][2 * j][0] + b0[0], o1 = acc2[f][2 * j][1] + b0[1], o2 = acc2[f][2 * j][2] + b0[2], o3 = acc2[f][2 * j][3] + b0[3];
-                float o4 = acc2[f][2 * j + 1][0] + b1[0], o5 = acc2[f][2 * j + 1][1] + b1[1], o6 = acc2[f][2 * j + 1][2] + b1[2], o7 = acc2[f][2 * j + 1][3] + b1[3];
-                if (rrow) {
-                    const u32x4 r = *reinterpret_cast<const u32x4*>(rrow + 32 * j);
+        for (int j = 0; j < FF_NCF / 2; ++j) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sb2 + 32 * j + 8 * g), b1 = *reinterpret_cast<const f32x4*>(sb2 + 32 * j + 8 * g + 4);
+            float o0 = acc2[f][2 * j][0] + b0[0], o1 = acc2[f][2 * j][1] + b0[1], o2 = acc2[f][2 * j][2] + b0[2], o3 = acc2[f][2 * j][3] + b0[3];
+            float o4 = acc2[f][2 * j + 1][0] + b1[0], o5 = acc2[f][2 * j + 1][1] + b1[1], o6 = acc2[f][2 * j + 1][2] + b1[2], o7 = acc2[f][2 * j + 1][3] + b1[3];
+            if (rrow) {
+                const u32x4 r = *reinterpret_cast<const u32x4*>(rrow + 32 * j);
+                o0 += bf16lo(r.x); o1 += bf16hi(r.x); o2 += bf16lo(r.y); o3 += bf16hi(r.y);
+                o4 += bf16lo(r.z); o5 += bf16hi(r.z); o6 += bf16lo(r.w); o7 += bf16hi(r.w);
+            }
+            const u32x4 pk = {pack_bf16x2(o0, o1), pack_bf16x2(o2, o3), pack_bf16x2(o4, o5), pack_bf16x2(o6, o7)};
+            if constexpr (PROJ) af[f][j] = pk;
+            else if (rok) *reinterpret_cast<u32x4*>(yrow + 32 * j) = pk;
+        }
+    }
+    if constexpr (PROJ) {
+        // ---- phase 3: Y[rows, 32 c .. + 32) = h2 W3[chunk c]^T + b3 + res3, ten chunks of 60 MFMAs (the row-panel GEMM's loop with one wave per row group:
+        // 5 % of the launch; the chunk epilogue is left to hipcc behind the chunk's MFMAs)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (hipcc has waited for its residual loads already, and with them for the first three items)
+#pragma unroll 1
+        for (int c = 0; c < FF_K / 32; ++c) {
+            ff_wait_dma<2 * FF_PPW>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue_item3(c + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            const char* const slot = smem + (c & (FF_NSLOT - 1)) * FF_SLOTB;
+            f32x4 acc3[FF_MF][2];
+            u32x4 wfr[5];
+            auto wread = [&](int i) { return *reinterpret_cast<const u32x4*>(slot + w1off[(i >> 1) & 1] + (i >> 2) * 128 + (i & 1) * 16 * FF_ROWB); };
+            wfr[0] = wread(0); wfr[1] = wread(1); wfr[2] = wread(2);
+            ff_static_for<0, 60>([&](auto pc) {
+                constexpr int P = decltype(pc)::value, i = P / 3, f = P % 3, ks = i >> 1, nf = i & 1;
+                if constexpr (f == 0 && i + 3 < 20) wfr[(i + 3) % 5] = wread(i + 3);
+                if constexpr (ks == 0) ff_mfma_v0(acc3[f][nf], wfr[i % 5], af[f][ks]);
+                else ff_mfma_v(acc3[f][nf], wfr[i % 5], af[f][ks]);
+                if constexpr (f == 1 && i >= 1) ff_keep(wfr[(i - 1) % 5]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            ff_keep(wfr[19 % 5]);
+            asm volatile("s_nop 15" : "+v"(acc3[0][0]), "+v"(acc3[0][1]), "+v"(acc3[1][0]), "+v"(acc3[1][1]), "+v"(acc3[2][0]), "+v"(acc3[2][1]));   // asm MFMA results -> VALU
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sb3 + 32 * c + 8 * g), b1 = *reinterpret_cast<const f32x4*>(sb3 + 32 * c + 8 * g + 4);
+#pragma unroll
+            for (int f = 0; f < FF_MF; ++f) {
+                const int rl = wave * (FF_MF * 16) + 16 * f + l15, row = m0 + 16 * f + l15;
+                float o0 = acc3[f][0][0] + b0[0], o1 = acc3[f][0][1] + b0[1], o2 = acc3[f][0][2] + b0[2], o3 = acc3[f][0][3] + b0[3];
+                float o4 = acc3[f][1][0] + b1[0], o5 = acc3[f][1][1] + b1[1], o6 = acc3[f][1][2] + b1[2], o7 = acc3[f][1][3] + b1[3];
+                if (p.res3) {
+                    const u32x4 r = *reinterpret_cast<const u32x4*>(slot + FF_CHUNKB + rl * 64 + (((g + 2 * (rl >> 2)) & 3) << 4));
                     o0 += bf16lo(r.x); o1 += bf16hi(r.x); o2 += bf16lo(r.y); o3 += bf16hi(r.y);
                     o4 += bf16lo(r.z); o5 += bf16hi(r.z); o6 += bf16lo(r.w); o7 += bf16hi(r.w);
                 }
-                *reinterpret_cast<u32x4*>(yrow + 32 * j) = (u32x4){pack_bf16x2(o0, o1), pack_bf16x2(o2, o3), pack_bf16x2(o4, o5), pack_bf16x2(o6, o7)};
+                if (row < p.M)
+                    *reinterpret_cast<u32x4*>(p.Y + (long)row * p.ldy + 32 * c + 8 * g) = (u32x4){pack_bf16x2(o0, o1), pack_bf16x2(o2, o3), pack_bf16x2(o4, o5), pack_bf16x2(o6, o7)};
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 
@@ -395,19 +477,34 @@ extern "C" int ae_ff_fused_supported(int M, int C, int H) {
 }
 
 extern "C" int ae_ff_fused_bf16(const void* X, long ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* W1, long ldw1, const float* b1,
-                                const void* W2img, const float* b2, const void* residual, long ldr, void* Y, long ldy, int M, int C, int H, void* stream) {
+                                const void* W2img, const float* b2, const void* residual, long ldr, const void* W3, long ldw3, const float* b3,
+                                const void* residual3, long ldr3, float* colstats, void* Y, long ldy, int M, int C, int H, void* stream) {
     AE_REQUIRE(X && W1 && b1 && ln_gamma && ln_beta && W2img && Y, "ae_ff_fused_bf16: null pointer");
     AE_REQUIRE(ae_ff_fused_supported(M, C, H), "ae_ff_fused_bf16: unsupported shape M=%d C=%d H=%d (C must be 320, H %% 64 == 0, H <= 1280)", M, C, H);
     AE_REQUIRE(ln_eps >= 0.f, "ae_ff_fused_bf16: eps");
     AE_REQUIRE(ldx % 8 == 0 && ldw1 % 8 == 0 && ldy % 8 == 0 && (!residual || ldr % 8 == 0), "ae_ff_fused_bf16: row strides must keep 16-byte alignment");
     AE_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)W1 & 15) == 0 && ((uintptr_t)W2img & 15) == 0 && ((uintptr_t)Y & 15) == 0 && ((uintptr_t)residual & 15) == 0,
                "ae_ff_fused_bf16: pointer alignment");
-    const long ldmax = ldx > ldy ? (ldx > ldr ? ldx : ldr) : (ldy > ldr ? ldy : ldr);
-    AE_REQUIRE((long)2 * H * ldw1 * 2 < (1L << 30) && ((long)M + FF_BM) * ldmax * 2 < (1L << 30), "ae_ff_fused_bf16: tensors must stay below 1 GiB (32-bit offsets, out-of-range marker)");
+    AE_REQUIRE(W3 || (!b3 && !residual3 && !colstats), "ae_ff_fused_bf16: b3 / residual3 / colstats go with the output projection W3");
+    AE_REQUIRE(!W3 || (ldw3 % 8 == 0 && ((uintptr_t)W3 & 15) == 0 && (!residual3 || (ldr3 % 8 == 0 && ((uintptr_t)residual3 & 15) == 0))), "ae_ff_fused_bf16: W3 / residual3 alignment");
+    AE_REQUIRE(Y != X && Y != residual3, "ae_ff_fused_bf16: in-place operation (Y aliasing X or residual3) is not supported");
+    long ldmax = ldx > ldy ? ldx : ldy;
+    if (residual && ldr > ldmax) ldmax = ldr;
+    if (residual3 && ldr3 > ldmax) ldmax = ldr3;
+    AE_REQUIRE((long)2 * H * ldw1 * 2 < (1L << 30) && ((long)M + FF_BM) * ldmax * 2 < (1L << 30) && (long)C * ldw3 * 2 < (1L << 30),
+               "ae_ff_fused_bf16: tensors must stay below 1 GiB (32-bit offsets, out-of-range marker)");
     FFArgs a{};
     a.X = (const bf16_t*)X; a.W1 = (const bf16_t*)W1; a.W2 = (const bf16_t*)W2img; a.Y = (bf16_t*)Y; a.res = (const bf16_t*)residual;
     a.b1 = b1; a.ln_g = ln_gamma; a.ln_b = ln_beta; a.b2 = b2; a.ln_eps = ln_eps; a.M = M; a.H = H;
     a.ldx = ldx; a.ldw1 = ldw1; a.ldy = ldy; a.ldr = ldr;
-    hipLaunchKernelGGL(ff_fused_kernel, dim3((unsigned)((M + FF_BM - 1) / FF_BM)), dim3(64 * FF_NW), 0, (hipStream_t)stream, a);
-    return ae_check_launch("ae_ff_fused_bf16");
+    a.W3 = (const bf16_t*)W3; a.b3 = b3; a.res3 = (const bf16_t*)residual3; a.ldw3 = ldw3; a.ldr3 = ldr3;
+    const dim3 grid((unsigned)((M + FF_BM - 1) / FF_BM)), block(64 * FF_NW);
+    if (W3) hipLaunchKernelGGL(ff_fused_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(ff_fused_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+    const int rc = ae_check_launch("ae_ff_fused_bf16");
+    if (rc || !colstats) return rc;
+    // per-channel statistics of the output for the GroupNorm that consumes it: a lane stays on ONE row across all columns here, so the column sums come from the
+    // stand-alone pass over the (L2-resident) output, as behind ae_ln_gemm_bf16
+    AE_REQUIRE(((uintptr_t)colstats & 15) == 0, "ae_ff_fused_bf16: colstats alignment");
+    return ae_launch_colstats((const bf16_t*)Y, ldy, M, C, colstats, (hipStream_t)stream);
 }

@@ -412,6 +412,10 @@ extern "C" int ae_ln_gemm_supported(int M, int N, int K, int epilogue) {
 int ae_rowpanel_fold_covers(int M, int N, int K, int epilogue, int mode) {
     static const int on = getenv("AE_RP_FOLD") ? atoi(getenv("AE_RP_FOLD")) : 1;
     if (!on || !ae_ln_gemm_supported(M, N, K, epilogue)) return 0;
+    // the 32-bit-offset envelope of ae_rowpanel_fold_launch, for contiguous rows of max(K, stored N) elements: a plan that says yes must not be refused at
+    // launch (UNet batches >= ~200 samples at 64x64 then got a hard error instead of the tiled plan)
+    const long ldmax = K > N ? K : N;
+    if (((long)M + RP_BM) * ldmax * 2 >= (1L << 31) || (long)N * K * 2 >= (1L << 31)) return 0;
     return mode == 2 || (mode == 1 && epilogue == RP_EPI_NONE);
 }
 int ae_rowpanel_fold_launch(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int N, int K, const float* bias, const void* residual,

@@ -15,6 +15,7 @@ from anyedit_amd.ldm.util import default, exists
 from anyedit_amd.ldm.modules.diffusionmodules.util import Linear, Conv2d, LayerNorm, checkpoint  # noqa: F401
 
 BF16 = torch.bfloat16
+_FF_TAIL = os.environ.get("AE_FF_TAIL", "1") != "0"   # tuning knob (A/B): 0 = proj_out stays its own launch behind the fused feed-forward
 _SEG2_160 = os.environ.get("AE_ATTN_SEG2_160", "1") != "0"  # tuning knob (A/B): 0 = the d = 160 expert segment as a second, accumulating launch
 
 
@@ -111,7 +112,9 @@ class FeedForward(nn.Module):
         """True where norm3 -> GEGLU -> ff2 (+ residual) runs as ONE launch (`ops.ff_fused`: the 64x64 UNet level at bench batch sizes)."""
         return ops.ff_fused_ok(M, C, self.net[2].weight.shape[1])
 
-    def rows(self, x, residual=None, norm=None, rowstats=None):
+    def rows(self, x, residual=None, norm=None, rowstats=None, tail=None):
+        """tail: optional (w3 [C, C] bf16, b3, residual3, colstats) — the projection that follows the block (SpatialTransformer.proj_out, attention.py:337-340);
+        only where `fused_ok` (the caller checks): it then rides in the fused launch and the result is proj_out's."""
         if norm is not None and self.fused_ok(x.shape[0], x.shape[1]):
             proj, ff2 = self.net[0].proj, self.net[2]
             if ops.cache_stale(self, "_pkf", proj.weight, proj.bias, ff2.weight, ff2.bias):
@@ -119,7 +122,11 @@ class FeedForward(nn.Module):
                 self._pkf = (w1, b1, ops.pack_ff2_fused(ff2.weight), None if ff2.bias is None else ff2.bias.detach().float().contiguous())
             w1, b1, w2img, b2 = self._pkf
             g, be = norm._affine()
+            if tail is not None:
+                w3, b3, res3, cs = tail
+                return ops.ff_fused(x, g, be, norm.eps, w1, b1, w2img, b2, residual=residual, w3=w3, b3=b3, residual3=res3, colstats=cs)
             return ops.ff_fused(x, g, be, norm.eps, w1, b1, w2img, b2, residual=residual)
+        assert tail is None, "FeedForward.rows: the projection tail goes with the fused launch only"
         return self.net[2].rows(self.net[0].rows(x, norm=norm, rowstats=rowstats), residual=residual)
 
     def forward(self, x):
@@ -262,13 +269,18 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = LayerNorm(dim)
         self.checkpoint = checkpoint
 
-    def rows(self, x, B, N, context_rows=None, kv_cache=None, rowstats=None):
+    def rows(self, x, B, N, context_rows=None, kv_cache=None, rowstats=None, tail=None):
         """x: [B*N, C] bf16.  kv_cache: optional dict id(attn)->projected K|V of the (step-invariant) context.
-        rowstats: row statistics of x from the GEMM that produced it (see `wants_rowstats`)."""
+        rowstats: row statistics of x from the GEMM that produced it (see `wants_rowstats`).
+        tail: the projection behind the block (see FeedForward.rows), only where `takes_tail(M, C)`."""
         tape = ops._TAPE
         if self.checkpoint and tape is not None and tape.active:  # attention.py:268: recompute this block in the backward pass
             return tape.checkpoint(lambda: self._rows(x, B, N, context_rows, kv_cache))
-        return self._rows(x, B, N, context_rows, kv_cache, rowstats)
+        return self._rows(x, B, N, context_rows, kv_cache, rowstats, tail)
+
+    def takes_tail(self, M, C):
+        """True where the block's feed-forward is the fused launch, which can carry the projection that follows the block."""
+        return _FF_TAIL and self.ff.fused_ok(M, C)
 
     def _fold_plan(self, M, C):
         """Which of the three norms can be folded into its projection at M rows: (norm1, norm2, norm3).  A norm folds when the GEMM behind it
@@ -290,7 +302,7 @@ class BasicTransformerBlock(nn.Module):
         """True when norm1 would be folded into attn1's projection given the row statistics of the block's input."""
         return self._fold_plan(M, C)[0]
 
-    def _rows(self, x, B, N, context_rows=None, kv_cache=None, rowstats=None):
+    def _rows(self, x, B, N, context_rows=None, kv_cache=None, rowstats=None, tail=None):
         c1 = context_rows if self.disable_self_attn else None
         M, C = x.shape
         f1, f2, f3 = self._fold_plan(M, C)
@@ -312,7 +324,7 @@ class BasicTransformerBlock(nn.Module):
             if callable(adapter):  # training: the expert K|V projection is recorded here, next to the attention that consumes it
                 adapter = adapter()
         x = self.attn2.rows(x, B, N, context_rows=context_rows, kv=kv2, residual=x, adapter=adapter, norm=self.norm2, rowstats=st2, out_rowstats=st3)
-        x = self.ff.rows(x, residual=x, norm=self.norm3, rowstats=st3)
+        x = self.ff.rows(x, residual=x, norm=self.norm3, rowstats=st3, tail=tail)
         return x
 
     def forward(self, x, context=None):
@@ -367,9 +379,15 @@ class SpatialTransformer(nn.Module):
         if self.transformer_blocks[0].wants_rowstats(M, Ci) and ops.ln_fold_plan(M, Ci, h.shape[1], ops.EPI_NONE, 1):
             st = ops.rowstats_buffer(M, Ci, h.device)
         h = ops.gemm(h, pin["w"], pin["b"], rowstats=st)
-        for i, blk in enumerate(self.transformer_blocks):
-            h = blk.rows(h, B, N, context_rows=ctxs[i], kv_cache=kv_cache, rowstats=st if i == 0 else None)
         pout = self.proj_out._packed()
+        last = len(self.transformer_blocks) - 1
+        # round 6: where the last block's feed-forward runs as the fused launch, proj_out + the residual (attention.py:337-340) ride in it
+        tail_ok = self.transformer_blocks[last].takes_tail(M, Ci) and pout["w"].shape == (Ci, Ci) and x.shape[1] == Ci
+        for i, blk in enumerate(self.transformer_blocks):
+            tail = (pout["w"], pout["b"], x, out_colstats) if (tail_ok and i == last) else None
+            h = blk.rows(h, B, N, context_rows=ctxs[i], kv_cache=kv_cache, rowstats=st if i == 0 else None, tail=tail)
+        if tail_ok:
+            return h
         return ops.gemm(h, pout["w"], pout["b"], residual=x, colstats=out_colstats)
 
     def forward(self, x, context=None):

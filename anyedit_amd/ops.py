@@ -236,9 +236,10 @@ def ff_fused_ok(M, C, H):
     return not (_TAPE is not None and _TAPE.active) and bool(lib.ae_ff_fused_supported(M, C, H))
 
 
-def ff_fused(x, gamma, beta, eps, w1, b1, w2img, b2, residual=None, out=None):
+def ff_fused(x, gamma, beta, eps, w1, b1, w2img, b2, residual=None, out=None, w3=None, b3=None, residual3=None, colstats=None):
     """out = FF(LayerNorm(x)) (+ residual) in ONE launch (attention.py:49-76 behind norm3, :271-275): x [M, 320] bf16 rows, (w1, b1) = `pack_geglu`,
-    w2img = `pack_ff2_fused`.  Callers ask `ff_fused_ok` first."""
+    w2img = `pack_ff2_fused`.  With w3 (bf16 [320, 320], `pack_linear`): out = bf16(that) @ w3^T + b3 (+ residual3) — SpatialTransformer.proj_out and its
+    residual (attention.py:337-340) in the same launch; colstats: `colstats_buffer(M, 320)` for the GroupNorm that consumes out.  Callers ask `ff_fused_ok` first."""
     _chk(x, BF16, "ff_fused.x", 2)
     _chk(w1, BF16, "ff_fused.w1", 2)
     _chk(w2img, BF16, "ff_fused.w2img", 3)
@@ -255,11 +256,26 @@ def ff_fused(x, gamma, beta, eps, w1, b1, w2img, b2, residual=None, out=None):
         _chk(b2, torch.float32, "ff_fused.b2", 1)
     if residual is not None:
         _chk(residual, BF16, "ff_fused.residual", 2)
+    if w3 is not None:
+        _chk(w3, BF16, "ff_fused.w3", 2)
+        if tuple(w3.shape) != (C, C) or w3.stride(1) != 1:
+            raise ValueError("ff_fused: w3 must be [C, C] with unit inner stride")
+        if b3 is not None:
+            _chk(b3, torch.float32, "ff_fused.b3", 1)
+        if residual3 is not None:
+            _chk(residual3, BF16, "ff_fused.residual3", 2)
+        if colstats is not None:
+            _chk(colstats, torch.float32, "ff_fused.colstats", 3)
+            if tuple(colstats.shape) != ((M + 31) // 32, C, 2) or not colstats.is_contiguous():
+                raise ValueError(f"ff_fused: colstats must be a contiguous [{(M + 31) // 32}, {C}, 2] fp32 buffer")
+    elif b3 is not None or residual3 is not None or colstats is not None:
+        raise ValueError("ff_fused: b3 / residual3 / colstats go with w3")
     if out is None:
         out = torch.empty(M, C, dtype=BF16, device=x.device)
     _chk(out, BF16, "ff_fused.out", 2)
     check(lib.ae_ff_fused_bf16(_p(x), x.stride(0), _p(gamma), _p(beta), float(eps), _p(w1), w1.stride(0), _p(b1), _p(w2img), _p(b2), _p(residual),
-                               residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), M, C, H, _s()), "ae_ff_fused_bf16")
+                               residual.stride(0) if residual is not None else 0, _p(w3), w3.stride(0) if w3 is not None else 0, _p(b3), _p(residual3),
+                               residual3.stride(0) if residual3 is not None else 0, _p(colstats), _p(out), out.stride(0), M, C, H, _s()), "ae_ff_fused_bf16")
     return out
 
 
@@ -1447,9 +1463,11 @@ def _up2_label(_r, x, w4, bias, B, H, W, **_):
 
 
 conv3x3_up2 = _wrap_profiled(conv3x3_up2, _up2_label)
-ff_fused = _wrap_profiled(ff_fused, lambda _r, x, gamma, beta, eps, w1, b1, w2img, b2, residual=None, out=None: (
-    f"ff_fused_kernel<C=320>|M={x.shape[0]} H={w1.shape[0] // 2}", 2.0 * x.shape[0] * x.shape[1] * 3 * (w1.shape[0] // 2),
-    float(2 * (x.numel() * (3 if residual is not None else 2) + w1.numel() + w2img.numel()))))
+ff_fused = _wrap_profiled(ff_fused, lambda _r, x, gamma, beta, eps, w1, b1, w2img, b2, residual=None, out=None, w3=None, b3=None, residual3=None, colstats=None: (
+    f"ff_fused_kernel<C=320{',proj_out' if w3 is not None else ''}>|M={x.shape[0]} H={w1.shape[0] // 2}",
+    2.0 * x.shape[0] * x.shape[1] * (3 * (w1.shape[0] // 2) + (x.shape[1] if w3 is not None else 0)),
+    float(2 * (x.numel() * (2 + (residual is not None and residual is not x) + (residual3 is not None)) + w1.numel() + w2img.numel() + (w3.numel() if w3 is not None else 0))),
+    2 if colstats is not None else 1))
 _ln_gemm_fused = _wrap_profiled(_ln_gemm_launch, _ln_gemm_label)
 _gemm_ln_launch = _wrap_profiled(_gemm_ln_launch, _gemm_ln_label)
 gemm = _wrap_profiled(gemm, _gemm_label)

@@ -30,6 +30,10 @@ SD15 = dict(image_size=64, in_channels=8, model_channels=320, out_channels=4, nu
             attention_resolutions=[4, 2, 1], channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
             transformer_depth=1, context_dim=768, legacy=False)
 GFLOP_PER_UNET_SAMPLE = 803.4  # BASELINE.md §2 (64x64 latent)
+# multiply-adds the four-2x2-conv form of the three Upsample convs does not execute (5/9 of 2 * HW_out * Cout * 9 * Cin; 1280 -> 1280 @16^2, 1280 -> 1280 @32^2,
+# 640 -> 640 @64^2 per sample), in GFLOP, by latent side; 0 when AE_UP2_SUBPIXEL=0 restores the gather form
+_up2 = lambda side: (5.0 / 9.0) * 2 * 9 * ((side // 4) ** 2 * 1280 * 1280 + (side // 2) ** 2 * 1280 * 1280 + side ** 2 * 640 * 640) / 1e9  # noqa: E731
+UP2_SKIPPED_GFLOP = {64: _up2(64) if os.environ.get("AE_UP2_SUBPIXEL", "1") != "0" else 0.0, 96: _up2(96) if os.environ.get("AE_UP2_SUBPIXEL", "1") != "0" else 0.0}
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBPS = 8000.0
 # What the matrix pipes SUSTAIN on this part under its 1400 W package-power limit with random bf16 operands, measured by a pure-MFMA loop on every SIMD
@@ -284,7 +288,13 @@ def main():
             "per_rank_ms_per_step": {"min": 1e3 * min(per_rank) / args.steps, "max": 1e3 * max(per_rank) / args.steps,
                                      "all": [round(1e3 * v / args.steps, 3) for v in per_rank]},
             "unet_step_ms": ms_per_step / n_unet_steps,
+            # MODEL FLOPs of the reference graph (803.4 GFLOP per sample and evaluation) per second — the Upsample convs execute 4/9 of their
+            # share since round 5 (four 2x2 convs), so the EXECUTED rate is lower: both are reported
             "unet_tflops": 3 * B * (GFLOP_PER_UNET_SAMPLE if args.latent == 64 else 2148.3 if args.latent == 96 else float("nan")) * n_unet_steps / (ms_per_step * 1e-3) / 1e3,
+            "unet_tflops_kind": "model FLOPs of the reference graph",
+            "unet_tflops_executed": 3 * B * ((GFLOP_PER_UNET_SAMPLE - UP2_SKIPPED_GFLOP[64]) if args.latent == 64 else (2148.3 - UP2_SKIPPED_GFLOP[96]) if args.latent == 96 else float("nan"))
+            * n_unet_steps / (ms_per_step * 1e-3) / 1e3,
+            "unet_step_ms_p50_note": "graph replay with the time-embedding chain hoisted out of the step since round 5 (4 launches fewer than rounds <= 4)",
         }
         # BASELINE.json's second metric: UNet-step ms p50 — per-replay HIP-event timing of the captured UNet evaluation
         if pipe._graph is not None:
@@ -301,7 +311,7 @@ def main():
             # eager (un-graphed) UNet evaluation with a HIP-event pair around every kernel launch on the launch stream
             pipe.prepare(img_lat, ehs, null, ref, code)
             pipe._x_in[:, :4].view(3, B, 4, args.latent, args.latent).copy_(x_T.unsqueeze(0))
-            pipe._t.fill_(501)
+            pipe.set_step(501)   # (also refreshes the hoisted time-embedding rows the evaluation reads: ADVICE r5)
             for _ in range(2):
                 pipe._denoise_static()
             torch.cuda.synchronize()

@@ -79,17 +79,23 @@ int ae_gemm_ln_bf16(const void* A, long lda, const void* W, long ldw, void* C, l
                     const float* ln_colsum, float ln_eps, void* stream);
 
 /* Fused feed-forward of a BasicTransformerBlock at the 64x64 UNet level (round 6; ldm/modules/attention.py:49-76 FeedForward / GEGLU behind norm3 of
- * BasicTransformerBlock._forward :271-275, `x = self.ff(self.norm3(x)) + x`) — ONE launch for LayerNorm -> GEGLU projection -> exact-erf gate -> ff2
- * (+ bias, + residual); the [M, H] gated hidden activation stays in registers (it was 126 MB written and re-read at UNet batch 12):
- *   Y[M,C] = ( a .* gelu(g) ) W2^T + b2 (+ residual),   [a | g] = LayerNorm(X; gamma, beta, eps) W1^T + b1,   C = 320.
- *   X, Y, residual bf16 rows (16-byte aligned, strides % 8 == 0); W1 bf16 [2H, C] and b1 fp32 [2H] in the AE_EPI_GEGLU row order (16 'a' rows then
- *   their 16 gate rows); W2img bf16 [H / 32][C][32]: ff2's weight as the kernel's LDS images (row order, k permutation and 16-byte piece rotation
- *   as the header of csrc/ff_fused.hip states them; ops.pack_ff2_fused builds it once per weight version); b2 fp32 [C] or NULL.
+ * BasicTransformerBlock._forward :271-275, `x = self.ff(self.norm3(x)) + x`, and — optionally — SpatialTransformer.proj_out + its residual behind the
+ * block, :337-340) — ONE launch for LayerNorm -> GEGLU projection -> exact-erf gate -> ff2 (+ bias, + residual) [-> proj_out (+ bias, + residual3)];
+ * the [M, H] gated hidden activation stays in registers (it was 126 MB written and re-read at UNet batch 12), and with W3 so does the block's output:
+ *   F[M,C] = ( a .* gelu(g) ) W2^T + b2 (+ residual),   [a | g] = LayerNorm(X; gamma, beta, eps) W1^T + b1,   C = 320;
+ *   Y = F (W3 == NULL)   or   Y[M,C] = bf16(F) W3^T + b3 (+ residual3).
+ *   X, Y, residual, residual3 bf16 rows (16-byte aligned, strides % 8 == 0; Y aliases neither X nor residual3); W1 bf16 [2H, C] and b1 fp32 [2H] in the
+ *   AE_EPI_GEGLU row order (16 'a' rows then their 16 gate rows); W2img bf16 [H / 32][C][32]: ff2's weight as the kernel's LDS images (row order, k
+ *   permutation and 16-byte piece rotation as the header of csrc/ff_fused.hip states them; ops.pack_ff2_fused builds it once per weight version); b2 fp32
+ *   [C] or NULL; W3 bf16 [C, C] row-major (ldw3) or NULL, b3 fp32 [C] or NULL; colstats: as for ae_gemm_bf16 (statistics of Y for the GroupNorm that
+ *   consumes it; with W3 only), NULL = none.
  * ae_ff_fused_supported(M, C, H): 1 where the kernel covers the shape (C == 320, H % 64 == 0, H <= 1280, M >= 192 * 192 rows: one 192-row block per
- * CU), 0 otherwise — callers then run ae_gemm_ln_bf16 / ae_ln_gemm_bf16 (GEGLU) + ae_gemm_bf16.  AE_FF_FUSED=0 answers 0 everywhere (A/B).       */
+ * CU), 0 otherwise — callers then run ae_gemm_ln_bf16 / ae_ln_gemm_bf16 (GEGLU) + ae_gemm_bf16 (+ ae_ln_gemm_bf16 for proj_out).  AE_FF_FUSED=0
+ * answers 0 everywhere (A/B).                                                                                                                     */
 int ae_ff_fused_supported(int M, int C, int H);
 int ae_ff_fused_bf16(const void* X, long ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* W1, long ldw1, const float* b1,
-                     const void* W2img, const float* b2, const void* residual, long ldr, void* Y, long ldy, int M, int C, int H, void* stream);
+                     const void* W2img, const float* b2, const void* residual, long ldr, const void* W3, long ldw3, const float* b3,
+                     const void* residual3, long ldr3, float* colstats, void* Y, long ldy, int M, int C, int H, void* stream);
 
 /* 3x3 convolution, padding 1, as implicit GEMM (ResBlock in/out convs openaimodel.py:200-231, stem :536-542, head :726-730,
  * Downsample stride 2 :157-159, Upsample nearest-x2 + conv :108-118 via upsample2x=1).

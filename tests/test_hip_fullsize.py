@@ -119,14 +119,14 @@ def test_masked_edit_5_steps_cfg_full_size_96():
             return A.moe_forward(unet_weights, SD15, weights, prefixes, x_in, t, text_embedding, ref3, code3)
         return D.ip2p_edit_loop(unet_fn, buffers, steps, x_T, img_lat, ehs, null, 7.5, 1.5, mask=mask, x0=x0, noise_for_blend=blend_noise)
 
-    # The bf16-storage control loop doubles the host time (~5 minutes for both on 32 threads), so it runs only on request
-    # (AE_TEST_EDIT_CONTROL=1, the evidence run: profiles/r02_pytest_gpu_full.txt — HIP 3.70e-2 / 51.4 dB, control 3.77e-2 / 51.2 dB);
-    # by default the bound is 1.5 x that recorded control.
+    # The bf16-storage control loop is measured in the same run (round 6: until then the default bound was 1.5 x a control RECORDED in round 2 and the
+    # control itself ran only under AE_TEST_EDIT_CONTROL=1 — a bound that does not move with the code is not derived).  It doubles the host time of this
+    # test (~2.5 minutes more on 32 threads); AE_TEST_EDIT_CONTROL=0 falls back to the recorded figure for quick local runs.
     t0 = time.time()
     with torch.no_grad():
         ref = run_oracle(sd, unet_sd)
         ctl = None
-        if os.environ.get("AE_TEST_EDIT_CONTROL") == "1":
+        if os.environ.get("AE_TEST_EDIT_CONTROL", "1") != "0":
             with L.bf16_storage():
                 sdb = L.bf16_weights(sd)
                 ctl = run_oracle(sdb, {k[5:]: v for k, v in sdb.items() if k.startswith("unet.")})
@@ -145,3 +145,65 @@ def test_masked_edit_5_steps_cfg_full_size_96():
     assert rel_l2(out[keep], ref[keep]) <= 1e-5
     assert math.isfinite(e_hip) and e_hip <= 1.5 * e_ctl, f"HIP {e_hip:.3e} vs control {e_ctl:.3e}"
     assert e_hip <= 4e-2 and psnr(out, ref) >= 36.0
+
+
+@pytest.mark.skipif(os.environ.get("AE_TEST_EDIT50") != "1", reason="~15 minutes of host oracle time: AE_TEST_EDIT50=1 (evidence visits; record in profiles/)")
+def test_edit_50_steps_cfg_full_size_64_metric_length():
+    """Parity at the METRIC's own length (BASELINE.json configs[1]; ldm/models/diffusion/ddim.py:122-251, tools/global_tool.py:160-184): 50 DDIM steps,
+    3-branch CFG 7.5 / 1.5 at 64x64 latents, AnySD routing and adapters on.  The HIP pipeline runs the PRODUCTION plan — four copies of the edit, UNet batch
+    12, captured graph, i.e. the tile plans, the fused feed-forward and the row-panel kernels the bench line is measured on — and its first image is compared
+    with `oracle.ddim_ref.ip2p_edit_loop` at batch 1 on the same weights, and with the bf16-storage control of the same loop: err(HIP) <= 1.5 x err(control).
+    The four copies must agree bit for bit (no kernel mixes samples)."""
+    from oracle import ddim_ref as D, schedule_ref as S, anysd_ref as A, ldm_ref as L
+    from anyedit_amd.anysd.pipeline import EditPipeline
+    from anyedit_amd.ldm.models.diffusion.ddpm import DDPM
+    _threads()
+    moe, sd = _model()
+    unet_sd = {k[5:]: v for k, v in sd.items() if k.startswith("unet.")}
+    prefixes = [n + ".attn2." for n, m in moe.unet.named_modules() if m.__class__.__name__ == "BasicTransformerBlock"]
+    H, steps, copies = 64, int(os.environ.get("AE_TEST_EDIT50_STEPS", "50")), 4
+    g = torch.Generator().manual_seed(77)
+    x_T = torch.randn(1, 4, H, H, generator=g)
+    img_lat = torch.randn(1, 4, H, H, generator=g) * 0.18215
+    ehs, null = torch.randn(1, 77, 768, generator=g), torch.randn(1, 77, 768, generator=g)
+    ref_emb = torch.randn(1, 257, 1280, generator=g)
+    code = torch.tensor([5])
+    buffers = S.register_schedule("linear", 1000, 0.00085, 0.0120)
+    ref3 = torch.cat([ref_emb, ref_emb, torch.zeros_like(ref_emb)])
+    code3 = torch.cat([code] * 3)
+    trace = {}
+
+    def run_oracle(weights, unet_weights, tag):
+        inter = []
+
+        def unet_fn(x_in, t, text_embedding):
+            inter.append(x_in[:1, :4].clone())          # the latent entering each step (branch 0 of the 3-branch batch)
+            return A.moe_forward(unet_weights, SD15, weights, prefixes, x_in, t, text_embedding, ref3, code3)
+        out = D.ip2p_edit_loop(unet_fn, buffers, steps, x_T, img_lat, ehs, null, 7.5, 1.5)
+        trace[tag] = inter
+        return out
+
+    t0 = time.time()
+    with torch.no_grad():
+        ref = run_oracle(sd, unet_sd, "ref")
+        with L.bf16_storage():
+            sdb = L.bf16_weights(sd)
+            ctl = run_oracle(sdb, {k[5:]: v for k, v in sdb.items() if k.startswith("unet.")}, "ctl")
+    t_oracle = time.time() - t0
+    sched = DDPM(moe.unet, timesteps=1000, linear_start=0.00085, linear_end=0.0120).to(DEV)
+    pipe = EditPipeline(moe, sched, use_graph=True)
+    rep = lambda t: t.repeat(copies, *([1] * (t.dim() - 1))).to(DEV)  # noqa: E731
+    out4 = pipe.edit(rep(x_T), rep(img_lat), rep(ehs), rep(null), rep(ref_emb), code.repeat(copies).to(DEV), steps=steps, s_txt=7.5, s_img=1.5).float().cpu()
+    for i in range(1, copies):
+        assert torch.equal(out4[i], out4[0]), f"copy {i} of the edit differs from copy 0"
+    out = out4[:1]
+    e_hip, e_ctl = rel_l2(out, ref), rel_l2(ctl, ref)
+    # growth of the control's distance over the loop (the latent entering step i), for the record
+    grow = [rel_l2(c, r) for c, r in zip(trace["ctl"], trace["ref"])]
+    marks = {i: grow[i] for i in (1, 2, 5, 10, 20, 30, 40, len(grow) - 1) if i < len(grow)}
+    nmse = float(((out - ref) ** 2).mean()) / float(ref.max() - ref.min()) ** 2
+    print(f"\n{steps}-step CFG edit @64x64 (UNet batch 12 plan): HIP rel-L2 {e_hip:.3e} ({psnr(out, ref):.1f} dB, MSE / range^2 {nmse:.2e}), bf16-storage control "
+          f"{e_ctl:.3e} ({psnr(ctl, ref):.1f} dB), ratio {e_hip / e_ctl:.2f}, oracle time {t_oracle:.0f} s; control rel-L2 of the latent entering step i: "
+          + ", ".join(f"{i}: {v:.2e}" for i, v in marks.items()))
+    assert math.isfinite(e_hip) and e_hip <= 1.5 * e_ctl, f"HIP {e_hip:.3e} vs control {e_ctl:.3e}"
+    assert nmse <= 1e-3, "north_star: within 1e-3 PSNR-equivalent, read as MSE / range^2 <= 1e-3 (DESIGN.md §4)"

@@ -228,6 +228,30 @@ def test_feed_forward_fused_one_launch(ops, M, H, res):
     assert e1 <= 1.25 * e2 + 5e-4, (e1, e2)
     y3 = ops.ff_fused(xd, gamma.to(DEV), beta.to(DEV), 1e-5, w1p, b1p, w2img, b2.to(DEV), residual=xd if res else None)
     assert torch.equal(y, y3), "the fused feed-forward is not run-to-run bit-equal"
+    # with the projection that follows the block in the same launch (SpatialTransformer.proj_out + its residual, attention.py:337-340): the bf16-rounded
+    # feed-forward result times W3^T — the same arithmetic as the separate launch on the stored result, so the two agree to the order of an fp32 sum
+    w3 = q(torch.randn(C, C, generator=g) / C ** 0.5)
+    b3 = 0.1 * torch.randn(C, generator=g)
+    r3 = q(torch.randn(M, C, generator=g))
+    cs = ops.colstats_buffer(M, C, DEV)
+    cs.fill_(float("nan"))
+    z3 = ops.ff_fused(xd, gamma.to(DEV), beta.to(DEV), 1e-5, w1p, b1p, w2img, b2.to(DEV), residual=xd if res else None, w3=w3.to(DEV, BF), b3=b3.to(DEV),
+                      residual3=r3.to(DEV, BF), colstats=cs)
+    z3_two = ops.gemm(y, w3.to(DEV, BF), bias=b3.to(DEV), residual=r3.to(DEV, BF))
+    ref3 = y.float().cpu().double() @ w3.double().t() + b3.double() + r3.double()
+    check_close(z3, ref3.float(), what=f"fused feed-forward + proj_out {M}x{H}")
+    e3 = rel_l2(z3.float().cpu(), z3_two.float().cpu())
+    assert e3 <= 2.5e-3, f"fused proj_out tail vs its own launch: {e3:.3e}"
+    zs = z3.float().cpu()
+    pad = (-M) % 32
+    zp = torch.cat([zs, torch.zeros(pad, C)]).reshape(-1, 32, C)
+    got = cs.cpu()
+    assert torch.isfinite(got).all()
+    assert float((got[..., 0] - zp.sum(1)).abs().max()) <= 1e-4 * float(zp.abs().sum(1).max())
+    assert float((got[..., 1] - (zp * zp).sum(1)).abs().max()) <= 1e-4 * float((zp * zp).sum(1).max())
+    z4 = ops.ff_fused(xd, gamma.to(DEV), beta.to(DEV), 1e-5, w1p, b1p, w2img, b2.to(DEV), residual=xd if res else None, w3=w3.to(DEV, BF), b3=b3.to(DEV),
+                      residual3=r3.to(DEV, BF))
+    assert torch.equal(z3, z4), "the fused feed-forward + proj_out is not run-to-run bit-equal"
 
 
 @pytest.mark.parametrize("B,H,W,Cout", [(2, 16, 16, 64), (1, 5, 7, 320), (12, 64, 64, 320)])

@@ -191,6 +191,27 @@ def test_edit_pipeline_vs_oracle_loop_and_graph_replay():
         e_hip = rel_l2(out.float().cpu(), ref)
         assert e_hip <= 1.5 * e_ctl + 1e-3, f"edit pipeline: HIP {e_hip:.3e} vs bf16-storage control {e_ctl:.3e}"
     assert torch.equal(outs[0], outs[1]), "HIP-graph replay must reproduce the eager launches bit for bit"
+    # the time-embedding chain hoisted out of the loop (one M = steps pass, a row broadcast per step) against the per-step chain (AE_HOIST_TEMB=0): the
+    # same GEMMs on the same rows -> the same latents; and `set_step` alone (what bench.py's roofline pass and the tools use) reproduces
+    # the embedding rows the loop would have installed for that timestep
+    import os
+    os.environ["AE_HOIST_TEMB"] = "0"
+    try:
+        pipe0 = EditPipeline(moe, sched, use_graph=False)
+        pipe0.randn = lambda shape, device=None: blend_noise.to(device)
+        out0 = pipe0.edit(x_T.to(DEV), img_lat.to(DEV), ehs.to(DEV), null.to(DEV), ref_emb.to(DEV), code.to(DEV), steps=steps,
+                          s_txt=7.5, s_img=1.5, mask=mask.to(DEV), x0=x0.to(DEV))
+        assert pipe0._emb_pack is None
+    finally:
+        del os.environ["AE_HOIST_TEMB"]
+    e_h = rel_l2(out0.float().cpu(), outs[0].float())
+    assert e_h <= 2e-3, f"hoisted vs per-step time embedding: {e_h:.3e}"
+    assert pipe._emb_pack is not None
+    last = pipe._emb_pack.all.clone()
+    pipe.set_step(int(np.flip(pipe.sampler.ddim_timesteps)[1]))
+    assert not torch.equal(pipe._emb_pack.all, last)
+    pipe.set_step(int(np.flip(pipe.sampler.ddim_timesteps)[-1]))
+    assert torch.equal(pipe._emb_pack.all, last), "set_step must install the rows the loop installs for the same timestep"
 
 
 # ------------------------------------------------------------------------------------------------------------ training step (A11)

@@ -19,7 +19,7 @@ def make_pipe(moe, sched, B, dev, rank):
     p = EditPipeline(moe, sched, use_graph=True)
     p.prepare(img_lat, ehs, null, ref, code)
     p._x_in[:, :4].copy_(torch.cat([x_T] * 3, 0))
-    p._t.fill_(500)
+    p.set_step(500)
     p._ensure_graph(("probe", B))
     return p
 

@@ -66,6 +66,18 @@ def main():
         ops.ln_gemm(xd, gd, bd, 1e-5, w1p, b1p, epilogue=ops.EPI_GEGLU, out=hbuf)
         ops.gemm(hbuf, w2d, bias=b2d, residual=xd, out=y2)
 
+    w3 = (torch.randn(C, C, generator=g) / C ** 0.5).to(DEV, BF)
+    b3 = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    r3 = torch.randn(M, C, generator=g).to(DEV, BF)
+    y3, y4 = torch.empty(M, C, dtype=BF, device=DEV), torch.empty(M, C, dtype=BF, device=DEV)
+
+    def fused_tail():
+        ops.ff_fused(xd, gd, bd, 1e-5, w1p, b1p, w2img, b2d, residual=xd, out=y3, w3=w3, b3=b3, residual3=r3)
+
+    def three_fold():
+        two_fold()
+        ops.gemm(y2, w3, bias=b3, residual=r3, out=y4)
+
     res = {"M": M, "C": C, "H": H, "iters": a.iters}
     if not ops.ff_fused_ok(M, C, H):
         print(json.dumps({"error": "fused kernel does not cover this shape", **res}))
@@ -84,14 +96,16 @@ def main():
     fused(); torch.cuda.synchronize()
     res["bit_equal_repeat"] = bool(torch.equal(y, y_first))
     flop = 3 * 2.0 * M * C * H
-    t = {"fused": [], "two_fold": [], "two_prologue": []}
+    fused_tail(); three_fold(); torch.cuda.synchronize()
+    res["rel_l2_tail_vs_three_launches"] = float((y3.float() - y4.float()).norm() / y4.float().norm())
+    t = {"fused": [], "two_fold": [], "two_prologue": [], "fused_tail": [], "three_fold": []}
     for _ in range(a.rounds):
-        for name, fn in (("fused", fused), ("two_fold", two_fold), ("two_prologue", two_prologue)):
+        for name, fn in (("fused", fused), ("two_fold", two_fold), ("two_prologue", two_prologue), ("fused_tail", fused_tail), ("three_fold", three_fold)):
             timed(fn, 20)
             t[name].append(timed(fn, a.iters))
     for name, v in t.items():
         res[name + "_us"] = [round(u, 2) for u in v]
-        res[name + "_tflops"] = round(flop / (min(v) * 1e-6) / 1e12, 1)
+        res[name + "_tflops"] = round((flop + (2.0 * M * C * C if name in ("fused_tail", "three_fold") else 0.0)) / (min(v) * 1e-6) / 1e12, 1)
     print(json.dumps(res))
 
 
