@@ -665,18 +665,22 @@ __global__ __launch_bounds__(64 * NWV, OCC) void attn_fast_kernel(const AttnArgs
 // the logits of the NEXT tile's first block can be multiplied while the current tile's second block is still being reduced (one barrier per
 // 64-key tile as before: tile t + 2 is issued into the buffer of tile t - 1 behind the barrier that proves every wave has left tile t - 1).
 // Envelope: head dim 40, Nk a multiple of 64 and >= 128, no bias / mask / second segment (everything else: attn_fast_kernel).
-template <int D>
+// KT: keys per LDS tile (64: rounds 5's form; 128, round 6: half the block barriers — DESIGN 7.00c priced the two barriers' worth of waiting per 64-key tile at
+// 16 % of the wave cycles — for 74 KiB instead of 31 KiB of LDS per block, still two blocks per CU).  Same MFMAs on the same operands in the same order: bit-identical.
+template <int D, int KT>
 __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
+    static_assert(KT == 64 || KT == 128, "keys per tile");
+    constexpr int NBLK = KT / 32, VDB = KT * 64, KP = KT * (D / 8) / 64;   // 32-key blocks per tile; bytes of a V image per 32-wide d-block; 1-KiB pieces of a K (or V) tile
     static_assert(D == 40, "pipelined kernel: head dim 40 (K steps 3 with a free slot, two 32-row output blocks)");
     constexpr int QG = 2;
     constexpr int KS = (D + 15) / 16;
     constexpr int NDB = D / 32 + 1, LDB = D / 32, LREG = 4 * ((D % 32) / 8);
-    constexpr int ROWB = 2 * D, CH = D / 8, TILEB = FKT * ROWB, BUFB = 2 * TILEB, NTB = 3;
+    constexpr int ROWB = 2 * D, CH = D / 8, TILEB = KT * ROWB, BUFB = 2 * TILEB, NTB = 3;
     constexpr int ONES_OFF = NTB * BUFB;
     constexpr int NFULL = D / 32, REM = D % 32, RS = REM * 2 > 16 ? REM * 2 : 16, RC = REM / 8;
     constexpr int VONES_OFF = ONES_OFF + TILEB + 64;
-    constexpr int LDSB = VONES_OFF + 64 * RS;
-    constexpr int NPIECE = 2 * CH, NWV = 4, MAXP = (NPIECE + NWV - 1) / NWV;
+    constexpr int LDSB = VONES_OFF + KT * RS;
+    constexpr int NPIECE = 2 * KP, NWV = 4, MAXP = (NPIECE + NWV - 1) / NWV;
     __shared__ __attribute__((aligned(16))) char smem[LDSB];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -689,8 +693,8 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
     const int b = bh / p.H, h = bh - b * p.H;
     const int q0 = qb * QB + wave * 32 * QG;
 
-    if (tid < FKT) *reinterpret_cast<u32x4*>(smem + ONES_OFF + tid * ROWB) = (u32x4){0x00003F80u, 0u, 0u, 0u};
-    if (tid < FKT) *reinterpret_cast<u32x4*>(smem + VONES_OFF + tid * RS) = (u32x4){0x00003F80u, 0u, 0u, 0u};
+    if (tid < KT) *reinterpret_cast<u32x4*>(smem + ONES_OFF + tid * ROWB) = (u32x4){0x00003F80u, 0u, 0u, 0u};
+    if (tid < KT) *reinterpret_cast<u32x4*>(smem + VONES_OFF + tid * RS) = (u32x4){0x00003F80u, 0u, 0u, 0u};
 
     // Q^T operand: lane (q = l31, hi) holds c Q[q][16 ks + 8 hi .. + 8], zero beyond head_dim (slot D carries -m~ later)
     const bf16_t* qp = p.q + (long)b * p.q_sb + (long)h * p.q_sh;
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
     const int vaddr = TILEB + vrow * 64 + (16 * (g & 1) + 4 * (l15 & 3)) * 2;
     const int vcol = 32 * LDB + 16 * (g & 1) + 4 * (l15 & 3);
     const bool ones_lane = vcol == D, zero_lane = vcol > D;
-    const int vlast0 = ones_lane ? VONES_OFF + vrow * RS : (zero_lane ? VONES_OFF + vrow * RS + 8 : TILEB + NFULL * 4096 + vrow * RS + (16 * (g & 1) + 4 * (l15 & 3)) * 2);
+    const int vlast0 = ones_lane ? VONES_OFF + vrow * RS : (zero_lane ? VONES_OFF + vrow * RS + 8 : TILEB + NFULL * VDB + vrow * RS + (16 * (g & 1) + 4 * (l15 & 3)) * 2);
     const int vl_mask = (ones_lane || zero_lane) ? 0 : -1;
 
     float mt[QG];
@@ -743,12 +747,12 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
         const int j = wave + NWV * i;
-        const bool isK = j < CH;
-        const int cidx = (isK ? j : j - CH) * 64 + lane;
+        const bool isK = j < KP;
+        const int cidx = (isK ? j : j - KP) * 64 + lane;
         int row = cidx / CH, cc = cidx - row * CH;
         if (!isK) {
-            if (cidx < NFULL * 256) { row = (cidx & 255) >> 2; cc = (cidx >> 8) * 4 + (cidx & 3); }
-            else { const int c2 = cidx - NFULL * 256; row = c2 / (RC > 0 ? RC : 1); cc = NFULL * 4 + (c2 - row * (RC > 0 ? RC : 1)); }
+            if (cidx < NFULL * KT * 4) { row = (cidx & (KT * 4 - 1)) >> 2; cc = (cidx / (KT * 4)) * 4 + (cidx & 3); }
+            else { const int c2 = cidx - NFULL * KT * 4; row = c2 / (RC > 0 ? RC : 1); cc = NFULL * 4 + (c2 - row * (RC > 0 ? RC : 1)); }
         }
         voff[i] = row * (isK ? ksn2 : vsn2) + cc * 16;
     }
@@ -758,8 +762,8 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
         for (int i = 0; i < MAXP; ++i) {
             const int j = wave + NWV * i;
             if (j < NPIECE) {
-                if (j < CH) dma16(rsK, lds0 + boff + j * 1024, voff[i] + t * FKT * ksn2);
-                else dma16(rsV, lds0 + boff + TILEB + (j - CH) * 1024, voff[i] + t * FKT * vsn2);
+                if (j < KP) dma16(rsK, lds0 + boff + j * 1024, voff[i] + t * KT * ksn2);
+                else dma16(rsV, lds0 + boff + TILEB + (j - KP) * 1024, voff[i] + t * KT * vsn2);
             }
         }
     };
@@ -857,7 +861,7 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int db = 0; db < NDB; ++db) {
-                    const int va = (db == LDB) ? vl + B2 * 32 * RS + kk * 16 * RS : vc + db * 4096 + B2 * 32 * 64 + kk * 16 * 64;
+                    const int va = (db == LDB) ? vl + B2 * 32 * RS + kk * 16 * RS : vc + db * VDB + B2 * 32 * 64 + kk * 16 * 64;
                     const int vstep = (db == LDB) ? 8 * RS : 8 * 64;
                     union { bf16x8_t b; u32x4 u; } cv;
                     cv.b = cat_tr(lds_tr16(smem + va), lds_tr16(smem + va + vstep));
@@ -898,7 +902,7 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
         if constexpr (NEXT) decide(sn, first, CUR ? kf[2] : kf[1], kf[2]);
     };
 
-    const int ntiles = p.Nk / FKT;   // launcher: Nk % 64 == 0, ntiles >= 2
+    const int ntiles = p.Nk / KT;   // launcher: Nk % KT == 0, ntiles >= 2
     f32x16 sA[QG], sB[QG];
     issue(0, 0);
     issue(1, BUFB);
@@ -906,25 +910,35 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
     if (ntiles > 2) issue(2, 2 * BUFB);
     using T0 = std::integral_constant<int, 0>;
     using T1 = std::integral_constant<int, 1>;
+    using T2 = std::integral_constant<int, 2>;
+    using T3 = std::integral_constant<int, 3>;
     using YES = std::true_type;
     using NO = std::false_type;
     step(T0{}, T0{}, NO{}, YES{}, 0, 0, sB, sA, true);   // prologue: logits of block (0, 0), the first offset
     int boff = 0, nboff = BUFB, iboff = 0;   // buffers of tile t, tile t + 1, and (after the rotation below) the one tile t + 2 lands in
     for (int t = 0; t + 1 < ntiles; ++t) {
-        // block (t, 0); next = (t, 1), same tile
+        // blocks (t, 0) .. (t, NBLK - 2); next = the following block of the same tile
         step(T0{}, T1{}, YES{}, YES{}, boff, boff, sA, sB, false);
-        // block (t, 1); next = (t + 1, 0): tile t + 1 must be visible to every wave.  Its pieces were issued a whole tile ago; the barrier also proves
+        if constexpr (NBLK == 4) {
+            step(T1{}, T2{}, YES{}, YES{}, boff, boff, sB, sA, false);
+            step(T2{}, T3{}, YES{}, YES{}, boff, boff, sA, sB, false);
+        }
+        // block (t, NBLK - 1); next = (t + 1, 0): tile t + 1 must be visible to every wave.  Its pieces were issued a whole tile ago; the barrier also proves
         // that every wave has left tile t - 1 (it has finished step (t, 0), which follows its last read of tile t - 1): tile t + 2 goes there.
         if (t > 0) {
             dma_wait_all_and_barrier();
             if (t + 2 < ntiles) issue(t + 2, iboff);
         }
-        step(T1{}, T0{}, YES{}, YES{}, boff, nboff, sB, sA, false);
+        step(std::integral_constant<int, NBLK - 1>{}, T0{}, YES{}, YES{}, boff, nboff, sB, sA, false);
         iboff = boff; boff = nboff; nboff = (nboff == 2 * BUFB) ? 0 : nboff + BUFB;
     }
-    // last tile: its second block has no successor
+    // last tile: its last block has no successor
     step(T0{}, T1{}, YES{}, YES{}, boff, boff, sA, sB, false);
-    step(T1{}, T0{}, YES{}, NO{}, boff, boff, sB, sA, false);
+    if constexpr (NBLK == 4) {
+        step(T1{}, T2{}, YES{}, YES{}, boff, boff, sB, sA, false);
+        step(T2{}, T3{}, YES{}, YES{}, boff, boff, sA, sB, false);
+    }
+    step(std::integral_constant<int, NBLK - 1>{}, T0{}, YES{}, NO{}, boff, boff, sB, sA, false);
 #undef AE_TIE0
 #undef AE_TIE1
 #undef AE_TIE2
@@ -1027,7 +1041,10 @@ int launch_fast(const AttnArgs& a, hipStream_t stream) {
     if constexpr (D == 40) {
         if ((var_env & 4) && (long)((a.Nq + 255) / 256) * a.B * a.H >= 512 && a.Nk % FKT == 0 && a.Nk >= 2 * FKT && !a.lse2) {
             dim3 grid2((unsigned)((long)((a.Nq + 255) / 256) * a.B * a.H));
-            hipLaunchKernelGGL((attn_pipe_kernel<D>), grid2, block, 0, stream, a);
+            // AE_ATTN_KT128 (round 6): 128-key tiles where the key count allows (one barrier per 128 keys); 0 = the 64-key form everywhere (A/B)
+            static const int kt128 = getenv("AE_ATTN_KT128") ? atoi(getenv("AE_ATTN_KT128")) : 1;
+            if (kt128 && a.Nk % 128 == 0 && a.Nk >= 256) hipLaunchKernelGGL((attn_pipe_kernel<D, 128>), grid2, block, 0, stream, a);
+            else hipLaunchKernelGGL((attn_pipe_kernel<D, 64>), grid2, block, 0, stream, a);
             return ae_check_launch("ae_attn_fwd_bf16(fast, pipelined)");
         }
     }

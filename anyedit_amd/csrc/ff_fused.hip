@@ -43,9 +43,6 @@ constexpr int FF_MAXH2 = 2560;
 #ifndef FF_LAB
 #define FF_LAB 0      // lab builds only (timing ablations, wrong results): 1 no DMA in the loop, 2 no gate arithmetic, 4 no W fragment reads, 8 no barrier / DMA wait
 #endif
-#ifndef FF_DMA_AT
-#define FF_DMA_AT 6   // a refill piece goes out behind MFMA 10 i + FF_DMA_AT of a phase
-#endif
 constexpr int FF_OOB = 0x40000000;                            // a per-lane offset beyond every descriptor: the piece reads zeros
 
 // MFMAs of the hand-placed loop (asm: program order is kept, the register file of each accumulator is the constraint's).  hipcc pads nothing around them:
@@ -266,8 +263,12 @@ __global__ __launch_bounds__(64 * FF_NW, 1) void ff_fused_kernel(const FFArgs p)
         }
     f32x4 acc1[2][FF_MF][2];
     u32x4 hf[2][FF_MF];
-#pragma unroll
-    for (int f = 0; f < FF_MF; ++f) hf[0][f] = hf[1][f] = (u32x4){0u, 0u, 0u, 0u};
+    // W fragment ring (slot k of a phase -> wfr[k % 6], read three slots ahead; 30 slots per phase, so the indices repeat phase after phase).  It lives
+    // ACROSS the phases: the fragments of a phase's last two slots (wfr[4], wfr[5]) are MFMA sources until two further MFMAs have been issued, i.e. until
+    // the second MFMA of the NEXT phase, whose own reads reach those entries only at its slots 1 and 2 — tests/test_isa_static.py found hipcc parking a
+    // constant in such a register two instructions behind its MFMA when the ring was local to a phase.
+    u32x4 wfr[6];
+    wfr[4] = wfr[5] = (u32x4){0u, 0u, 0u, 0u};
 
     // ---- One phase over the item at `slot` (30 fragment slots of three MFMAs: P1, P1, P2, ...):
     //   P1: acc1[WB] = [a | g] pre-activations of the item's W1 chunk (20 slots);
@@ -286,30 +287,41 @@ __global__ __launch_bounds__(64 * FF_NW, 1) void ff_fused_kernel(const FFArgs p)
             ba = *reinterpret_cast<const f32x4*>(sc1 + gate_n0 + 4 * g);
             bg = *reinterpret_cast<const f32x4*>(sc1 + gate_n0 + 16 + 4 * g);
         }
-        u32x4 wfr[5];
-        // fragment slot k: k % 3 == 2 -> P2 column fragment k / 3 of the half; else P1 fragment i = 2 (k / 3) + k % 3 (ks = i >> 1, nf = i & 1)
-        auto wread = [&](int k) {
+        // Fragment slots of the phase, in issue order (three MFMAs each): a full phase runs the 30 slots P1, P1, P2, ...; the prologue (P1 alone) and the tail
+        // (P2 alone) run the 20 / 10 slots of their kind back to back, so that "two further MFMAs" means the same everywhere.  Slot e is fragment k(e) of
+        // the item: k % 3 == 2 -> P2 column fragment k / 3 of the half; else P1 fragment i = 2 (k / 3) + k % 3 (ks = i >> 1, nf = i & 1).  Ring entry of slot
+        // e: (e + 30 - NS) % 6 — the last two slots of EVERY phase sit in wfr[4], wfr[5].
+        constexpr int NS = (DP1 ? 20 : 0) + (DP2 ? 10 : 0), NP = 3 * NS, ROFF = 30 - NS;
+        constexpr int DSTEP = NP / 9, DOFF = DSTEP > 6 ? 6 : DSTEP / 2;           // refill piece i behind MFMA DSTEP i + DOFF (full phase: 10 i + 6)
+        auto kslot = [](int e) { return (DP1 && DP2) ? e : (DP1 ? (e / 2) * 3 + e % 2 : 3 * e + 2); };
+        auto wread = [&](int e) {
+            const int k = kslot(e);
             if (k % 3 == 2) return *reinterpret_cast<const u32x4*>(slot + w2o + (k / 3) * 1024);
             const int i = 2 * (k / 3) + k % 3;
             return *reinterpret_cast<const u32x4*>(slot + (((i >> 1) & 1) ? w1o1 : w1o0) + (i >> 2) * 128 + (i & 1) * 16 * FF_ROWB);
         };
-        wfr[0] = wread(0); wfr[1] = wread(1); wfr[2] = wread(2);
+        wfr[ROFF % 6] = wread(0); wfr[(ROFF + 1) % 6] = wread(1); wfr[(ROFF + 2) % 6] = wread(2);
         float xa[4], xg[4], t4[4], pl[4], e4[4];
-        ff_static_for<0, 90>([&](auto pc) {
-            constexpr int P = decltype(pc)::value, k = P / 3, f = P % 3;
-            if constexpr (!(FF_LAB & 4) && f == 0 && k + 3 < 30) wfr[(k + 3) % 5] = wread(k + 3);
+        ff_static_for<0, NP>([&](auto pc) {
+            constexpr int P = decltype(pc)::value, e = P / 3, f = P % 3, k = (DP1 && DP2) ? e : (DP1 ? (e / 2) * 3 + e % 2 : 3 * e + 2);
+            if constexpr (!(FF_LAB & 4) && f == 0 && e + 3 < NS) wfr[(e + 3 + ROFF) % 6] = wread(e + 3);
             if constexpr (k % 3 == 2) {
-                if constexpr (DP2) ff_mfma_a(acc2[f][10 * HALF + k / 3], wfr[k % 5], hf[1 - HB][f]);
-            } else if constexpr (DP1) {
+                ff_mfma_a(acc2[f][10 * HALF + k / 3], wfr[(e + ROFF) % 6], hf[1 - HB][f]);
+            } else {
                 constexpr int i = 2 * (k / 3) + k % 3, ks = i >> 1, nf = i & 1;
-                if constexpr (ks == 0) ff_mfma_v0(acc1[WB][f][nf], wfr[k % 5], af[f][ks]);
-                else ff_mfma_v(acc1[WB][f][nf], wfr[k % 5], af[f][ks]);
+                if constexpr (ks == 0) ff_mfma_v0(acc1[WB][f][nf], wfr[(e + ROFF) % 6], af[f][ks]);
+                else ff_mfma_v(acc1[WB][f][nf], wfr[(e + ROFF) % 6], af[f][ks]);
             }
-            if constexpr (f == 1 && k >= 1) ff_keep(wfr[(k - 1) % 5]);   // the slot before: its last MFMA is two MFMAs back now
-            if constexpr (!(FF_LAB & 1) && P % 10 == FF_DMA_AT && P / 10 < FF_PPW) issue_piece(rit, P / 10);
+            if constexpr (f == 1 && e >= 1) ff_keep(wfr[(e - 1 + ROFF) % 6]);   // the slot before: its last MFMA is two MFMAs back now
+            if constexpr (P == 1) {   // sources of the last MFMAs of the phase before: its last two W fragments, and the gated values its P2 read (the buffer this step's gate refills)
+                ff_keep(wfr[4]); ff_keep(wfr[5]);
+                ff_keep(hf[HB][0]); ff_keep(hf[HB][1]); ff_keep(hf[HB][2]);
+            }
+            if constexpr (!(FF_LAB & 1) && P % DSTEP == DOFF && P / DSTEP < FF_PPW) issue_piece(rit, P / DSTEP);
             // the gate arithmetic as single VALU operations, two (sometimes three) behind every MFMA: 3 fragments x 62 operations over the 90 MFMAs.  (In
             // slices of eight behind every fourth MFMA — the first form — the wave hid two of each eight: +30 us per launch, profiles/r06_ff_fused_notes.txt.)
             if constexpr (DOG) {
+                static_assert(!DOG || NP == 90, "the gate rides in full phases");
                 ff_static_for<ff_op_lo(P), ff_op_lo(P + 1)>([&](auto tc) {
                     constexpr int t = decltype(tc)::value, gf = t / 62, u = t % 62;
                     ff_gate_op<u>(acc1[1 - WB][gf][0], acc1[1 - WB][gf][1], ba, bg, xa, xg, t4, pl, e4, hf[HB][gf], HALF);
@@ -317,7 +329,6 @@ __global__ __launch_bounds__(64 * FF_NW, 1) void ff_fused_kernel(const FFArgs p)
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        ff_keep(wfr[29 % 5]);
     };
     // phase item j: its pieces (and every other wave's) have landed; every wave is done with item j - 1, whose slot takes item j + 3
     auto open_item = [&]() {
@@ -326,8 +337,6 @@ __global__ __launch_bounds__(64 * FF_NW, 1) void ff_fused_kernel(const FFArgs p)
             __builtin_amdgcn_s_barrier();
         }
         asm volatile("" ::: "memory");
-#pragma unroll
-        for (int f = 0; f < FF_MF; ++f) { ff_keep(hf[0][f]); ff_keep(hf[1][f]); }   // MFMA sources of the phase before: no temporaries in them yet
         __builtin_amdgcn_sched_barrier(0);
     };
     using C0 = std::integral_constant<int, 0>;
@@ -358,11 +367,16 @@ __global__ __launch_bounds__(64 * FF_NW, 1) void ff_fused_kernel(const FFArgs p)
     phase(C1{}, C0{}, C0{}, F{}, F{}, T{}, C1{}, 0, 2 * nsteps + 4);
     open_item();
     phase(C0{}, C0{}, C1{}, F{}, F{}, T{}, C2{}, 0, 2 * nsteps + 5);
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results are read below (asm MFMAs: hipcc pads nothing)
+    asm volatile("s_nop 15\n\ts_nop 15" ::"v"(wfr[0]), "v"(wfr[1]), "v"(wfr[2]), "v"(wfr[3]), "v"(wfr[4]), "v"(wfr[5]) : "memory");   // the last MFMAs' results are read below (asm MFMAs: hipcc pads nothing); their sources live until here
 #pragma unroll
     for (int f = 0; f < FF_MF; ++f)
 #pragma unroll
         for (int cf = 0; cf < FF_NCF; ++cf) asm volatile("" : "+a"(acc2[f][cf]));
+    {   // the W fragments stay sources until an instruction has READ the result of the last MFMA issued (in-order matrix pipe: everything before it has finished)
+        float pr = acc2[FF_MF - 1][FF_NCF - 1][3];
+        asm volatile("" : "+v"(pr) : "v"(wfr[0]), "v"(wfr[1]), "v"(wfr[2]), "v"(wfr[3]), "v"(wfr[4]), "v"(wfr[5]));
+        acc2[FF_MF - 1][FF_NCF - 1][3] = pr;
+    }
 
     // ---- epilogue of the feed-forward: + b2 + residual.  A lane's fragments 2 j / 2 j + 1 are eight consecutive columns 32 j + 8 g .. + 7 (the W2 image's row
     // order): a 16-byte store — or, PROJ, exactly the B operand fragment of k step j of the next product: the rounded result replaces the X fragments in `af`.
@@ -433,19 +447,24 @@ __global__ __launch_bounds__(64 * FF_NW, 1) void ff_fused_kernel(const FFArgs p)
             __builtin_amdgcn_sched_barrier(0);
             const char* const slot = smem + (c & (FF_NSLOT - 1)) * FF_SLOTB;
             f32x4 acc3[FF_MF][2];
-            u32x4 wfr[5];
             auto wread = [&](int i) { return *reinterpret_cast<const u32x4*>(slot + w1off[(i >> 1) & 1] + (i >> 2) * 128 + (i & 1) * 16 * FF_ROWB); };
             wfr[0] = wread(0); wfr[1] = wread(1); wfr[2] = wread(2);
             ff_static_for<0, 60>([&](auto pc) {
                 constexpr int P = decltype(pc)::value, i = P / 3, f = P % 3, ks = i >> 1, nf = i & 1;
-                if constexpr (f == 0 && i + 3 < 20) wfr[(i + 3) % 5] = wread(i + 3);
-                if constexpr (ks == 0) ff_mfma_v0(acc3[f][nf], wfr[i % 5], af[f][ks]);
-                else ff_mfma_v(acc3[f][nf], wfr[i % 5], af[f][ks]);
-                if constexpr (f == 1 && i >= 1) ff_keep(wfr[(i - 1) % 5]);
+                if constexpr (f == 0 && i + 3 < 20) wfr[(i + 3) % 6] = wread(i + 3);
+                if constexpr (ks == 0) ff_mfma_v0(acc3[f][nf], wfr[i % 6], af[f][ks]);
+                else ff_mfma_v(acc3[f][nf], wfr[i % 6], af[f][ks]);
+                if constexpr (f == 1 && i >= 1) ff_keep(wfr[(i - 1) % 6]);
                 __builtin_amdgcn_sched_barrier(0);
             });
-            ff_keep(wfr[19 % 5]);
-            asm volatile("s_nop 15" : "+v"(acc3[0][0]), "+v"(acc3[0][1]), "+v"(acc3[1][0]), "+v"(acc3[1][1]), "+v"(acc3[2][0]), "+v"(acc3[2][1]));   // asm MFMA results -> VALU
+            // asm MFMA results -> VALU; the last two slots' fragments (18, 19 -> wfr[0], wfr[1]) stay sources until the nops are through (the epilogue below
+            // depends on this statement's outputs, the next chunk's reads sit behind a scheduling barrier)
+            asm volatile("s_nop 15" : "+v"(acc3[0][0]), "+v"(acc3[0][1]), "+v"(acc3[1][0]), "+v"(acc3[1][1]), "+v"(acc3[2][0]), "+v"(acc3[2][1]) : "v"(wfr[0]), "v"(wfr[1]));
+            {   // ... and until a VALU instruction has READ the result of the chunk's last MFMA (in-order matrix pipe: everything before it has finished too)
+                float pr = acc3[FF_MF - 1][1][3];
+                asm volatile("v_mov_b32 %0, %0" : "+v"(pr) : "v"(wfr[0]), "v"(wfr[1]));
+                acc3[FF_MF - 1][1][3] = pr;
+            }
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(sb3 + 32 * c + 8 * g), b1 = *reinterpret_cast<const f32x4*>(sb3 + 32 * c + 8 * g + 4);
 #pragma unroll
             for (int f = 0; f < FF_MF; ++f) {

@@ -754,10 +754,11 @@ def test_attention_pipelined_equals_two_group_kernel():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_pipe_check.py"), "3", "7"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
-    print(r.stdout[-1500:])
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_pipe_check.py"), "3", "7k0", "7"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+    print(r.stdout[-2000:])
     assert r.returncode == 0, r.stdout[-3000:]
-    assert "bit-identical on all" in r.stdout and "FAIL" not in r.stdout and "bit-identical: False" not in r.stdout
+    # three variants: the two-group kernel, the pipelined kernel on 64-key tiles (round 5) and on 128-key tiles (round 6, the default)
+    assert r.stdout.count("bit-identical on all") == 2 and "FAIL" not in r.stdout and "bit-identical: False" not in r.stdout
 
 
 def test_conv3x3_linearity_and_groupnorm_scale_invariance_full_size(ops):

@@ -151,15 +151,51 @@ def test_no_vgpr_write_to_the_sources_of_a_running_mfma(tmp_path):
     # round 5: the software-pipelined kernel — its 14 MFMAs per step are chained into one program order and every fragment is tied to the MFMA two
     # positions behind its last reader (the first listing of that kernel, without the ties, had 186 such writes)
     pipe = A.mfma_source_overwrites(asm, "attn_pipe_kernel<")
-    assert len(pipe) == 1
+    assert len(pipe) == 2                           # keys per tile 64 (round 5) and 128 (round 6)
     for k, hits in pipe.items():
         assert not hits, (k, hits[:3])
     rows = [(n, md, loop) for n, md, loop in A.audit_named(asm) if "attn_pipe_kernel<" in n]
-    assert len(rows) == 1
-    _, md, loop = rows[0]
-    assert md["vgpr_spill_count"] == "0" and md["private_segment_fixed_size"] == "0" and int(md["vgpr_count"]) <= 256, md   # two waves per SIMD
-    assert loop[0] == 28 and loop[2] == 0, loop     # one 64-key tile per loop trip: 2 steps x 14 MFMAs, no scratch traffic
-    assert loop[7] <= 160, loop                     # VALU per trip (148 at the time of writing: 64 exp2, 32 converts, 34 max3, addresses): register copies would show here
+    assert len(rows) == 2
+    for n, md, loop in rows:
+        steps = 4 if "128>" in n else 2             # 32-key blocks (pipeline steps) per loop trip = per tile
+        assert md["vgpr_spill_count"] == "0" and md["private_segment_fixed_size"] == "0" and int(md["vgpr_count"]) <= 256, (n, md)   # two waves per SIMD
+        assert loop[0] == 14 * steps and loop[2] == 0, (n, loop)   # one tile per loop trip: 14 MFMAs per step, no scratch traffic
+        assert loop[7] <= 80 * steps, (n, loop)     # VALU per trip (74 per step at the time of writing: 32 exp2, 16 converts, 17 max3, addresses): register copies would show here
+
+
+def test_fused_feed_forward_stream_is_the_hand_placed_one(tmp_path):
+    """Round 6 (csrc/ff_fused.hip): the fused feed-forward kernel lives at the edge of the register file (one wave per SIMD, 240 output accumulators in
+    the accumulator half, ~245 VGPRs) and its MFMAs are asm statements hipcc neither pads nor tracks.  The listing must show: no spills, no scratch;
+    the main loop (two steps = four phases per trip) holds 4 x 90 MFMAs, its LDS-DMA pieces (4 x 8) and NOTHING moving between the two register files
+    (the compiler-scheduled forms moved ~80 values per step, profiles/r06_ff_fused_notes.txt); only counted DMA waits inside the loop; and no VALU / LDS
+    result lands in a source register of an MFMA before two further MFMAs were issued (W fragments are kept live by empty asm uses)."""
+    import isa_audit as A
+    asm = A.compile_asm(["ff_fused.hip"], str(tmp_path))[0]
+    rows = [(n, md, loop) for n, md, loop in A.audit_named(asm) if "ff_fused_kernel<" in n]
+    assert len(rows) == 2, [r[0] for r in rows]            # with and without the proj_out tail
+    for n, md, loop in rows:
+        assert md["vgpr_spill_count"] == "0" and md["private_segment_fixed_size"] == "0", (n, md)
+        assert int(md["agpr_count"]) >= 240 and int(md["vgpr_count"]) <= 512, (n, md)
+        n_mfma, n_vm0, n_scratch, n_dma, n_gloads, _, n_vmn = loop[:7]
+        assert n_mfma == 360 and n_dma == 32 and n_scratch == 0 and n_gloads == 0 and n_vm0 == 0 and n_vmn == 4, (n, loop)
+    txt = open(asm).read()
+    for m in re.finditer(r"^(\S+ff_fused_kernel\S+):\s*; @\1\n(.*?)^\s+s_endpgm", txt, re.S | re.M):
+        body = m.group(2).split("\n")
+        # the main loop: the backward branch with the most MFMAs between label and branch
+        labels = {mm.group(1): i for i, l in enumerate(body) for mm in [re.match(r"^(\.LBB\d+_\d+):", l)] if mm}
+        best = (0, 0, 0)
+        for i, l in enumerate(body):
+            mm = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", l)
+            if mm and mm.group(1) in labels and labels[mm.group(1)] < i:
+                seg = body[labels[mm.group(1)]:i]
+                best = max(best, (sum("v_mfma" in x for x in seg), labels[mm.group(1)], i))
+        seg = body[best[1]:best[2]]
+        assert best[0] == 360
+        assert sum("v_accvgpr" in x for x in seg) <= 2, [x for x in seg if "v_accvgpr" in x][:5]
+    res = A.mfma_source_overwrites(asm, "ff_fused_kernel<")
+    assert len(res) == 2
+    for k, hits in res.items():
+        assert not hits, (k, hits[:3])
 
 
 def test_attention_backward_keeps_valu_writes_behind_its_mfma_phases(tmp_path):

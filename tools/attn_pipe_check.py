@@ -45,7 +45,7 @@ def cases(dev):
     st = (N * 3 * C, D, 3 * C)
     out["fused_qkv"] = ops.attention(qkv, qkv[:, C:], qkv[:, 2 * C:], B, h, N, N, D, D ** -0.5, st, st, st)
     # 4: short key counts: two tiles (the minimum), three tiles (every buffer once), and a large logit scale (frequent rebases)
-    for nk in (128, 192, 1024):
+    for nk in (128, 192, 256, 384, 1024):   # (256 / 384: two / three tiles of the 128-key form, round 6)
         kk, vv = rnd(BH, nk, D), rnd(BH, nk, D)
         out[f"nk{nk}"] = ops.attention_bhnd(q, kk, vv)
         out[f"nk{nk}_hot"] = ops.attention_bhnd(q, kk, vv, scale=3.0)
@@ -74,18 +74,21 @@ def cases(dev):
 def child(path):
     out, ref_err, same, us = cases("cuda")
     torch.save({k: v.cpu() for k, v in out.items()}, path)
-    print(f"AE_ATTN_V={os.environ.get('AE_ATTN_V')}: rel-L2 vs fp32 torch {ref_err:.3e} {'OK' if ref_err < 6e-3 else 'FAIL'}; 20 launches bit-identical: {same}; "
+    print(f"AE_ATTN_V={os.environ.get('AE_ATTN_V')} AE_ATTN_KT128={os.environ.get('AE_ATTN_KT128', 'default')}: rel-L2 vs fp32 torch {ref_err:.3e} {'OK' if ref_err < 6e-3 else 'FAIL'}; 20 launches bit-identical: {same}; "
           f"{us:.1f} us = {4.0 * 96 * 4096 * 4096 * 40 / us / 1e6:.1f} TFLOP/s (algorithmic, d = 40)", flush=True)
 
 
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--child":
         return child(sys.argv[2])
-    variants = sys.argv[1:] or ["3", "7"]
+    variants = sys.argv[1:] or ["3", "7k0", "7"]
     paths = {}
     for v in variants:
         paths[v] = f"/tmp/attn_pipe_check_{v}.pt"
-        env = dict(os.environ, AE_ATTN_V=v)
+        # "7" = AE_ATTN_V 7; "7k0" = the same with AE_ATTN_KT128=0 (the 64-key tiles of round 5)
+        env = dict(os.environ, AE_ATTN_V=v.split("k")[0])
+        if "k" in v:
+            env["AE_ATTN_KT128"] = v.split("k")[1]
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", paths[v]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         print(r.stdout.strip()[-600:])
         if r.returncode:
