@@ -61,6 +61,10 @@ SIGNATURES = {
     "ae_ln_gemm_bf16": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_long, c_void_p, c_void_p,
                         c_float, c_int, c_void_p, c_void_p],
     "ae_gemm_ln_plan": [c_int, c_int, c_int, c_int, c_int],
+    "ae_xattn_fused_supported": [c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+    "ae_xattn_fused_kv_bytes": [],
+    "ae_xattn_fused_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int,
+                            c_float, c_void_p],
     "ae_ff_fused_supported": [c_int, c_int, c_int],
     "ae_ff_fused_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long,
                          c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p],
@@ -109,7 +113,8 @@ SIGNATURES = {
     "ae_task_gate": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
 }
 _RESTYPES = {"ae_last_error": ctypes.c_char_p, "ae_groupnorm_workspace_floats": c_long, "ae_conv3x3_workspace_floats": c_long,
-             "ae_groupnorm_bwd_workspace_floats": c_long, "ae_attn_fp8_workspace_bytes": c_long, "ae_attn_bwd_workspace_floats": c_long}
+             "ae_groupnorm_bwd_workspace_floats": c_long, "ae_attn_fp8_workspace_bytes": c_long, "ae_attn_bwd_workspace_floats": c_long,
+             "ae_xattn_fused_kv_bytes": c_long}
 
 
 class AnyEditHipError(RuntimeError):

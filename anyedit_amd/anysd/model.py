@@ -104,6 +104,10 @@ class MoE(nn.Module):
                 Wm = Wm.float().contiguous()
             kv_ip = ops.expert_kv(ip_rows, Wm, top1, T_ip)
             kv_cache[("adapter", id(attn))] = (kv_ip, gate.float().contiguous())
+            # round 6: the same K | V as the LDS images of the fused cross-attention launch (the 64x64-level layers; None elsewhere) — step-invariant like them
+            img = attn.fused_kv_images(kv_cache[id(attn)], kv_cache[("adapter", id(attn))], B)
+            if img is not None:
+                kv_cache[("xattn_img", id(attn))] = img
         return context_rows, kv_cache
 
     @torch.no_grad()

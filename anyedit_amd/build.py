@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libanyedit_hip.so")
-SOURCES = ["c_api.hip", "gemm_conv.hip", "gemm_rowpanel.hip", "ff_fused.hip", "attention.hip", "attention_fast.hip", "attention_fp8.hip", "attention_bwd.hip", "norm.hip", "elementwise.hip", "backward.hip", "gate.hip", "expert_kv.hip", "msda.hip",
+SOURCES = ["c_api.hip", "gemm_conv.hip", "gemm_rowpanel.hip", "ff_fused.hip", "xattn_fused.hip", "attention.hip", "attention_fast.hip", "attention_fp8.hip", "attention_bwd.hip", "norm.hip", "elementwise.hip", "backward.hip", "gate.hip", "expert_kv.hip", "msda.hip",
            "sam_decoder.hip"]
 # Per-file flags.
 #  * -ffinite-math-only (attention kernels): no NaN / Inf semantics are relied on (masked logits are a finite -1e30) -> fmaxf compiles to
@@ -22,7 +22,7 @@ SOURCES = ["c_api.hip", "gemm_conv.hip", "gemm_rowpanel.hip", "ff_fused.hip", "a
 #    self-attention +1.1 % (d = 40), +1.5 % (d = 80), SAM global attention +2.2 % (profiles/r03_v49_attn_no_slp.txt); UNet step
 #    13.50 -> 13.44 ms in alternating A/B runs with the two GEMM files (profiles/r03_v50_gemm_no_slp.txt).  Not applied (not measured) to
 #    attention.hip / attention_bwd.hip; norm.hip has no MFMA to compete with.  `python -m anyedit_amd.build --variant` builds an A/B copy.
-EXTRA = {"gemm_conv.hip": ["-fno-slp-vectorize"], "gemm_rowpanel.hip": ["-fno-slp-vectorize"], "ff_fused.hip": ["-fno-slp-vectorize"], "attention.hip": ["-ffinite-math-only"],
+EXTRA = {"gemm_conv.hip": ["-fno-slp-vectorize"], "gemm_rowpanel.hip": ["-fno-slp-vectorize"], "ff_fused.hip": ["-fno-slp-vectorize"], "xattn_fused.hip": ["-fno-slp-vectorize"], "attention.hip": ["-ffinite-math-only"],
          "attention_fast.hip": ["-ffinite-math-only", "-fno-slp-vectorize"], "attention_fp8.hip": ["-ffinite-math-only"],
          "attention_bwd.hip": ["-ffinite-math-only"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]

@@ -20,8 +20,8 @@
 //   * weights stream through a four-slot LDS ring of 32 KiB phase items (W1 chunk image 20 KiB, as gemm_rowpanel.hip; W2 half-chunk image 10 KiB)
 //     by LDS-DMA with counted waits: two phases of lead, ONE barrier per phase (two per 32 hidden units).
 #include "common.hpp"
+#include "handplaced.hpp"
 #include <stdlib.h>
-#include <type_traits>
 
 namespace {
 
@@ -45,27 +45,6 @@ constexpr int FF_MAXH2 = 2560;
 #endif
 constexpr int FF_OOB = 0x40000000;                            // a per-lane offset beyond every descriptor: the piece reads zeros
 
-// MFMAs of the hand-placed loop (asm: program order is kept, the register file of each accumulator is the constraint's).  hipcc pads nothing around them:
-// operands written by VALU (the gated values) are a phase old when P2 reads them; P1 results are read by VALU a phase later; the output accumulators after
-// explicit nops.  W fragments stay live (empty asm uses) until two further MFMAs have been issued (the MFMA-source rule of tools/isa_audit.py).
-__device__ __forceinline__ void ff_mfma_v(f32x4& acc, const u32x4& a, const u32x4& b) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-}
-__device__ __forceinline__ void ff_mfma_v0(f32x4& acc, const u32x4& a, const u32x4& b) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
-}
-__device__ __forceinline__ void ff_mfma_a(f32x4& acc, const u32x4& a, const u32x4& b) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
-__device__ __forceinline__ void ff_keep(const u32x4& v) { asm volatile("" ::"v"(v)); }
-
-template <int I, int N, class F>
-__device__ __forceinline__ void ff_static_for(F&& fn) {
-    if constexpr (I < N) {
-        fn(std::integral_constant<int, I>{});
-        ff_static_for<I + 1, N>(fn);
-    }
-}
 // The gate of one row fragment (four values of a lane: a_half * (g + |g| w(g)), the arithmetic of geglu_half_f / gelu_w_f in common.hpp — bit-identical gated
 // values to the row-panel GEGLU epilogue) as 62 single VALU operations; operation u of a stage works on chain r = u & 3, so dependent operations sit four apart.
 // Gate operations [ff_op_lo(P), ff_op_lo(P + 1)) of a phase (186 = 3 fragments x 62) go behind its MFMA P (90).
@@ -91,11 +70,6 @@ __device__ __forceinline__ void ff_gate_op(const f32x4& va, const f32x4& vg, con
     else if constexpr (U < 60) xa[r] = xa[r] * e4[r];
     else if constexpr (U == 60) { if (hi) h.z = pack_bf16x2(xa[0], xa[1]); else h.x = pack_bf16x2(xa[0], xa[1]); }
     else { if (hi) h.w = pack_bf16x2(xa[2], xa[3]); else h.y = pack_bf16x2(xa[2], xa[3]); }
-}
-
-template <int N>
-__device__ __forceinline__ void ff_wait_dma() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 template <bool PROJ>
@@ -166,7 +140,7 @@ __global__ __launch_bounds__(64 * FF_NW, 1) void ff_fused_kernel(const FFArgs p)
     }
     for (int i = tid; i < H2; i += 64 * FF_NW) sc1[i] = p.b1[i] * ((i & 16) == 0 ? 0.5f : 1.0f);   // the bias of an 'a' column is kept halved (geglu_half_f)
     for (int i = tid; i < FF_K; i += 64 * FF_NW) { sb2[i] = p.b2 ? p.b2[i] : 0.f; sln[i] = p.ln_g[i]; sln[FF_K + i] = p.ln_b[i]; sb3[i] = (PROJ && p.b3) ? p.b3[i] : 0.f; }
-    ff_wait_dma<0>();
+    hp_wait_dma<0>();
     __syncthreads();
     u32x4 af[FF_MF][FF_KS];
 #pragma unroll
@@ -302,27 +276,27 @@ __global__ __launch_bounds__(64 * FF_NW, 1) void ff_fused_kernel(const FFArgs p)
         };
         wfr[ROFF % 6] = wread(0); wfr[(ROFF + 1) % 6] = wread(1); wfr[(ROFF + 2) % 6] = wread(2);
         float xa[4], xg[4], t4[4], pl[4], e4[4];
-        ff_static_for<0, NP>([&](auto pc) {
+        hp_static_for<0, NP>([&](auto pc) {
             constexpr int P = decltype(pc)::value, e = P / 3, f = P % 3, k = (DP1 && DP2) ? e : (DP1 ? (e / 2) * 3 + e % 2 : 3 * e + 2);
             if constexpr (!(FF_LAB & 4) && f == 0 && e + 3 < NS) wfr[(e + 3 + ROFF) % 6] = wread(e + 3);
             if constexpr (k % 3 == 2) {
-                ff_mfma_a(acc2[f][10 * HALF + k / 3], wfr[(e + ROFF) % 6], hf[1 - HB][f]);
+                hp_mfma_a(acc2[f][10 * HALF + k / 3], wfr[(e + ROFF) % 6], hf[1 - HB][f]);
             } else {
                 constexpr int i = 2 * (k / 3) + k % 3, ks = i >> 1, nf = i & 1;
-                if constexpr (ks == 0) ff_mfma_v0(acc1[WB][f][nf], wfr[(e + ROFF) % 6], af[f][ks]);
-                else ff_mfma_v(acc1[WB][f][nf], wfr[(e + ROFF) % 6], af[f][ks]);
+                if constexpr (ks == 0) hp_mfma_v0(acc1[WB][f][nf], wfr[(e + ROFF) % 6], af[f][ks]);
+                else hp_mfma_v(acc1[WB][f][nf], wfr[(e + ROFF) % 6], af[f][ks]);
             }
-            if constexpr (f == 1 && e >= 1) ff_keep(wfr[(e - 1 + ROFF) % 6]);   // the slot before: its last MFMA is two MFMAs back now
+            if constexpr (f == 1 && e >= 1) hp_keep(wfr[(e - 1 + ROFF) % 6]);   // the slot before: its last MFMA is two MFMAs back now
             if constexpr (P == 1) {   // sources of the last MFMAs of the phase before: its last two W fragments, and the gated values its P2 read (the buffer this step's gate refills)
-                ff_keep(wfr[4]); ff_keep(wfr[5]);
-                ff_keep(hf[HB][0]); ff_keep(hf[HB][1]); ff_keep(hf[HB][2]);
+                hp_keep(wfr[4]); hp_keep(wfr[5]);
+                hp_keep(hf[HB][0]); hp_keep(hf[HB][1]); hp_keep(hf[HB][2]);
             }
             if constexpr (!(FF_LAB & 1) && P % DSTEP == DOFF && P / DSTEP < FF_PPW) issue_piece(rit, P / DSTEP);
             // the gate arithmetic as single VALU operations, two (sometimes three) behind every MFMA: 3 fragments x 62 operations over the 90 MFMAs.  (In
             // slices of eight behind every fourth MFMA — the first form — the wave hid two of each eight: +30 us per launch, profiles/r06_ff_fused_notes.txt.)
             if constexpr (DOG) {
                 static_assert(!DOG || NP == 90, "the gate rides in full phases");
-                ff_static_for<ff_op_lo(P), ff_op_lo(P + 1)>([&](auto tc) {
+                hp_static_for<ff_op_lo(P), ff_op_lo(P + 1)>([&](auto tc) {
                     constexpr int t = decltype(tc)::value, gf = t / 62, u = t % 62;
                     ff_gate_op<u>(acc1[1 - WB][gf][0], acc1[1 - WB][gf][1], ba, bg, xa, xg, t4, pl, e4, hf[HB][gf], HALF);
                 });
@@ -333,7 +307,7 @@ __global__ __launch_bounds__(64 * FF_NW, 1) void ff_fused_kernel(const FFArgs p)
     // phase item j: its pieces (and every other wave's) have landed; every wave is done with item j - 1, whose slot takes item j + 3
     auto open_item = [&]() {
         if (!(FF_LAB & 8)) {
-            ff_wait_dma<2 * FF_PPW>();
+            hp_wait_dma<2 * FF_PPW>();
             __builtin_amdgcn_s_barrier();
         }
         asm volatile("" ::: "memory");
@@ -440,7 +414,7 @@ __global__ __launch_bounds__(64 * FF_NW, 1) void ff_fused_kernel(const FFArgs p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (hipcc has waited for its residual loads already, and with them for the first three items)
 #pragma unroll 1
         for (int c = 0; c < FF_K / 32; ++c) {
-            ff_wait_dma<2 * FF_PPW>();
+            hp_wait_dma<2 * FF_PPW>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             issue_item3(c + 3);
@@ -449,12 +423,12 @@ __global__ __launch_bounds__(64 * FF_NW, 1) void ff_fused_kernel(const FFArgs p)
             f32x4 acc3[FF_MF][2];
             auto wread = [&](int i) { return *reinterpret_cast<const u32x4*>(slot + w1off[(i >> 1) & 1] + (i >> 2) * 128 + (i & 1) * 16 * FF_ROWB); };
             wfr[0] = wread(0); wfr[1] = wread(1); wfr[2] = wread(2);
-            ff_static_for<0, 60>([&](auto pc) {
+            hp_static_for<0, 60>([&](auto pc) {
                 constexpr int P = decltype(pc)::value, i = P / 3, f = P % 3, ks = i >> 1, nf = i & 1;
                 if constexpr (f == 0 && i + 3 < 20) wfr[(i + 3) % 6] = wread(i + 3);
-                if constexpr (ks == 0) ff_mfma_v0(acc3[f][nf], wfr[i % 6], af[f][ks]);
-                else ff_mfma_v(acc3[f][nf], wfr[i % 6], af[f][ks]);
-                if constexpr (f == 1 && i >= 1) ff_keep(wfr[(i - 1) % 6]);
+                if constexpr (ks == 0) hp_mfma_v0(acc3[f][nf], wfr[i % 6], af[f][ks]);
+                else hp_mfma_v(acc3[f][nf], wfr[i % 6], af[f][ks]);
+                if constexpr (f == 1 && i >= 1) hp_keep(wfr[(i - 1) % 6]);
                 __builtin_amdgcn_sched_barrier(0);
             });
             // asm MFMA results -> VALU; the last two slots' fragments (18, 19 -> wfr[0], wfr[1]) stay sources until the nops are through (the epilogue below

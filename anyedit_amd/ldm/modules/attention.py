@@ -15,6 +15,9 @@ from anyedit_amd.ldm.util import default, exists
 from anyedit_amd.ldm.modules.diffusionmodules.util import Linear, Conv2d, LayerNorm, checkpoint  # noqa: F401
 
 BF16 = torch.bfloat16
+# tuning knob (the library reads the same variable): 1 = the cross-attention half of the 64x64-level blocks as ONE launch (ops.xattn_fused).  Off by default: parity-green
+# but measured slower than the three launches it replaces (profiles/r06_xattn_fused_notes.txt)
+_XATTN_FUSED = os.environ.get("AE_XATTN_FUSED", "0") != "0"
 _FF_TAIL = os.environ.get("AE_FF_TAIL", "1") != "0"   # tuning knob (A/B): 0 = proj_out stays its own launch behind the fused feed-forward
 _SEG2_160 = os.environ.get("AE_ATTN_SEG2_160", "1") != "0"  # tuning knob (A/B): 0 = the d = 160 expert segment as a second, accumulating launch
 
@@ -154,6 +157,7 @@ class CrossAttention(nn.Module):
 
     def repack(self):
         self._pk = None
+        self._pkx = None
         self._pkln_q = self._pkln_qkv = None
 
     def _packed_ln(self, wname, norm):
@@ -174,20 +178,46 @@ class CrossAttention(nn.Module):
             self._pk = pk
         return self._pk
 
+    def _packed_x(self):
+        """(Wq images, Wo images, to_out bias) of the fused cross-attention launch (`ops.xattn_fused`), once per weight version."""
+        if ops.cache_stale(self, "_pkx", self.to_q.weight, self.to_out[0].weight, self.to_out[0].bias):
+            bo = self.to_out[0].bias
+            self._pkx = (ops.pack_xattn_wq(self.to_q.weight), ops.pack_xattn_wo(self.to_out[0].weight), None if bo is None else bo.detach().float().contiguous())
+        return self._pkx
+
+    def fused_kv_images(self, kv, adapter, B):
+        """The K | V images of `ops.xattn_fused` for this layer's (step-invariant) context, or None where the fused launch does not apply to the layer at all
+        (it needs C = 320 as 8 heads of 40, 65 .. 80 text keys, at most 16 expert keys).  Built once per edit (AnySD: MoE.prepare_conditioning)."""
+        if not _XATTN_FUSED or self.is_self or self.heads != 8 or self.dim_head != 40 or self.to_q.weight.shape[1] != 320:
+            return None
+        Nk = kv.shape[0] // B
+        T = 0 if adapter is None else adapter[0].shape[0] // B
+        if not (64 < Nk <= 80 and T <= 16):
+            return None
+        return ops.pack_xattn_kv(kv, None if adapter is None else adapter[0], B, Nk, T)
+
     def project_kv(self, ctx_rows):
         """K|V of a context [B*Nk, Dc] -> [B*Nk, 2*inner] (step-invariant for text conditioning: cache it)."""
         return ops.gemm(ctx_rows, self._packed()["kv"])
 
     def rows(self, x, B, N, context_rows=None, Nk=None, kv=None, key_mask=None, residual=None, adapter=None, norm=None, rowstats=None,
-             out_rowstats=None):
+             out_rowstats=None, kv_img=None):
         """x: [B*N, C] bf16 rows.  context_rows: [B*Nk, Dc] or None (self-attention).  Returns to_out(attn) (+residual).
         rowstats: row statistics of x from the GEMM that produced it (`ops.rowstats_buffer`): `norm` is then folded into the query-side
         projection; out_rowstats: buffer that receives the statistics of the result (to_out's epilogue) for the next block norm.
         adapter: optional (kv_ip [B*T, 2*inner] bf16, gate [B] fp32): decoupled expert attention added to the output,
         out = Attn(q,K,V) + gate_b * Attn(q,K_ip,V_ip)  (AnySD row A9, shape template ip_adapter/attention_processor.py:141-173)."""
-        pk = self._packed()
         h, d = self.heads, self.dim_head
         inner = h * d
+        if kv_img is not None and kv is not None and norm is not None and residual is x and key_mask is None and out_rowstats is None:
+            # round 6: norm2 -> to_q -> softmax(QK^T)V (+ the gated expert segment) -> to_out + residual as ONE launch where the kernel covers the shape
+            Nk_ = kv.shape[0] // B
+            T_ = 0 if adapter is None else adapter[0].shape[0] // B
+            if ops.xattn_fused_ok(x.shape[0], x.shape[1], h, d, N, Nk_, T_):
+                wq_img, wo_img, bo = self._packed_x()
+                g_, be_ = norm._affine()
+                return ops.xattn_fused(x, g_, be_, norm.eps, wq_img, kv_img, None if adapter is None else adapter[1], wo_img, bo, N, Nk_, T_, self.scale)
+        pk = self._packed()
 
         def proj(wname):  # norm: the block's LayerNorm fused in front of the query-side projection (x = UN-normalised rows)
             if norm is None:
@@ -306,10 +336,14 @@ class BasicTransformerBlock(nn.Module):
         c1 = context_rows if self.disable_self_attn else None
         M, C = x.shape
         f1, f2, f3 = self._fold_plan(M, C)
-        st2 = ops.rowstats_buffer(M, C, x.device) if f2 else None
+        kv2, adapter, kv_img = None, None, None
+        if kv_cache is not None and context_rows is not None and not (ops._TAPE is not None and ops._TAPE.active):
+            kv_img = kv_cache.get(("xattn_img", id(self.attn2)))     # the fused cross-attention launch's K | V images (MoE.prepare_conditioning, or built below)
+        # where the cross-attention half runs as the fused launch (it normalises its rows itself) attn1's to_out need not emit row statistics
+        use_x = kv_img is not None and not f3 and ops.xattn_fused_ok(M, C, self.attn2.heads, self.attn2.dim_head, N, 78, 0)
+        st2 = ops.rowstats_buffer(M, C, x.device) if (f2 and not use_x) else None
         st3 = ops.rowstats_buffer(M, C, x.device) if f3 else None
         x = self.attn1.rows(x, B, N, context_rows=c1, residual=x, norm=self.norm1, rowstats=rowstats if f1 else None, out_rowstats=st2)
-        kv2, adapter = None, None
         if kv_cache is not None and context_rows is not None:
             key = id(self.attn2)
             kv2 = kv_cache.get(key)
@@ -323,7 +357,14 @@ class BasicTransformerBlock(nn.Module):
             adapter = kv_cache.get(("adapter", key))  # installed by anysd.MoE.prepare_conditioning
             if callable(adapter):  # training: the expert K|V projection is recorded here, next to the attention that consumes it
                 adapter = adapter()
-        x = self.attn2.rows(x, B, N, context_rows=context_rows, kv=kv2, residual=x, adapter=adapter, norm=self.norm2, rowstats=st2, out_rowstats=st3)
+            if kv_img is None and not f3 and not (ops._TAPE is not None and ops._TAPE.active):
+                # plain (non-AnySD) callers: the images are built on the first evaluation with this cache — outside a graph capture, whose warm-up runs come
+                # first — and used from the next one on (layers the fused launch does not apply to answer None at once and store nothing)
+                img = self.attn2.fused_kv_images(kv2, adapter, B)
+                if img is not None:
+                    kv_cache[("xattn_img", key)] = img
+        x = self.attn2.rows(x, B, N, context_rows=context_rows, kv=kv2, residual=x, adapter=adapter, norm=self.norm2, rowstats=st2, out_rowstats=st3,
+                            kv_img=kv_img if use_x else None)
         x = self.ff.rows(x, residual=x, norm=self.norm3, rowstats=st3, tail=tail)
         return x
 

@@ -279,6 +279,110 @@ def ff_fused(x, gamma, beta, eps, w1, b1, w2img, b2, residual=None, out=None, w3
     return out
 
 
+# --------------------------------------------------------------------------- fused cross-attention half (csrc/xattn_fused.hip)
+def pack_xattn_wq(wq):
+    """to_q weight [320, 320] (8 heads of 40) -> the Wq_h LDS images of `ae_xattn_fused_bf16`: bf16 [8, 48, 320], rows 40 .. 47 of a head zero, the 16-byte pieces of a
+    row XOR-swizzled inside groups of eight (piece c of image row i at position (c & ~7) | ((c ^ (i >> 1)) & 7): the row-panel kernel's image).  Once per weight version."""
+    assert tuple(wq.shape) == (320, 320)
+    dev = wq.device
+    img = torch.zeros(8, 48, 40, 8, dtype=torch.float32, device=dev)                       # [head][row][piece][8 elements]
+    img[:, :40] = wq.detach().float().reshape(8, 40, 40, 8)
+    i = torch.arange(48, device=dev)[:, None]
+    c = torch.arange(40, device=dev)[None, :]
+    pos = (c & ~7) | ((c ^ (i >> 1)) & 7)                                                   # [48, 40]: where piece c of row i is stored
+    out = torch.zeros_like(img)
+    out.scatter_(2, pos[None, :, :, None].expand(8, 48, 40, 8), img)
+    return out.reshape(8, 48, 320).to(BF16).contiguous()
+
+
+def pack_xattn_wo(wo):
+    """to_out weight [320, 320 = 8 heads x 40] -> bf16 [4 head pairs, 320, 112]: image row i holds output column 32 (i >> 5) + 8 ((i & 15) >> 2) + 4 ((i & 31) >> 4) + (i & 3);
+    its bytes are three K steps of 64 B (+ 32 B pad, row stride 224 B: conflict-free fragment reads); K step t, lane group g, element e is d slot 16 (q % 3) + 4 g + (e & 3) of head
+    2 pair + (q >= 3), q = 2 t + (e >> 2) — the order the attention output of two heads sits in the result registers — and zero for slots 40 .. 47."""
+    assert tuple(wo.shape) == (320, 320)
+    dev = wo.device
+    i = torch.arange(320, device=dev)
+    i5 = i & 31
+    col = 32 * (i >> 5) + 8 * ((i5 & 15) >> 2) + 4 * (i5 >> 4) + (i5 & 3)
+    s = torch.arange(96, device=dev)
+    t, g, e = s >> 5, (s >> 3) & 3, s & 7
+    q6 = 2 * t + (e >> 2)
+    dslot = 16 * (q6 % 3) + 4 * g + (e & 3)
+    hloc = (q6 >= 3).long()
+    wf = torch.cat([wo.detach().float()[col].reshape(320, 8, 40), torch.zeros(320, 8, 8, device=dev)], dim=2)   # [row, head, 48 slots]
+    out = torch.zeros(4, 320, 112, dtype=torch.float32, device=dev)
+    for pr in range(4):
+        out[pr, :, :96] = wf[:, 2 * pr + hloc, dslot]
+    return out.to(BF16).contiguous()
+
+
+def pack_xattn_kv(kv, kv_ip, B, Nk, T):
+    """K | V of a cross-attention layer's context [B * Nk, 640] (and of its T-token expert segment [B * T, 640] or None) -> the per-(sample, head) LDS images of
+    `ae_xattn_fused_bf16`, bf16 [B, 8, 14848]: K image [96 key rows (80 text, 16 expert)][80] (64 d slots in the order the q results sit in registers + 16 pad: 160-byte rows)
+    then V^T image [48 d rows][144] (4 K steps of 32 key slots in the logits' order + 16 pad; row 40 = ones: the softmax denominator) + 256 pad.  Step-invariant: once per edit."""
+    assert 64 < Nk <= 80 and 0 <= T <= 16
+    dev = kv.device
+    kvb = kv.reshape(B, Nk, 640).float()
+    Kt = torch.zeros(B, 96, 320, device=dev)
+    Vt = torch.zeros(B, 96, 320, device=dev)
+    Kt[:, :Nk], Vt[:, :Nk] = kvb[:, :, :320], kvb[:, :, 320:]
+    if kv_ip is not None and T > 0:
+        ipb = kv_ip.reshape(B, T, 640).float()
+        Kt[:, 80:80 + T], Vt[:, 80:80 + T] = ipb[:, :, :320], ipb[:, :, 320:]
+    s = torch.arange(64, device=dev)
+    t, g, e = s >> 5, (s >> 3) & 3, s & 7
+    dslot = 16 * (2 * t + (e >> 2)) + 4 * g + (e & 3)                                       # 0 .. 63 (>= 40: zero)
+    Kh = torch.cat([Kt.reshape(B, 96, 8, 40).permute(0, 2, 1, 3), torch.zeros(B, 8, 96, 24, device=dev)], dim=3)
+    Kimg = torch.zeros(B, 8, 96, 80, device=dev)
+    Kimg[..., :64] = Kh[..., dslot]
+    s = torch.arange(128, device=dev)
+    t, g, e = s >> 5, (s >> 3) & 3, s & 7
+    j = e >> 2
+    key = torch.where(t < 3, 16 * (2 * t + j) + 4 * g + (e & 3), 80 + 4 * g + (e & 3))      # text K steps: key index; expert K step: rows 80 ..
+    ok = torch.where(t < 3, key < 80, j == 0)
+    Vh = Vt.reshape(B, 96, 8, 40).permute(0, 2, 3, 1)                                       # [B, 8, 40, 96]
+    Vimg = torch.zeros(B, 8, 48, 144, device=dev)
+    Vimg[:, :, :40, :128] = Vh[..., key.clamp(max=95)] * ok.float()
+    Vimg[:, :, 40, :128] = 1.0
+    out = torch.zeros(B, 8, 14848, device=dev)
+    out[..., :7680] = Kimg.reshape(B, 8, 7680)
+    out[..., 7680:7680 + 6912] = Vimg.reshape(B, 8, 6912)
+    return out.to(BF16).contiguous()
+
+
+def xattn_fused_ok(M, C, heads, head_dim, rows_per_sample, Nk, T):
+    """True where `xattn_fused` covers the cross-attention half of a transformer block (never while the training tape records)."""
+    return not (_TAPE is not None and _TAPE.active) and bool(lib.ae_xattn_fused_supported(M, C, heads, head_dim, rows_per_sample, Nk, T))
+
+
+def xattn_fused(x, gamma, beta, eps, wq_img, kv_img, gate, wo_img, bo, rows_per_sample, Nk, T, scale, out=None):
+    """out = to_out(Attn(to_q(LayerNorm(x)), K, V) + gate_b Attn(., K_ip, V_ip)) + x in ONE launch (attention.py:273 `x = attn2(norm2(x), context) + x`): x [M, 320] bf16
+    rows, (wq_img, wo_img, kv_img) = `pack_xattn_wq / _wo / _kv`, gate fp32 [B] or None.  Callers ask `xattn_fused_ok` first."""
+    _chk(x, BF16, "xattn_fused.x", 2)
+    _chk(wq_img, BF16, "xattn_fused.wq_img", 3)
+    _chk(wo_img, BF16, "xattn_fused.wo_img", 3)
+    _chk(kv_img, BF16, "xattn_fused.kv_img", 3)
+    _chk(gamma, torch.float32, "xattn_fused.gamma", 1)
+    _chk(beta, torch.float32, "xattn_fused.beta", 1)
+    M, C = x.shape
+    B = M // rows_per_sample
+    if tuple(wq_img.shape) != (8, 48, 320) or tuple(wo_img.shape) != (4, 320, 112) or tuple(kv_img.shape) != (B, 8, 14848) or not (wq_img.is_contiguous() and wo_img.is_contiguous()
+                                                                                                                                    and kv_img.is_contiguous()) or x.stride(1) != 1:
+        raise ValueError(f"xattn_fused: x {tuple(x.shape)}, images {tuple(wq_img.shape)} / {tuple(wo_img.shape)} / {tuple(kv_img.shape)} do not fit together")
+    if gate is not None:
+        _chk(gate, torch.float32, "xattn_fused.gate", 1)
+        if gate.numel() != B:
+            raise ValueError("xattn_fused: one gate per sample")
+    if bo is not None:
+        _chk(bo, torch.float32, "xattn_fused.bo", 1)
+    if out is None:
+        out = torch.empty(M, C, dtype=BF16, device=x.device)
+    _chk(out, BF16, "xattn_fused.out", 2)
+    check(lib.ae_xattn_fused_bf16(_p(x), x.stride(0), _p(gamma), _p(beta), float(eps), _p(wq_img), _p(kv_img), _p(gate), _p(wo_img), _p(bo), _p(out), out.stride(0), M,
+                                  rows_per_sample, Nk, T, float(scale), _s()), "ae_xattn_fused_bf16")
+    return out
+
+
 # --------------------------------------------------------------------------- GEMM / conv
 def colstats_buffer(M, N, device):
     """fp32 [ceil(M/32), N, 2]: per-channel (sum, sum of squares) over each 32-row slab of a bf16 [M, N] activation — filled by the kernel
@@ -1463,6 +1567,8 @@ def _up2_label(_r, x, w4, bias, B, H, W, **_):
 
 
 conv3x3_up2 = _wrap_profiled(conv3x3_up2, _up2_label)
+xattn_fused = _wrap_profiled(xattn_fused, lambda _r, x, gamma, beta, eps, wq_img, kv_img, gate, wo_img, bo, rows_per_sample, Nk, T, scale, out=None: (
+    f"xattn_fused_kernel<C=320>|M={x.shape[0]} Nk={Nk}+{T}", 2.0 * x.shape[0] * 320 * (2 * 320 + 2 * (Nk + T)), float(2 * (3 * x.numel() + wq_img.numel() + wo_img.numel() + kv_img.numel()))))
 ff_fused = _wrap_profiled(ff_fused, lambda _r, x, gamma, beta, eps, w1, b1, w2img, b2, residual=None, out=None, w3=None, b3=None, residual3=None, colstats=None: (
     f"ff_fused_kernel<C=320{',proj_out' if w3 is not None else ''}>|M={x.shape[0]} H={w1.shape[0] // 2}",
     2.0 * x.shape[0] * x.shape[1] * (3 * (w1.shape[0] // 2) + (x.shape[1] if w3 is not None else 0)),

@@ -97,6 +97,22 @@ int ae_ff_fused_bf16(const void* X, long ldx, const float* ln_gamma, const float
                      const void* W2img, const float* b2, const void* residual, long ldr, const void* W3, long ldw3, const float* b3,
                      const void* residual3, long ldr3, float* colstats, void* Y, long ldy, int M, int C, int H, void* stream);
 
+/* Fused cross-attention half of a BasicTransformerBlock at the 64x64 UNet level (round 6; ldm/modules/attention.py:273 `x = self.attn2(self.norm2(x), context=context) + x`:
+ * norm2, CrossAttention.forward :163-194 (to_q, softmax(QK^T)V over the text keys, to_out) and the residual; with AnySD's decoupled expert segment, DESIGN.md §6) — ONE launch
+ * instead of three (LayerNorm-fold q projection, short-K/V attention, to_out); q, logits, probabilities and the attention output stay in registers:
+ *   Y[M,320] = ( softmax(q K^T) V + gate_b softmax(q K_ip^T) V_ip ) Wo^T + bo + X,    q = LayerNorm(X; gamma, beta, eps) Wq^T,   8 heads of 40, logits scaled by `scale`.
+ *   X, Y bf16 rows (16-byte aligned, strides % 8 == 0, Y != X); rows_per_sample = tokens per sample (a multiple of 128; M a multiple of it);
+ *   Wq_img bf16 [8][48][320], Wo_img bf16 [4][320][112], KV_img bf16 [B][8][ae_xattn_fused_kv_bytes() / 2]: the weights and the sample's K | V (Nk text keys, 64 < Nk <= 80,
+ *   T <= 16 expert keys) as the kernel's LDS images (layouts: header of csrc/xattn_fused.hip; ops.pack_xattn_wq / _wo / _kv build them — the K | V images once per edit: they are
+ *   step-invariant); gate fp32 [B] or NULL (no expert segment: T = 0); bo fp32 [320] or NULL.
+ * ae_xattn_fused_supported(M, C, heads, head_dim, rows_per_sample, Nk, T): 1 where the kernel covers the shape (C == 320, 8 heads of 40, M >= 256 * 128 rows: one
+ * 128-row block per CU and round) AND AE_XATTN_FUSED=1 is set, 0 otherwise — callers then run ae_gemm_ln_bf16 + ae_attn_fwd_bf16 + ae_gemm_ln_bf16.  Opt-in: results
+ * match the three launches (tests/test_hip_ops.py), the launch is slower than they are at UNet batch 12 (profiles/r06_xattn_fused_notes.txt).                          */
+int ae_xattn_fused_supported(int M, int C, int heads, int head_dim, int rows_per_sample, int Nk, int T);
+long ae_xattn_fused_kv_bytes(void);
+int ae_xattn_fused_bf16(const void* X, long ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* Wq_img, const void* KV_img, const float* gate,
+                        const void* Wo_img, const float* bo, void* Y, long ldy, int M, int rows_per_sample, int Nk, int T, float scale, void* stream);
+
 /* 3x3 convolution, padding 1, as implicit GEMM (ResBlock in/out convs openaimodel.py:200-231, stem :536-542, head :726-730,
  * Downsample stride 2 :157-159, Upsample nearest-x2 + conv :108-118 via upsample2x=1).
  *   x [B,H,W,Cin] bf16 channels-last (Cin % 8 == 0), w [Cout, 9*CinPad] bf16 packed (ky,kx,cin) with CinPad = Cin

@@ -10,6 +10,7 @@ Tolerances (stated per the north-star "within a stated fp tolerance"):
 import os
 
 os.environ.setdefault("AE_ROWPANEL_ANY_M", "1")  # read once by the library: lets the small row-panel GEMM cases reach the kernel
+os.environ.setdefault("AE_XATTN_FUSED", "1")     # the fused cross-attention kernel is opt-in (measured slower than the launches it replaces); its operator test runs it
 
 import numpy as np
 import pytest
@@ -252,6 +253,60 @@ def test_feed_forward_fused_one_launch(ops, M, H, res):
     z4 = ops.ff_fused(xd, gamma.to(DEV), beta.to(DEV), 1e-5, w1p, b1p, w2img, b2.to(DEV), residual=xd if res else None, w3=w3.to(DEV, BF), b3=b3.to(DEV),
                       residual3=r3.to(DEV, BF))
     assert torch.equal(z3, z4), "the fused feed-forward + proj_out is not run-to-run bit-equal"
+
+
+@pytest.mark.parametrize("B,N,Nk,T", [(1, 128, 78, 4), (2, 256, 77, 0), (3, 384, 80, 16), (12, 4096, 78, 4)])
+def test_cross_attention_half_fused_one_launch(ops, B, N, Nk, T):
+    """attention.py:273 `x = attn2(norm2(x), context) + x` as ONE launch (ae_xattn_fused_bf16, round 6): LayerNorm -> to_q -> softmax(QK^T)V over the text keys (+ the gated expert
+    segment of DESIGN.md §6) -> to_out + bias + residual, with q / logits / probabilities / attention output kept in registers.
+      1. against the fp64 module arithmetic on the same bf16 inputs (operator tolerance);
+      2. no worse than the three-launch HIP path it replaces (LayerNorm + q projection, short-K/V attention with the second segment, to_out + residual) by more than 25 % + 5e-4;
+      3. run-to-run bit-equal; key counts 77 / 78 / 80 (padding masks), no expert segment, a full 16-key expert segment; samples never mix (per-sample K | V and gate)."""
+    C, H, D = 320, 8, 40
+    M = B * N
+    assert ops.lib.ae_xattn_fused_supported(M, C, H, D, N, Nk, T) == 1, "AE_ROWPANEL_ANY_M lets the small cases reach the kernel"
+    g = torch.Generator().manual_seed(B * 1000 + Nk + T)
+    x = q(torch.randn(M, C, generator=g) * 1.3 + torch.randn(M, 1, generator=g) * 2.0)
+    wq = torch.randn(C, C, generator=g) / C ** 0.5
+    wo = torch.randn(C, C, generator=g) / C ** 0.5
+    bo = 0.1 * torch.randn(C, generator=g)
+    gamma, beta = 1.0 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    kv = q(torch.randn(B * Nk, 2 * C, generator=g))
+    kv_ip = q(torch.randn(B * T, 2 * C, generator=g)) if T else None
+    gate = torch.rand(B, generator=g) if T else None
+    scale = D ** -0.5
+    # fp64 reference
+    xn = F.layer_norm(x.double(), (C,), gamma.double(), beta.double(), 1e-5)
+    qq = (xn @ q(wq).double().t()).reshape(B, N, H, D).permute(0, 2, 1, 3)
+    kk = kv.double().reshape(B, Nk, 2, H, D)
+    att = torch.softmax(qq @ kk[:, :, 0].permute(0, 2, 3, 1) * scale, -1) @ kk[:, :, 1].permute(0, 2, 1, 3)
+    if T:
+        ki = kv_ip.double().reshape(B, T, 2, H, D)
+        att = att + gate.double()[:, None, None, None] * (torch.softmax(qq @ ki[:, :, 0].permute(0, 2, 3, 1) * scale, -1) @ ki[:, :, 1].permute(0, 2, 1, 3))
+    ref = (att.permute(0, 2, 1, 3).reshape(M, C) @ q(wo).double().t() + bo.double() + x.double()).float()
+    xd, gd, bd = x.to(DEV, BF), gamma.to(DEV), beta.to(DEV)
+    wq_img, wo_img = ops.pack_xattn_wq(wq.to(DEV)), ops.pack_xattn_wo(wo.to(DEV))
+    kv_img = ops.pack_xattn_kv(kv.to(DEV, BF), None if kv_ip is None else kv_ip.to(DEV, BF), B, Nk, T)
+    assert kv_img.shape == (B, 8, ops.lib.ae_xattn_fused_kv_bytes() // 2)
+    gated = None if gate is None else gate.to(DEV)
+    y = ops.xattn_fused(xd, gd, bd, 1e-5, wq_img, kv_img, gated, wo_img, bo.to(DEV), N, Nk, T, scale)
+    # the three launches it replaces
+    qd = ops.ln_gemm(xd, gd, bd, 1e-5, wq.to(DEV, BF))
+    kvd = kv.to(DEV, BF)
+    qs, ks = (N * C, D, C), (Nk * 2 * C, D, 2 * C)
+    if T:
+        kid = kv_ip.to(DEV, BF)
+        ksi = (T * 2 * C, D, 2 * C)
+        o = ops.attention(qd, kvd, kvd[:, C:], B, H, N, Nk, D, scale, qs, ks, ks, seg2=(kid, kid[:, C:], T, ksi, ksi, gated))
+    else:
+        o = ops.attention(qd, kvd, kvd[:, C:], B, H, N, Nk, D, scale, qs, ks, ks)
+    y3 = ops.gemm(o.reshape(M, C), wo.to(DEV, BF), bias=bo.to(DEV), residual=xd)
+    e1, e3 = rel_l2(y.float().cpu(), ref), rel_l2(y3.float().cpu(), ref)
+    print(f"fused cross-attention half B={B} N={N} Nk={Nk}+{T}: rel-L2 fused {e1:.3e}, three launches {e3:.3e}")
+    check_close(y, ref, rl2=5e-3, mabs=3e-2, what=f"fused cross-attention half B={B} N={N} Nk={Nk}+{T}")
+    assert e1 <= 1.25 * e3 + 5e-4, (e1, e3)
+    y2 = ops.xattn_fused(xd, gd, bd, 1e-5, wq_img, kv_img, gated, wo_img, bo.to(DEV), N, Nk, T, scale)
+    assert torch.equal(y, y2), "the fused cross-attention half is not run-to-run bit-equal"
 
 
 @pytest.mark.parametrize("B,H,W,Cout", [(2, 16, 16, 64), (1, 5, 7, 320), (12, 64, 64, 320)])

@@ -532,6 +532,96 @@ def test_fused_feed_forward_weight_image_index_map():
         assert len(slots) == 16
 
 
+def test_fused_cross_attention_image_index_maps():
+    """Round 6 (attention.py:163-194, 273): `ops.pack_xattn_wq / _wo / _kv` against the data flow of csrc/xattn_fused.hip restated with index arithmetic on the CPU, for one
+    16-row fragment.  MFMA facts used (the ones csrc/ff_fused.hip rests on): D[i][n] = sum over (g, e) of A(lane (i, g), e) B(lane (n, g), e); a result fragment leaves lane
+    (n, g') with rows i = 4 g' + r.  Chain: Q (Wq image, XOR-swizzled rows) -> q slots 16 nf + 4 g + r -> logits against the K image (K step t, element e <-> slot
+    16 (2 t + (e >> 2)) + 4 g + (e & 3)) -> probabilities in the same element order against the V^T image (row 40 = ones) -> two heads' outputs against the Wo image."""
+    from anyedit_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    B, Nk, T, R, C, H, D = 2, 78, 4, 16, 320, 8, 40
+    bf = lambda t_: t_.to(torch.bfloat16).float()  # noqa: E731
+    wq, wo = bf(torch.randn(C, C, generator=gen) / 18), bf(torch.randn(C, C, generator=gen) / 18)
+    kv, kv_ip = bf(torch.randn(B * Nk, 2 * C, generator=gen)), bf(torch.randn(B * T, 2 * C, generator=gen))
+    xn = bf(torch.randn(R, C, generator=gen))
+    gate = 0.7
+    wq_img, wo_img = ops.pack_xattn_wq(wq).float(), ops.pack_xattn_wo(wo).float()
+    kv_img = ops.pack_xattn_kv(kv.to(torch.bfloat16), kv_ip.to(torch.bfloat16), B, Nk, T).float()
+    b = 1
+    scale = D ** -0.5
+    out = torch.zeros(R, C)
+    o_pair = {}
+    for h in range(H):
+        # ---- Q: lane (i = l15, g) of fragment nf reads piece 4 ks + g of image row 16 nf + l15 at position (c & ~7) | ((c ^ (l15 >> 1)) & 7)
+        qslot = torch.zeros(48, R)
+        for nf in range(3):
+            for i in range(16):
+                row = wq_img[h, 16 * nf + i].reshape(40, 8)
+                w = torch.stack([row[(c & ~7) | ((c ^ (i >> 1)) & 7)] for c in range(40)]).reshape(320)   # the logical row the reads reassemble
+                qslot[16 * nf + i] = xn @ w
+        assert float((qslot[:40] - (xn @ wq[40 * h:40 * h + 40].t()).t()).abs().max()) < 1e-4 and float(qslot[40:].abs().max()) == 0.0
+        kimg = kv_img[b, h, :7680].reshape(96, 80)
+        vimg = kv_img[b, h, 7680:7680 + 6912].reshape(48, 144)
+        # ---- logits: B operand element (t, g, e) = q slot 16 (2 t + (e >> 2)) + 4 g + (e & 3) (zero from slot 48 on)
+        S = torch.zeros(96, R)
+        for t in range(2):
+            for g in range(4):
+                for e in range(8):
+                    slot = 16 * (2 * t + (e >> 2)) + 4 * g + (e & 3)
+                    if slot < 48:
+                        S += kimg[:, 32 * t + 8 * g + e][:, None] * qslot[slot][None, :]
+        S = S * scale
+        kb = kv[b * Nk:(b + 1) * Nk].reshape(Nk, 2, H, D)
+        kib = kv_ip[b * T:(b + 1) * T].reshape(T, 2, H, D)
+        ref_s = (xn @ wq[40 * h:40 * h + 40].t()) @ kb[:, 0, h].t() * scale
+        assert float((S[:Nk].t() - ref_s).abs().max()) < 1e-3 and float(S[Nk:80].abs().max()) == 0.0
+        P1 = torch.zeros(96, R)
+        P1[:Nk] = torch.softmax(S[:Nk], 0)
+        P2 = torch.zeros(16, R)
+        P2[:T] = torch.softmax(S[80:80 + T], 0)
+        # ---- PV: K steps 0 .. 2 carry text keys 16 (2 t + j) + 4 g + r (j = 1 of step 2: zeros), step 3 expert keys 4 g + r (j = 0)
+        O1, O2 = torch.zeros(48, R), torch.zeros(48, R)
+        for t in range(4):
+            for g in range(4):
+                for e in range(8):
+                    j, r = e >> 2, e & 3
+                    a = vimg[:, 32 * t + 8 * g + e]
+                    if t < 3:
+                        key = 16 * (2 * t + j) + 4 * g + r
+                        pk = P1[key] if (key < 80 and not (t == 2 and j == 1)) else torch.zeros(R)
+                        O1 += a[:, None] * pk[None, :]
+                    elif j == 0:
+                        O2 += a[:, None] * P2[4 * g + r][None, :]
+        o = O1 / O1[40] + gate * O2 / O2[40]                    # row 40: the denominators
+        ref_o = torch.softmax(ref_s, -1) @ kb[:, 1, h] + gate * torch.softmax((xn @ wq[40 * h:40 * h + 40].t()) @ kib[:, 0, h].t() * scale, -1) @ kib[:, 1, h]
+        assert float((o[:40].t() - ref_o).abs().max()) < 1e-3
+        o_pair[h & 1] = o
+        if h & 1:
+            # ---- output projection: K step t, element e <-> fragment q6 = 2 t + (e >> 2) of the pair: head q6 >= 3, d slot 16 (q6 % 3) + 4 g + (e & 3)
+            img = wo_img[h >> 1]
+            D_ = torch.zeros(320, R)
+            for t in range(3):
+                for g in range(4):
+                    for e in range(8):
+                        q6 = 2 * t + (e >> 2)
+                        D_ += img[:, 32 * t + 8 * g + e][:, None] * o_pair[int(q6 >= 3)][16 * (q6 % 3) + 4 * g + (e & 3)][None, :]
+            for cf in range(20):
+                for gp in range(4):
+                    for r in range(4):
+                        out[:, 32 * (cf >> 1) + 8 * gp + 4 * (cf & 1) + r] += D_[16 * cf + 4 * gp + r]
+    qf = (xn @ wq.t()).reshape(R, H, D)
+    kb = kv[b * Nk:(b + 1) * Nk].reshape(Nk, 2, H, D)
+    kib = kv_ip[b * T:(b + 1) * T].reshape(T, 2, H, D)
+    att = torch.einsum("rhk,khd->rhd", torch.softmax(torch.einsum("rhd,khd->rhk", qf, kb[:, 0]) * scale, -1), kb[:, 1]) + \
+        gate * torch.einsum("rhk,khd->rhd", torch.softmax(torch.einsum("rhd,khd->rhk", qf, kib[:, 0]) * scale, -1), kib[:, 1])
+    ref = att.reshape(R, C) @ wo.t()
+    assert float((out - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+    # conflict-free fragment reads: row strides 160 / 288 / 224 bytes put the 16 lanes of a ds_read_b128 group on 16 different 16-byte slots of the 256-byte bank row
+    for stride in (160, 288, 224):
+        for grp in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]):
+            assert len({((lane & 15) * stride + (lane >> 4) * 16) % 256 // 16 for lane in grp}) == 16, stride
+
+
 def test_mask_tool_box_logic_on_cpu():
     """tools/tool.py:184-222 (no GPU involved): box conversion and the phrase-based target filter, including its fallbacks and the
     list form of `target_object`."""
