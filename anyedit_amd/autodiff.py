@@ -44,6 +44,9 @@ class Tape:
         self.nodes = []          # backward closures in forward order
         self.req = {}            # id(base tensor) -> base tensor: tensors that need a gradient
         self.grads = {}          # id(base tensor) -> gradient (shape of the base)
+        self.owned = set()       # data_ptr of the gradient buffers THIS tape allocated: only those are ever written in place.  A first gradient is
+                                 # stored by reference (it may be another node's dy, or an outer tape's gradient); the second contribution sums out of place
+                                 # into a buffer of the tape's own, and from then on backward kernels may add to it directly (`into`)
         self.param_grads = {}    # name -> fp32 tensor
         self.trainable = {}      # id(tensor) -> name (packed weights / vectors registered as trainable leaves)
         self._wt = {}            # id(packed weight) -> transposed packed weight
@@ -96,8 +99,12 @@ class Tape:
         cur = self.grads.get(id(b))
         if cur is None:
             self.grads[id(b)] = g if g.is_contiguous() else g.contiguous()
-        else:
+        elif cur.data_ptr() in self.owned:
             ops.add(cur, g, out=cur)
+        else:   # the stored gradient is borrowed: never written — the sum goes to a buffer of this tape's own (same launch count, one allocation)
+            new = ops.add(cur, g)
+            self.owned.add(new.data_ptr())
+            self.grads[id(b)] = new
 
     def into(self, t, *not_aliasing):
         """The gradient buffer `t` already has (viewed in t's shape), for backward kernels that can ADD their result to it in place instead of
@@ -108,6 +115,8 @@ class Tape:
         b = _base(t)
         cur = self.grads.get(id(b))
         if cur is None or t.numel() != b.numel() or cur.dtype != BF16 or not cur.is_contiguous() or not t.is_contiguous():
+            return None
+        if cur.data_ptr() not in self.owned:   # a borrowed first gradient (by-reference store): the caller produces a tensor and `accumulate` sums out of place
             return None
         if any(o is not None and o.data_ptr() == cur.data_ptr() for o in not_aliasing):
             return None
@@ -380,11 +389,20 @@ class Tape:
                 return
             # one pass: each half is written to a fresh gradient buffer or added to the one its tensor already has
             ga, gb = (self.grads.get(id(ba)) if na else None), (self.grads.get(id(bb)) if nb else None)
+            if (ga is not None and ga.data_ptr() not in self.owned) or (gb is not None and gb.data_ptr() not in self.owned):
+                # a borrowed gradient is never written in place: the two-launch route sums out of place
+                if na:
+                    self.accumulate(a, dy[:, :ca].contiguous())
+                if nb:
+                    self.accumulate(b, dy[:, ca:].contiguous())
+                return
             da, db = ops.split_channels(dy, ca, None if ga is None else ga.reshape(a.shape), None if gb is None else gb.reshape(b.shape), na, nb)
             if na and ga is None:
                 self.grads[id(ba)] = da.reshape(ba.shape)
+                self.owned.add(da.data_ptr())
             if nb and gb is None:
                 self.grads[id(bb)] = db.reshape(bb.shape)
+                self.owned.add(db.data_ptr())
 
         self._record([y], [a, b], bwd)
         return y

@@ -389,6 +389,35 @@ def test_tape_trainable_linear_and_layernorm(ops):
     check_close(pg["beta"], ber.grad, rl2=1e-2, what="dbeta")
 
 
+def test_tape_never_writes_into_a_borrowed_gradient(ops):
+    """the tape stores a FIRST gradient by reference (a residual's gradient is its consumer's dy) and backward kernels may add to an existing gradient
+    in place (`Tape.into`).  In-place writes are allowed only into buffers the tape allocated itself: here x fans out into a LayerNorm branch and a residual add,
+    the residual's gradient is the caller's `dy` tensor — which must come back bit-for-bit unchanged — and dx must still be the sum of both contributions."""
+    from anyedit_amd.autodiff import Tape
+    g = torch.Generator().manual_seed(12)
+    M, C = 256, 320
+    x = q(torch.randn(M, C, generator=g))
+    w = q(torch.randn(C, C, generator=g) / C ** 0.5)
+    gam, bet = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    dy = q(torch.randn(M, C, generator=g))
+    xr = x.clone().requires_grad_(True)
+    (F.layer_norm(xr, (C,), gam, bet, 1e-5) @ w.t() + xr).backward(dy)
+    tape = Tape()
+    xd = x.to(DEV, BF)
+    tape.require(xd)
+    with tape.recording():
+        h = ops.layernorm(xd, gam.to(DEV), bet.to(DEV), 1e-5)
+        y = ops.gemm(h, w.to(DEV, BF), residual=xd)
+    dyd = dy.to(DEV, BF)
+    keep = dyd.clone()
+    tape.accumulate(y, dyd)
+    tape.backward()
+    assert torch.equal(dyd, keep), "the backward pass wrote into the caller's gradient tensor"
+    dx = tape.grad(xd)
+    check_close(dx, xr.grad, rl2=1e-2, what="dx through LayerNorm + residual")
+    assert dx.data_ptr() != dyd.data_ptr() and dx.data_ptr() in tape.owned
+
+
 # ------------------------------------------------------------------------------------------------- small kernels
 def test_sumpool_add_mse_grad_rowsum(ops):
     g = torch.Generator().manual_seed(6)
