@@ -74,6 +74,17 @@ def main():
         res = rnd(M, N) if tag.startswith(("proj", "ff2")) else None   # to_out / proj_out / ff2 add the residual stream in their epilogue
         case(f"gemm {tag} M={M} N={N} K={K}", lambda a=a, w=w, bias=bias, epi=epi, res=res: ops.gemm(a, w, bias, residual=res, epilogue=epi),
              2.0 * M * N * K, 2.0 * (M * K + N * K + M * (N // 2 if epi else N) + (M * N if res is not None else 0)))
+    # ---- round 6: the fused feed-forward launch of the 64x64 level (LayerNorm -> GEGLU -> ff2 + residual [-> proj_out + residual])
+    if B * 4096 >= 192 * 192:
+        M, C, Hd = B * 4096, 320, 1280
+        xf = rnd(M, C)
+        w1p, b1p = ops.pack_geglu(torch.randn(2 * Hd, C, device=DEV) / C ** 0.5, 0.1 * torch.randn(2 * Hd, device=DEV))
+        w2img = ops.pack_ff2_fused(torch.randn(C, Hd, device=DEV) / Hd ** 0.5)
+        gam, bet, b2 = torch.ones(C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        w3, r3 = rnd(C, C), rnd(M, C)
+        case(f"ff_fused L1 M={M} H={Hd}", lambda: ops.ff_fused(xf, gam, bet, 1e-5, w1p, b1p, w2img, b2, residual=xf), 6.0 * M * C * Hd, 2.0 * (3 * M * C + 3 * C * Hd))
+        case(f"ff_fused+proj_out L1 M={M} H={Hd}", lambda: ops.ff_fused(xf, gam, bet, 1e-5, w1p, b1p, w2img, b2, residual=xf, w3=w3, b3=b2, residual3=r3),
+             6.0 * M * C * Hd + 2.0 * M * C * C, 2.0 * (4 * M * C + 3 * C * Hd + C * C))
     # ---- conv3x3
     for (H, Cin, Cout, stride, ups, tag) in ((64, 320, 320, 1, False, "res L1"), (64, 960, 320, 1, False, "res dec L1"),
                                              (32, 640, 640, 1, False, "res L2"), (32, 1920, 640, 1, False, "res dec L2"),

@@ -13,7 +13,7 @@ for r in rows:
     agg[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(sys.argv[2], "w") as f:
     for k, d in agg.items():
-        if "attn" in k or "gemm" in k or "gn_" in k:
+        if "attn" in k or "gemm" in k or "gn_" in k or "ff_fused" in k:
             f.write(k + "\n")
             for c, v in sorted(d.items()):
                 f.write(f"   {c:32s} n={len(v):4d} avg={sum(v)/len(v):16.1f}\n")
