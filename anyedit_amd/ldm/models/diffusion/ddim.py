@@ -184,8 +184,8 @@ class DDIMSampler(object):
                       unconditional_guidance_scale=1., unconditional_conditioning=None, dynamic_threshold=None):
         """ddim.py:180-251."""
         b, device = x.shape[0], x.device
-        if quantize_denoised or score_corrector is not None or noise_dropout > 0.:
-            raise NotImplementedError("quantize_denoised / score_corrector / noise_dropout are not used by any AnyEdit caller")
+        if quantize_denoised:
+            raise NotImplementedError("quantize_denoised needs a VQ first stage (ddim.py:234-235); the AnyEdit path decodes with AutoencoderKL")
         if dynamic_threshold is not None:
             raise NotImplementedError()
         param = getattr(self.model, "parameterization", "eps")
@@ -193,7 +193,18 @@ class DDIMSampler(object):
             raise NotImplementedError("x0-parameterisation: DDIMSampler handles eps- and v-prediction models (ddim.py:214-217)")
         eps, branches = self._model_eps(x, c, t, unconditional_guidance_scale, unconditional_conditioning)
         noise = self.randn((1, *x.shape[1:]), device=device).repeat(b, 1, 1, 1) if repeat_noise else self.randn(x.shape, device=device)
+        if noise_dropout > 0.:
+            # ddim.py:246-247 drops (and rescales) sigma_t * noise * temperature; the mask and its 1 / (1 - p) commute with those two scalars, which the
+            # fused step kernel applies
+            noise = torch.nn.functional.dropout(noise, p=noise_dropout)
         coeffs = self._coeffs(index, use_original_steps)
+        if score_corrector is not None:
+            # ddim.py:219-221: the corrector sees the guidance-combined eps — one launch writes it out, the corrector runs, the update takes ONE branch
+            assert param == "eps", 'not implemented'
+            _, _, e_t = ops.ddim_step(x.float(), eps.float(), coeffs, branches, s0=float(unconditional_guidance_scale), noise=noise.float().contiguous(),
+                                      temperature=float(temperature), want_pred_x0=False, want_e=True)
+            e_t = score_corrector.modify_score(self.model, e_t, x, t, c, **(corrector_kwargs or {}))
+            return ops.ddim_step(x.float(), e_t.float().contiguous(), coeffs, 1, noise=noise.float().contiguous(), temperature=float(temperature))
         if param == "v":
             return self._v_step(x.float().contiguous(), eps.float(), t, coeffs, branches, float(unconditional_guidance_scale),
                                 noise.float().contiguous(), float(temperature))

@@ -103,9 +103,10 @@ class FeedForward(nn.Module):
         super().__init__()
         inner_dim = int(dim * mult)
         dim_out = default(dim_out, dim)
-        if not glu:
-            raise NotImplementedError("FeedForward(glu=False) is not used on the SD-1.5 path (gated_ff=True)")
-        project_in = GEGLU(dim, inner_dim)
+        self.glu = glu
+        # attention.py:66-70: nn.Sequential(nn.Linear(dim, inner_dim), nn.GELU()) — the exact-erf GELU rides in the projection GEMM's epilogue (same state-dict keys:
+        # net.0.0.weight / net.0.0.bias)
+        project_in = GEGLU(dim, inner_dim) if glu else nn.Sequential(Linear(dim, inner_dim), nn.GELU())
         self.net = nn.Sequential(project_in, nn.Dropout(dropout), Linear(inner_dim, dim_out))
 
     def repack(self):
@@ -113,7 +114,7 @@ class FeedForward(nn.Module):
 
     def fused_ok(self, M, C):
         """True where norm3 -> GEGLU -> ff2 (+ residual) runs as ONE launch (`ops.ff_fused`: the 64x64 UNet level at bench batch sizes)."""
-        return ops.ff_fused_ok(M, C, self.net[2].weight.shape[1])
+        return self.glu and ops.ff_fused_ok(M, C, self.net[2].weight.shape[1])
 
     def rows(self, x, residual=None, norm=None, rowstats=None, tail=None):
         """tail: optional (w3 [C, C] bf16, b3, residual3, colstats) — the projection that follows the block (SpatialTransformer.proj_out, attention.py:337-340);
@@ -130,6 +131,10 @@ class FeedForward(nn.Module):
                 return ops.ff_fused(x, g, be, norm.eps, w1, b1, w2img, b2, residual=residual, w3=w3, b3=b3, residual3=res3, colstats=cs)
             return ops.ff_fused(x, g, be, norm.eps, w1, b1, w2img, b2, residual=residual)
         assert tail is None, "FeedForward.rows: the projection tail goes with the fused launch only"
+        if not self.glu:
+            if norm is not None:
+                x = norm.rows(x)
+            return self.net[2].rows(self.net[0][0].rows(x, epilogue=ops.EPI_GELU), residual=residual)
         return self.net[2].rows(self.net[0].rows(x, norm=norm, rowstats=rowstats), residual=residual)
 
     def forward(self, x):
@@ -323,7 +328,7 @@ class BasicTransformerBlock(nn.Module):
             f1 = ops.ln_fold_plan(M, n1, C, ops.EPI_NONE, 2)
             f2 = ops.ln_fold_plan(M, inner2, C, ops.EPI_NONE, 2) and ops.ln_fold_plan(M, C, inner1, ops.EPI_NONE, 1)
             # (where the feed-forward runs as one fused launch it normalises its rows itself: attn2's to_out need not emit statistics)
-            f3 = not self.ff.fused_ok(M, C) and ops.ln_fold_plan(M, self.ff.net[0].proj.weight.shape[0], C, ops.EPI_GEGLU, 2) \
+            f3 = self.ff.glu and not self.ff.fused_ok(M, C) and ops.ln_fold_plan(M, self.ff.net[0].proj.weight.shape[0], C, ops.EPI_GEGLU, 2) \
                 and ops.ln_fold_plan(M, C, inner2, ops.EPI_NONE, 1)
             self._fold_key, self._fold = key, (f1, f2, f3)
         return self._fold

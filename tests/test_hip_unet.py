@@ -7,6 +7,7 @@ the reference output); DDIM integer bookkeeping bit-exact.
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import load_golden, sub_sd, T, rel_l2, psnr
 
@@ -569,6 +570,78 @@ def test_ddim_sampler_vs_oracle_same_eps():
     # torch-CPU sqrt of the schedule scalars may differ from the correctly rounded one by 1 ulp (see test_host_logic), which
     # perturbs the trajectory at the 1e-7 level; everything else is bit-identical arithmetic
     assert float((got.cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_p_sample_ddim_score_corrector_and_noise_dropout():
+    """ddim.py:219-221, 246-247: the two p_sample_ddim options this mirror refused until round 6.  score_corrector.modify_score sees the guidance-combined eps and its
+    return value drives the update; noise_dropout drops (and rescales) the step noise.  Against the unfused fp32 statements of the reference on the same eps / noise / mask."""
+    from anyedit_amd.ldm.models.diffusion.ddim import DDIMSampler
+    from oracle import schedule_ref as S
+
+    class FakeModel:
+        parameterization = "eps"
+
+        def __init__(self, dev):
+            self.num_timesteps = 1000
+            for k, v in S.register_schedule("linear", 1000, 0.00085, 0.0120).items():
+                if isinstance(v, torch.Tensor):
+                    setattr(self, k, v.to(dev))
+            self.device = torch.device(dev)
+
+        def apply_model(self, x, t, c):
+            return torch.sin(x.float() * 1.7) * 0.5 + c.float()[:, :, None, None] * x.float()
+
+    class Corrector:
+        def modify_score(self, model, e_t, x, t, c, gain=1.0):
+            self.seen = e_t.clone()
+            return e_t * gain - 0.1 * x
+
+    B = 2
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, 4, 8, 8, generator=g)
+    c, uc = torch.full((B, 1), 0.3), torch.full((B, 1), -0.2)
+    noise = torch.randn(B, 4, 8, 8, generator=g)
+    s = DDIMSampler(FakeModel(DEV))
+    s.make_schedule(ddim_num_steps=20, ddim_eta=0.5, verbose=False)
+    s.randn = lambda shape, device=None: noise.to(device)
+    index, scale, temp, p_drop = 7, 4.0, 0.9, 0.25
+    t = torch.full((B,), int(s.ddim_timesteps[index]), dtype=torch.long, device=DEV)
+    cor = Corrector()
+    torch.manual_seed(5)
+    x_prev, pred_x0 = s.p_sample_ddim(x.to(DEV), c.to(DEV), t, index, temperature=temp, noise_dropout=p_drop, score_corrector=cor, corrector_kwargs={"gain": 1.2},
+                                      unconditional_guidance_scale=scale, unconditional_conditioning=uc.to(DEV))
+    # the reference's statements (fp32, torch): the dropout mask is re-drawn from the same seed on the same device
+    m = FakeModel("cpu")
+    e_u, e_c = m.apply_model(x, None, uc), m.apply_model(x, None, c)
+    e_t = e_u + scale * (e_c - e_u)
+    assert float((cor.seen.cpu() - e_t).abs().max()) <= 1e-6 * float(e_t.abs().max()) + 1e-6
+    e_t = e_t * 1.2 - 0.1 * x
+    full = lambda v: torch.full((B, 1, 1, 1), float(v))  # noqa: E731
+    a_t, a_prev, sig, s1m = full(s.ddim_alphas[index]), full(s.ddim_alphas_prev[index]), full(s.ddim_sigmas[index]), full(s.ddim_sqrt_one_minus_alphas[index])
+    px0 = (x - s1m * e_t) / a_t.sqrt()
+    torch.manual_seed(5)
+    dn = torch.nn.functional.dropout(noise.to(DEV), p=p_drop).cpu()
+    ref = a_prev.sqrt() * px0 + (1.0 - a_prev - sig ** 2).sqrt() * e_t + sig * dn * temp
+    assert float((pred_x0.cpu() - px0).abs().max()) <= 1e-5 * float(px0.abs().max())
+    assert float((x_prev.cpu() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert float((dn == 0).float().mean()) > 0.1, "the dropout must have dropped something"
+
+
+def test_feed_forward_without_glu_and_ungated_block():
+    """attention.py:61-76 with glu=False (BasicTransformerBlock(gated_ff=False)): Linear -> exact-erf GELU -> Linear, the GELU in the projection GEMM's epilogue;
+    state-dict keys net.0.0.* / net.2.* as the reference's nn.Sequential gives them."""
+    from anyedit_amd.ldm.modules.attention import FeedForward, BasicTransformerBlock
+    torch.manual_seed(3)
+    ff = FeedForward(64, glu=False)
+    assert sorted(ff.state_dict().keys()) == ["net.0.0.bias", "net.0.0.weight", "net.2.bias", "net.2.weight"]
+    x = torch.randn(2, 10, 64)
+    qb = lambda t_: t_.to(torch.bfloat16).float()  # noqa: E731
+    ref = F.linear(F.gelu(F.linear(qb(x), qb(ff.net[0][0].weight), ff.net[0][0].bias)), qb(ff.net[2].weight), ff.net[2].bias)
+    got = ff.to(DEV)(x.to(DEV)).float().cpu()
+    assert rel_l2(got, ref) <= 6e-3
+    blk = BasicTransformerBlock(64, 2, 32, context_dim=16, gated_ff=False).to(DEV)
+    y = blk(x.to(DEV), context=torch.randn(2, 5, 16).to(DEV))
+    assert y.shape == x.shape and torch.isfinite(y).all()
 
 
 # ------------------------------------------------------------------------------------------------------------ first stage (N1)
