@@ -13,6 +13,11 @@
 #include "common.hpp"
 #include <stdlib.h>
 
+#ifndef GN_CS_U
+#define GN_CS_U 4   // independent loads per thread of gn_finalize_cs_kernel.  Round 6: 8 (one round trip for the 1 280 / 1 920 slab sums of a group) measured
+                    // 12.479 / 12.458 / 12.444 vs 12.457 / 12.443 / 12.436 ms per UNet step for 4 in three alternating pairs — nothing; 4 stays (-DGN_CS_U=8 builds it)
+#endif
+
 namespace {
 
 constexpr int GN_MAXR = 8;  // rows per thread kept in flight
@@ -177,14 +182,15 @@ __global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const GNArgs p) {
     const int g = blockIdx.x, b = blockIdx.y;
     const int cpg = p.C / p.groups, nslab = p.HW / 32, C2 = p.C - p.C1;
     float a = 0.f, c = 0.f;
-    // four independent loads per thread in flight (the launch is nothing but their latency: 6.2 -> ~3.5 us per GroupNorm); the slab index
-    // comes from a float reciprocal — (idx + 0.5) / cpg is never closer than 0.5 / cpg to an integer, exact for idx < 2^20
+    // GN_CS_U independent loads per thread in flight (the launch is nothing but their latency: 6.2 -> ~3.5 us per GroupNorm with four); the slab index comes from a
+    // float reciprocal —
+    // (idx + 0.5) / cpg is never closer than 0.5 / cpg to an integer, exact for idx < 2^20.  The order of the thread's additions is fixed (u ascending).
     const int total = nslab * cpg;
     const float inv_cpg = 1.0f / (float)cpg;
-    for (int base = threadIdx.x; base < total; base += 1024) {
-        f32x2 v[4];
+    for (int base = threadIdx.x; base < total; base += 256 * GN_CS_U) {
+        f32x2 v[GN_CS_U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < GN_CS_U; ++u) {
             const int idx = base + 256 * u;
             const int i = (int)(((float)idx + 0.5f) * inv_cpg), ch = g * cpg + (idx - i * cpg);
             const long slab = (long)b * nslab + i;
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const GNArgs p) {
                                  : *reinterpret_cast<const f32x2*>(p.cs2 + (slab * C2 + (ch - p.C1)) * 2);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { a += v[u][0]; c += v[u][1]; }
+        for (int u = 0; u < GN_CS_U; ++u) { a += v[u][0]; c += v[u][1]; }
     }
     a = wave_reduce_sum(a);
     c = wave_reduce_sum(c);

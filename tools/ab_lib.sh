@@ -9,6 +9,6 @@ TAG=$1; ROUNDS=$2; shift 2
 VAR=$PWD/anyedit_amd/libanyedit_hip_$TAG.so
 [ -f "$VAR" ] || { echo "missing $VAR: build it first (python -m anyedit_amd.build --variant $TAG file.hip=-flag ...)"; exit 2; }
 for i in $(seq 1 $ROUNDS); do
-  echo "== product library (round $i)"; env -u AE_LIB_PATH "$@" 2>/dev/null | tail -1 | cut -c1-400
-  echo "== variant $TAG (round $i)"; AE_LIB_PATH=$VAR "$@" 2>/dev/null | tail -1 | cut -c1-400
+  echo "== product library (round $i)"; env -u AE_LIB_PATH "$@" 2>/dev/null | tail -1
+  echo "== variant $TAG (round $i)"; AE_LIB_PATH=$VAR "$@" 2>/dev/null | tail -1
 done
