@@ -1046,6 +1046,10 @@ extern "C" int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, con
         // gn_finalize_cs_kernel finds (slab, channel) from a flat index by a float reciprocal: exact below 2^20 terms per group
         AE_REQUIRE((long)(HW / 32) * (C / groups) < (1L << 20), "ae_groupnorm_nhwc_bf16: %ld slab sums per group exceed the 2^20 the statistics fold indexes exactly", (long)(HW / 32) * (C / groups));
         p.cs1 = colstats; p.cs2 = colstats2;
+        // lab knob (timing only, WRONG results): AE_GN_LAB_SKIP_FINALIZE=1 leaves this launch out — the upper bound of what ANY scheme that removes the finalize
+        // launch could return (round 6: measured before building one)
+        static const int lab_skip = getenv("AE_GN_LAB_SKIP_FINALIZE") ? atoi(getenv("AE_GN_LAB_SKIP_FINALIZE")) : 0;
+        if (!lab_skip)
         hipLaunchKernelGGL(gn_finalize_cs_kernel, dim3(groups, B), dim3(256), 0, s, p);
         int rc0 = ae_check_launch("ae_groupnorm_nhwc_bf16(finalize from producer statistics)");
         if (rc0) return rc0;

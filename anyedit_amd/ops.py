@@ -621,6 +621,8 @@ def conv3x3(x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2
 
 # --------------------------------------------------------------------------- norms
 _GN_COUNTERS = {}
+_GN_LAB_SKIP = os.environ.get("AE_GN_LAB_SKIP_FINALIZE") == "1"   # see csrc/norm.hip: upper bound of removing the finalize launch
+_GN_LAB_WS = {}
 
 
 _GN_TAIL = os.environ.get("AE_GN_TAIL") == "1"   # the last-block finalize is a measured loss on MI355X: opt-in only
@@ -658,7 +660,16 @@ def groupnorm(x, gamma, beta, B, HW, eps, silu=False, groups=32, x2=None, out=No
         for t, c, n in ((colstats, C1, "colstats"), (colstats2, C - C1, "colstats2")):
             if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != (B * HW // 32, c, 2) or not t.is_contiguous() or HW % 32):
                 raise ValueError(f"groupnorm: {n} must be a contiguous fp32 [{B * HW // 32}, {c}, 2] buffer (HW % 32 == 0), got {tuple(t.shape)}")
-    ws = torch.empty(lib.ae_groupnorm_workspace_floats(B, HW, C, groups), dtype=torch.float32, device=x.device)
+    nws = int(lib.ae_groupnorm_workspace_floats(B, HW, C, groups))
+    if _GN_LAB_SKIP and colstats is not None:   # lab (timing only, wrong results): the finalize launch is left out, the apply reads an all-zero coefficient buffer
+        ws = _GN_LAB_WS.get((nws, x.device))
+        if ws is None:
+            ws = _GN_LAB_WS[(nws, x.device)] = torch.zeros(nws, dtype=torch.float32, device=x.device)
+            rpc = int(lib.ae_groupnorm_rows_per_chunk(HW, C))
+            off = ((B * ((HW + rpc - 1) // rpc) * groups * 2 + 3) // 4) * 4
+            ws[off:off + B * 2 * C].view(B, 2, C)[:, 0] = 1.0   # scale 1, shift 0: the data keeps flowing (all-zero activations would run the chip at zero-data clocks)
+    else:
+        ws = torch.empty(nws, dtype=torch.float32, device=x.device)
     check(lib.ae_groupnorm_nhwc_bf16(_p(x), _p(x2), C1, _p(gamma), _p(beta), _p(out), B, HW, C, groups, eps,
                                      1 if silu else 0, _p(ws), _p(_gn_counters(x.device, B)), _p(stat_out), _p(colstats), _p(colstats2), _s()),
           "ae_groupnorm_nhwc_bf16")
