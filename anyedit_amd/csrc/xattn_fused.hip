@@ -269,7 +269,13 @@ __global__ __launch_bounds__(64 * XA_NW, 1) void xattn_fused_kernel(const XAArgs
     };
     // q -> B operand: rounded to bf16 (what the separate projection stores), scaled by 40^-1/2 log2 e, rounded again (what the attention kernels multiply)
     auto pack_q = [&]() {
-        asm volatile("s_nop 11" : "+v"(accq[0][0]), "+v"(accq[0][1]), "+v"(accq[0][2]), "+v"(accq[1][0]), "+v"(accq[1][1]), "+v"(accq[1][2]));   // asm MFMA results -> VALU
+        // asm MFMA results -> VALU; the W fragments of the phase's last slots stay sources until a VALU instruction has READ the last result (in-order matrix pipe)
+        asm volatile("s_nop 11" : "+v"(accq[0][0]), "+v"(accq[0][1]), "+v"(accq[0][2]), "+v"(accq[1][0]), "+v"(accq[1][1]), "+v"(accq[1][2]) : "v"(wfr[XA_RING - 2]), "v"(wfr[XA_RING - 1]));
+        {
+            float pr = accq[XA_MF - 1][2][3];
+            asm volatile("v_mov_b32 %0, %0" : "+v"(pr) : "v"(wfr[XA_RING - 2]), "v"(wfr[XA_RING - 1]));
+            accq[XA_MF - 1][2][3] = pr;
+        }
         const float c = p.qscale;
 #pragma unroll
         for (int f = 0; f < XA_MF; ++f) {
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(64 * XA_NW, 1) void xattn_fused_kernel(const XAArgs
                      "+v"(S[1][0]), "+v"(S[1][1]), "+v"(S[1][2]), "+v"(S[1][3]), "+v"(S[1][4]), "+v"(S[1][5]) : "v"(wfr[XA_RING - 2]), "v"(wfr[XA_RING - 1]));
         {   // the K fragments stay sources until a VALU instruction has read the last logit result
             float pr = S[XA_MF - 1][5][3];
-            asm volatile("v_mov_b32 %0, %0" : "+v"(pr) : "v"(wfr[XA_RING - 2]), "v"(wfr[XA_RING - 1]));
+            asm volatile("v_mov_b32 %0, %0" : "+v"(pr) : "v"(wfr[XA_RING - 2]), "v"(wfr[XA_RING - 1]), "v"(qf[0][0]), "v"(qf[0][1]), "v"(qf[1][0]), "v"(qf[1][1]));   // (and the q operands)
             S[XA_MF - 1][5][3] = pr;
         }
         // softmax of a row: its text logits sit in the row's four lanes (g) x five fragments x four registers; the expert logits in fragment 5
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(64 * XA_NW, 1) void xattn_fused_kernel(const XAArgs
                      "+v"(acco2[0][0]), "+v"(acco2[0][1]), "+v"(acco2[0][2]), "+v"(acco2[1][0]), "+v"(acco2[1][1]), "+v"(acco2[1][2]) : "v"(wfr[XA_RING - 2]), "v"(wfr[XA_RING - 1]));
         {
             float pr = acco2[XA_MF - 1][2][3];
-            asm volatile("v_mov_b32 %0, %0" : "+v"(pr) : "v"(wfr[XA_RING - 2]), "v"(wfr[XA_RING - 1]));
+            asm volatile("v_mov_b32 %0, %0" : "+v"(pr) : "v"(wfr[XA_RING - 2]), "v"(wfr[XA_RING - 1]), "v"(Pf[0][2]), "v"(Pf[0][3]), "v"(Pf[1][2]), "v"(Pf[1][3]));   // (and the probabilities)
             acco2[XA_MF - 1][2][3] = pr;
         }
 #pragma unroll
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(64 * XA_NW, 1) void xattn_fused_kernel(const XAArgs
         for (int cf = 0; cf < XA_NCF; ++cf) asm volatile("" : "+a"(acc_out[f][cf]));
     {
         float pr = acc_out[XA_MF - 1][XA_NCF - 1][3];
-        asm volatile("" : "+v"(pr) : "v"(wfr[0]), "v"(wfr[1]), "v"(wfr[2]), "v"(wfr[3]), "v"(wfr[4]), "v"(wfr[5]), "v"(wfr[6]), "v"(wfr[7]));
+        asm volatile("" : "+v"(pr) : "v"(wfr[0]), "v"(wfr[1]), "v"(wfr[2]), "v"(wfr[3]), "v"(wfr[4]), "v"(wfr[5]), "v"(wfr[6]), "v"(wfr[7]), "v"(of[0][2]), "v"(of[1][2]));
         acc_out[XA_MF - 1][XA_NCF - 1][3] = pr;
     }
 

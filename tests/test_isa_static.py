@@ -198,6 +198,23 @@ def test_fused_feed_forward_stream_is_the_hand_placed_one(tmp_path):
         assert not hits, (k, hits[:3])
 
 
+def test_fused_cross_attention_stream_keeps_its_mfma_sources(tmp_path):
+    """Round 6 (csrc/xattn_fused.hip, opt-in): the same hand-placed technique as the fused feed-forward — asm MFMAs hipcc neither pads nor tracks, with q, probabilities and
+    attention outputs written by VALU and consumed as MFMA operands a few instructions later.  The listing must show no spills / scratch and no VALU result landing in a source
+    register of an MFMA before two further MFMAs were issued or a read of that MFMA's (or a later one's) result (the first listing had 26 such writes: pack temporaries in the W
+    fragments of a phase's last slots, the row maximum in the q operands)."""
+    import isa_audit as A
+    asm = A.compile_asm(["xattn_fused.hip"], str(tmp_path))[0]
+    rows = [(n, md, loop) for n, md, loop in A.audit_named(asm) if "xattn_fused_kernel" in n]
+    assert len(rows) == 1
+    _, md, _ = rows[0]
+    assert md["vgpr_spill_count"] == "0" and md["private_segment_fixed_size"] == "0" and int(md["agpr_count"]) >= 160, md
+    res = A.mfma_source_overwrites(asm, "xattn_fused_kernel")
+    assert len(res) == 1
+    for k, hits in res.items():
+        assert not hits, (k, hits[:3])
+
+
 def test_attention_backward_keeps_valu_writes_behind_its_mfma_phases(tmp_path):
     """Round 5: the same listing check on EVERY instantiation of attn_bwd_kernel (training step).  The passes are phase-structured — first-product MFMAs,
     the exp2 / P block, second-product MFMAs — and hipcc re-uses the operand registers of a phase's last MFMAs for the first VALU results of the next (the
