@@ -90,6 +90,9 @@ SIGNATURES = {
     "ae_silu_to_bf16": [c_void_p, c_int, c_void_p, c_long, c_void_p],
     "ae_add_bcast_bf16": [c_void_p, c_void_p, c_void_p, c_long, c_long, c_void_p],
     "ae_window_partition_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "ae_layernorm_window_supported": [c_int],
+    "ae_layernorm_window_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                 c_void_p],
     "ae_sam_relpos_terms": [c_void_p, c_long, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                             c_int, c_int, c_int, c_void_p],
     "ae_softmax_rows_f32_bf16": [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_float, c_void_p],

@@ -354,6 +354,87 @@ __global__ __launch_bounds__(256) void relpos_line_kernel(const bf16_t* q, long 
     }
 }
 
+// Round 6: the same contraction on the matrix pipe in fp32 (v_mfma_f32_16x16x4_f32: fp32 products, fp32 accumulation — the terms keep their
+// fp32 precision).  Per query line (PART 0: image row y, PART 1: column x) the terms are a small GEMM: the line's (batch, head, query)
+// triples [BH * Lq, D] times the line's table slice [K, D]^T.  A wave takes one line, up to 16 table rows (the A operand: 16 rows x 4
+// channels per step) and 64 triples (four B-operand tiles of 16), D / 4 steps per tile.  The contraction order is free, so step s of lane
+// group g covers channel 16 (s / 4) + 4 g + s % 4: a lane's A values are 16-byte loads of the table and its B values 8-byte loads of the bf16
+// query row.  Triples are ordered head-fastest, so with the heads of a token contiguous (a fused qkv row) a tile's loads fall on whole lines.
+// The line kernel above staged both operands in LDS and spent two 16-byte LDS reads per four multiply-adds on 196 of 256 threads: 24 us per
+// launch, two launches per SAM block = 1.55 ms of an 11.5 ms ViT-H encoder pass (profiles/r06_v20_sam_kernel_stats.csv) for 176 M
+// multiply-adds and 21 MB of traffic; a form with the table through the scalar unit measured 21 us (70 dependent scalar-load round trips per
+// wave: profiles/r06_v21_sam_relpos.txt).
+struct RelposArgs {
+    long q_sb, q_sh, q_sn;
+    int BH, Hh, qH, qW, kH, kW;
+    int items[2];   // wave items of PART 0 / PART 1
+};
+
+template <int D16>
+__global__ __launch_bounds__(256) void relpos_mfma_kernel(const bf16_t* __restrict__ q, const float* __restrict__ Rh, const float* __restrict__ Rw,
+                                                          float* __restrict__ rel_h, float* __restrict__ rel_w, const RelposArgs p) {
+    constexpr int D = 16 * D16;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
+    long item = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int part = 0;
+    if (item >= p.items[0]) { item -= p.items[0]; part = 1; }
+    if (item >= p.items[part]) return;
+    const int Lq = part == 0 ? p.qW : p.qH, K = part == 0 ? p.kH : p.kW;
+    const int nks = (K + 15) / 16;
+    const long ntrip = (long)p.BH * Lq;                 // triples on a line
+    const int ngrp = (int)((ntrip + 63) / 64);
+    // item -> (line, k chunk, group of 64 triples): consecutive waves share the line and the k chunk = the same table rows
+    int r = (int)item;
+    const int grp = r % ngrp; r /= ngrp;
+    const int ks = r % nks; r /= nks;
+    const int line = r;
+    const int k0 = ks * 16;
+    // A operand: table row k0 + l15, channels 16 u + 4 g .. + 3 (rows past K read row K - 1 and are never stored)
+    const int krow = k0 + l15 < K ? k0 + l15 : K - 1;
+    const float* Rrow = (part == 0 ? Rh : Rw) + ((long)line * K + krow) * D + 4 * g;
+    f32x4 av[D16];
+#pragma unroll
+    for (int u = 0; u < D16; ++u) av[u] = *reinterpret_cast<const f32x4*>(Rrow + 16 * u);
+    float* outp = part == 0 ? rel_h : rel_w;
+    const long N = (long)p.qH * p.qW;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        long trip = (long)grp * 64 + t * 16 + l15;      // head fastest, then the query on the line, then the batch
+        const bool live = trip < ntrip;
+        if (!live) trip = ntrip - 1;
+        const int h = (int)(trip % p.Hh);
+        const long rest = trip / p.Hh;
+        const int qi = (int)(rest % Lq), b = (int)(rest / Lq);
+        const long n = part == 0 ? (long)line * p.qW + qi : (long)qi * p.qW + line;
+        const bf16_t* qr = q + (long)b * p.q_sb + (long)h * p.q_sh + n * p.q_sn + 4 * g;
+        uint2 bv[D16];
+#pragma unroll
+        for (int u = 0; u < D16; ++u) bv[u] = *reinterpret_cast<const uint2*>(qr + 16 * u);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < D16; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][0], bf16lo(bv[u].x), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][1], bf16hi(bv[u].x), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][2], bf16lo(bv[u].y), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][3], bf16hi(bv[u].y), acc, 0, 0, 0);
+        }
+        // lane (l15, g) holds the triple's terms k0 + 4 g .. + 3
+        if (live) {
+            float* o = outp + (((long)b * p.Hh + h) * N + n) * K;
+            const int kk = k0 + 4 * g;
+            if ((K & 3) == 0 && kk + 3 < K) *reinterpret_cast<f32x4*>(o + kk) = acc;
+            else if ((K & 1) == 0) {
+                if (kk + 1 < K) *reinterpret_cast<float2*>(o + kk) = make_float2(acc[0], acc[1]);
+                if (kk + 3 < K) *reinterpret_cast<float2*>(o + kk + 2) = make_float2(acc[2], acc[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (kk + e < K) o[kk + e] = acc[e];
+            }
+        }
+    }
+}
+
 // Row softmax for the first-stage AttnBlock (diffusionmodules/model.py:188-192: single head, c = 512, N = h*w = 4096 tokens): the
 // logits are materialised by the GEMM kernel in fp32 (N x N per image: 67 MB at 512 px — outside the denoising loop, once per
 // image) and this kernel writes softmax(scale * S) as the bf16 operand of the P V GEMM.  One block per row.
@@ -591,6 +672,25 @@ extern "C" int ae_sam_relpos_terms(const void* q, long q_sb, long q_sh, long q_s
                                    float* rel_w, int B, int heads, int qH, int qW, int kH, int kW, int D, void* stream) {
     AE_REQUIRE(q && Rh && Rw && rel_h && rel_w && B > 0 && heads > 0 && D > 0, "ae_sam_relpos_terms: bad arguments");
     AE_REQUIRE((long)B * heads <= 65535, "ae_sam_relpos_terms: B*heads too large for grid.y");
+    // round 6: both terms in ONE launch on the fp32 matrix pipe (relpos_mfma_kernel).  AE_RELPOS_MFMA=0: the two line launches (A/B)
+    static const int mf = getenv("AE_RELPOS_MFMA") ? atoi(getenv("AE_RELPOS_MFMA")) : 1;
+    if (mf && D % 16 == 0 && D <= 96 && (q_sn % 4) == 0 && (q_sb % 4) == 0 && (q_sh % 4) == 0 && (reinterpret_cast<uintptr_t>(q) & 7) == 0 &&
+        (reinterpret_cast<uintptr_t>(Rh) & 15) == 0 && (reinterpret_cast<uintptr_t>(Rw) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(rel_h) & 15) == 0 && (reinterpret_cast<uintptr_t>(rel_w) & 15) == 0) {
+        RelposArgs p{};
+        p.q_sb = q_sb; p.q_sh = q_sh; p.q_sn = q_sn;
+        p.BH = B * heads; p.Hh = heads; p.qH = qH; p.qW = qW; p.kH = kH; p.kW = kW;
+        const long i0 = (long)qH * ((kH + 15) / 16) * (((long)p.BH * qW + 63) / 64), i1 = (long)qW * ((kW + 15) / 16) * (((long)p.BH * qH + 63) / 64);
+        AE_REQUIRE(i0 + i1 < (1L << 31), "ae_sam_relpos_terms: too many wave items");
+        p.items[0] = (int)i0; p.items[1] = (int)i1;
+        const unsigned blocks = (unsigned)((i0 + i1 + 3) / 4);
+        hipStream_t s = (hipStream_t)stream;
+#define AE_RPM(n) hipLaunchKernelGGL(relpos_mfma_kernel<n>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)q, Rh, Rw, rel_h, rel_w, p)
+        switch (D / 16) { case 1: AE_RPM(1); break; case 2: AE_RPM(2); break; case 3: AE_RPM(3); break; case 4: AE_RPM(4); break;
+                          case 5: AE_RPM(5); break; default: AE_RPM(6); break; }
+#undef AE_RPM
+        return ae_check_launch("ae_sam_relpos_terms(mfma)");
+    }
     if (qH <= 64 && qW <= 64 && kH <= 64 && kW <= 64 && D % 8 == 0 && D <= 160 && (q_sn % 8) == 0 && (q_sb % 8) == 0 && (q_sh % 8) == 0 &&
         (reinterpret_cast<uintptr_t>(q) & 15) == 0 && (reinterpret_cast<uintptr_t>(Rh) & 15) == 0 && (reinterpret_cast<uintptr_t>(Rw) & 15) == 0) {
         const size_t lds = (size_t)2 * 64 * (D + 4) * sizeof(float);

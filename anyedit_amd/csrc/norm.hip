@@ -922,6 +922,108 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* x, co
     }
 }
 
+// SAM's windowed blocks (image_encoder.py:166-182, 243-289): the LayerNorm of layernorm_rows_kernel with the window partition / un-partition
+// folded into its row addressing — the same operations in the same order per row as the launches they replace (the residual sum bit for bit; the
+// normalised values up to hipcc's per-kernel choice of fused / unfused multiply-adds: a few elements per million, one bf16 step).
+//   MODE 1 (norm1 + window_partition): one OUTPUT row (window order, [B*nH*nW*ws*ws, C]) per row slot; rows of the bottom / right padding
+//          are written as zeros (the padding is applied AFTER the norm: :169-173), the others are LayerNorm(x[image row]).
+//   MODE 2 (window_unpartition + shortcut + norm2): one IMAGE row per row slot; v = bf16(windows[window row] + shortcut[row]) is written to
+//          `xsum` (the block's residual stream, :175-181) and LayerNorm(v) to y.
+struct LnWinArgs {
+    const bf16_t* x;         // MODE 1: image rows; MODE 2: window rows (attention output)
+    const bf16_t* shortcut;  // MODE 2: image rows
+    const float* gamma;
+    const float* beta;
+    bf16_t* y;               // MODE 1: window rows; MODE 2: image rows
+    bf16_t* xsum;            // MODE 2
+    int B, H, W, C, ws, nH, nW;
+    long rows;               // row slots: MODE 1 B*nH*nW*ws*ws, MODE 2 B*H*W
+    float eps;
+};
+
+template <int L, int NCH, int MODE>
+__global__ __launch_bounds__(256) void layernorm_window_kernel(LnWinArgs p) {
+    const int lane = threadIdx.x & 63, sub = lane % L;
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / L) + lane / L;
+    const bool live = row < p.rows;
+    const long rowc = live ? row : p.rows - 1;
+    const int C = p.C, ws = p.ws;
+    long img, win;
+    bool pad = false;
+    if (MODE == 1) {
+        long r = rowc;
+        const int wx = (int)(r % ws); r /= ws;
+        const int wy = (int)(r % ws); r /= ws;
+        const int jw = (int)(r % p.nW); r /= p.nW;
+        const int jh = (int)(r % p.nH); r /= p.nH;
+        const int yy = jh * ws + wy, xx = jw * ws + wx;
+        pad = yy >= p.H || xx >= p.W;
+        img = pad ? 0 : (r * p.H + yy) * p.W + xx;
+        win = rowc;
+    } else {
+        long r = rowc;
+        const int xx = (int)(r % p.W); r /= p.W;
+        const int yy = (int)(r % p.H); r /= p.H;
+        win = (((r * p.nH + yy / ws) * p.nW + xx / ws) * ws + yy % ws) * ws + xx % ws;
+        img = rowc;
+    }
+    u32x4 v[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) v[i] = *reinterpret_cast<const u32x4*>(p.x + (MODE == 1 ? img : win) * C + (sub + i * L) * 8);
+    if (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const u32x4 b = *reinterpret_cast<const u32x4*>(p.shortcut + img * C + (sub + i * L) * 8);
+            // the argument order of ops.add_bcast(windows, shortcut): bf16(windows + shortcut)
+            v[i].x = pack_bf16x2(bf16lo(v[i].x) + bf16lo(b.x), bf16hi(v[i].x) + bf16hi(b.x));
+            v[i].y = pack_bf16x2(bf16lo(v[i].y) + bf16lo(b.y), bf16hi(v[i].y) + bf16hi(b.y));
+            v[i].z = pack_bf16x2(bf16lo(v[i].z) + bf16lo(b.z), bf16hi(v[i].z) + bf16hi(b.z));
+            v[i].w = pack_bf16x2(bf16lo(v[i].w) + bf16lo(b.w), bf16hi(v[i].w) + bf16hi(b.w));
+            if (live) *reinterpret_cast<u32x4*>(p.xsum + img * C + (sub + i * L) * 8) = v[i];
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += bf16lo(w[e]) + bf16hi(w[e]);
+    }
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mu = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = bf16lo(w[e]) - mu, c = bf16hi(w[e]) - mu;
+            q += a * a + c * c;
+        }
+    }
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / (float)C + p.eps);
+    if (!live) return;
+    bf16_t* yrow = p.y + (MODE == 1 ? win : img) * C;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c0 = (sub + i * L) * 8;
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if (!pad) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + c0), g1 = *reinterpret_cast<const f32x4*>(p.gamma + c0 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + c0), b1 = *reinterpret_cast<const f32x4*>(p.beta + c0 + 4);
+            const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            o.x = pack_bf16x2((bf16lo(w[0]) - mu) * rstd * g0[0] + b0[0], (bf16hi(w[0]) - mu) * rstd * g0[1] + b0[1]);
+            o.y = pack_bf16x2((bf16lo(w[1]) - mu) * rstd * g0[2] + b0[2], (bf16hi(w[1]) - mu) * rstd * g0[3] + b0[3]);
+            o.z = pack_bf16x2((bf16lo(w[2]) - mu) * rstd * g1[0] + b1[0], (bf16hi(w[2]) - mu) * rstd * g1[1] + b1[1]);
+            o.w = pack_bf16x2((bf16lo(w[3]) - mu) * rstd * g1[2] + b1[2], (bf16hi(w[3]) - mu) * rstd * g1[3] + b1[3]);
+        }
+        *reinterpret_cast<u32x4*>(yrow + c0) = o;
+    }
+}
+
 // LayerNorm over a narrow last dim (C <= 512) with an optional fused GELU: L = pow2 lanes per row, 64 / L rows per wave, so the
 // LayerNorm2d + GELU pairs of the SAM mask decoder (mask_decoder.py:53-60; C = 64 over 16384*B pixels) keep every lane busy.
 template <int L, int ACT>
@@ -1117,6 +1219,34 @@ extern "C" int ae_layernorm_bf16(const void* x, const float* gamma, const float*
     else if (ncc <= 192) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);
     else hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps);
     return ae_check_launch("ae_layernorm_bf16");
+}
+
+// LayerNorm with SAM's window partition folded in (layernorm_window_kernel).  mode 1: y[windows] = partition(LayerNorm(x[image])), padding
+// rows zero; mode 2: xsum[image] = bf16(x[windows] + shortcut[image]), y[image] = LayerNorm(xsum).  C = 40 L channels, L in {8, 16, 32, 64}.
+extern "C" int ae_layernorm_window_supported(int C) {
+    const int ncc = C / 8;
+    return C % 8 == 0 && (ncc == 40 || ncc == 80 || ncc == 160 || ncc == 320);
+}
+
+extern "C" int ae_layernorm_window_bf16(const void* x, const void* shortcut, const float* gamma, const float* beta, void* y, void* xsum,
+                                        int B, int H, int W, int C, int ws, int mode, float eps, void* stream) {
+    AE_REQUIRE(x && gamma && beta && y && (mode == 1 || (mode == 2 && shortcut && xsum)), "ae_layernorm_window_bf16: null pointer / mode %d", mode);
+    AE_REQUIRE(B > 0 && H > 0 && W > 0 && ws > 0 && ae_layernorm_window_supported(C), "ae_layernorm_window_bf16: unsupported shape (C=%d)", C);
+    AE_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)shortcut | (uintptr_t)xsum | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0,
+               "ae_layernorm_window_bf16: 16-byte alignment");
+    LnWinArgs p{};
+    p.x = (const bf16_t*)x; p.shortcut = (const bf16_t*)shortcut; p.gamma = gamma; p.beta = beta; p.y = (bf16_t*)y; p.xsum = (bf16_t*)xsum;
+    p.B = B; p.H = H; p.W = W; p.C = C; p.ws = ws; p.nH = (H + ws - 1) / ws; p.nW = (W + ws - 1) / ws; p.eps = eps;
+    p.rows = mode == 1 ? (long)B * p.nH * p.nW * ws * ws : (long)B * H * W;
+    const int L = C / 40, rpb = 4 * (64 / L);
+    dim3 grid((unsigned)((p.rows + rpb - 1) / rpb)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define AE_LNW(LL) \
+    if (mode == 1) hipLaunchKernelGGL((layernorm_window_kernel<LL, 5, 1>), grid, block, 0, s, p); \
+    else hipLaunchKernelGGL((layernorm_window_kernel<LL, 5, 2>), grid, block, 0, s, p)
+    if (L == 8) { AE_LNW(8); } else if (L == 16) { AE_LNW(16); } else if (L == 32) { AE_LNW(32); } else { AE_LNW(64); }
+#undef AE_LNW
+    return ae_check_launch("ae_layernorm_window_bf16");
 }
 
 extern "C" long ae_groupnorm_bwd_workspace_floats(int B, int HW, int C, int groups) {

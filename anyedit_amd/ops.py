@@ -950,6 +950,33 @@ def window_unpartition(windows, B, H, W, ws):
     return out
 
 
+def layernorm_window_ok(C):
+    return bool(lib.ae_layernorm_window_supported(int(C)))
+
+
+def layernorm_window_partition(x, gamma, beta, eps, B, H, W, ws):
+    """window_partition(LayerNorm(x)) in one launch (SAM Block norm1 + partition, image_encoder.py:166-173): x [B*H*W, C] image rows ->
+    ([B*nH*nW*ws*ws, C] window rows with zero padding rows, (Hp, Wp))."""
+    _chk(x, BF16, "layernorm_window_partition.x", 2)
+    C = x.shape[1]
+    nH, nW = (H + ws - 1) // ws, (W + ws - 1) // ws
+    out = torch.empty(B * nH * nW * ws * ws, C, dtype=BF16, device=x.device)
+    check(lib.ae_layernorm_window_bf16(_p(x), None, _p(gamma), _p(beta), _p(out), None, B, H, W, C, ws, 1, eps, _s()),
+          "ae_layernorm_window_bf16")
+    return out, (nH * ws, nW * ws)
+
+
+def window_merge_layernorm(windows, shortcut, gamma, beta, eps, B, H, W, ws):
+    """(x, LayerNorm(x)) with x = shortcut + window_unpartition(windows) in one launch (SAM Block :175-181: un-partition, residual add, norm2)."""
+    _chk(windows, BF16, "window_merge_layernorm.windows", 2)
+    _chk(shortcut, BF16, "window_merge_layernorm.shortcut", 2)
+    C = shortcut.shape[1]
+    xsum, y = torch.empty_like(shortcut), torch.empty_like(shortcut)
+    check(lib.ae_layernorm_window_bf16(_p(windows), _p(shortcut), _p(gamma), _p(beta), _p(y), _p(xsum), B, H, W, C, ws, 2, eps, _s()),
+          "ae_layernorm_window_bf16")
+    return xsum, y
+
+
 def sam_relpos_terms(q, q_strides, Rh, Rw, B, heads, qH, qW, D):
     kH, kW = Rh.shape[1], Rw.shape[1]
     rel_h = torch.empty(B * heads, qH * qW, kH, dtype=torch.float32, device=q.device)

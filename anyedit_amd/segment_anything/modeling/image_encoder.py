@@ -16,6 +16,7 @@ from anyedit_amd.ldm.modules.diffusionmodules.util import Linear, Conv2d, LayerN
 
 BF16 = torch.bfloat16
 _ENV_FP8 = __import__("os").environ.get("AE_SAM_ATTN", "") == "fp8"
+_WIN_FUSED = __import__("os").environ.get("AE_SAM_WIN_FUSED", "1") != "0"  # 0: the five-launch sequence around a windowed block (A/B)
 
 
 class MLPBlock(nn.Module):
@@ -142,8 +143,17 @@ class Block(nn.Module):
         self.window_size = window_size
 
     def rows(self, x, B, H, W):
-        h = self.norm1.rows(x)
         ws = self.window_size
+        if ws > 0 and _WIN_FUSED and ops.layernorm_window_ok(x.shape[1]):
+            # round 6: norm1 + partition and un-partition + shortcut + norm2 as ONE launch each (ae_layernorm_window_bf16): the window
+            # permutation is the row addressing of the LayerNorm that stands next to it — five launches -> two, the same arithmetic per row
+            g1, b1 = self.norm1._affine()
+            win, (Hp, Wp) = ops.layernorm_window_partition(x, g1, b1, self.norm1.eps, B, H, W, ws)
+            a = self.attn.rows(win, B * (Hp // ws) * (Wp // ws), ws, ws)
+            g2, b2 = self.norm2._affine()
+            x, h2 = ops.window_merge_layernorm(a, x, g2, b2, self.norm2.eps, B, H, W, ws)
+            return self.mlp.rows(h2, residual=x)
+        h = self.norm1.rows(x)
         if ws > 0:
             win, (Hp, Wp) = ops.window_partition(h, B, H, W, ws)
             nwin = B * (Hp // ws) * (Wp // ws)

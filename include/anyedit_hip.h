@@ -298,6 +298,13 @@ int ae_silu_to_bf16(const void* x, int in_bf16, void* y, long n, void* stream);
 int ae_add_bcast_bf16(const void* x, const void* p, void* y, long n, long period, void* stream);
 /* window_partition / window_unpartition (image_encoder.py:243-289); arguments are always (image, windows).                    */
 int ae_window_partition_bf16(const void* image, void* windows, int B, int H, int W, int C, int ws, int reverse, void* stream);
+/* LayerNorm with the window partition of SAM's windowed blocks folded into its row addressing (image_encoder.py:166-182, 243-289).
+ * mode 1: y[window rows] = window_partition(LayerNorm(x[image rows])), padding rows zero (norm1 + partition);
+ * mode 2: xsum[image rows] = bf16(x[window rows] + shortcut[image rows]), y = LayerNorm(xsum) (un-partition + shortcut + norm2).
+ * Same arithmetic as ae_layernorm_bf16 / ae_window_partition_bf16 / ae_add_bcast_bf16 in sequence (xsum bit for bit).             */
+int ae_layernorm_window_supported(int C);
+int ae_layernorm_window_bf16(const void* x, const void* shortcut, const float* gamma, const float* beta, void* y, void* xsum,
+                             int B, int H, int W, int C, int ws, int mode, float eps, void* stream);
 /* rel_h / rel_w einsums of add_decomposed_rel_pos (image_encoder.py:349-355); Rh [qH,kH,D], Rw [qW,kW,D] fp32.                */
 int ae_sam_relpos_terms(const void* q, long q_sb, long q_sh, long q_sn, const float* Rh, const float* Rw, float* rel_h,
                         float* rel_w, int B, int heads, int qH, int qW, int kH, int kW, int D, void* stream);

@@ -40,6 +40,44 @@ def test_window_partition_bit_exact():
         assert torch.equal(back, xq.float())
 
 
+def same_up_to_contraction(a, b):
+    """Two kernels with the same source arithmetic: hipcc's fp-contract=fast picks the fused / unfused form per kernel, so a few elements per
+    million (those where the affine part cancels) may differ by one bf16 rounding step; everything else — and every padding row — is identical."""
+    a, b = a.float(), b.float()
+    d = (a - b).abs()
+    nd = int((d > 0).sum())
+    # one bf16 step at the larger magnitude, plus the fp32 rounding of the O(1) addends where x_hat * gamma and beta cancel
+    step = torch.maximum(a.abs(), b.abs()) * 2.0 ** -7 + 1e-6
+    return nd <= max(2, a.numel() // 100000) and bool((d <= step).all()) and bool(((a == 0) == (b == 0)).all())
+
+
+def test_layernorm_with_window_addressing():
+    """ae_layernorm_window_bf16 (norm1 + partition; un-partition + shortcut + norm2: image_encoder.py:166-181) against the launches it
+    replaces (same values up to the compiler's contraction choice, the residual sum bit for bit) and against the fp64 statement of the same
+    lines on the bf16 inputs."""
+    from anyedit_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for (B, H, W, C, ws) in ((1, 64, 64, 1280, 14), (2, 10, 13, 320, 4), (1, 14, 14, 640, 14), (3, 5, 9, 2560, 7), (1, 33, 2, 1280, 8)):
+        assert ops.layernorm_window_ok(C)
+        x = (torch.randn(B * H * W, C, generator=g) * 2 + 0.3).to(BF).to(DEV)
+        gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV), (0.2 * torch.randn(C, generator=g)).to(DEV)
+        win, pad = ops.layernorm_window_partition(x, gamma, beta, 1e-6, B, H, W, ws)
+        ref, pad2 = ops.window_partition(ops.layernorm(x, gamma, beta, 1e-6), B, H, W, ws)
+        assert pad == pad2 and same_up_to_contraction(win, ref), (B, H, W, C, ws)
+        xr = x.double().cpu().reshape(B, H, W, C)
+        ln = torch.nn.functional.layer_norm(xr, (C,), gamma.double().cpu(), beta.double().cpu(), 1e-6)
+        lnp = torch.nn.functional.pad(ln, (0, 0, 0, pad[1] - W, 0, pad[0] - H))
+        lnw = lnp.reshape(B, pad[0] // ws, ws, pad[1] // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, C)
+        assert rel_l2(win.double().cpu(), lnw) < 4e-3
+        npad = int((lnw.abs().sum(-1) == 0).sum())
+        assert npad == B * (pad[0] * pad[1] - H * W) and int((win.float().abs().sum(-1) == 0).sum()) == npad
+        a = torch.randn(win.shape[0], C, generator=g).to(BF).to(DEV)   # the attention output in window order
+        xs, h2 = ops.window_merge_layernorm(a, x, gamma, beta, 1e-6, B, H, W, ws)
+        xs_ref = ops.add_bcast(ops.window_unpartition(a, B, H, W, ws), x)
+        assert torch.equal(xs, xs_ref) and same_up_to_contraction(h2, ops.layernorm(xs_ref, gamma, beta, 1e-6)), (B, H, W, C, ws)
+    assert not ops.layernorm_window_ok(256)
+
+
 def test_relpos_terms_and_biased_attention():
     from anyedit_amd import ops
     from oracle import sam_ref as M, ldm_ref as L
@@ -59,6 +97,24 @@ def test_relpos_terms_and_biased_attention():
                             (N * d, 0, d), rel_h=gh, rel_w=gw, kH=H, kW=W)
         e = rel_l2(out.float().cpu().reshape(ref.shape), ref)
         assert e < 6e-3, (H, W, d, e)
+
+
+def test_relpos_terms_wave_groupings():
+    """ae_sam_relpos_terms' matrix-pipe kernel (head dims 16 k; the line kernels otherwise): ragged tiles of (batch, head, query) triples, ragged
+    line lengths, and the (batch, head) strides of a fused qkv row (image_encoder.py:227, 349-355) against the oracle's einsum."""
+    from anyedit_amd import ops
+    from oracle import sam_ref as M
+    g = torch.Generator().manual_seed(22)
+    for (B, heads, H, W, d) in ((1, 1, 5, 7, 32), (2, 3, 6, 5, 40), (4, 4, 7, 9, 64), (13, 4, 14, 14, 80), (1, 16, 9, 20, 80), (2, 40, 3, 2, 64)):
+        N, C = H * W, heads * d
+        qkv = torch.randn(B, N, 3, heads, d, generator=g).to(BF)
+        q = qkv[:, :, 0].permute(0, 2, 1, 3).reshape(B * heads, N, d).float()
+        rph, rpw = torch.randn(2 * H - 1, d, generator=g) * 0.3, torch.randn(2 * W - 1, d, generator=g) * 0.3
+        rel_h, rel_w = M.decomposed_rel_pos_terms(q, rph, rpw, (H, W), (H, W))
+        Rh, Rw = M.get_rel_pos(H, H, rph).contiguous().to(DEV), M.get_rel_pos(W, W, rpw).contiguous().to(DEV)
+        gh, gw = ops.sam_relpos_terms(qkv.to(DEV).reshape(B * N, 3 * C), (N * 3 * C, d, 3 * C), Rh, Rw, B, heads, H, W, d)
+        eh, ew = rel_l2(gh.cpu().reshape(rel_h.shape), rel_h), rel_l2(gw.cpu().reshape(rel_w.shape), rel_w)
+        assert eh < 1e-5 and ew < 1e-5, (B, heads, H, W, d, eh, ew)
 
 
 def test_sam_modules_golden():
