@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Our dense GEMM kernels against the ROCm GEMM library (torch.matmul -> hipBLASLt / rocBLAS) on the UNet's plain linear layers
 (no GEGLU): same operands, HIP-event timing, operands rotated through a pool larger than L2 + MALL so neither side sees them hot.
-    python tools/gemm_vs_lib.py
+    python tools/gemm_vs_lib.py [--sam]     (--sam: the ViT-H image encoder's five GEMM shapes instead)
 """
 import os
 import sys
@@ -16,6 +16,8 @@ SHAPES = [(12288, 640, 640, "to_out / proj L2"), (12288, 1920, 640, "qkv L2"), (
           (3072, 1280, 1280, "to_out / proj L3"), (3072, 3840, 1280, "qkv L3"), (3072, 1280, 5120, "ff2 L3"), (3072, 1280, 2560, "skip1x1 L3"),
           (768, 1280, 1280, "to_out L4"), (768, 3840, 1280, "qkv L4"), (768, 1280, 5120, "ff2 L4"),
           (49152, 320, 320, "to_out L1 (row-panel)"), (49152, 960, 320, "qkv L1")]
+SAM_SHAPES = [(4900, 3840, 1280, "SAM qkv (windows)"), (4900, 1280, 1280, "SAM proj (windows)"), (4096, 5120, 1280, "SAM lin1"),
+              (4096, 1280, 5120, "SAM lin2"), (4096, 3840, 1280, "SAM qkv (global)")]
 
 
 def timeit(fn, n_pool, iters=24, warm=4):
@@ -33,7 +35,7 @@ def timeit(fn, n_pool, iters=24, warm=4):
 
 def main():
     print(f"{'shape':44s} {'ours us':>9s} {'TF/s':>7s} {'lib us':>9s} {'TF/s':>7s}  lib/ours   (+bias+residual: ours / lib addmm-style)")
-    for M, N, K, tag in SHAPES:
+    for M, N, K, tag in (SAM_SHAPES if "--sam" in sys.argv else SHAPES):
         per = 2 * (M * K + N * K + 2 * M * N)
         n_pool = max(2, min(16, (600 << 20) // per))   # > 512 MB of distinct operands in rotation
         A = [torch.randn(M, K, device=DEV).to(BF) for _ in range(n_pool)]
