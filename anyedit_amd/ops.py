@@ -958,7 +958,11 @@ def layernorm_window_partition(x, gamma, beta, eps, B, H, W, ws):
     """window_partition(LayerNorm(x)) in one launch (SAM Block norm1 + partition, image_encoder.py:166-173): x [B*H*W, C] image rows ->
     ([B*nH*nW*ws*ws, C] window rows with zero padding rows, (Hp, Wp))."""
     _chk(x, BF16, "layernorm_window_partition.x", 2)
+    _chk(gamma, torch.float32, "layernorm_window_partition.gamma", 1)
+    _chk(beta, torch.float32, "layernorm_window_partition.beta", 1)
     C = x.shape[1]
+    if not x.is_contiguous() or x.shape[0] != B * H * W or gamma.numel() != C or beta.numel() != C:
+        raise ValueError("layernorm_window_partition: x must be contiguous [B*H*W, C] rows, gamma / beta [C]")
     nH, nW = (H + ws - 1) // ws, (W + ws - 1) // ws
     out = torch.empty(B * nH * nW * ws * ws, C, dtype=BF16, device=x.device)
     check(lib.ae_layernorm_window_bf16(_p(x), None, _p(gamma), _p(beta), _p(out), None, B, H, W, C, ws, 1, eps, _s()),
@@ -970,7 +974,13 @@ def window_merge_layernorm(windows, shortcut, gamma, beta, eps, B, H, W, ws):
     """(x, LayerNorm(x)) with x = shortcut + window_unpartition(windows) in one launch (SAM Block :175-181: un-partition, residual add, norm2)."""
     _chk(windows, BF16, "window_merge_layernorm.windows", 2)
     _chk(shortcut, BF16, "window_merge_layernorm.shortcut", 2)
+    _chk(gamma, torch.float32, "window_merge_layernorm.gamma", 1)
+    _chk(beta, torch.float32, "window_merge_layernorm.beta", 1)
     C = shortcut.shape[1]
+    nwin_rows = B * ((H + ws - 1) // ws) * ((W + ws - 1) // ws) * ws * ws
+    if not (windows.is_contiguous() and shortcut.is_contiguous()) or shortcut.shape[0] != B * H * W or tuple(windows.shape) != (nwin_rows, C) \
+            or gamma.numel() != C or beta.numel() != C:
+        raise ValueError("window_merge_layernorm: windows must be contiguous [B*nH*nW*ws*ws, C], shortcut [B*H*W, C], gamma / beta [C]")
     xsum, y = torch.empty_like(shortcut), torch.empty_like(shortcut)
     check(lib.ae_layernorm_window_bf16(_p(windows), _p(shortcut), _p(gamma), _p(beta), _p(y), _p(xsum), B, H, W, C, ws, 2, eps, _s()),
           "ae_layernorm_window_bf16")

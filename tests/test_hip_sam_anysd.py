@@ -76,6 +76,8 @@ def test_layernorm_with_window_addressing():
         xs_ref = ops.add_bcast(ops.window_unpartition(a, B, H, W, ws), x)
         assert torch.equal(xs, xs_ref) and same_up_to_contraction(h2, ops.layernorm(xs_ref, gamma, beta, 1e-6)), (B, H, W, C, ws)
     assert not ops.layernorm_window_ok(256)
+    with pytest.raises(RuntimeError):   # outside the envelope: an error, not a silent other path
+        ops.layernorm_window_partition(torch.zeros(16, 256, dtype=BF, device=DEV), torch.ones(256, device=DEV), torch.zeros(256, device=DEV), 1e-6, 1, 4, 4, 2)
 
 
 def test_relpos_terms_and_biased_attention():
