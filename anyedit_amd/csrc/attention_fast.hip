@@ -667,7 +667,11 @@ __global__ __launch_bounds__(64 * NWV, OCC) void attn_fast_kernel(const AttnArgs
 // Envelope: head dim 40, Nk a multiple of 64 and >= 128, no bias / mask / second segment (everything else: attn_fast_kernel).
 // KT: keys per LDS tile (64: rounds 5's form; 128, round 6: half the block barriers — DESIGN 7.00c priced the two barriers' worth of waiting per 64-key tile at
 // 16 % of the wave cycles — for 74 KiB instead of 31 KiB of LDS per block, still two blocks per CU).  Same MFMAs on the same operands in the same order: bit-identical.
-template <int D, int KT>
+// PV16 (round 6): the PV products as v_mfma_f32_16x16x32_bf16 on 48 output rows (d = 40 real, row 40 the denominator, 7 rows of zeros) instead of
+// 32x32x16 on 64 rows: 12 MFMAs of 16 cycles per step and query-group pair instead of 8 of 32.  The probabilities leave the logit MFMAs as (query = lane & 31,
+// keys by lane >> 5); the B operand of the 16-wide shape wants (query = lane & 15, keys by lane >> 4): one v_permlane16_swap per register between the two
+// 16-key halves does exactly that exchange (lane bit 4 <-> key half), and the key order inside the contraction is free as long as the V^T fragments follow it.
+template <int D, int KT, bool PV16 = false>
 __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
     static_assert(KT == 64 || KT == 128, "keys per tile");
     constexpr int NBLK = KT / 32, VDB = KT * 64, KP = KT * (D / 8) / 64;   // 32-key blocks per tile; bytes of a V image per 32-wide d-block; 1-KiB pieces of a K (or V) tile
@@ -725,9 +729,17 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
     const bool ones_lane = vcol == D, zero_lane = vcol > D;
     const int vlast0 = ones_lane ? VONES_OFF + vrow * RS : (zero_lane ? VONES_OFF + vrow * RS + 8 : TILEB + NFULL * VDB + vrow * RS + (16 * (g & 1) + 4 * (l15 & 3)) * 2);
     const int vl_mask = (ones_lane || zero_lane) ? 0 : -1;
+    // PV16: 16-lane group g reads the [4 keys][16 d] blocks of its key group — keys 16 (g & 1) + 4 (g >> 1) + {0..3} and + 8 (the order the swapped probabilities have)
+    const int vrow16 = 16 * (g & 1) + 4 * (g >> 1) + (l15 >> 2);
+    const int vaddr16 = TILEB + vrow16 * 64 + 8 * (l15 & 3);
+    const bool ones16 = (l15 & 3) == 2, zero16 = (l15 & 3) == 3;   // third 16-row block = d 32..47: columns 40..43 read {1,0,0,0}, 44..47 zeros
+    const int vlast16 = ones16 ? VONES_OFF + vrow16 * RS : (zero16 ? VONES_OFF + vrow16 * RS + 8 : TILEB + NFULL * VDB + vrow16 * RS + 8 * (l15 & 3));
+    const int vl16_mask = (ones16 || zero16) ? 0 : -1;
+    static_assert(!PV16 || (D == 40 && NFULL == 1 && RS == 16), "PV16 is written out for head dim 40");
 
     float mt[QG];
     f32x16 o[QG][NDB];
+    f32x4 o16[QG][2][3];   // PV16: [query group][query half][16-row block of O^T]; lane (l15, g) holds rows 4 g .. 4 g + 3 of query 16 half + l15
 #pragma unroll
     for (int gq = 0; gq < QG; ++gq) {
         mt[gq] = 0.f;
@@ -735,6 +747,10 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[gq][db][r] = 0.f;
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh)
+#pragma unroll
+            for (int db3 = 0; db3 < 3; ++db3) o16[gq][qh][db3] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
     // ---- LDS-DMA plan (as attn_fast_kernel, VSPLIT): piece j of a tile (K pieces 0..CH-1, V pieces CH..2CH-1) is issued by wave j % 4
@@ -817,10 +833,19 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
                 const float alpha = __builtin_amdgcn_exp2f(-d);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sn[gq][r] -= d;
+                if constexpr (PV16) {
+#pragma unroll
+                    for (int qh = 0; qh < 2; ++qh) {
+                        const float aq = __shfl(alpha, 16 * qh + l15, 64);   // the factor of THIS lane's query in the 16-wide layout
+#pragma unroll
+                        for (int db3 = 0; db3 < 3; ++db3) o16[gq][qh][db3] *= aq;
+                    }
+                } else {
 #pragma unroll
                 for (int db = 0; db < NDB; ++db)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[gq][db][r] *= alpha;
+                }
             }
         }
     };
@@ -836,16 +861,21 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
             const int kc = kaddr + nboff, kl = klast0 + (nboff & kl_mask);
             kf[0] = rdK(kc + BO); kf[1] = rdK(kc + BO + 32); kf[2] = rdK(kl + BO);
             // MFMA 1, 2: K step 0 of both groups (C = 0); ordered behind the previous step's last MFMA through the Q operand
-            AE_TIE1(qf[0][0], o[QG - 1][NDB - 1], hp[0]);
+            // (PV16: the carried sources retire one MFMA later than in the 32-row form — a tie sits anywhere between the value it takes and the MFMA it feeds, so
+            //  "behind MFMA 1" needs MFMA 1's RESULT as the ordering input: the source of the previous step's second-to-last MFMA behind 1, those of its last behind 2)
+            if constexpr (PV16) AE_TIE0(qf[0][0], o16[QG - 1][1][2]);
+            else AE_TIE1(qf[0][0], o[QG - 1][NDB - 1], hp[0]);
             {
                 f32x16 z;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] = 0.f;
                 sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf[0]), as_bf16x8(qf[0][0]), z, 0, 0, 0);
-                AE_TIE2(qf[1][0], sn[0], hv, hp[1]);
+                if constexpr (PV16) AE_TIE1(qf[1][0], sn[0], hp[0]);
+                else AE_TIE2(qf[1][0], sn[0], hv, hp[1]);
                 sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf[0]), as_bf16x8(qf[1][0]), z, 0, 0, 0);
             }
-            AE_TIE0(sn[0], sn[1]);
+            if constexpr (PV16) AE_TIE2(sn[0], sn[1], hv, hp[1]);
+            else AE_TIE0(sn[0], sn[1]);
             sn[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf[1]), as_bf16x8(qf[0][1]), sn[0], 0, 0, 0);     // 3
             AE_TIE0(sn[1], sn[0]);
             sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf[1]), as_bf16x8(qf[1][1]), sn[1], 0, 0, 0);     // 4
@@ -854,7 +884,68 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
             AE_TIE0(sn[1], sn[0]);
             sn[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf[2]), as_bf16x8(qf[1][2]), sn[1], 0, 0, 0);     // 6
         }
-        if constexpr (CUR) {
+        if constexpr (CUR && PV16) {
+            const int vc = vaddr16 + boff, vl = vlast16 + (boff & vl16_mask);
+            u32x4 vf3[3];
+#pragma unroll
+            for (int db3 = 0; db3 < 3; ++db3) {
+                const int va = (db3 == 2) ? vl + B2 * 32 * RS : vc + db3 * 32 + B2 * 32 * 64;
+                const int vstep = (db3 == 2) ? 8 * RS : 8 * 64;
+                union { bf16x8_t b; u32x4 u; } cv;
+                cv.b = cat_tr(lds_tr16(smem + va), lds_tr16(smem + va + vstep));
+                vf3[db3] = cv.u;
+            }
+            u32x4 pk[QG][2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int gq = 0; gq < QG; ++gq) {
+                    uint32_t w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = pack_bf16x2(__builtin_amdgcn_exp2f(sc[gq][8 * kk + 2 * j]), __builtin_amdgcn_exp2f(sc[gq][8 * kk + 2 * j + 1]));
+                    pk[gq][kk] = (u32x4){w[0], w[1], w[2], w[3]};
+                }
+            // (query = lane & 31, 16-key half kk) -> (query = lane & 15 of half qh, key group): rows 1 / 3 of the kk = 0 register <-> rows 0 / 2 of the kk = 1 register
+#pragma unroll
+            for (int gq = 0; gq < QG; ++gq) {
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(pk[gq][0].x), "+v"(pk[gq][1].x));
+                asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(pk[gq][0].y), "+v"(pk[gq][1].y));
+                asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(pk[gq][0].z), "+v"(pk[gq][1].z));
+                asm volatile("v_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(pk[gq][0].w), "+v"(pk[gq][1].w));
+            }
+#define AE_PV(gq_, qh_, db_) o16[gq_][qh_][db_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(vf3[db_]), as_bf16x8(pk[gq_][qh_]), o16[gq_][qh_][db_], 0, 0, 0)
+            if constexpr (NEXT) AE_TIE1(o16[0][0][0], sn[1], kf[1]);               // behind MFMA 6: K step 1's fragment (read by 3, 4) is free
+            else AE_TIE0(o16[0][0][0], o16[QG - 1][1][2]);
+            AE_PV(0, 0, 0);                                                        // 7
+            if constexpr (NEXT) AE_TIE0(o16[0][1][0], o16[0][0][0]);
+            else AE_TIE1(o16[0][1][0], o16[0][0][0], hp[0]);
+            AE_PV(0, 1, 0);                                                        // 8
+            // behind MFMA 8: the last K step's fragments of BOTH operands (read by 5, 6) are free — Q's matter in the last step that computes logits, where Q dies
+            if constexpr (NEXT) asm volatile("" : "+v"(o16[1][0][0]) : "v"(o16[0][1][0]), "v"(kf[2]), "v"(qf[0][KS - 1]), "v"(qf[1][KS - 1]));
+            else AE_TIE2(o16[1][0][0], o16[0][1][0], hv, hp[1]);
+            AE_PV(1, 0, 0);                                                        // 9
+            AE_TIE0(o16[1][1][0], o16[1][0][0]);
+            AE_PV(1, 1, 0);                                                        // 10
+            AE_TIE0(o16[0][0][1], o16[1][1][0]);
+            AE_PV(0, 0, 1);                                                        // 11
+            AE_TIE0(o16[0][1][1], o16[0][0][1]);
+            AE_PV(0, 1, 1);                                                        // 12
+            AE_TIE1(o16[1][0][1], o16[0][1][1], vf3[0]);                           // block 0's V fragment (last read by 10) is free behind 12
+            AE_PV(1, 0, 1);                                                        // 13
+            AE_TIE0(o16[1][1][1], o16[1][0][1]);
+            AE_PV(1, 1, 1);                                                        // 14
+            AE_TIE0(o16[0][0][2], o16[1][1][1]);
+            AE_PV(0, 0, 2);                                                        // 15
+            AE_TIE0(o16[0][1][2], o16[0][0][2]);
+            AE_PV(0, 1, 2);                                                        // 16
+            AE_TIE1(o16[1][0][2], o16[0][1][2], vf3[1]);                           // block 1's V fragment (last read by 14) is free behind 16
+            AE_PV(1, 0, 2);                                                        // 17
+            AE_TIE0(o16[1][1][2], o16[1][0][2]);
+            AE_PV(1, 1, 2);                                                        // 18
+#undef AE_PV
+            asm volatile("" : "+v"(o16[1][1][2]) : "v"(pk[0][0]), "v"(pk[0][1]));  // behind MFMA 18: group 0's probabilities (last read by 15, 16) are free
+            hv = vf3[2]; hp[0] = pk[1][0]; hp[1] = pk[1][1];                       // sources of 17, 18: retired behind the next step's first two MFMAs
+        } else if constexpr (CUR) {
             const int vc = vaddr + boff, vl = vlast0 + (boff & vl_mask);
             u32x4 vf[2][NDB];
 #pragma unroll
@@ -947,7 +1038,44 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
     bf16_t* op = p.o + (long)b * p.o_sb + (long)h * p.o_sh;
     // (the Q operand is dead behind the last logit MFMA: keep it a live value until here — asm volatile statements keep their order, and the last
     // step's ties sit eight MFMAs behind that MFMA)
-    asm volatile("" ::"v"(qf[0][0]), "v"(qf[0][1]), "v"(qf[0][2]), "v"(qf[1][0]), "v"(qf[1][1]), "v"(qf[1][2]));
+    // (PV16 ties the last K step's Q fragments behind PV MFMA 8 of every step instead: a use this far away made hipcc keep a COPY of them live and free the
+    //  registers the MFMA reads — the listing of the first form had the block maximum written into one 15 instructions behind logit MFMA 6)
+    if constexpr (!PV16) asm volatile("" ::"v"(qf[0][0]), "v"(qf[0][1]), "v"(qf[0][2]), "v"(qf[1][0]), "v"(qf[1][1]), "v"(qf[1][2]));
+    if constexpr (PV16) {
+        // denominators: row 40 of O^T = third block, local row 8 = register 0 of the lanes g == 2; query 16 qh + l15 sits in column l15
+        float ls[QG][2];
+#pragma unroll
+        for (int gq = QG - 1; gq >= 0; --gq)
+#pragma unroll
+            for (int qh = 1; qh >= 0; --qh) ls[gq][qh] = __shfl(o16[gq][qh][2][0], 32 + l15, 64);   // first: the result of the LAST MFMA issued ...
+        asm volatile("" : "+v"(ls[QG - 1][1]) : "v"(hv), "v"(hp[0]), "v"(hp[1]));                 // ... whose sources stay live until that read is out
+#pragma unroll
+        for (int gq = 0; gq < QG; ++gq)
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh) {
+                const float lsum = ls[gq][qh];
+                const float inv = (p.out_scale ? p.out_scale[b] : 1.0f) / lsum;
+                const float mq = __shfl(mt[gq], 16 * qh + l15, 64);
+                const int qrow = q0 + 32 * gq + 16 * qh + l15;
+                if (p.lse && g == 0 && qrow < p.Nq) p.lse[((long)b * p.H + h) * p.Nq + qrow] = mq + __builtin_amdgcn_logf(lsum);
+                if (qrow < p.Nq) {
+#pragma unroll
+                    for (int db3 = 0; db3 < 3; ++db3) {
+                        const int d = 16 * db3 + 4 * g;
+                        if (d < D) {
+                            float r0 = o16[gq][qh][db3][0] * inv, r1 = o16[gq][qh][db3][1] * inv, r2 = o16[gq][qh][db3][2] * inv, r3 = o16[gq][qh][db3][3] * inv;
+                            u32x2* dst = reinterpret_cast<u32x2*>(op + (long)qrow * p.o_sn + d);
+                            if (p.accum) {
+                                const u32x2 prev = *dst;
+                                r0 += bf16lo(prev.x); r1 += bf16hi(prev.x); r2 += bf16lo(prev.y); r3 += bf16hi(prev.y);
+                            }
+                            *dst = (u32x2){pack_bf16x2(r0, r1), pack_bf16x2(r2, r3)};
+                        }
+                    }
+                }
+            }
+        return;
+    }
     float lsum_g[QG];
 #pragma unroll
     for (int gq = QG - 1; gq >= 0; --gq) lsum_g[gq] = __shfl(o[gq][LDB][LREG], l31, 64);   // group 1 first: it reads the result of the LAST MFMA issued ...
@@ -978,6 +1106,9 @@ __global__ __launch_bounds__(256, 2) void attn_pipe_kernel(const AttnArgs p) {
     }
 }
 
+#ifndef AE_ATTN_PV16_DEFAULT
+#define AE_ATTN_PV16_DEFAULT 0
+#endif
 template <int D>
 int launch_fast(const AttnArgs& a, hipStream_t stream) {
     const long blocks = (long)((a.Nq + 127) / 128) * a.B * a.H;
@@ -1043,6 +1174,10 @@ int launch_fast(const AttnArgs& a, hipStream_t stream) {
             dim3 grid2((unsigned)((long)((a.Nq + 255) / 256) * a.B * a.H));
             // AE_ATTN_KT128 (round 6): 128-key tiles where the key count allows (one barrier per 128 keys); 0 = the 64-key form everywhere (A/B)
             static const int kt128 = getenv("AE_ATTN_KT128") ? atoi(getenv("AE_ATTN_KT128")) : 1;
+            // AE_ATTN_PV16 (round 6): the 48-row 16x16x32 PV products on the 128-key form (A/B; see the kernel)
+            static const int pv16 = getenv("AE_ATTN_PV16") ? atoi(getenv("AE_ATTN_PV16")) : AE_ATTN_PV16_DEFAULT;
+            if (pv16 && kt128 && a.Nk % 128 == 0 && a.Nk >= 256) hipLaunchKernelGGL((attn_pipe_kernel<D, 128, true>), grid2, block, 0, stream, a);
+            else
             if (kt128 && a.Nk % 128 == 0 && a.Nk >= 256) hipLaunchKernelGGL((attn_pipe_kernel<D, 128>), grid2, block, 0, stream, a);
             else hipLaunchKernelGGL((attn_pipe_kernel<D, 64>), grid2, block, 0, stream, a);
             return ae_check_launch("ae_attn_fwd_bf16(fast, pipelined)");

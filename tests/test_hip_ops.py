@@ -809,11 +809,14 @@ def test_attention_pipelined_equals_two_group_kernel():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_pipe_check.py"), "3", "7k0", "7"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_pipe_check.py"), "3", "7k0", "7", "7p"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
     print(r.stdout[-2000:])
     assert r.returncode == 0, r.stdout[-3000:]
-    # three variants: the two-group kernel, the pipelined kernel on 64-key tiles (round 5) and on 128-key tiles (round 6, the default)
+    # four variants: the two-group kernel, the pipelined kernel on 64-key tiles (round 5) and on 128-key tiles (round 6, the default), and — opt-in, AE_ATTN_PV16=1,
+    # measured slower in the graph — the 128-key form with the PV products on 48 rows of v_mfma_f32_16x16x32_bf16: another summation order inside PV,
+    # so it is held to 2.5e-3 of the two-group kernel's outputs (3.9e-5 at the time of writing) instead of to identity
     assert r.stdout.count("bit-identical on all") == 2 and "FAIL" not in r.stdout and "bit-identical: False" not in r.stdout
+    assert r.stdout.count("tolerance, not identity") == 1
 
 
 def test_conv3x3_linearity_and_groupnorm_scale_invariance_full_size(ops):

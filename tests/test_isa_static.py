@@ -151,16 +151,17 @@ def test_no_vgpr_write_to_the_sources_of_a_running_mfma(tmp_path):
     # round 5: the software-pipelined kernel — its 14 MFMAs per step are chained into one program order and every fragment is tied to the MFMA two
     # positions behind its last reader (the first listing of that kernel, without the ties, had 186 such writes)
     pipe = A.mfma_source_overwrites(asm, "attn_pipe_kernel<")
-    assert len(pipe) == 2                           # keys per tile 64 (round 5) and 128 (round 6)
+    assert len(pipe) == 3                           # keys per tile 64 (round 5), 128 (round 6), and 128 with the 48-row 16x16x32 PV products (round 6, opt-in)
     for k, hits in pipe.items():
         assert not hits, (k, hits[:3])
     rows = [(n, md, loop) for n, md, loop in A.audit_named(asm) if "attn_pipe_kernel<" in n]
-    assert len(rows) == 2
+    assert len(rows) == 3
     for n, md, loop in rows:
-        steps = 4 if "128>" in n else 2             # 32-key blocks (pipeline steps) per loop trip = per tile
+        steps = 4 if "<40, 128" in n else 2         # 32-key blocks (pipeline steps) per loop trip = per tile
+        pv16 = "true>" in n                         # 6 logit MFMAs + 12 PV MFMAs of 16x16x32 per step instead of 6 + 8 of 32x32x16; 8 lane swaps more
         assert md["vgpr_spill_count"] == "0" and md["private_segment_fixed_size"] == "0" and int(md["vgpr_count"]) <= 256, (n, md)   # two waves per SIMD
-        assert loop[0] == 14 * steps and loop[2] == 0, (n, loop)   # one tile per loop trip: 14 MFMAs per step, no scratch traffic
-        assert loop[7] <= 80 * steps, (n, loop)     # VALU per trip (74 per step at the time of writing: 32 exp2, 16 converts, 17 max3, addresses): register copies would show here
+        assert loop[0] == (18 if pv16 else 14) * steps and loop[2] == 0, (n, loop)   # one tile per loop trip, no scratch traffic
+        assert loop[7] <= (88 if pv16 else 80) * steps, (n, loop)     # VALU per trip (74 per step at the time of writing: 32 exp2, 16 converts, 17 max3, addresses): register copies would show here
 
 
 def test_fused_feed_forward_stream_is_the_hand_placed_one(tmp_path):

@@ -74,7 +74,7 @@ def cases(dev):
 def child(path):
     out, ref_err, same, us = cases("cuda")
     torch.save({k: v.cpu() for k, v in out.items()}, path)
-    print(f"AE_ATTN_V={os.environ.get('AE_ATTN_V')} AE_ATTN_KT128={os.environ.get('AE_ATTN_KT128', 'default')}: rel-L2 vs fp32 torch {ref_err:.3e} {'OK' if ref_err < 6e-3 else 'FAIL'}; 20 launches bit-identical: {same}; "
+    print(f"AE_ATTN_V={os.environ.get('AE_ATTN_V')} AE_ATTN_KT128={os.environ.get('AE_ATTN_KT128', 'default')} AE_ATTN_PV16={os.environ.get('AE_ATTN_PV16', '0')}: rel-L2 vs fp32 torch {ref_err:.3e} {'OK' if ref_err < 6e-3 else 'FAIL'}; 20 launches bit-identical: {same}; "
           f"{us:.1f} us = {4.0 * 96 * 4096 * 4096 * 40 / us / 1e6:.1f} TFLOP/s (algorithmic, d = 40)", flush=True)
 
 
@@ -86,9 +86,11 @@ def main():
     for v in variants:
         paths[v] = f"/tmp/attn_pipe_check_{v}.pt"
         # "7" = AE_ATTN_V 7; "7k0" = the same with AE_ATTN_KT128=0 (the 64-key tiles of round 5)
-        env = dict(os.environ, AE_ATTN_V=v.split("k")[0])
-        if "k" in v:
-            env["AE_ATTN_KT128"] = v.split("k")[1]
+        # "7p" = AE_ATTN_V 7 with AE_ATTN_PV16=1 (round 6: the 48-row 16x16x32 PV products — another summation order, compared by tolerance, not bit for bit)
+        core = v.replace("p", "")
+        env = dict(os.environ, AE_ATTN_V=core.split("k")[0], AE_ATTN_PV16="1" if "p" in v else "0")
+        if "k" in core:
+            env["AE_ATTN_KT128"] = core.split("k")[1]
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", paths[v]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         print(r.stdout.strip()[-600:])
         if r.returncode:
@@ -98,6 +100,17 @@ def main():
     ok = True
     for v in variants[1:]:
         b = torch.load(paths[v])
+        if "p" in v or "p" in variants[0]:
+            worst = 0.0
+            for k in a:
+                d = a[k].float() - b[k].float()
+                e = float(d.norm() / a[k].float().norm())
+                worst = max(worst, e)
+                assert torch.isfinite(b[k].float()).all(), k
+            close = worst < 2.5e-3   # two bf16 roundings of the same fp32 sums taken in another order
+            print(f"variants {variants[0]} / {v}: worst rel-L2 over {len(a)} outputs {worst:.3e} {'OK' if close else 'FAIL'} (another PV summation order: tolerance, not identity)")
+            ok &= close
+            continue
         for k in a:
             eq = torch.equal(a[k], b[k])
             if not eq:
