@@ -62,6 +62,7 @@ SIGNATURES = {
                         c_float, c_int, c_void_p, c_void_p],
     "ae_gemm_ln_plan": [c_int, c_int, c_int, c_int, c_int],
     "ae_xattn_fused_supported": [c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+    "ae_xattn_fused_covers": [c_int, c_int, c_int, c_int, c_int, c_int, c_int],
     "ae_xattn_fused_kv_bytes": [],
     "ae_xattn_fused_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int,
                             c_float, c_void_p],

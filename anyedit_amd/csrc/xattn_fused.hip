@@ -448,13 +448,18 @@ __global__ __launch_bounds__(64 * XA_NW, 1) void xattn_fused_kernel(const XAArgs
 // it replaces (74.9 vs 67.1 us isolated and hot, +0.03 .. +0.07 ms per UNet evaluation in three alternating pairs: profiles/r06_xattn_fused_notes.txt) — 128-row blocks are
 // one and a half rounds on 256 CUs, and with one block of one wave per SIMD on a CU nothing overlaps a block's 80 KB prologue read / LayerNorm and its epilogue's residual
 // read + store (18 of the 54 us that remain with DMA, softmax and barriers ablated away).
+// ae_xattn_fused_covers: the shapes the kernel can run (what ae_xattn_fused_bf16 itself requires).  ae_xattn_fused_supported: the PLAN question the module asks — switched on
+// AND covered AND at least one block per CU (AE_ROWPANEL_ANY_M lifts the last for small test shapes).
+extern "C" int ae_xattn_fused_covers(int M, int C, int heads, int head_dim, int rows_per_sample, int Nk, int T) {
+    return (C == XA_K && heads == XA_H && head_dim == 40 && M % XA_BM == 0 && M >= XA_BM && rows_per_sample % XA_BM == 0 && rows_per_sample > 0 && M % rows_per_sample == 0 &&
+            Nk > 64 && Nk <= 80 && T >= 0 && T <= 16) ? 1 : 0;
+}
 extern "C" int ae_xattn_fused_supported(int M, int C, int heads, int head_dim, int rows_per_sample, int Nk, int T) {
     static const int on = getenv("AE_XATTN_FUSED") ? atoi(getenv("AE_XATTN_FUSED")) : 0;
     static const int any_m = getenv("AE_ROWPANEL_ANY_M") ? atoi(getenv("AE_ROWPANEL_ANY_M")) : 0;
     if (!on) return 0;
     if (!any_m && M / XA_BM < 256) return 0;   // 128-row blocks: below one block per CU the three-launch path fills the chip better
-    return (C == XA_K && heads == XA_H && head_dim == 40 && M % XA_BM == 0 && M >= XA_BM && rows_per_sample % XA_BM == 0 && rows_per_sample > 0 && M % rows_per_sample == 0 &&
-            Nk > 64 && Nk <= 80 && T >= 0 && T <= 16) ? 1 : 0;
+    return ae_xattn_fused_covers(M, C, heads, head_dim, rows_per_sample, Nk, T);
 }
 extern "C" long ae_xattn_fused_kv_bytes(void) { return XA_KVB; }
 
@@ -462,7 +467,7 @@ extern "C" int ae_xattn_fused_bf16(const void* X, long ldx, const float* ln_gamm
                                    const float* gate, const void* Wo_img, const float* bo, void* Y, long ldy, int M, int rows_per_sample, int Nk, int T,
                                    float scale, void* stream) {
     AE_REQUIRE(X && ln_gamma && ln_beta && Wq_img && KV_img && Wo_img && Y, "ae_xattn_fused_bf16: null pointer");
-    AE_REQUIRE(ae_xattn_fused_supported(M, XA_K, XA_H, 40, rows_per_sample, Nk, T), "ae_xattn_fused_bf16: unsupported shape M=%d rows/sample=%d Nk=%d T=%d (C = 320, 8 heads of 40, "
+    AE_REQUIRE(ae_xattn_fused_covers(M, XA_K, XA_H, 40, rows_per_sample, Nk, T), "ae_xattn_fused_bf16: unsupported shape M=%d rows/sample=%d Nk=%d T=%d (C = 320, 8 heads of 40, "
                "M and rows per sample multiples of 128, 64 < Nk <= 80, T <= 16)", M, rows_per_sample, Nk, T);
     AE_REQUIRE(ln_eps >= 0.f && scale > 0.f, "ae_xattn_fused_bf16: eps / scale");
     AE_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)Y & 15) == 0 && ((uintptr_t)Wq_img & 15) == 0 && ((uintptr_t)KV_img & 15) == 0 &&

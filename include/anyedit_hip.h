@@ -109,6 +109,8 @@ int ae_ff_fused_bf16(const void* X, long ldx, const float* ln_gamma, const float
  * 128-row block per CU and round) AND AE_XATTN_FUSED=1 is set, 0 otherwise — callers then run ae_gemm_ln_bf16 + ae_attn_fwd_bf16 + ae_gemm_ln_bf16.  Opt-in: results
  * match the three launches (tests/test_hip_ops.py), the launch is slower than they are at UNet batch 12 (profiles/r06_xattn_fused_notes.txt).                          */
 int ae_xattn_fused_supported(int M, int C, int heads, int head_dim, int rows_per_sample, int Nk, int T);
+/* shape envelope alone (what ae_xattn_fused_bf16 requires); ae_xattn_fused_supported adds the AE_XATTN_FUSED switch and the one-block-per-CU plan rule */
+int ae_xattn_fused_covers(int M, int C, int heads, int head_dim, int rows_per_sample, int Nk, int T);
 long ae_xattn_fused_kv_bytes(void);
 int ae_xattn_fused_bf16(const void* X, long ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* Wq_img, const void* KV_img, const float* gate,
                         const void* Wo_img, const float* bo, void* Y, long ldy, int M, int rows_per_sample, int Nk, int T, float scale, void* stream);
