@@ -90,6 +90,8 @@ SIGNATURES = {
     "ae_q_sample_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p],
     "ae_silu_to_bf16": [c_void_p, c_int, c_void_p, c_long, c_void_p],
     "ae_add_bcast_bf16": [c_void_p, c_void_p, c_void_p, c_long, c_long, c_void_p],
+    "ae_resample2x_rows_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "ae_scale_shift_rows_bf16": [c_void_p, c_void_p, c_long, c_void_p, c_int, c_long, c_int, c_int, c_void_p],
     "ae_window_partition_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ae_layernorm_window_supported": [c_int],
     "ae_layernorm_window_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float,

@@ -257,6 +257,58 @@ __global__ void silu_kernel(const void* x, int in_bf16, bf16_t* y, long n) {
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) y[i] = f32_to_bf16(silu_f(ld_any(x, i, in_bf16)));
 }
 
+// Resampling WITHOUT a convolution on channels-last rows (openaimodel.py:108-118 with use_conv=False; :154-155 avg_pool_nd — what ResBlock(up= / down=) puts
+// between its GroupNorm + SiLU and its first conv, :215-221, 254-260).  mode 0: nearest x2, out [B, 2H, 2W, C]; mode 1: 2x2 mean, out [B, H/2, W/2, C]
+// (floor, as AvgPool2d(2, 2) drops an odd last row / column), summed in fp32 in (ky, kx) order and rounded once.  One thread per 8 output channels.
+__global__ void resample2x_rows_kernel(const bf16_t* x, bf16_t* y, int B, int H, int W, int C, int mode) {
+    const int ncc = C / 8, Ho = mode ? H / 2 : 2 * H, Wo = mode ? W / 2 : 2 * W;
+    const long n = (long)B * Ho * Wo * ncc;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const int cc = (int)(i % ncc);
+        long r = i / ncc;
+        const int xo = (int)(r % Wo);
+        r /= Wo;
+        const int yo = (int)(r % Ho), b = (int)(r / Ho);
+        u32x4 o;
+        if (mode == 0) {
+            o = *reinterpret_cast<const u32x4*>(x + (((long)b * H + (yo >> 1)) * W + (xo >> 1)) * C + cc * 8);
+        } else {
+            const bf16_t* s = x + (((long)b * H + 2 * yo) * W + 2 * xo) * C + cc * 8;
+            const u32x4 p00 = *reinterpret_cast<const u32x4*>(s), p01 = *reinterpret_cast<const u32x4*>(s + C);
+            const u32x4 p10 = *reinterpret_cast<const u32x4*>(s + (long)W * C), p11 = *reinterpret_cast<const u32x4*>(s + (long)W * C + C);
+            const uint32_t a[4] = {p00.x, p00.y, p00.z, p00.w}, bb[4] = {p01.x, p01.y, p01.z, p01.w}, c[4] = {p10.x, p10.y, p10.z, p10.w}, d[4] = {p11.x, p11.y, p11.z, p11.w};
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                w[e] = pack_bf16x2((((bf16lo(a[e]) + bf16lo(bb[e])) + bf16lo(c[e])) + bf16lo(d[e])) * 0.25f, (((bf16hi(a[e]) + bf16hi(bb[e])) + bf16hi(c[e])) + bf16hi(d[e])) * 0.25f);
+            o = (u32x4){w[0], w[1], w[2], w[3]};
+        }
+        *reinterpret_cast<u32x4*>(y + i * 8) = o;
+    }
+}
+
+// ResBlock(use_scale_shift_norm=True), openaimodel.py:264-268: h = out_norm(h) * (1 + scale) + shift, then SiLU (out_rest[0]); scale | shift are the two
+// halves of the block's emb_layers output, fp32 [B, 2C] with row stride ld (a column slice of the batched time-embedding projection).  x: the GroupNorm's
+// output rows [B * HW, C] bf16.
+__global__ void scale_shift_rows_kernel(const bf16_t* x, const float* emb, long ld, bf16_t* y, long HW, int C, long n, int silu) {
+    const int ncc = C / 8;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const int cc = (int)(i % ncc);
+        const long row = i / ncc;
+        const float* e = emb + (row / HW) * ld + cc * 8;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + i * 8);
+        const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float lo = bf16lo(vw[k]) * (1.0f + e[2 * k]) + e[C + 2 * k], hi = bf16hi(vw[k]) * (1.0f + e[2 * k + 1]) + e[C + 2 * k + 1];
+            if (silu) { lo = silu_f(lo); hi = silu_f(hi); }
+            o[k] = pack_bf16x2(lo, hi);
+        }
+        *reinterpret_cast<u32x4*>(y + i * 8) = (u32x4){o[0], o[1], o[2], o[3]};
+    }
+}
+
 // x [B,H,W,C] -> windows [B*nH*nW, ws, ws, C], zero padded bottom/right (image_encoder.py:243-264); reverse drops padding.
 __global__ void window_kernel(const bf16_t* src, bf16_t* dst, int B, int H, int W, int C, int ws, int nH, int nW, int reverse) {
     const int ncc = C / 8;
@@ -654,6 +706,23 @@ extern "C" int ae_add_bcast_bf16(const void* x, const void* p, void* y, long n, 
     hipLaunchKernelGGL(add_bcast_kernel, dim3(grid_for(n, 8)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)p,
                        (bf16_t*)y, n, period);
     return ae_check_launch("ae_add_bcast_bf16");
+}
+
+extern "C" int ae_resample2x_rows_bf16(const void* x, void* y, int B, int H, int W, int C, int mode, void* stream) {
+    AE_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && (mode == 0 || mode == 1), "ae_resample2x_rows_bf16: bad arguments (C %% 8 == 0, mode 0 = nearest x2, 1 = 2x2 mean)");
+    AE_REQUIRE(mode == 0 || (H >= 2 && W >= 2), "ae_resample2x_rows_bf16: a 2x2 mean needs H, W >= 2");
+    AE_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "ae_resample2x_rows_bf16: 16-byte alignment");
+    const long n = (long)B * (mode ? H / 2 : 2 * H) * (mode ? W / 2 : 2 * W) * (C / 8);
+    hipLaunchKernelGGL(resample2x_rows_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, mode);
+    return ae_check_launch("ae_resample2x_rows_bf16");
+}
+
+extern "C" int ae_scale_shift_rows_bf16(const void* x, const float* emb, long ld_emb, void* y, int B, long HW, int C, int silu, void* stream) {
+    AE_REQUIRE(x && emb && y && B > 0 && HW > 0 && C > 0 && C % 8 == 0 && ld_emb >= 2L * C, "ae_scale_shift_rows_bf16: bad arguments (C %% 8 == 0, emb rows hold scale | shift = 2 C floats)");
+    AE_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)emb & 3) == 0, "ae_scale_shift_rows_bf16: alignment");
+    const long n = (long)B * HW * (C / 8);
+    hipLaunchKernelGGL(scale_shift_rows_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, emb, ld_emb, (bf16_t*)y, HW, C, n, silu);
+    return ae_check_launch("ae_scale_shift_rows_bf16");
 }
 
 extern "C" int ae_window_partition_bf16(const void* x, void* windows, int B, int H, int W, int C, int ws, int reverse, void* stream) {

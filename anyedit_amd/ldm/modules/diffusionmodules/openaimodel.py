@@ -13,7 +13,7 @@ import torch.nn as nn
 from anyedit_amd import ops
 from anyedit_amd.ldm.util import exists
 from anyedit_amd.ldm.modules.attention import SpatialTransformer
-from anyedit_amd.ldm.modules.diffusionmodules.util import conv_nd, linear, normalization, zero_module
+from anyedit_amd.ldm.modules.diffusionmodules.util import avg_pool_nd, conv_nd, linear, normalization, zero_module
 
 BF16 = torch.bfloat16
 
@@ -85,7 +85,8 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
 
 
 class Upsample(nn.Module):
-    """openaimodel.py:90-118: nearest x2 folded into the conv's gather (no 4x intermediate tensor)."""
+    """openaimodel.py:90-118: nearest x2 folded into the conv's gather (no 4x intermediate tensor); use_conv=False (conv_resample=False, and the
+    h_upd / x_upd of ResBlock(up=True)) is the nearest x2 alone."""
 
     def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
         super().__init__()
@@ -93,11 +94,15 @@ class Upsample(nn.Module):
         self.out_channels = out_channels or channels
         self.use_conv = use_conv
         self.dims = dims
-        if not use_conv or dims != 2:
-            raise NotImplementedError("Upsample without conv / non-2D is not on the SD-1.5 path")
-        self.conv = conv_nd(dims, self.channels, self.out_channels, 3, padding=padding)
+        if dims != 2:
+            raise NotImplementedError("Upsample: only dims=2 (the 1-D / 3-D forms of openaimodel.py:108-112 have no caller in AnyEdit)")
+        if use_conv:
+            self.conv = conv_nd(dims, self.channels, self.out_channels, 3, padding=padding)
 
     def rows(self, f):
+        if not self.use_conv:
+            y, Ho, Wo = ops.resample2x_rows(f.materialize(), f.B, f.H, f.W)
+            return Feat(y, f.B, Ho, Wo)
         Ho, Wo = self.conv.out_hw(f.H, f.W, upsample2x=True)
         st = _stats_for(f.B, Ho, Wo, self.out_channels, f.t.device)
         y, Ho, Wo = self.conv.rows(f.materialize(), f.B, f.H, f.W, upsample2x=True, colstats=st)
@@ -111,7 +116,7 @@ class Upsample(nn.Module):
 
 
 class Downsample(nn.Module):
-    """openaimodel.py:131-159: conv3x3 stride 2 pad 1."""
+    """openaimodel.py:131-159: conv3x3 stride 2 pad 1, or with use_conv=False the 2x2 mean of avg_pool_nd (:152-155)."""
 
     def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
         super().__init__()
@@ -119,11 +124,18 @@ class Downsample(nn.Module):
         self.out_channels = out_channels or channels
         self.use_conv = use_conv
         self.dims = dims
-        if not use_conv or dims != 2:
-            raise NotImplementedError("Downsample without conv / non-2D is not on the SD-1.5 path")
-        self.op = conv_nd(dims, self.channels, self.out_channels, 3, stride=2, padding=padding)
+        if dims != 2:
+            raise NotImplementedError("Downsample: only dims=2 (the 1-D / 3-D forms of openaimodel.py:146 have no caller in AnyEdit)")
+        if use_conv:
+            self.op = conv_nd(dims, self.channels, self.out_channels, 3, stride=2, padding=padding)
+        else:
+            assert self.channels == self.out_channels
+            self.op = avg_pool_nd(dims, kernel_size=2, stride=2)
 
     def rows(self, f):
+        if not self.use_conv:
+            y, Ho, Wo = self.op.rows(f.materialize(), f.B, f.H, f.W)
+            return Feat(y, f.B, Ho, Wo)
         Ho, Wo = self.op.out_hw(f.H, f.W)
         st = _stats_for(f.B, Ho, Wo, self.out_channels, f.t.device)
         y, Ho, Wo = self.op.rows(f.materialize(), f.B, f.H, f.W, colstats=st)
@@ -137,11 +149,14 @@ class Downsample(nn.Module):
 
 
 class ResBlock(TimestepBlock):
-    """openaimodel.py:162-274 (SD configuration: no up/down, no scale-shift norm).
+    """openaimodel.py:162-274.
 
     HIP data flow: GN+SiLU kernel -> conv3x3 (+bias +time-embedding vector in the epilogue) -> GN+SiLU -> conv3x3
     (+bias +skip residual in the epilogue).  The skip is the input itself or a 1x1-conv GEMM; a pending channel-concat
-    input (decoder) is consumed in place by the GN and the skip GEMM (two-source kernels), never materialised."""
+    input (decoder) is consumed in place by the GN and the skip GEMM (two-source kernels), never materialised.
+    up / down (resblock_updown, :215-221, 254-260): the nearest x2 of h rides in conv1's gather, the 2x2 mean and the resampling of x are
+    `ops.resample2x_rows`; use_scale_shift_norm (:264-268): GroupNorm, then `ops.scale_shift_rows` applies (1 + scale), shift and the SiLU.
+    Neither is on the SD-1.5 / AnySD configuration (forward only: no tape closures)."""
 
     def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False, use_scale_shift_norm=False,
                  dims=2, use_checkpoint=False, up=False, down=False):
@@ -153,12 +168,16 @@ class ResBlock(TimestepBlock):
         self.use_conv = use_conv
         self.use_checkpoint = use_checkpoint
         self.use_scale_shift_norm = use_scale_shift_norm
-        if up or down or use_scale_shift_norm:
-            raise NotImplementedError("resblock_updown / use_scale_shift_norm are not on the SD-1.5 path")
         self.in_layers = nn.Sequential(normalization(channels), nn.SiLU(), conv_nd(dims, channels, self.out_channels, 3, padding=1))
-        self.updown = False
-        self.h_upd = self.x_upd = nn.Identity()
-        self.emb_layers = nn.Sequential(nn.SiLU(), linear(emb_channels, self.out_channels))
+        self.updown = up or down
+        self.up, self.down = bool(up), bool(down) and not up
+        if up:
+            self.h_upd, self.x_upd = Upsample(channels, False, dims), Upsample(channels, False, dims)
+        elif down:
+            self.h_upd, self.x_upd = Downsample(channels, False, dims), Downsample(channels, False, dims)
+        else:
+            self.h_upd = self.x_upd = nn.Identity()
+        self.emb_layers = nn.Sequential(nn.SiLU(), linear(emb_channels, 2 * self.out_channels if use_scale_shift_norm else self.out_channels))
         self.out_layers = nn.Sequential(normalization(self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
                                         zero_module(conv_nd(dims, self.out_channels, self.out_channels, 3, padding=1)))
         if self.out_channels == channels:
@@ -179,32 +198,46 @@ class ResBlock(TimestepBlock):
         B, H, W = f.B, f.H, f.W
         if isinstance(emb_silu, EmbPack) and id(self) in emb_silu.offsets:
             off = emb_silu.offsets[id(self)]
-            emb_out = emb_silu.all[:, off:off + self.out_channels]  # column slice of the batched projection (fp32, strided rows)
+            emb_out = emb_silu.all[:, off:off + self.emb_layers[1].out_features]  # column slice of the batched projection (fp32, strided rows)
         else:
             silu = emb_silu.silu if isinstance(emb_silu, EmbPack) else emb_silu
-            emb_out = self.emb_layers[1].rows(silu, out_f32=True)  # [B, Cout] fp32
+            emb_out = self.emb_layers[1].rows(silu, out_f32=True)  # [B, Cout] (scale-shift: [B, 2 Cout]) fp32
         dev = f.t.device
+        ssn = self.use_scale_shift_norm
         h = self.in_layers[0].rows(f.t, B, H * W, silu=True, x2=f.t2, colstats=f.st, colstats2=f.st2)
-        st1 = _stats_for(B, H, W, self.out_channels, dev)       # conv1's epilogue delivers the statistics out_layers[0] needs
-        h, _, _ = self.in_layers[2].rows(h, B, H, W, addvec=emb_out, colstats=st1)
-        h = self.out_layers[0].rows(h, B, H * W, silu=True, colstats=st1)
         # This body may run twice as a checkpoint segment (throw-away forward + recompute): it must not change `f` — a concat
         # materialised into f.t on the throw-away tape would be unknown to the recompute's tape and its gradient dropped.
         whole = (lambda: f.t if f.t2 is None else ops.concat_channels(f.t, f.t2))
+        Ho, Wo, xs = H, W, None
+        if self.up:        # openaimodel.py:255-260: h = in_conv(h_upd(in_rest(x))), x = x_upd(x); the x2 of h is conv1's gather
+            Ho, Wo = 2 * H, 2 * W
+            xs, _, _ = ops.resample2x_rows(whole(), B, H, W)
+        elif self.down:
+            h, Ho, Wo = ops.resample2x_rows(h, B, H, W, down=True)
+            xs, _, _ = ops.resample2x_rows(whole(), B, H, W, down=True)
+        st1 = _stats_for(B, Ho, Wo, self.out_channels, dev)     # conv1's epilogue delivers the statistics out_layers[0] needs
+        if self.up:
+            h, _, _ = self.in_layers[2].rows(h, B, H, W, addvec=None if ssn else emb_out, upsample2x=True, colstats=st1)
+        else:
+            h, _, _ = self.in_layers[2].rows(h, B, Ho, Wo, addvec=None if ssn else emb_out, colstats=st1)
+        if ssn:            # :264-268: out_norm(h) * (1 + scale) + shift, then out_rest (SiLU, dropout, conv)
+            h = ops.scale_shift_rows(self.out_layers[0].rows(h, B, Ho * Wo, silu=False, colstats=st1), emb_out, B, Ho * Wo, silu=True)
+        else:
+            h = self.out_layers[0].rows(h, B, Ho * Wo, silu=True, colstats=st1)
         if isinstance(self.skip_connection, nn.Identity):
-            res = whole()
-        elif self.skip_connection.kernel_size[0] == 1:
+            res = whole() if xs is None else xs
+        elif self.skip_connection.kernel_size[0] == 1 and xs is None:
             res, _, _ = self.skip_connection.rows(f.t, B, H, W, a2=f.t2)
         else:
-            res, _, _ = self.skip_connection.rows(whole(), B, H, W)
-        st = _stats_for(B, H, W, self.out_channels, dev)        # ... and conv2's those of the block's output (next norm / decoder concat)
-        y, _, _ = self.out_layers[3].rows(h, B, H, W, residual=res, colstats=st)
-        return Feat(y, B, H, W, st=st)
+            res, _, _ = self.skip_connection.rows(whole() if xs is None else xs, B, Ho, Wo)
+        st = _stats_for(B, Ho, Wo, self.out_channels, dev)      # ... and conv2's those of the block's output (next norm / decoder concat)
+        y, _, _ = self.out_layers[3].rows(h, B, Ho, Wo, residual=res, colstats=st)
+        return Feat(y, B, Ho, Wo, st=st)
 
     def forward(self, x, emb):
         B, C, H, W = x.shape
         f = self.rows(Feat(ops.nchw_to_rows(x), B, H, W), ops.silu_to_bf16(emb))
-        return ops.rows_to_nchw(f.t, B, H, W, out_dtype=x.dtype)
+        return ops.rows_to_nchw(f.t, B, f.H, f.W, out_dtype=x.dtype)
 
     _forward = forward
 
@@ -224,8 +257,8 @@ class UNetModel(nn.Module):
         assert context_dim is not None, "use_spatial_transformer needs context_dim (openaimodel.py:474-475)"
         if not isinstance(context_dim, (int, type(None))):
             context_dim = list(context_dim)
-        if n_embed is not None or resblock_updown or use_scale_shift_norm or dims != 2:
-            raise NotImplementedError("n_embed / resblock_updown / scale-shift / dims!=2 are outside the AnyEdit hot path")
+        if n_embed is not None or dims != 2:
+            raise NotImplementedError("n_embed (codebook-id head) / dims != 2 are outside the AnyEdit hot path")
         if num_classes is not None and not isinstance(num_classes, int) and num_classes != "continuous":
             raise ValueError(f"num_classes must be None, an int or 'continuous' (openaimodel.py:533-540), got {num_classes!r}")
         if num_heads_upsample == -1:
@@ -295,7 +328,10 @@ class UNetModel(nn.Module):
                 input_block_chans.append(ch)
             if level != len(channel_mult) - 1:
                 out_ch = ch
-                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, conv_resample, dims=dims, out_channels=out_ch)))
+                self.input_blocks.append(TimestepEmbedSequential(
+                    ResBlock(ch, time_embed_dim, dropout, out_channels=out_ch, dims=dims, use_checkpoint=use_checkpoint,
+                             use_scale_shift_norm=use_scale_shift_norm, down=True)
+                    if resblock_updown else Downsample(ch, conv_resample, dims=dims, out_channels=out_ch)))
                 ch = out_ch
                 input_block_chans.append(ch)
                 ds *= 2
@@ -317,7 +353,9 @@ class UNetModel(nn.Module):
                         layers.append(make_st(ch, num_heads_upsample, level))
                 if level and i == self.num_res_blocks[level]:
                     out_ch = ch
-                    layers.append(Upsample(ch, conv_resample, dims=dims, out_channels=out_ch))
+                    layers.append(ResBlock(ch, time_embed_dim, dropout, out_channels=out_ch, dims=dims, use_checkpoint=use_checkpoint,
+                                           use_scale_shift_norm=use_scale_shift_norm, up=True)
+                                  if resblock_updown else Upsample(ch, conv_resample, dims=dims, out_channels=out_ch))
                     ds //= 2
                 self.output_blocks.append(TimestepEmbedSequential(*layers))
                 self._feature_size += ch
@@ -343,7 +381,7 @@ class UNetModel(nn.Module):
             offsets, off = {}, 0
             for b in blocks:
                 offsets[id(b)] = off
-                off += b.out_channels
+                off += b.emb_layers[1].out_features
             pk = (w, bias, offsets)
             self._emb_pk = pk
         w, bias, offsets = pk

@@ -234,5 +234,27 @@ def normalization(channels):
     return GroupNorm32(32, channels)
 
 
+class AvgPool2d(nn.AvgPool2d):
+    """nn.AvgPool2d(2, 2) (what Downsample(use_conv=False) holds, openaimodel.py:152-155; no parameters, no state-dict keys) on the HIP resampling kernel."""
+
+    def __init__(self, kernel_size=2, stride=None, **kw):
+        super().__init__(kernel_size, stride, **kw)
+        ks = self.kernel_size if isinstance(self.kernel_size, int) else self.kernel_size[0]
+        st = self.stride if isinstance(self.stride, int) else self.stride[0]
+        if ks != 2 or st != 2 or kw:
+            raise NotImplementedError("AvgPool2d: only the 2x2 / stride-2 mean of openaimodel.py:146-155")
+
+    def rows(self, x, B, H, W):
+        return ops.resample2x_rows(x, B, H, W, down=True)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        y, Ho, Wo = self.rows(ops.nchw_to_rows(x), B, H, W)
+        return ops.rows_to_nchw(y, B, Ho, Wo, out_dtype=x.dtype)
+
+
 def avg_pool_nd(dims, *args, **kwargs):
-    raise NotImplementedError("avg_pool_nd: conv_resample=False is not on the AnyEdit/SD-1.5 path")
+    """util.py:241-251."""
+    if dims == 2:
+        return AvgPool2d(*args, **kwargs)
+    raise ValueError(f"unsupported dimensions: {dims} (the AnyEdit hot path is 2-D)")

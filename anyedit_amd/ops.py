@@ -935,6 +935,37 @@ def add_bcast(x, p):
     return out
 
 
+def _no_tape(what):
+    if _TAPE is not None and _TAPE.active:
+        raise NotImplementedError(f"{what}: forward only (no backward closure on the tape; the AnyEdit training step never builds it)")
+
+
+def resample2x_rows(x, B, H, W, down=False):
+    """Channels-last rows [B*H*W, C] bf16 -> nearest x2 (Upsample(use_conv=False), openaimodel.py:108-118) or, down=True, the 2x2 mean of
+    avg_pool_nd (Downsample(use_conv=False), :154-155).  Returns (rows, Ho, Wo)."""
+    _no_tape("resample2x_rows")
+    C = x.shape[1]
+    if x.dtype != BF16 or not x.is_contiguous() or x.shape[0] != B * H * W or C % 8:
+        raise ValueError(f"resample2x_rows: bf16 contiguous rows [B*H*W, C % 8 == 0] expected, got {tuple(x.shape)} {x.dtype}")
+    Ho, Wo = (H // 2, W // 2) if down else (2 * H, 2 * W)
+    out = torch.empty(B * Ho * Wo, C, dtype=BF16, device=x.device)
+    check(lib.ae_resample2x_rows_bf16(_p(x), _p(out), B, H, W, C, 1 if down else 0, _s()), "ae_resample2x_rows_bf16")
+    return out, Ho, Wo
+
+
+def scale_shift_rows(x, emb, B, HW, silu=True):
+    """ResBlock(use_scale_shift_norm=True), openaimodel.py:264-268: act(x * (1 + scale) + shift) over GroupNorm output rows x [B*HW, C] bf16; emb fp32
+    [B, 2C] (rows may be strided: a column slice of the batched projection) = scale | shift."""
+    _no_tape("scale_shift_rows")
+    C = x.shape[1]
+    if (x.dtype != BF16 or not x.is_contiguous() or x.shape[0] != B * HW or C % 8 or emb.dtype != torch.float32 or tuple(emb.shape) != (B, 2 * C)
+            or emb.stride(1) != 1):
+        raise ValueError(f"scale_shift_rows: x bf16 rows [B*HW, C % 8 == 0], emb fp32 [B, 2C] expected, got {tuple(x.shape)} {x.dtype} / {tuple(emb.shape)} {emb.dtype}")
+    out = torch.empty_like(x)
+    check(lib.ae_scale_shift_rows_bf16(_p(x), _p(emb), emb.stride(0), _p(out), B, HW, C, 1 if silu else 0, _s()), "ae_scale_shift_rows_bf16")
+    return out
+
+
 def window_partition(x, B, H, W, ws):
     C = x.shape[-1]
     nH, nW = (H + ws - 1) // ws, (W + ws - 1) // ws

@@ -298,6 +298,13 @@ int ae_q_sample_f32(const float* x0, const float* noise, const float* sqrt_ac, c
 int ae_silu_to_bf16(const void* x, int in_bf16, void* y, long n, void* stream);
 /* y = x + p broadcast with period (pos_embed add, image_encoder.py:108-109).                                                 */
 int ae_add_bcast_bf16(const void* x, const void* p, void* y, long n, long period, void* stream);
+/* Resampling without a convolution on channels-last rows: mode 0 = nearest x2 (Upsample(use_conv=False), openaimodel.py:108-118), mode 1 = 2x2 mean
+ * (Downsample(use_conv=False) = avg_pool_nd, openaimodel.py:154-155; floor on odd sizes) — the h_upd / x_upd of ResBlock(up= / down=), :215-221, 254-260.
+ * x [B, H, W, C] bf16 -> y [B, 2H, 2W, C] / [B, H/2, W/2, C]; C % 8 == 0.                                                                              */
+int ae_resample2x_rows_bf16(const void* x, void* y, int B, int H, int W, int C, int mode, void* stream);
+/* ResBlock(use_scale_shift_norm=True), openaimodel.py:264-268: y = act(x * (1 + scale[b]) + shift[b]) on the GroupNorm's output rows x [B * HW, C] bf16;
+ * emb fp32 [B, >= 2C] with row stride ld_emb holds scale | shift (th.chunk(emb_out, 2, dim=1)); silu != 0 applies out_rest's SiLU.                     */
+int ae_scale_shift_rows_bf16(const void* x, const float* emb, long ld_emb, void* y, int B, long HW, int C, int silu, void* stream);
 /* window_partition / window_unpartition (image_encoder.py:243-289); arguments are always (image, windows).                    */
 int ae_window_partition_bf16(const void* image, void* windows, int B, int H, int W, int C, int ws, int reverse, void* stream);
 /* LayerNorm with the window partition of SAM's windowed blocks folded into its row addressing (image_encoder.py:166-182, 243-289).

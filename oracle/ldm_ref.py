@@ -148,13 +148,23 @@ def spatial_transformer(sd, p, x, context, heads, depth=1, use_linear=False, ada
 
 
 # ------------------------------------------------------------------ A5 resblock & resampling
-def resblock(sd, p, x, emb):
-    """openaimodel.py:254-274 (no up/down, no scale-shift — the SD-1.5 configuration)."""
+def resblock(sd, p, x, emb, up=False, down=False, scale_shift=False):
+    """openaimodel.py:254-274.  up / down (resblock_updown, :215-221): the resampling WITHOUT a conv sits between in_rest (GroupNorm + SiLU) and in_conv,
+    and on x in front of the skip (:255-260); scale_shift (use_scale_shift_norm, :264-268): emb_out is (scale | shift) and h = out_norm(h) * (1 + scale) + shift."""
     h = _st(silu(group_norm32(x, sd[p + "in_layers.0.weight"], sd[p + "in_layers.0.bias"])))
+    if up:
+        h, x = F.interpolate(h, scale_factor=2, mode="nearest"), F.interpolate(x, scale_factor=2, mode="nearest")
+    elif down:
+        h, x = _st(F.avg_pool2d(h, 2, 2)), _st(F.avg_pool2d(x, 2, 2))
     h = F.conv2d(h, sd[p + "in_layers.2.weight"], sd[p + "in_layers.2.bias"], padding=1)
     emb_out = F.linear(silu(emb), sd[p + "emb_layers.1.weight"], sd[p + "emb_layers.1.bias"])
-    h = _st(h + emb_out[:, :, None, None])
-    h = _st(silu(group_norm32(h, sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"])))
+    if scale_shift:
+        scale, shift = torch.chunk(emb_out[:, :, None, None], 2, dim=1)
+        h = _st(group_norm32(_st(h), sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"]))
+        h = _st(silu(h * (1 + scale) + shift))
+    else:
+        h = _st(h + emb_out[:, :, None, None])
+        h = _st(silu(group_norm32(h, sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"])))
     h = F.conv2d(h, sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"], padding=1)
     if (p + "skip_connection.weight") in sd:
         wsk = sd[p + "skip_connection.weight"]
@@ -163,13 +173,17 @@ def resblock(sd, p, x, emb):
 
 
 def downsample(sd, p, x):
-    """openaimodel.py:157-159: conv3x3 stride 2 pad 1."""
+    """openaimodel.py:157-159: conv3x3 stride 2 pad 1; without a conv (conv_resample=False, :152-155) the 2x2 mean."""
+    if (p + "op.weight") not in sd:
+        return _st(F.avg_pool2d(x, 2, 2))
     return _st(F.conv2d(x, sd[p + "op.weight"], sd[p + "op.bias"], stride=2, padding=1))
 
 
 def upsample(sd, p, x):
-    """openaimodel.py:108-118: nearest x2 then conv3x3."""
+    """openaimodel.py:108-118: nearest x2 then conv3x3 (no conv with conv_resample=False)."""
     x = F.interpolate(x, scale_factor=2, mode="nearest")
+    if (p + "conv.weight") not in sd:
+        return x
     return _st(F.conv2d(x, sd[p + "conv.weight"], sd[p + "conv.bias"], padding=1))
 
 
@@ -197,7 +211,7 @@ def unet_plan(cfg):
             inp.append(layers)
             chans.append(ch)
         if level != len(mult) - 1:
-            inp.append([("down", ch, ch)])
+            inp.append([("resdown" if cfg.get("resblock_updown") else "down", ch, ch)])   # openaimodel.py:600-616
             chans.append(ch)
             ds *= 2
     mid = [("res", ch, ch), ("st", ch, *hd(ch), depth), ("res", ch, ch)]
@@ -210,20 +224,22 @@ def unet_plan(cfg):
             if ds in attn_res:
                 layers.append(("st", ch, *hd(ch), depth))
             if level and i == nrb[level]:
-                layers.append(("up", ch, ch))
+                layers.append(("resup" if cfg.get("resblock_updown") else "up", ch, ch))   # openaimodel.py:707-721
                 ds //= 2
             out.append(layers)
     return inp, mid, out
 
 
-def _run_layers(sd, prefix, layers, h, emb, context, use_linear, adapters=None):
+def _run_layers(sd, prefix, layers, h, emb, context, use_linear, adapters=None, scale_shift=False):
     for j, L in enumerate(layers):
         p = f"{prefix}{j}."
         kind = L[0]
         if kind == "conv":
             h = _st(F.conv2d(h, sd[p + "weight"], sd[p + "bias"], padding=1))
         elif kind == "res":
-            h = resblock(sd, p, h, emb)
+            h = resblock(sd, p, h, emb, scale_shift=scale_shift)
+        elif kind in ("resdown", "resup"):
+            h = resblock(sd, p, h, emb, up=kind == "resup", down=kind == "resdown", scale_shift=scale_shift)
         elif kind == "st":
             h = spatial_transformer(sd, p, h, context, heads=L[2], depth=L[4], use_linear=use_linear, adapters=adapters)
         elif kind == "down":
@@ -238,6 +254,7 @@ def unet_forward(sd, cfg, x, timesteps, context, adapters=None, y=None):
     [B, 1] for num_classes == "continuous" (a Linear(1, 4*mc) label embedding, :536-538)."""
     inp, mid, out = unet_plan(cfg)
     use_linear = cfg.get("use_linear_in_transformer", False)
+    ssn = bool(cfg.get("use_scale_shift_norm", False))
     t_emb = timestep_embedding(timesteps, cfg["model_channels"])
     emb = F.linear(t_emb, sd["time_embed.0.weight"], sd["time_embed.0.bias"])
     emb = F.linear(silu(emb), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
@@ -251,12 +268,12 @@ def unet_forward(sd, cfg, x, timesteps, context, adapters=None, y=None):
     h = _st(x.float())
     context = None if context is None else _st(context)
     for i, layers in enumerate(inp):
-        h = _run_layers(sd, f"input_blocks.{i}.", layers, h, emb, context, use_linear, adapters)
+        h = _run_layers(sd, f"input_blocks.{i}.", layers, h, emb, context, use_linear, adapters, ssn)
         hs.append(h)
-    h = _run_layers(sd, "middle_block.", mid, h, emb, context, use_linear, adapters)
+    h = _run_layers(sd, "middle_block.", mid, h, emb, context, use_linear, adapters, ssn)
     for i, layers in enumerate(out):
         h = torch.cat([h, hs.pop()], dim=1)
-        h = _run_layers(sd, f"output_blocks.{i}.", layers, h, emb, context, use_linear, adapters)
+        h = _run_layers(sd, f"output_blocks.{i}.", layers, h, emb, context, use_linear, adapters, ssn)
     h = _st(silu(group_norm32(h, sd["out.0.weight"], sd["out.0.bias"])))
     return F.conv2d(h, sd["out.2.weight"], sd["out.2.bias"], padding=1)
 

@@ -55,6 +55,70 @@ def test_resblock_and_resampling_golden():
     close(up.to(DEV)(T(g["up.x"]).to(DEV)), g["up.y"], rl2=6e-3, what="Upsample")
 
 
+def test_resample_and_scale_shift_kernels_vs_torch():
+    """ae_resample2x_rows_bf16 (nearest x2: bit-exact copy; 2x2 mean: the fp32 mean of the four bf16 values rounded once, incl. odd sizes that floor) and
+    ae_scale_shift_rows_bf16 (act(x (1 + scale) + shift), openaimodel.py:264-268) against the fp32 statements; refusals of malformed arguments."""
+    from anyedit_amd import ops
+    g = torch.Generator().manual_seed(7)
+    for (B, H, W, C) in ((2, 6, 10, 32), (1, 7, 9, 64), (3, 16, 16, 320)):
+        x = torch.randn(B, C, H, W, generator=g).bfloat16()
+        rows = x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous().to(DEV)
+        up, Ho, Wo = ops.resample2x_rows(rows, B, H, W)
+        ref = F.interpolate(x.float(), scale_factor=2, mode="nearest").bfloat16().permute(0, 2, 3, 1).reshape(-1, C)
+        assert (Ho, Wo) == (2 * H, 2 * W) and torch.equal(up.cpu(), ref)
+        dn, Ho, Wo = ops.resample2x_rows(rows, B, H, W, down=True)
+        ref = F.avg_pool2d(x.float(), 2, 2).permute(0, 2, 3, 1).reshape(-1, C)
+        assert (Ho, Wo) == (H // 2, W // 2) and dn.shape == ref.shape
+        d = (dn.float().cpu() - ref).abs()
+        assert float((d / (ref.abs() + 1e-3)).max()) <= 2.0 ** -8, "2x2 mean: within one bf16 rounding of the fp32 mean"
+        HW = H * W
+        emb = torch.randn(B, 2 * C + 8, generator=g).to(DEV)[:, 8:]        # strided rows: a column slice, as the batched projection hands it over
+        for act in (True, False):
+            y = ops.scale_shift_rows(rows, emb, B, HW, silu=act)
+            sc, sh = emb[:, :C].cpu().repeat_interleave(HW, 0), emb[:, C:].cpu().repeat_interleave(HW, 0)
+            ref = rows.float().cpu() * (1 + sc) + sh
+            ref = F.silu(ref) if act else ref
+            assert float(((y.float().cpu() - ref).abs() / (ref.abs() + 1e-2)).max()) <= 2.0 ** -7
+    with pytest.raises(ValueError):
+        ops.resample2x_rows(rows[:, :12].contiguous(), B, H, W)            # channels not a multiple of 8
+    with pytest.raises(ValueError):
+        ops.scale_shift_rows(rows, emb[:, :C], B, HW)                      # emb must hold scale | shift
+    with pytest.raises(Exception):
+        ops.resample2x_rows(torch.zeros(8, 8, dtype=torch.bfloat16, device=DEV), 8, 1, 1, down=True)   # a 2x2 mean of a 1x1 map
+
+
+def test_unet_guided_diffusion_options_golden():
+    """The constructor options VERDICT r5 listed as refused — ResBlock(up= / down= / use_scale_shift_norm=) (openaimodel.py:215-221, 254-268), Upsample /
+    Downsample without a conv (:108-118, 152-155), UNetModel(resblock_updown=, use_scale_shift_norm=, conv_resample=False) (:600-616, 707-721) — against the
+    reference's outputs (tests/golden/unet_gd_tiny.npz, tools/gen_golden.py::gen_unet_gd); state-dict keys are the reference's."""
+    from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import ResBlock, Downsample, Upsample, UNetModel
+    from test_oracle_golden import GD_TINY
+    g = load_golden("unet_gd_tiny")
+    cases = {"up": (64, 32, True, False, False, False), "down": (32, 64, False, True, False, True), "ssn": (64, 64, False, False, True, False),
+             "up_ssn": (32, 32, True, False, True, False), "down_ssn": (64, 96, False, True, True, False)}
+    for tag, (cin, cout, up, down, ssn, use_conv) in cases.items():
+        rb = ResBlock(cin, 128, 0.0, out_channels=cout, use_conv=use_conv, use_scale_shift_norm=ssn, dims=2, up=up, down=down)
+        rb.load_state_dict(sub_sd(g, f"rb.{tag}.w."))          # strict: the key set is the reference's (h_upd / x_upd / AvgPool hold no parameters)
+        close(rb.to(DEV)(T(g[f"rb.{tag}.x"]).to(DEV), T(g[f"rb.{tag}.emb"]).to(DEV)), g[f"rb.{tag}.y"], what=f"ResBlock {tag}")
+    x = T(g["pool.x"]).to(DEV)
+    close(Downsample(32, False, dims=2)(x), g["pool.down"], rl2=4e-3, what="Downsample(use_conv=False)")
+    close(Downsample(32, False, dims=2)(T(g["pool.x7"]).to(DEV)), g["pool.down7"], rl2=4e-3, what="Downsample(use_conv=False), odd size")
+    close(Upsample(32, False, dims=2)(x), g["pool.up"], rl2=4e-3, what="Upsample(use_conv=False)")
+    x, t, ctx = T(g["x"]).to(DEV), T(g["t"]).to(DEV), T(g["ctx"]).to(DEV)
+    for tag, extra in {"updown_ssn": dict(resblock_updown=True, use_scale_shift_norm=True), "noconv": dict(conv_resample=False)}.items():
+        with torch.device(DEV):
+            unet = UNetModel(**dict(GD_TINY, **extra))
+        unet.load_state_dict({k: v.to(DEV) for k, v in sub_sd(g, f"{tag}.w.").items()})
+        unet.eval().requires_grad_(False)
+        with torch.no_grad():
+            y = unet(x, t, context=ctx)
+            close(y, g[f"{tag}.y"], what=f"UNetModel {tag}")
+            assert torch.equal(unet(x, t, context=ctx), y), "run-to-run bit-equal"
+            emb = unet.time_embedding_rows(t)                   # the hoisted time-embedding pack carries 2 x Cout columns per scale-shift block
+            y2 = unet.forward_rows(x, None, unet.context_rows(ctx), emb_pack=emb)
+            assert torch.equal(y2, y), "hoisted time-embedding path = per-step path"
+
+
 @pytest.fixture(scope="module")
 def tiny_unet():
     from util_models import build_tiny_unet

@@ -51,6 +51,23 @@ def test_constructor_matches_reference_init_and_state_dict_keys():
         assert torch.equal(sd[k], torch.from_numpy(g["w." + k])), k
 
 
+def test_guided_diffusion_options_key_schema():
+    """resblock_updown / use_scale_shift_norm / conv_resample=False (openaimodel.py:178-274, 600-616, 707-721): the mirror's key set and shapes are the reference's
+    (tests/golden/unet_gd_tiny.npz holds the reference constructor's state dicts)."""
+    from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel, ResBlock
+    from test_oracle_golden import GD_TINY
+    g = load_golden("unet_gd_tiny")
+    for tag, extra in {"updown_ssn": dict(resblock_updown=True, use_scale_shift_norm=True), "noconv": dict(conv_resample=False)}.items():
+        sd = UNetModel(**dict(GD_TINY, **extra)).state_dict()
+        ref = {k[len(tag) + 3:]: v.shape for k, v in g.items() if k.startswith(tag + ".w.")}
+        assert set(sd.keys()) == set(ref.keys()), tag
+        assert all(tuple(sd[k].shape) == tuple(ref[k]) for k in ref), tag
+    rb = ResBlock(64, 128, 0.0, out_channels=96, use_scale_shift_norm=True, down=True)
+    assert rb.emb_layers[1].weight.shape == (192, 128) and rb.updown and not any(True for _ in rb.h_upd.parameters())
+    with pytest.raises(NotImplementedError):
+        UNetModel(**dict(GD_TINY, n_embed=16))
+
+
 def test_sd15_key_schema_and_param_count():
     """Appendix A of SURVEY.md: 686 tensors, 859 532 484 parameters (meta device, no memory)."""
     from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel

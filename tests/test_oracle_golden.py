@@ -420,6 +420,26 @@ def test_unet_class_conditional_and_adm_keys():
                               c_adm=T(g["y_cont"])), g["out.continuous"], tol=2e-4)
 
 
+GD_TINY = dict(image_size=8, in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[1, 2],
+               channel_mult=[1, 2], num_heads=4, use_spatial_transformer=True, transformer_depth=1, context_dim=16, legacy=False)
+GD_BLOCKS = {"up": dict(up=True), "down": dict(down=True), "ssn": dict(scale_shift=True), "up_ssn": dict(up=True, scale_shift=True),
+             "down_ssn": dict(down=True, scale_shift=True)}
+
+
+def test_unet_guided_diffusion_options():
+    """ResBlock(up= / down= / use_scale_shift_norm=) (openaimodel.py:215-221, 254-268), Upsample / Downsample without a conv (:108-118, 152-155) and the UNets that
+    use them (resblock_updown :600-616, 707-721; conv_resample=False) against the reference's outputs."""
+    g = load_golden("unet_gd_tiny")
+    for tag, kw in GD_BLOCKS.items():
+        close(L.resblock(sub_sd(g, f"rb.{tag}.w."), "", T(g[f"rb.{tag}.x"]), T(g[f"rb.{tag}.emb"]), **kw), g[f"rb.{tag}.y"], tol=2e-5)
+    close(L.downsample({}, "", T(g["pool.x"])), g["pool.down"], tol=1e-6)
+    close(L.downsample({}, "", T(g["pool.x7"])), g["pool.down7"], tol=1e-6)
+    close(L.upsample({}, "", T(g["pool.x"])), g["pool.up"], tol=0)
+    x, t, ctx = T(g["x"]), T(g["t"]), T(g["ctx"])
+    close(L.unet_forward(sub_sd(g, "updown_ssn.w."), dict(GD_TINY, resblock_updown=True, use_scale_shift_norm=True), x, t, ctx), g["updown_ssn.y"], tol=2e-4)
+    close(L.unet_forward(sub_sd(g, "noconv.w."), dict(GD_TINY, conv_resample=False), x, t, ctx), g["noconv.y"], tol=2e-4)
+
+
 def test_ddim_sampler_v_prediction():
     """DDIM on a v-prediction model (ddim.py:214-217, 232-235) and the three v helpers of ddpm.py:290-302, 361-365."""
     g = load_golden("ddim_v")

@@ -381,6 +381,60 @@ def gen_unet_adm():
     npz("unet_adm_tiny", **arrs)
 
 
+GD_TINY_UNET = dict(image_size=8, in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[1, 2],
+                    channel_mult=[1, 2], num_heads=4, use_spatial_transformer=True, transformer_depth=1, context_dim=16, legacy=False,
+                    use_checkpoint=False)
+
+
+@torch.no_grad()
+def gen_unet_gd():
+    """The guided-diffusion constructor options no AnyEdit config switches on but the reference implements (openaimodel.py:178-274, 600-616, 707-721):
+    ResBlock(up= / down=) (resblock_updown), use_scale_shift_norm, and Upsample / Downsample without a conv (conv_resample=False).  Weights are stored
+    as bf16 bit patterns (the reference ran on those values)."""
+    print("[unet_gd]")
+    arrs = {}
+    g = G(58)
+
+    def frozen(m):
+        unzero(m, g, std=0.05)
+        randomize_norm_affine(m, g)
+        m.eval()
+        for p_ in m.parameters():
+            p_.copy_(p_.bfloat16().float())
+        return m
+
+    def put_sd(m, prefix):
+        for k, v in m.state_dict().items():
+            arrs[prefix + k] = v.bfloat16().view(torch.int16)
+
+    # single blocks: (channels, out_channels, up, down, scale_shift, 3x3 skip)
+    for tag, (cin, cout, up, down, ssn, use_conv) in {"up": (64, 32, True, False, False, False), "down": (32, 64, False, True, False, True),
+                                                       "ssn": (64, 64, False, False, True, False), "up_ssn": (32, 32, True, False, True, False),
+                                                       "down_ssn": (64, 96, False, True, True, False)}.items():
+        torch.manual_seed(59)
+        rb = frozen(rom.ResBlock(cin, 128, 0.0, out_channels=cout, use_conv=use_conv, use_scale_shift_norm=ssn, dims=2, use_checkpoint=False,
+                                 up=up, down=down))
+        x = torch.randn(2, cin, 8, 6, generator=g)
+        emb = torch.randn(2, 128, generator=g)
+        arrs.update({f"rb.{tag}.x": x, f"rb.{tag}.emb": emb, f"rb.{tag}.y": rb(x, emb)})
+        put_sd(rb, f"rb.{tag}.w.")
+    x = torch.randn(2, 32, 6, 10, generator=g)
+    arrs.update({"pool.x": x, "pool.down": rom.Downsample(32, False, dims=2)(x), "pool.up": rom.Upsample(32, False, dims=2)(x)})
+    x7 = torch.randn(1, 32, 7, 9, generator=g)   # odd sizes: AvgPool2d(2, 2) floors
+    arrs.update({"pool.x7": x7, "pool.down7": rom.Downsample(32, False, dims=2)(x7)})
+    # whole UNets
+    t = torch.tensor([11, 971], dtype=torch.long)
+    ctx = torch.randn(2, 5, 16, generator=g)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    arrs.update({"x": x, "t": t, "ctx": ctx})
+    for tag, extra in {"updown_ssn": dict(resblock_updown=True, use_scale_shift_norm=True), "noconv": dict(conv_resample=False)}.items():
+        torch.manual_seed(60)
+        unet = frozen(rom.UNetModel(**dict(GD_TINY_UNET, **extra)))
+        arrs[f"{tag}.y"] = unet(x, t, context=ctx)
+        put_sd(unet, f"{tag}.w.")
+    npz("unet_gd_tiny", **arrs)
+
+
 def build_ldm(unet_params):
     ldm = OracleLDM(first_stage_config=None, cond_stage_config="__is_unconditional__",
                     force_null_conditioning=True, conditioning_key="hybrid",
@@ -1049,7 +1103,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     only = set(sys.argv[1:])  # e.g. `python tools/gen_golden.py ddim_encode` regenerates one fixture
     for name, fn in (("schedule", gen_schedule), ("norms", gen_norms), ("attention", gen_attention), ("transformer", gen_transformer),
-                     ("resblock", gen_resblock), ("unet", gen_unet), ("unet_sd2", gen_unet_sd2), ("unet_adm", gen_unet_adm), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode), ("ddim_hacked", gen_ddim_hacked), ("ddim_v", gen_ddim_v),
+                     ("resblock", gen_resblock), ("unet", gen_unet), ("unet_sd2", gen_unet_sd2), ("unet_adm", gen_unet_adm), ("unet_gd", gen_unet_gd), ("ddim", gen_ddim), ("ddim_encode", gen_ddim_encode), ("ddim_hacked", gen_ddim_hacked), ("ddim_v", gen_ddim_v),
                      ("vae", gen_vae), ("plms", gen_plms), ("dpm_solver", gen_dpm_solver), ("dpm_solver_general", gen_dpm_solver_general), ("cldm", gen_cldm), ("msda", gen_msda), ("msda_bwd", gen_msda_bwd), ("sam", gen_sam), ("sam_decoder", gen_sam_decoder),
                      ("misc", gen_ldm_misc)):
         if not only or name in only:
