@@ -88,11 +88,12 @@ class Upsample(nn.Module, _Rows):
     def __init__(self, in_channels, with_conv):
         super().__init__()
         self.with_conv = with_conv
-        if not with_conv:
-            raise NotImplementedError("Upsample(with_conv=False) is not used by the kl-f8 autoencoder")
-        self.conv = torch.nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+        if with_conv:
+            self.conv = torch.nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
 
     def rows(self, x, B, H, W):
+        if not self.with_conv:   # model.py:54-58: the nearest x2 alone
+            return ops.resample2x_rows(x, B, H, W)
         w, b, _ = _conv3x3_packed(self._cache(), "conv", self.conv)
         return ops.conv3x3(x, w, b, B, H, W, upsample2x=True)  # nearest x2 folded into the gather (model.py:61-65)
 
@@ -106,12 +107,13 @@ class Downsample(nn.Module, _Rows):
     def __init__(self, in_channels, with_conv):
         super().__init__()
         self.with_conv = with_conv
-        if not with_conv:
-            raise NotImplementedError("Downsample(with_conv=False) is not used by the kl-f8 autoencoder")
-        self.conv = torch.nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
+        if with_conv:
+            self.conv = torch.nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
 
     def rows(self, x, B, H, W):
-        """pad (0,1,0,1) + stride-2 valid conv (model.py:80-84) == flip(conv_s2_pad1(flip(x), flip(w))) for even H, W."""
+        """pad (0,1,0,1) + stride-2 valid conv (model.py:80-84) == flip(conv_s2_pad1(flip(x), flip(w))) for even H, W; with_conv=False: avg_pool2d(2, 2) (:85-86)."""
+        if not self.with_conv:
+            return ops.resample2x_rows(x, B, H, W, down=True)
         if H % 2 or W % 2:
             raise NotImplementedError("Downsample: odd spatial sizes are not on the AnyEdit path")
         C = x.shape[1]

@@ -709,6 +709,19 @@ def test_feed_forward_without_glu_and_ungated_block():
 
 
 # ------------------------------------------------------------------------------------------------------------ first stage (N1)
+def test_first_stage_resampling_without_conv():
+    """diffusionmodules/model.py:44-89 with with_conv=False (no kl-f8 config uses it; the reference implements it): Upsample = F.interpolate(nearest x2),
+    Downsample = avg_pool2d(2, 2) — the reference's own statements, on channel counts that need the 8-channel padding too."""
+    from anyedit_amd.ldm.modules.diffusionmodules.model import Upsample, Downsample
+    g = torch.Generator().manual_seed(11)
+    for C in (4, 32):
+        x = torch.randn(2, C, 6, 10, generator=g).bfloat16().float()
+        up, dn = Upsample(C, False), Downsample(C, False)
+        assert len(up.state_dict()) == 0 and len(dn.state_dict()) == 0
+        assert torch.equal(up(x.to(DEV)).cpu(), F.interpolate(x, scale_factor=2.0, mode="nearest"))
+        close(dn(x.to(DEV)), F.avg_pool2d(x, kernel_size=2, stride=2), rl2=4e-3, what="Downsample(with_conv=False)")
+
+
 def test_first_stage_autoencoder_golden():
     """AutoencoderKL encode / decode and its blocks on the HIP path vs the reference's outputs (tests/golden/vae_tiny.npz)."""
     from anyedit_amd.ldm.models.autoencoder import AutoencoderKL
