@@ -87,8 +87,12 @@ class PLMSSampler(DDIMSampler):
                       noise_dropout=0., score_corrector=None, corrector_kwargs=None, unconditional_guidance_scale=1.,
                       unconditional_conditioning=None, old_eps=None, t_next=None, dynamic_threshold=None):
         """plms.py:178-244."""
-        if quantize_denoised or score_corrector is not None or noise_dropout > 0. or dynamic_threshold is not None:
-            raise NotImplementedError("quantize_denoised / score_corrector / noise_dropout / dynamic_threshold: unused by AnyEdit")
+        if quantize_denoised:
+            raise NotImplementedError("quantize_denoised needs a VQ first stage (plms.py:216-217); the AnyEdit path decodes with AutoencoderKL")
+        if dynamic_threshold is not None:
+            raise NotImplementedError("dynamic_threshold: norm_thresholding is for pixel-space models (plms.py:218-219); no AnyEdit caller passes it")
+        if score_corrector is not None:
+            assert getattr(self.model, "parameterization", "eps") == "eps"      # plms.py:196
         b, device = x.shape[0], x.device
         coeffs = self._coeffs(index, use_original_steps)
         cfg = not (unconditional_conditioning is None or unconditional_guidance_scale == 1.)
@@ -103,9 +107,29 @@ class PLMSSampler(DDIMSampler):
 
         def x_prev_and_pred_x0(e, branches, want_e=False):
             noise = self.randn((1, *x.shape[1:]), device=device).repeat(b, 1, 1, 1) if repeat_noise else self.randn(x.shape, device=device)
+            if noise_dropout > 0.:
+                # plms.py:222-224 drops (and rescales) sigma_t * noise * temperature; the mask and its 1 / (1 - p) commute with those two scalars, which the
+                # fused step kernel applies
+                noise = torch.nn.functional.dropout(noise, p=noise_dropout)
             return ops.ddim_step(x, e, coeffs, branches, s0=float(unconditional_guidance_scale), noise=noise.float().contiguous(),
                                  temperature=float(temperature), want_e=want_e)
 
+        if score_corrector is not None:
+            # plms.py:195-197: the corrector sees the guidance-combined eps of EVERY network evaluation (also the provisional one of the first step), so the
+            # fused "guidance + update" launch cannot serve; guidance is one launch (its update values unused), the corrector runs, the update takes ONE branch
+            def corrected(xx, tt):
+                raw_ = model_output(xx, tt)
+                e_ = ops.ddim_step(xx, raw_, coeffs, 2, s0=float(unconditional_guidance_scale), want_e=True)[2] if cfg else raw_.contiguous()
+                return score_corrector.modify_score(self.model, e_, xx, tt, c, **(corrector_kwargs or {})).float().contiguous()
+
+            e_t = corrected(x, t)
+            if len(old_eps) == 0:
+                x_prov, _ = x_prev_and_pred_x0(e_t, 1)
+                e_t_prime = ops.plms_combine_first(e_t, corrected(x_prov, t_next))
+            else:
+                e_t_prime = ops.plms_combine(e_t, old_eps)
+            x_prev, pred_x0 = x_prev_and_pred_x0(e_t_prime, 1)
+            return x_prev, pred_x0, e_t
         raw = model_output(x, t)
         if len(old_eps) == 0:
             # pseudo improved Euler: evaluate the network again at the provisional x_prev (plms.py:227-231)

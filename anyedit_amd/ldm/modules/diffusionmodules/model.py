@@ -100,6 +100,8 @@ class Upsample(nn.Module, _Rows):
     def forward(self, x):
         r, B, H, W = _to_rows(x)
         y, Ho, Wo = self.rows(r, B, H, W)
+        if y.shape[1] != x.shape[1] and not self.with_conv:   # rows carry the 8-channel padding of _to_rows; a conv's output does not
+            y = y[:, :x.shape[1]].contiguous()
         return ops.rows_to_nchw(y, B, Ho, Wo, out_dtype=x.dtype)
 
 
@@ -125,6 +127,8 @@ class Downsample(nn.Module, _Rows):
     def forward(self, x):
         r, B, H, W = _to_rows(x)
         y, Ho, Wo = self.rows(r, B, H, W)
+        if y.shape[1] != x.shape[1] and not self.with_conv:   # rows carry the 8-channel padding of _to_rows; a conv's output does not
+            y = y[:, :x.shape[1]].contiguous()
         return ops.rows_to_nchw(y, B, Ho, Wo, out_dtype=x.dtype)
 
 

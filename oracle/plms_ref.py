@@ -7,7 +7,10 @@ from . import schedule_ref as S
 from .ddim_ref import q_sample, _cat_cond
 
 
-def plms_sample(apply_model, buffers, S_steps, shape, cond, x_T, scale=1.0, uc=None, mask=None, x0=None, log_every_t=100):
+def plms_sample(apply_model, buffers, S_steps, shape, cond, x_T, scale=1.0, uc=None, mask=None, x0=None, log_every_t=100, score_corrector=None,
+                noise_dropout=0.0):
+    """score_corrector: callable (e_t, x, t, c) -> e_t applied to the guidance-combined eps of every network evaluation (plms.py:195-197); noise_dropout:
+    plms.py:222-224 (sigma_t = 0 in PLMS: only the RNG consumption shows)."""
     sched = S.make_ddim_schedule(buffers, S_steps, "uniform", 0.0)
     timesteps = sched["ddim_timesteps"]
     time_range = np.flip(timesteps)
@@ -22,6 +25,12 @@ def plms_sample(apply_model, buffers, S_steps, shape, cond, x_T, scale=1.0, uc=N
             return apply_model(x, t, cond)
         e_u, e_c = apply_model(torch.cat([x] * 2), torch.cat([t] * 2), _cat_cond(uc, cond)).chunk(2)
         return e_u + scale * (e_c - e_u)
+
+    if score_corrector is not None:
+        raw_output = model_output
+
+        def model_output(x, t):   # noqa: F811
+            return score_corrector(raw_output(x, t), x, t, cond)
 
     for i, step in enumerate(time_range):
         index = total - i - 1
@@ -38,6 +47,8 @@ def plms_sample(apply_model, buffers, S_steps, shape, cond, x_T, scale=1.0, uc=N
             pred_x0 = (x - s1m * e) / a_t.sqrt()
             dir_xt = (1.0 - a_prev - sigma_t ** 2).sqrt() * e
             noise = sigma_t * torch.randn(x.shape)
+            if noise_dropout > 0.0:
+                noise = torch.nn.functional.dropout(noise, p=noise_dropout)
             return a_prev.sqrt() * pred_x0 + dir_xt + noise, pred_x0
 
         e_t = model_output(img, ts)

@@ -285,6 +285,16 @@ def test_plms_sampler_golden():
         assert len(inter["x_inter"]) == g[f"{tag}.x_inter"].shape[0]
         assert float((samples.cpu() - T(g[f"{tag}.samples"])).abs().max()) <= 2e-5, tag
         assert float((torch.stack(inter["pred_x0"]).cpu() - T(g[f"{tag}.pred_x0"])).abs().max()) <= 2e-5, tag
+
+    class Corrector:   # tools/gen_golden.py::AnalyticCorrector (plms.py:195-197); noise_dropout (:222-224) only moves the RNG at eta = 0
+        def modify_score(self, model, e_t, x, t, c, gain=1.0):
+            return e_t * gain - 0.05 * x + 0.01 * c[:, :, None, None]
+
+    torch.manual_seed(4321)
+    samples, inter = sampler.sample(6, 2, (4, 8, 8), dev("c"), eta=0.0, x_T=dev("x_T"), verbose=False, unconditional_guidance_scale=3.0,
+                                    unconditional_conditioning=dev("uc"), log_every_t=1, score_corrector=Corrector(), corrector_kwargs={"gain": 1.1}, noise_dropout=0.3)
+    assert float((samples.cpu() - T(g["s6_cfg_corr.samples"])).abs().max()) <= 2e-5
+    assert float((torch.stack(inter["pred_x0"]).cpu() - T(g["s6_cfg_corr.pred_x0"])).abs().max()) <= 2e-5
     with pytest.raises(ValueError):
         sampler.make_schedule(5, ddim_eta=0.5, verbose=False)
 

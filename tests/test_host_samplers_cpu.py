@@ -148,8 +148,20 @@ def test_plms_sampler_host_logic(standin_ops):
         assert len(inter["x_inter"]) == g[f"{tag}.x_inter"].shape[0]
         assert _maxabs(samples, T(g[f"{tag}.samples"])) <= 2e-5, tag
         assert _maxabs(torch.stack(inter["pred_x0"]), T(g[f"{tag}.pred_x0"])) <= 2e-5, tag
+    torch.manual_seed(4321)   # score_corrector + noise_dropout (plms.py:195-197, 222-224) against the reference run with the same corrector
+    samples, inter = sampler.sample(6, 2, (4, 8, 8), T(g["c"]), eta=0.0, x_T=T(g["x_T"]), verbose=False, unconditional_guidance_scale=3.0,
+                                    unconditional_conditioning=T(g["uc"]), log_every_t=1, score_corrector=_Corrector(), corrector_kwargs={"gain": 1.1}, noise_dropout=0.3)
+    assert _maxabs(samples, T(g["s6_cfg_corr.samples"])) <= 2e-5
+    assert _maxabs(torch.stack(inter["pred_x0"]), T(g["s6_cfg_corr.pred_x0"])) <= 2e-5
     with pytest.raises(ValueError):
         sampler.make_schedule(5, ddim_eta=0.5, verbose=False)
+
+
+class _Corrector:
+    """tools/gen_golden.py::AnalyticCorrector."""
+
+    def modify_score(self, model, e_t, x, t, c, gain=1.0):
+        return e_t * gain - 0.05 * x + 0.01 * c[:, :, None, None]
 
 
 def test_ddim_sampler_v_prediction_host_logic(standin_ops):

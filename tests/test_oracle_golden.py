@@ -258,6 +258,12 @@ def test_plms_sampler():
         assert len(inter["x_inter"]) == g[f"{tag}.x_inter"].shape[0]
         close(img, g[f"{tag}.samples"], tol=1e-5)
         close(torch.stack(inter["pred_x0"]), g[f"{tag}.pred_x0"], tol=1e-5)
+    # score_corrector + noise_dropout (plms.py:195-197, 222-224): the corrector of tools/gen_golden.py::AnalyticCorrector with gain 1.1
+    torch.manual_seed(4321)
+    img, inter, _ = P.plms_sample(_analytic_eps, buffers, 6, tuple(x_T.shape), c, x_T, scale=3.0, uc=uc, log_every_t=1, noise_dropout=0.3,
+                                  score_corrector=lambda e, x, t, cc: e * 1.1 - 0.05 * x + 0.01 * cc[:, :, None, None])
+    close(img, g["s6_cfg_corr.samples"], tol=1e-5)
+    close(torch.stack(inter["pred_x0"]), g["s6_cfg_corr.pred_x0"], tol=1e-5)
 
 
 def test_controlnet_and_controlled_unet():

@@ -798,7 +798,22 @@ def gen_plms():
         arrs[f"{tag}.x_inter"] = torch.stack(inter["x_inter"])
         arrs[f"{tag}.pred_x0"] = torch.stack(inter["pred_x0"])
         arrs[f"{tag}.ddim_timesteps"] = sampler.ddim_timesteps
+    # score_corrector (plms.py:195-197: applied to the guidance-combined eps of every network evaluation) + noise_dropout (:222-224; PLMS runs eta = 0, so
+    # only its RNG consumption is observable).  Appended LAST: the arrays above keep their values when the fixture is regenerated.
+    tag = "s6_cfg_corr"
+    torch.manual_seed(4321)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        samples, inter = sampler.sample(6, B, (4, 8, 8), c, eta=0.0, x_T=x_T, verbose=False, unconditional_guidance_scale=3.0, unconditional_conditioning=uc,
+                                        log_every_t=1, score_corrector=AnalyticCorrector(), corrector_kwargs={"gain": 1.1}, noise_dropout=0.3)
+    arrs[f"{tag}.samples"], arrs[f"{tag}.x_inter"], arrs[f"{tag}.pred_x0"] = samples, torch.stack(inter["x_inter"]), torch.stack(inter["pred_x0"])
     npz("plms", **arrs)
+
+
+class AnalyticCorrector:
+    """Deterministic stand-in for a score corrector (the reference ships none): what modify_score returns drives the update."""
+
+    def modify_score(self, model, e_t, x, t, c, gain=1.0):
+        return e_t * gain - 0.05 * x + 0.01 * c[:, :, None, None]
 
 
 @torch.no_grad()
