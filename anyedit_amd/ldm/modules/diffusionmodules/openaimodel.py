@@ -6,6 +6,7 @@ same initial weights as the reference constructor.  Forward data flow (openaimod
 rows end to end; NCHW fp32 exists only at the model boundary.
 """
 from abc import abstractmethod
+import math
 
 import torch
 import torch.nn as nn
@@ -69,6 +70,9 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
                 st = _stats_for(f.B, f.H, f.W, x.shape[1], x.device)
                 f = Feat(layer.rows(x, f.B, f.H, f.W, context_rows=context_rows, kv_cache=kv_cache, colstats=x_st, out_colstats=st),
                          f.B, f.H, f.W, st=st)
+            elif isinstance(layer, AttentionBlock):
+                x_st = f.st if f.t2 is None else None
+                f = Feat(layer.rows(f.materialize(), f.B, f.H * f.W, colstats=x_st), f.B, f.H, f.W)
             else:
                 f = layer.rows(f)
         return f
@@ -242,8 +246,80 @@ class ResBlock(TimestepBlock):
     _forward = forward
 
 
+class _QKVAttentionBase(nn.Module):
+    """openaimodel.py:344-409: softmax(q k^T / sqrt(ch)) v per head over the packed [N, 3 H ch, T] projection (the reference scales q and k by ch^-1/4 each).
+    `rows` takes the projection as channels-last rows [N*T, 3 H ch]: a head's q / k / v are column slices, handed to the attention kernel as strides."""
+
+    def __init__(self, n_heads):
+        super().__init__()
+        self.n_heads = n_heads
+
+    def _offsets(self, ch):
+        raise NotImplementedError
+
+    def rows(self, qkv, B, T):
+        width = qkv.shape[1]
+        assert width % (3 * self.n_heads) == 0
+        ch = width // (3 * self.n_heads)
+        (oq, ok, ov), hs = self._offsets(ch)
+        st = (T * width, hs, width)                                  # (batch, head, row) element strides, the same for q, k and v
+        return ops.attention(qkv[:, oq:], qkv[:, ok:], qkv[:, ov:], B, self.n_heads, T, T, ch, 1.0 / math.sqrt(ch), st, st, st).reshape(B * T, self.n_heads * ch)
+
+    def forward(self, qkv):
+        bs, width, length = qkv.shape
+        y = self.rows(ops.nchw_to_rows(qkv.reshape(bs, width, length, 1)), bs, length)
+        return ops.rows_to_nchw(y, bs, length, 1, out_dtype=qkv.dtype).reshape(bs, -1, length)
+
+
+class QKVAttentionLegacy(_QKVAttentionBase):
+    """openaimodel.py:344-373: heads split first — channels are (head, {q, k, v}, ch)."""
+
+    def _offsets(self, ch):
+        return (0, ch, 2 * ch), 3 * ch
+
+
+class QKVAttention(_QKVAttentionBase):
+    """openaimodel.py:376-409 (use_new_attention_order): q | k | v split first — channels are ({q, k, v}, head, ch)."""
+
+    def _offsets(self, ch):
+        return (0, self.n_heads * ch, 2 * self.n_heads * ch), ch
+
+
+class AttentionBlock(nn.Module):
+    """openaimodel.py:277-324: GroupNorm -> pointwise qkv -> per-head attention over all positions -> zero-init pointwise proj_out + residual: the UNet's
+    attention layer when use_spatial_transformer=False (no AnyEdit configuration; forward only).  State-dict keys and shapes are the reference's
+    (Conv1d weights [Cout, Cin, 1])."""
+
+    def __init__(self, channels, num_heads=1, num_head_channels=-1, use_checkpoint=False, use_new_attention_order=False):
+        super().__init__()
+        self.channels = channels
+        if num_head_channels == -1:
+            self.num_heads = num_heads
+        else:
+            assert channels % num_head_channels == 0, f"q,k,v channels {channels} is not divisible by num_head_channels {num_head_channels}"
+            self.num_heads = channels // num_head_channels
+        self.use_checkpoint = use_checkpoint
+        self.norm = normalization(channels)
+        self.qkv = conv_nd(1, channels, channels * 3, 1)
+        self.attention = QKVAttention(self.num_heads) if use_new_attention_order else QKVAttentionLegacy(self.num_heads)
+        self.proj_out = zero_module(conv_nd(1, channels, channels, 1))
+
+    def rows(self, x, B, T, colstats=None):
+        h = self.norm.rows(x, B, T, silu=False, colstats=colstats)
+        return self.proj_out.rows(self.attention.rows(self.qkv.rows(h), B, T), residual=x)
+
+    def forward(self, x):
+        b, c = x.shape[:2]
+        T = int(x.numel() // (b * c))
+        y = self.rows(ops.nchw_to_rows(x.reshape(b, c, T, 1)), b, T)
+        return ops.rows_to_nchw(y, b, T, 1, out_dtype=x.dtype).reshape(x.shape)
+
+    _forward = forward
+
+
 class UNetModel(nn.Module):
-    """openaimodel.py:412-786 for use_spatial_transformer=True (the AnySD / SD-1.5 / AnyDoor configurations)."""
+    """openaimodel.py:412-786: use_spatial_transformer=True is the AnySD / SD-1.5 / AnyDoor configuration; False builds the guided-diffusion UNet with
+    AttentionBlock layers (:277-324, forward only)."""
 
     def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
                  dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, use_checkpoint=False,
@@ -252,11 +328,12 @@ class UNetModel(nn.Module):
                  context_dim=None, n_embed=None, legacy=True, disable_self_attentions=None, num_attention_blocks=None,
                  disable_middle_self_attn=False, use_linear_in_transformer=False):
         super().__init__()
-        if not use_spatial_transformer:
-            raise NotImplementedError("legacy AttentionBlock path (use_spatial_transformer=False) is unused by AnyEdit (SURVEY §2 C2)")
-        assert context_dim is not None, "use_spatial_transformer needs context_dim (openaimodel.py:474-475)"
-        if not isinstance(context_dim, (int, type(None))):
-            context_dim = list(context_dim)
+        if use_spatial_transformer:
+            assert context_dim is not None, "use_spatial_transformer needs context_dim (openaimodel.py:474-475)"
+        if context_dim is not None:
+            assert use_spatial_transformer, "a cross-attention context_dim needs use_spatial_transformer (openaimodel.py:477-478)"
+            if not isinstance(context_dim, int):
+                context_dim = list(context_dim)
         if n_embed is not None or dims != 2:
             raise NotImplementedError("n_embed (codebook-id head) / dims != 2 are outside the AnyEdit hot path")
         if num_classes is not None and not isinstance(num_classes, int) and num_classes != "continuous":
@@ -299,6 +376,11 @@ class UNetModel(nn.Module):
             return ch // num_head_channels, num_head_channels
 
         def make_st(ch, nh, level, is_middle=False):
+            if not use_spatial_transformer:
+                # openaimodel.py:568-575, 583-588 (and :640-645, 680-699): dim_head follows num_head_channels; with neither it nor `legacy` set it is
+                # ch // num_heads of the INPUT side's head count (the reference computes it from `num_heads` in the output blocks too)
+                d_h = num_head_channels if (num_head_channels != -1 or legacy) else ch // num_heads
+                return AttentionBlock(ch, use_checkpoint=use_checkpoint, num_heads=nh, num_head_channels=d_h, use_new_attention_order=use_new_attention_order)
             n_h, d_h = heads_for(ch, nh)
             if legacy:
                 d_h = ch // n_h

@@ -217,8 +217,28 @@ class LayerNorm(nn.LayerNorm):
         return self.rows(x.reshape(-1, shp[-1]).to(torch.bfloat16).contiguous()).reshape(shp).to(x.dtype)
 
 
+class Conv1d(nn.Conv1d, _Packed):
+    """nn.Conv1d with kernel_size 1 (what AttentionBlock's qkv / proj_out are, openaimodel.py:304, 312) as the dense GEMM over rows [B*T, Cin]."""
+
+    def _pack(self):
+        if self.kernel_size[0] != 1 or self.stride[0] != 1 or self.padding[0] != 0 or self.groups != 1:
+            raise NotImplementedError(f"anyedit_amd Conv1d: only the 1-wide pointwise form (k={self.kernel_size} stride={self.stride} padding={self.padding})")
+        return {"w": ops.pack_linear(self.weight), "b": None if self.bias is None else self.bias.detach().float().contiguous()}
+
+    def rows(self, x, residual=None):
+        pk = self._packed()
+        return ops.gemm(x, pk["w"], pk["b"], residual=residual)
+
+    def forward(self, x):
+        B, C, T = x.shape
+        y = self.rows(ops.nchw_to_rows(x.reshape(B, C, T, 1)))
+        return ops.rows_to_nchw(y, B, T, 1, out_dtype=x.dtype).reshape(B, -1, T)
+
+
 def conv_nd(dims, *args, **kwargs):
     """util.py:222-232."""
+    if dims == 1:
+        return Conv1d(*args, **kwargs)
     if dims == 2:
         return Conv2d(*args, **kwargs)
     raise ValueError(f"unsupported dimensions: {dims} (the AnyEdit hot path is 2-D)")

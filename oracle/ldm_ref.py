@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 
 import contextlib
+import math
 import threading
 
 from .schedule_ref import timestep_embedding
@@ -187,6 +188,25 @@ def upsample(sd, p, x):
     return _st(F.conv2d(x, sd[p + "conv.weight"], sd[p + "conv.bias"], padding=1))
 
 
+def attention_block(sd, p, x, heads, new_order=False):
+    """openaimodel.py:316-322 + QKVAttentionLegacy (:344-373) / QKVAttention (:376-409): GroupNorm -> pointwise qkv -> per-head softmax(q k^T / sqrt(ch)) v over
+    all positions -> pointwise proj_out + residual.  Legacy order: channels (head, {q, k, v}, ch); new order: ({q, k, v}, head, ch)."""
+    b, c = x.shape[:2]
+    xf = x.reshape(b, c, -1)
+    T = xf.shape[-1]
+    qkv = _st(F.conv1d(_st(group_norm32(xf, sd[p + "norm.weight"], sd[p + "norm.bias"])), sd[p + "qkv.weight"], sd[p + "qkv.bias"]))
+    ch = qkv.shape[1] // (3 * heads)
+    if new_order:
+        q, k, v = (t.reshape(b * heads, ch, T) for t in qkv.chunk(3, dim=1))
+    else:
+        q, k, v = qkv.reshape(b * heads, ch * 3, T).split(ch, dim=1)
+    scale = 1.0 / math.sqrt(math.sqrt(ch))
+    w = torch.softmax(torch.einsum("bct,bcs->bts", q * scale, k * scale).float(), dim=-1)
+    a = _st(torch.einsum("bts,bcs->bct", w, v).reshape(b, -1, T))
+    h = F.conv1d(a, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"])
+    return _st(xf + h).reshape(x.shape)
+
+
 # ------------------------------------------------------------------ A7 UNet
 def unet_plan(cfg):
     """Walk of UNetModel.__init__ (openaimodel.py:542-730) for use_spatial_transformer=True, legacy=False
@@ -199,6 +219,20 @@ def unet_plan(cfg):
     nhc = cfg.get("num_head_channels", -1)
     hd = (lambda c: (cfg["num_heads"], c // cfg["num_heads"])) if nhc == -1 else (lambda c: (c // nhc, nhc))   # openaimodel.py:586-592
     depth = cfg.get("transformer_depth", 1)
+    if not cfg.get("use_spatial_transformer", cfg.get("context_dim") is not None):   # (configs written before this branch existed carry a context_dim and no flag)
+        # AttentionBlock layers (openaimodel.py:568-588, 640-645, 680-699): heads from num_head_channels when given, else num_heads (input / middle) or
+        # num_heads_upsample (output) under `legacy`, else ch // (ch // num_heads)
+        legacy, nh_in = cfg.get("legacy", True), cfg.get("num_heads", -1)
+        nh_up = cfg.get("num_heads_upsample", -1)
+        nh_up = nh_in if nh_up == -1 else nh_up
+        new_order = bool(cfg.get("use_new_attention_order", False))
+
+        def attn_entry(ch, side_heads):
+            if nhc != -1:
+                return ("attn", ch, ch // nhc, new_order)
+            return ("attn", ch, side_heads if legacy else ch // (ch // nh_in), new_order)
+    else:
+        attn_entry = None
     inp = [[("conv", cfg["in_channels"], mc)]]
     chans = [mc]
     ch, ds = mc, 1
@@ -207,14 +241,14 @@ def unet_plan(cfg):
             layers = [("res", ch, m * mc)]
             ch = m * mc
             if ds in attn_res:
-                layers.append(("st", ch, *hd(ch), depth))
+                layers.append(("st", ch, *hd(ch), depth) if attn_entry is None else attn_entry(ch, nh_in))
             inp.append(layers)
             chans.append(ch)
         if level != len(mult) - 1:
             inp.append([("resdown" if cfg.get("resblock_updown") else "down", ch, ch)])   # openaimodel.py:600-616
             chans.append(ch)
             ds *= 2
-    mid = [("res", ch, ch), ("st", ch, *hd(ch), depth), ("res", ch, ch)]
+    mid = [("res", ch, ch), ("st", ch, *hd(ch), depth) if attn_entry is None else attn_entry(ch, nh_in), ("res", ch, ch)]
     out = []
     for level, m in list(enumerate(mult))[::-1]:
         for i in range(nrb[level] + 1):
@@ -222,7 +256,7 @@ def unet_plan(cfg):
             layers = [("res", ch + ich, mc * m)]
             ch = mc * m
             if ds in attn_res:
-                layers.append(("st", ch, *hd(ch), depth))
+                layers.append(("st", ch, *hd(ch), depth) if attn_entry is None else attn_entry(ch, nh_up))
             if level and i == nrb[level]:
                 layers.append(("resup" if cfg.get("resblock_updown") else "up", ch, ch))   # openaimodel.py:707-721
                 ds //= 2
@@ -240,6 +274,8 @@ def _run_layers(sd, prefix, layers, h, emb, context, use_linear, adapters=None, 
             h = resblock(sd, p, h, emb, scale_shift=scale_shift)
         elif kind in ("resdown", "resup"):
             h = resblock(sd, p, h, emb, up=kind == "resup", down=kind == "resdown", scale_shift=scale_shift)
+        elif kind == "attn":
+            h = attention_block(sd, p, h, heads=L[2], new_order=L[3])
         elif kind == "st":
             h = spatial_transformer(sd, p, h, context, heads=L[2], depth=L[4], use_linear=use_linear, adapters=adapters)
         elif kind == "down":

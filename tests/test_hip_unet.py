@@ -89,7 +89,8 @@ def test_resample_and_scale_shift_kernels_vs_torch():
 
 def test_unet_guided_diffusion_options_golden():
     """The constructor options VERDICT r5 listed as refused — ResBlock(up= / down= / use_scale_shift_norm=) (openaimodel.py:215-221, 254-268), Upsample /
-    Downsample without a conv (:108-118, 152-155), UNetModel(resblock_updown=, use_scale_shift_norm=, conv_resample=False) (:600-616, 707-721) — against the
+    Downsample without a conv (:108-118, 152-155), UNetModel(resblock_updown=, use_scale_shift_norm=, conv_resample=False) (:600-616, 707-721), and the
+    AttentionBlock UNet (use_spatial_transformer=False, :277-324, 344-409) — against the
     reference's outputs (tests/golden/unet_gd_tiny.npz, tools/gen_golden.py::gen_unet_gd); state-dict keys are the reference's."""
     from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import ResBlock, Downsample, Upsample, UNetModel
     from test_oracle_golden import GD_TINY
@@ -117,6 +118,22 @@ def test_unet_guided_diffusion_options_golden():
             emb = unet.time_embedding_rows(t)                   # the hoisted time-embedding pack carries 2 x Cout columns per scale-shift block
             y2 = unet.forward_rows(x, None, unet.context_rows(ctx), emb_pack=emb)
             assert torch.equal(y2, y), "hoisted time-embedding path = per-step path"
+    # use_spatial_transformer=False: AttentionBlock layers (openaimodel.py:277-324; QKVAttentionLegacy / QKVAttention :344-409), no context
+    from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import AttentionBlock
+    from test_oracle_golden import GD_ADM
+    for tag, (ch, kw) in {"legacy": (64, dict(num_heads=4)), "new": (64, dict(num_head_channels=16, use_new_attention_order=True)), "one_head": (32, dict())}.items():
+        ab = AttentionBlock(ch, **kw)
+        ab.load_state_dict(sub_sd(g, f"ab.{tag}.w."))
+        close(ab.to(DEV)(T(g[f"ab.{tag}.x"]).to(DEV)), g[f"ab.{tag}.y"], what=f"AttentionBlock {tag}")
+    for tag, extra in GD_ADM.items():
+        with torch.device(DEV):
+            unet = UNetModel(**dict(GD_TINY, **extra))
+        unet.load_state_dict({k: v.to(DEV) for k, v in sub_sd(g, f"{tag}.w.").items()})
+        unet.eval().requires_grad_(False)
+        with torch.no_grad():
+            y = unet(x, t)
+            close(y, g[f"{tag}.y"], what=f"UNetModel {tag}")
+            assert torch.equal(unet(x, t), y), "run-to-run bit-equal"
 
 
 @pytest.fixture(scope="module")

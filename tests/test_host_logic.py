@@ -57,7 +57,8 @@ def test_guided_diffusion_options_key_schema():
     from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel, ResBlock
     from test_oracle_golden import GD_TINY
     g = load_golden("unet_gd_tiny")
-    for tag, extra in {"updown_ssn": dict(resblock_updown=True, use_scale_shift_norm=True), "noconv": dict(conv_resample=False)}.items():
+    from test_oracle_golden import GD_ADM
+    for tag, extra in dict({"updown_ssn": dict(resblock_updown=True, use_scale_shift_norm=True), "noconv": dict(conv_resample=False)}, **GD_ADM).items():
         sd = UNetModel(**dict(GD_TINY, **extra)).state_dict()
         ref = {k[len(tag) + 3:]: v.shape for k, v in g.items() if k.startswith(tag + ".w.")}
         assert set(sd.keys()) == set(ref.keys()), tag
@@ -66,6 +67,15 @@ def test_guided_diffusion_options_key_schema():
     assert rb.emb_layers[1].weight.shape == (192, 128) and rb.updown and not any(True for _ in rb.h_upd.parameters())
     with pytest.raises(NotImplementedError):
         UNetModel(**dict(GD_TINY, n_embed=16))
+    with pytest.raises(AssertionError):
+        UNetModel(**dict(GD_TINY, use_spatial_transformer=False))        # a context_dim without the spatial transformer (openaimodel.py:477-478)
+    from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import AttentionBlock, QKVAttention, QKVAttentionLegacy
+    heads = lambda m: [b.num_heads for b in m.modules() if isinstance(b, AttentionBlock)]   # noqa: E731
+    assert heads(UNetModel(**dict(GD_TINY, **GD_ADM["adm"]))) == [2, 4, 4, 4, 4, 2, 2]         # ch // 16 at 32 / 64 channels
+    assert heads(UNetModel(**dict(GD_TINY, **GD_ADM["adm_legacy"]))) == [2] * 7
+    assert heads(UNetModel(**dict(GD_TINY, use_spatial_transformer=False, context_dim=None, num_heads=4, num_heads_upsample=2, legacy=True))) == [4, 4, 4, 2, 2, 2, 2]
+    assert isinstance(AttentionBlock(64, num_head_channels=16, use_new_attention_order=True).attention, QKVAttention)
+    assert isinstance(AttentionBlock(64, num_heads=4).attention, QKVAttentionLegacy)
 
 
 def test_sd15_key_schema_and_param_count():

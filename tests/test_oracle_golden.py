@@ -428,6 +428,9 @@ def test_unet_class_conditional_and_adm_keys():
 
 GD_TINY = dict(image_size=8, in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[1, 2],
                channel_mult=[1, 2], num_heads=4, use_spatial_transformer=True, transformer_depth=1, context_dim=16, legacy=False)
+GD_ADM = {"adm": dict(use_spatial_transformer=False, context_dim=None, num_heads=-1, num_head_channels=16, use_new_attention_order=True, resblock_updown=True,
+                      use_scale_shift_norm=True),
+          "adm_legacy": dict(use_spatial_transformer=False, context_dim=None, num_heads=2, legacy=True)}
 GD_BLOCKS = {"up": dict(up=True), "down": dict(down=True), "ssn": dict(scale_shift=True), "up_ssn": dict(up=True, scale_shift=True),
              "down_ssn": dict(down=True, scale_shift=True)}
 
@@ -444,6 +447,11 @@ def test_unet_guided_diffusion_options():
     x, t, ctx = T(g["x"]), T(g["t"]), T(g["ctx"])
     close(L.unet_forward(sub_sd(g, "updown_ssn.w."), dict(GD_TINY, resblock_updown=True, use_scale_shift_norm=True), x, t, ctx), g["updown_ssn.y"], tol=2e-4)
     close(L.unet_forward(sub_sd(g, "noconv.w."), dict(GD_TINY, conv_resample=False), x, t, ctx), g["noconv.y"], tol=2e-4)
+    # AttentionBlock (use_spatial_transformer=False, openaimodel.py:277-324) with QKVAttentionLegacy / QKVAttention (:344-409)
+    for tag, (heads, new) in {"legacy": (4, False), "new": (4, True), "one_head": (1, False)}.items():
+        close(L.attention_block(sub_sd(g, f"ab.{tag}.w."), "", T(g[f"ab.{tag}.x"]), heads, new_order=new), g[f"ab.{tag}.y"], tol=2e-5)
+    for tag, extra in GD_ADM.items():
+        close(L.unet_forward(sub_sd(g, f"{tag}.w."), dict(GD_TINY, **extra), x, t, None), g[f"{tag}.y"], tol=2e-4)
 
 
 def test_ddim_sampler_v_prediction():

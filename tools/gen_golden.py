@@ -432,6 +432,30 @@ def gen_unet_gd():
         unet = frozen(rom.UNetModel(**dict(GD_TINY_UNET, **extra)))
         arrs[f"{tag}.y"] = unet(x, t, context=ctx)
         put_sd(unet, f"{tag}.w.")
+    # the AttentionBlock UNet (use_spatial_transformer=False, openaimodel.py:277-324, 344-409): single blocks in both channel orders, then a whole
+    # guided-diffusion-style network (head width 16, new attention order, resblock_updown, scale-shift norm; no context)
+    for tag, (ch, kw) in {"legacy": (64, dict(num_heads=4)), "new": (64, dict(num_head_channels=16, use_new_attention_order=True)),
+                          "one_head": (32, dict())}.items():
+        torch.manual_seed(61)
+        ab = rom.AttentionBlock(ch, **kw)
+        for p_ in ab.proj_out.parameters():
+            p_.data = torch.randn(p_.shape, generator=g) * 0.05
+        ab = frozen(ab)
+        xa = torch.randn(2, ch, 6, 5, generator=g)
+        arrs.update({f"ab.{tag}.x": xa, f"ab.{tag}.y": ab._forward(xa)})
+        put_sd(ab, f"ab.{tag}.w.")
+    for tag, extra in {"adm": dict(use_spatial_transformer=False, context_dim=None, num_heads=-1, num_head_channels=16, use_new_attention_order=True,
+                                   resblock_updown=True, use_scale_shift_norm=True),
+                       "adm_legacy": dict(use_spatial_transformer=False, context_dim=None, num_heads=2, legacy=True)}.items():
+        torch.manual_seed(62)
+        unet = rom.UNetModel(**dict(GD_TINY_UNET, **extra))
+        for m in unet.modules():
+            if isinstance(m, rom.AttentionBlock):
+                for p_ in m.proj_out.parameters():
+                    p_.data = torch.randn(p_.shape, generator=g) * 0.05
+        unet = frozen(unet)
+        arrs[f"{tag}.y"] = unet(x, t)
+        put_sd(unet, f"{tag}.w.")
     npz("unet_gd_tiny", **arrs)
 
 
