@@ -334,8 +334,8 @@ class UNetModel(nn.Module):
             assert use_spatial_transformer, "a cross-attention context_dim needs use_spatial_transformer (openaimodel.py:477-478)"
             if not isinstance(context_dim, int):
                 context_dim = list(context_dim)
-        if n_embed is not None or dims != 2:
-            raise NotImplementedError("n_embed (codebook-id head) / dims != 2 are outside the AnyEdit hot path")
+        if dims != 2:
+            raise NotImplementedError("dims != 2: the 1-D / 3-D UNets of openaimodel.py have no caller in AnyEdit")
         if num_classes is not None and not isinstance(num_classes, int) and num_classes != "continuous":
             raise ValueError(f"num_classes must be None, an int or 'continuous' (openaimodel.py:533-540), got {num_classes!r}")
         if num_heads_upsample == -1:
@@ -368,7 +368,7 @@ class UNetModel(nn.Module):
         self.num_heads = num_heads
         self.num_head_channels = num_head_channels
         self.num_heads_upsample = num_heads_upsample
-        self.predict_codebook_ids = False
+        self.predict_codebook_ids = n_embed is not None       # openaimodel.py:524
 
         def heads_for(ch, nh):
             if num_head_channels == -1:
@@ -442,6 +442,8 @@ class UNetModel(nn.Module):
                 self.output_blocks.append(TimestepEmbedSequential(*layers))
                 self._feature_size += ch
         self.out = nn.Sequential(normalization(ch), nn.SiLU(), zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
+        if self.predict_codebook_ids:   # openaimodel.py:731-736: GroupNorm + pointwise conv to n_embed logits per position (no SiLU; `out` stays in the state dict unused)
+            self.id_predictor = nn.Sequential(normalization(ch), conv_nd(dims, model_channels, n_embed, 1))
 
     # ------------------------------------------------------------------------------------------------ forward
     def repack(self):
@@ -539,6 +541,10 @@ class UNetModel(nn.Module):
             st_b = skip.st if skip.t2 is None else None
             f = Feat(f.materialize(), f.B, f.H, f.W, t2=skip.materialize(), st=st_a, st2=st_b)  # th.cat([h, hs.pop()], 1), deferred
             f = module.rows(f, emb_silu, context_rows, kv_cache)
+        if self.predict_codebook_ids:   # openaimodel.py:783-784
+            h = self.id_predictor[0].rows(f.materialize(), f.B, f.H * f.W, silu=False, colstats=f.st if f.t2 is None else None)
+            logits, _, _ = self.id_predictor[1].rows(h, f.B, f.H, f.W, out_f32=True)
+            return ops.rows_to_nchw(logits, f.B, f.H, f.W, out_dtype=torch.float32)
         h = self.out[0].rows(f.materialize(), f.B, f.H * f.W, silu=True, colstats=f.st if f.t2 is None else None)
         eps, _, _ = self.out[2].rows(h, f.B, f.H, f.W, out_f32=True)
         return ops.rows_to_nchw(eps, f.B, f.H, f.W, out_dtype=torch.float32)

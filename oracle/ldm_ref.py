@@ -310,6 +310,8 @@ def unet_forward(sd, cfg, x, timesteps, context, adapters=None, y=None):
     for i, layers in enumerate(out):
         h = torch.cat([h, hs.pop()], dim=1)
         h = _run_layers(sd, f"output_blocks.{i}.", layers, h, emb, context, use_linear, adapters, ssn)
+    if cfg.get("n_embed") is not None:   # predict_codebook_ids (openaimodel.py:731-736, 783-784): GroupNorm + pointwise conv, no SiLU
+        return F.conv2d(_st(group_norm32(h, sd["id_predictor.0.weight"], sd["id_predictor.0.bias"])), sd["id_predictor.1.weight"], sd["id_predictor.1.bias"])
     h = _st(silu(group_norm32(h, sd["out.0.weight"], sd["out.0.bias"])))
     return F.conv2d(h, sd["out.2.weight"], sd["out.2.bias"], padding=1)
 

@@ -118,6 +118,13 @@ def test_unet_guided_diffusion_options_golden():
             emb = unet.time_embedding_rows(t)                   # the hoisted time-embedding pack carries 2 x Cout columns per scale-shift block
             y2 = unet.forward_rows(x, None, unet.context_rows(ctx), emb_pack=emb)
             assert torch.equal(y2, y), "hoisted time-embedding path = per-step path"
+    # predict_codebook_ids (n_embed, openaimodel.py:731-736, 783-784): the "noconv" weights + the id_predictor head -> logits [B, 24, H, W]
+    with torch.device(DEV):
+        unet = UNetModel(**dict(GD_TINY, conv_resample=False, n_embed=24))
+    unet.load_state_dict({k: v.to(DEV) for k, v in dict(sub_sd(g, "noconv.w."), **sub_sd(g, "codebook.w.")).items()})
+    unet.eval().requires_grad_(False)
+    with torch.no_grad():
+        close(unet(x, t, context=ctx), g["codebook.y"], what="UNetModel n_embed (codebook logits)")
     # use_spatial_transformer=False: AttentionBlock layers (openaimodel.py:277-324; QKVAttentionLegacy / QKVAttention :344-409), no context
     from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import AttentionBlock
     from test_oracle_golden import GD_ADM

@@ -65,8 +65,11 @@ def test_guided_diffusion_options_key_schema():
         assert all(tuple(sd[k].shape) == tuple(ref[k]) for k in ref), tag
     rb = ResBlock(64, 128, 0.0, out_channels=96, use_scale_shift_norm=True, down=True)
     assert rb.emb_layers[1].weight.shape == (192, 128) and rb.updown and not any(True for _ in rb.h_upd.parameters())
+    cb = UNetModel(**dict(GD_TINY, conv_resample=False, n_embed=24)).state_dict()                 # predict_codebook_ids: `out` stays, id_predictor is added
+    ref = {k[len("noconv.w."):] for k in g if k.startswith("noconv.w.")} | {k[len("codebook.w."):] for k in g if k.startswith("codebook.w.")}
+    assert set(cb.keys()) == ref and tuple(cb["id_predictor.1.weight"].shape) == (24, 32, 1, 1)
     with pytest.raises(NotImplementedError):
-        UNetModel(**dict(GD_TINY, n_embed=16))
+        UNetModel(**dict(GD_TINY, dims=3))
     with pytest.raises(AssertionError):
         UNetModel(**dict(GD_TINY, use_spatial_transformer=False))        # a context_dim without the spatial transformer (openaimodel.py:477-478)
     from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import AttentionBlock, QKVAttention, QKVAttentionLegacy

@@ -452,6 +452,9 @@ def test_unet_guided_diffusion_options():
         close(L.attention_block(sub_sd(g, f"ab.{tag}.w."), "", T(g[f"ab.{tag}.x"]), heads, new_order=new), g[f"ab.{tag}.y"], tol=2e-5)
     for tag, extra in GD_ADM.items():
         close(L.unet_forward(sub_sd(g, f"{tag}.w."), dict(GD_TINY, **extra), x, t, None), g[f"{tag}.y"], tol=2e-4)
+    # predict_codebook_ids (n_embed, openaimodel.py:731-736, 783-784): the "noconv" weights + the stored id_predictor head -> logits [B, n_embed, H, W]
+    sd = dict(sub_sd(g, "noconv.w."), **sub_sd(g, "codebook.w."))
+    close(L.unet_forward(sd, dict(GD_TINY, conv_resample=False, n_embed=24), x, t, ctx), g["codebook.y"], tol=2e-4)
 
 
 def test_ddim_sampler_v_prediction():

@@ -432,6 +432,7 @@ def gen_unet_gd():
         unet = frozen(rom.UNetModel(**dict(GD_TINY_UNET, **extra)))
         arrs[f"{tag}.y"] = unet(x, t, context=ctx)
         put_sd(unet, f"{tag}.w.")
+    noconv_sd = {k: v.clone() for k, v in unet.state_dict().items()}   # (the last network of the loop above; the codebook-head case at the end reuses it)
     # the AttentionBlock UNet (use_spatial_transformer=False, openaimodel.py:277-324, 344-409): single blocks in both channel orders, then a whole
     # guided-diffusion-style network (head width 16, new attention order, resblock_updown, scale-shift norm; no context)
     for tag, (ch, kw) in {"legacy": (64, dict(num_heads=4)), "new": (64, dict(num_head_channels=16, use_new_attention_order=True)),
@@ -456,6 +457,16 @@ def gen_unet_gd():
         unet = frozen(unet)
         arrs[f"{tag}.y"] = unet(x, t)
         put_sd(unet, f"{tag}.w.")
+    # predict_codebook_ids (n_embed, openaimodel.py:731-736, 783-784): the "noconv" network's weights + an id_predictor head; only the head is stored.  LAST: appended cases must not move the RNG stream of the arrays above
+    torch.manual_seed(63)
+    unet_c = rom.UNetModel(**dict(GD_TINY_UNET, conv_resample=False, n_embed=24))
+    sd = dict(noconv_sd)
+    for k, v in unet_c.state_dict().items():
+        if k.startswith("id_predictor."):
+            sd[k] = (torch.randn(v.shape, generator=g) * (0.1 if v.dim() > 1 else 0.3) + (1.0 if k == "id_predictor.0.weight" else 0.0)).bfloat16().float()
+            arrs["codebook.w." + k] = sd[k].bfloat16().view(torch.int16)
+    unet_c.load_state_dict(sd)
+    arrs["codebook.y"] = unet_c.eval()(x, t, context=ctx)
     npz("unet_gd_tiny", **arrs)
 
 
