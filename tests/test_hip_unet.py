@@ -178,6 +178,38 @@ def test_resblock_guided_diffusion_options_at_map_sizes_with_producer_statistics
     assert e <= 1.5 * c + 1e-4, (tag, e, c)
 
 
+@pytest.mark.parametrize("tag,ch,hw,kw,heads,new", [("legacy_d64", 256, 32, dict(num_head_channels=64), 4, False), ("new_d32", 128, 24, dict(num_head_channels=32, use_new_attention_order=True), 4, True),
+                                                     ("legacy_8_heads_d40", 320, 16, dict(num_heads=8), 8, False)])
+def test_attention_block_at_map_sizes(tag, ch, hw, kw, heads, new):
+    """AttentionBlock (openaimodel.py:277-324) at guided-diffusion sizes — up to 1 024 positions, head widths 32 / 40 / 64, both channel orders of the packed
+    projection — HIP against the oracle restatement with its bf16-storage control."""
+    from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import AttentionBlock
+    from oracle import ldm_ref as L
+    torch.manual_seed(19)
+    ab = AttentionBlock(ch, **kw)
+    assert ab.num_heads == heads
+    g = torch.Generator().manual_seed(20)
+    with torch.no_grad():
+        for p_ in ab.proj_out.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * 0.05)
+        ab.norm.weight.copy_(1.0 + 0.1 * torch.randn(ch, generator=g))
+        ab.norm.bias.copy_(0.1 * torch.randn(ch, generator=g))
+        ab.qkv.weight.mul_(3.0)                                  # logits of O(1): the softmax is not flat
+        for p_ in ab.parameters():
+            p_.copy_(p_.bfloat16().float())
+    x = torch.randn(2, ch, hw, hw, generator=g).bfloat16().float()
+    sd = {k: v.float() for k, v in ab.state_dict().items()}
+    ref = L.attention_block(sd, "", x, heads, new_order=new)
+    with L.bf16_storage():
+        ctl = L.attention_block(sd, "", x, heads, new_order=new)
+    with torch.no_grad():
+        got = ab.to(DEV)(x.to(DEV)).float().cpu()
+    h_ref = ref - x                                                # the block's own contribution (the residual passes through exactly)
+    e, c = rel_l2(got - x, h_ref), rel_l2(ctl - x, h_ref)
+    print(f"AttentionBlock {tag} ({hw * hw} positions): HIP rel-L2 of the attention branch {e:.3e}, bf16-storage control {c:.3e}")
+    assert e <= 1.5 * c + 2e-3, (tag, e, c)
+
+
 @pytest.fixture(scope="module")
 def tiny_unet():
     from util_models import build_tiny_unet
