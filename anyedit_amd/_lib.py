@@ -23,6 +23,9 @@ SIGNATURES = {
     "ae_gemm_bf16": [c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int,
                      c_void_p, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p],
     "ae_conv3x3_workspace_floats": [c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+    "ae_conv3x3_partials_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p],
+    "ae_groupnorm_splitk_supported": [c_int, c_int, c_int, c_int, c_int],
+    "ae_groupnorm_splitk_nhwc_bf16": [c_void_p, c_int, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p],
     "ae_conv3x3_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                         c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "ae_conv3x3_up2_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],

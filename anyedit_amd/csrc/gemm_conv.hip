@@ -92,6 +92,9 @@ struct GemmArgs {
     // (the split-K index of a launch that does not split) multiplies against weight set `par` ([N, 4 CinPad] each, K ordered (tap, channel) with tap =
     // 2 i + j over the window rows / columns) and scatters its rows to the parity's pixels of the [B, 2H, 2W] output.
     int sub2;
+    // split-K launches only: 1 = stop at the fp32 partials (no splitk_reduce_kernel launch): the consumer folds the K ranges itself (ae_groupnorm_splitk_nhwc_bf16:
+    // the GroupNorm of the 16x16 / 8x8 levels reads the partials instead of the reduced tensor — one launch and one round trip of the activation less)
+    int defer_reduce;
 };
 
 // LDS-DMA: one wave moves 64 x 16 B from global straight into LDS at (wave-uniform dst) + lane*16.  The builtin exists only
@@ -1782,7 +1785,7 @@ int launch(const GemmArgs& a_in, hipStream_t stream) {
         return AE_ERR_UNSUPPORTED;
     }
     if (g_plan_query) return 0;
-    if (a.splitk > 1) {
+    if (a.splitk > 1 && !a.defer_reduce) {
         long nb = ((long)a.M * a.N / 4 + 255) / 256;
         if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a);
@@ -1961,6 +1964,32 @@ extern "C" long ae_conv3x3_workspace_floats(int B, int H, int W, int Cin, int Co
     const long M = (long)B * Ho * Wo;
     const int s = make_plan((int)M, Cout, 9 * CinPad, true).splitk;
     return s > 1 ? (long)s * M * Cout : 0;
+}
+
+// The split-K plan of ae_conv3x3_bf16 (stride 1, no upsampling) stopped at its fp32 partials: workspace [splitk][B*H*W][Cout] holds the K ranges' raw products
+// (no bias); *splitk_out = the number of ranges, 0 when the plan does not split this shape (nothing is launched then: call ae_conv3x3_bf16).
+extern "C" int ae_conv3x3_partials_bf16(const void* x, const void* w, int B, int H, int W, int Cin, int Cout, float* workspace, int k_order, int* splitk_out, void* stream) {
+    AE_REQUIRE(x && w && workspace && splitk_out, "ae_conv3x3_partials_bf16: null pointer");
+    AE_REQUIRE(k_order == 0 || k_order == 1, "ae_conv3x3_partials_bf16: k_order must be 0 (tap, channel) or 1 (64-channel chunk, tap, channel)");
+    AE_REQUIRE(k_order == 0 || Cin % 64 == 0, "ae_conv3x3_partials_bf16: the chunk-major K order needs Cin %% 64 == 0 (Cin=%d)", Cin);
+    AE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout % 4 == 0, "ae_conv3x3_partials_bf16: bad shape B=%d H=%d W=%d Cin=%d Cout=%d", B, H, W, Cin, Cout);
+    AE_REQUIRE(aligned16(x) && aligned16(w) && aligned16(workspace), "ae_conv3x3_partials_bf16: pointers must be 16-byte aligned");
+    GemmArgs a{};
+    a.A = (const bf16_t*)x; a.W = (const bf16_t*)w; a.C = nullptr;
+    const int CinPad = (Cin + BK - 1) / BK * BK;
+    a.M = B * H * W; a.N = Cout; a.K = 9 * CinPad; a.Ksplit = a.K;
+    a.ldw = 9L * CinPad; a.ldc = Cout; a.ldr = Cout; a.ldav = Cout;
+    a.epi = EPI_NONE; a.rows_per_batch = H * W;
+    a.H = H; a.Wd = W; a.Cin = Cin; a.CinPad = CinPad; a.Ho = H; a.Wo = W; a.stride = 1; a.ups = 0;
+    a.a_bytes = (unsigned)((long)B * H * W * Cin * 2); a.w_bytes = (unsigned)((long)Cout * 9 * CinPad * 2);
+    AE_REQUIRE((long)B * H * W * Cin * 2 < (1L << 31) && (long)Cout * 9 * CinPad * 2 < (1L << 31), "ae_conv3x3_partials_bf16: operands must be smaller than 2 GiB");
+    a.splitk = make_plan(a.M, a.N, a.K, true).splitk;
+    *splitk_out = a.splitk > 1 ? a.splitk : 0;
+    if (a.splitk <= 1) return AE_OK;
+    a.partial = workspace;
+    a.kmajor = k_order;
+    a.defer_reduce = 1;
+    return launch<A_CONV3>(a, (hipStream_t)stream);
 }
 
 extern "C" int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float* addvec, long addvec_ld,

@@ -40,6 +40,9 @@ struct GNArgs {
     const float* cs1; const float* cs2;  // optional per-channel (sum, sumsq) over 32-row slabs of x / x2, written by their PRODUCERS
                                          // ([B*HW/32][C1][2], [B*HW/32][C-C1][2]): replaces the statistics pass over the activation
     int accum;     // backward: bit 0 dx += (the tensor already holds a gradient from another consumer of x), bit 1 dx2 +=
+    // ae_groupnorm_splitk_nhwc_bf16: x is not in memory yet — it is the fold of a split-K conv's fp32 partials [sk_n][B*HW][C] (+ bias + the per-sample vector)
+    const float* sk_partial; const float* sk_bias; const float* sk_addvec;
+    int sk_n; long sk_ldav, sk_MN;
 };
 
 // Fold of the per-chunk partials of sample b by the calling block (any block size): 16 slices x 64 group lanes, slice i takes chunks
@@ -106,6 +109,46 @@ __device__ __forceinline__ u32x4 gn_load(const GNArgs& p, long row, int cc) {
     const int ch = cc * 8;
     if (ch < p.C1) return *reinterpret_cast<const u32x4*>(p.x + row * p.C1 + ch);
     return *reinterpret_cast<const u32x4*>(p.x2 + row * (p.C - p.C1) + (ch - p.C1));
+}
+
+// The 8-channel piece (row, cc) of x = bf16(sum_s partial[s] + bias + addvec[b]): splitk_reduce_kernel's arithmetic statement for statement (K ranges added in
+// order, then the bias, then the vector, ONE rounding), so a GroupNorm fed this way returns what it returns behind the reduce launch, bit for bit.
+__device__ __forceinline__ u32x4 gn_load_splitk(const GNArgs& p, long row, int cc, int b) {
+    const long e = row * p.C + cc * 8;
+    f32x4 bz0 = {0.f, 0.f, 0.f, 0.f}, bz1 = bz0, az0 = bz0, az1 = bz0;
+    if (p.sk_bias) { bz0 = *reinterpret_cast<const f32x4*>(p.sk_bias + cc * 8); bz1 = *reinterpret_cast<const f32x4*>(p.sk_bias + cc * 8 + 4); }
+    if (p.sk_addvec) {
+        const float* av = p.sk_addvec + (long)b * p.sk_ldav + cc * 8;
+        az0 = *reinterpret_cast<const f32x4*>(av); az1 = *reinterpret_cast<const f32x4*>(av + 4);
+    }
+    // K ranges in two batches of four (eight 16-byte loads per piece and batch); the order of the adds is the reduce kernel's
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+#pragma unroll
+    for (int h4 = 0; h4 < 8; h4 += 4) {
+        if (h4 < p.sk_n) {   // block-uniform
+            f32x4 w0[4], w1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool on = h4 + j < p.sk_n;
+                w0[j] = on ? *reinterpret_cast<const f32x4*>(p.sk_partial + (long)(h4 + j) * p.sk_MN + e) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                w1[j] = on ? *reinterpret_cast<const f32x4*>(p.sk_partial + (long)(h4 + j) * p.sk_MN + e + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (h4 + j == 0) { v0 = w0[0]; v1 = w1[0]; }
+                else if (h4 + j < p.sk_n) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v0[r] += w0[j][r]; v1[r] += w1[j][r]; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (p.sk_bias) { v0[r] += bz0[r]; v1[r] += bz1[r]; }
+        if (p.sk_addvec) { v0[r] += az0[r]; v1[r] += az1[r]; }
+    }
+    return (u32x4){pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
 }
 
 // (1) partial sums.  blockDim.x = ncc * rpp (ncc = C/8 column chunks, rpp rows in flight); grid = (nchunk, B).
@@ -312,8 +355,10 @@ __global__ void gn_apply_kernel(const GNArgs p) {
 // activation, exact two-pass statistics (mean, then centred sum of squares), normalise + SiLU, one write.  Replaces the
 // stats / finalize / apply launches (3 passes over the data, 15-20 us for 2-15 MB) where the tensor is too small to fill the
 // chip per launch anyway.  GP = 1, 2 or 4 groups per block makes the slab's row segment a multiple of 16 bytes.
-template <int MAXCH, int GP>
-__global__ __launch_bounds__(1024) void gn_slab_kernel(const GNArgs p, int ncc, int cpg) {
+// SK (round 6): the slab's pieces come from a split-K conv's partials (gn_load_splitk) instead of the reduced tensor — the reduce launch and one round trip of the
+// activation vanish; everything after the load is the same code on the same bf16 values.
+template <int MAXCH, int GP, int SK = 0>
+__global__ __launch_bounds__(SK == 1 ? 256 : 1024) void gn_slab_kernel(const GNArgs p, int ncc, int cpg) {
     __shared__ float red[16][GP];
     __shared__ float bc[2][GP];
     const int tid = threadIdx.x, T = blockDim.x, nw = T >> 6;
@@ -326,7 +371,10 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const GNArgs p, int ncc, 
         const int i = tid + k * T;
         const int ii = min(i, total - 1);
         const int row = ii / ncc, cc = ii - row * ncc;
-        v[k] = gn_load(p, (long)b * p.HW + row, ch0 / 8 + cc);
+        // SK blocks are 256 threads (the same thread <-> piece map and block-sum order as the plain launch of these shapes: the statistics come out bit-identical),
+        // so a lane may hold several pieces' partial loads in flight
+        v[k] = SK ? gn_load_splitk(p, (long)b * p.HW + row, ch0 / 8 + cc, b) : gn_load(p, (long)b * p.HW + row, ch0 / 8 + cc);
+        if (SK == 2) __builtin_amdgcn_sched_barrier(0);   // lab form (AE_GN_SPLITK_T=1024): 1024-thread blocks, one piece's partial loads in flight at a time (128 registers per lane)
         int gbits = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -447,6 +495,28 @@ bool launch_gn_slab(const GNArgs& p, int cpg, hipStream_t s) {
     else if (per <= 4) hipLaunchKernelGGL((gn_slab_kernel<4, GP>), grid, dim3(T), 0, s, p, ncc, cpg);
     else if (per <= 8) hipLaunchKernelGGL((gn_slab_kernel<8, GP>), grid, dim3(T), 0, s, p, ncc, cpg);
     else hipLaunchKernelGGL((gn_slab_kernel<16, GP>), grid, dim3(T), 0, s, p, ncc, cpg);
+    return true;
+}
+
+template <int GP>
+bool launch_gn_slab_splitk(const GNArgs& p, int cpg, hipStream_t s) {
+    const int ncc = GP * cpg / 8;
+    const long total = (long)p.HW * ncc;
+    static const int t_env = getenv("AE_GN_SPLITK_T") ? atoi(getenv("AE_GN_SPLITK_T")) : 256;   // lab knob: 1024 = wide blocks (statistics summed in another order: not bit-identical to the plain path)
+    if (t_env == 1024) {
+        int T2 = 256;
+        while (T2 < 1024 && total > (long)T2 * 2) T2 *= 2;
+        if ((total + T2 - 1) / T2 > 2) return false;
+        hipLaunchKernelGGL((gn_slab_kernel<2, GP, 2>), dim3(p.groups / GP, p.B), dim3(T2), 0, s, p, ncc, cpg);
+        return true;
+    }
+    const int T = 256;                       // launch_gn_slab's choice for total <= 2048 pieces: same thread <-> piece map, same block-sum order
+    const long per = (total + T - 1) / T;
+    if (per > 8) return false;
+    dim3 grid(p.groups / GP, p.B);
+    if (per <= 2) hipLaunchKernelGGL((gn_slab_kernel<2, GP, 1>), grid, dim3(T), 0, s, p, ncc, cpg);
+    else if (per <= 4) hipLaunchKernelGGL((gn_slab_kernel<4, GP, 1>), grid, dim3(T), 0, s, p, ncc, cpg);
+    else hipLaunchKernelGGL((gn_slab_kernel<8, GP, 1>), grid, dim3(T), 0, s, p, ncc, cpg);
     return true;
 }
 
@@ -1191,6 +1261,42 @@ extern "C" int ae_groupnorm_nhwc_bf16(const void* x, const void* x2, int C1, con
     if (rc) return rc;
     hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(threads), 0, s, p);
     return ae_check_launch("ae_groupnorm_nhwc_bf16(apply)");
+}
+
+// 1 when ae_groupnorm_splitk_nhwc_bf16 covers the shape (the one-launch slab form on 256-thread blocks, at most eight 16-byte pieces per thread: maps up to 16 x 16 at 40 channels per group)
+extern "C" int ae_groupnorm_splitk_supported(int B, int HW, int C, int groups, int splitk) {
+    if (B <= 0 || B > 65535 || HW <= 0 || HW > 256 || C <= 0 || groups <= 0 || groups > 64 || C % groups || C % 8 || splitk < 2 || splitk > 8) return 0;
+    const int cpg = C / groups;
+    const int gp = (cpg % 8 == 0) ? 1 : ((2 * cpg) % 8 == 0 ? 2 : ((4 * cpg) % 8 == 0 ? 4 : 0));
+    if (gp == 0 || groups % gp) return 0;
+    const long total = (long)HW * (gp * cpg / 8);
+    return total <= 2048 ? 1 : 0;
+}
+
+// GroupNorm(+SiLU) of x = sum_s partial[s] + bias + addvec[b] where x has not been written: `partial` = the fp32 K ranges of ae_conv3x3_partials_bf16
+// ([splitk][B*HW][C]), bias [C] / addvec [B, >= C] (row stride addvec_ld) fp32 or NULL.  Bit-identical to ae_conv3x3_bf16 (its reduce launch) followed by
+// ae_groupnorm_nhwc_bf16 on the small-map slab path.  openaimodel.py:262-272: h = in_conv(...) + emb_out; h = out_layers[0:2](h).
+extern "C" int ae_groupnorm_splitk_nhwc_bf16(const float* partial, int splitk, const float* bias, const float* addvec, long addvec_ld, const float* gamma, const float* beta,
+                                             void* y, int B, int HW, int C, int groups, float eps, int act, void* stream) {
+    AE_REQUIRE(partial && gamma && beta && y, "ae_groupnorm_splitk_nhwc_bf16: null pointer");
+    AE_REQUIRE(act == 0 || act == 1, "ae_groupnorm_splitk_nhwc_bf16: act must be 0 (none) or 1 (SiLU)");
+    AE_REQUIRE(ae_groupnorm_splitk_supported(B, HW, C, groups, splitk), "ae_groupnorm_splitk_nhwc_bf16: unsupported shape B=%d HW=%d C=%d groups=%d splitk=%d (maps up to 256 positions, "
+               "2..8 K ranges, at most 2048 16-byte pieces per group pack)", B, HW, C, groups, splitk);
+    AE_REQUIRE(((uintptr_t)partial & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)bias & 15) == 0 && ((uintptr_t)addvec & 15) == 0 && ((uintptr_t)gamma & 15) == 0 &&
+               ((uintptr_t)beta & 15) == 0 && (!addvec || (addvec_ld >= C && addvec_ld % 4 == 0)), "ae_groupnorm_splitk_nhwc_bf16: 16-byte alignment (addvec rows too)");
+    GNArgs p{};
+    p.C1 = C; p.gamma = gamma; p.beta = beta; p.y = (bf16_t*)y;
+    p.B = B; p.HW = HW; p.C = C; p.groups = groups; p.act = act; p.eps = eps;
+    p.sk_partial = partial; p.sk_n = splitk; p.sk_bias = bias; p.sk_addvec = addvec; p.sk_ldav = addvec_ld; p.sk_MN = (long)B * HW * C;
+    const int cpg = C / groups;
+    const int gp = (cpg % 8 == 0) ? 1 : ((2 * cpg) % 8 == 0 ? 2 : 4);
+    hipStream_t s = (hipStream_t)stream;
+    bool done = false;
+    if (gp == 1) done = launch_gn_slab_splitk<1>(p, cpg, s);
+    else if (gp == 2) done = launch_gn_slab_splitk<2>(p, cpg, s);
+    else done = launch_gn_slab_splitk<4>(p, cpg, s);
+    if (!done) { ae_set_error("ae_groupnorm_splitk_nhwc_bf16: the slab does not fit eight pieces per thread of a 256-thread block"); return AE_ERR_UNSUPPORTED; }
+    return ae_check_launch("ae_groupnorm_splitk_nhwc_bf16");
 }
 
 extern "C" int ae_layernorm_bf16(const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps,

@@ -219,15 +219,22 @@ class ResBlock(TimestepBlock):
         elif self.down:
             h, Ho, Wo = ops.resample2x_rows(h, B, H, W, down=True)
             xs, _, _ = ops.resample2x_rows(whole(), B, H, W, down=True)
-        st1 = _stats_for(B, Ho, Wo, self.out_channels, dev)     # conv1's epilogue delivers the statistics out_layers[0] needs
-        if self.up:
-            h, _, _ = self.in_layers[2].rows(h, B, H, W, addvec=None if ssn else emb_out, upsample2x=True, colstats=st1)
+        conv1, norm2 = self.in_layers[2], self.out_layers[0]
+        if not self.up and not ssn and ops.conv3x3_gn_splitk_ok(B, Ho, Wo, conv1.in_channels, self.out_channels, norm2.num_groups):
+            # 16x16 / 8x8 levels: conv1's plan cuts K, and `h + emb_out` (:272) exists only as the input of out_norm — the GroupNorm folds the K ranges (+ bias +
+            # time-embedding vector) itself instead of reading what a reduce launch wrote (bit-identical; one launch and one round trip of h less)
+            g2, b2 = norm2._affine()
+            h = ops.groupnorm_splitk(conv1.rows_partials(h, B, Ho, Wo), conv1.packed_bias(), emb_out, g2, b2, B, Ho * Wo, norm2.eps, silu=True, groups=norm2.num_groups)
         else:
-            h, _, _ = self.in_layers[2].rows(h, B, Ho, Wo, addvec=None if ssn else emb_out, colstats=st1)
-        if ssn:            # :264-268: out_norm(h) * (1 + scale) + shift, then out_rest (SiLU, dropout, conv)
-            h = ops.scale_shift_rows(self.out_layers[0].rows(h, B, Ho * Wo, silu=False, colstats=st1), emb_out, B, Ho * Wo, silu=True)
-        else:
-            h = self.out_layers[0].rows(h, B, Ho * Wo, silu=True, colstats=st1)
+            st1 = _stats_for(B, Ho, Wo, self.out_channels, dev)   # conv1's epilogue delivers the statistics out_layers[0] needs
+            if self.up:
+                h, _, _ = conv1.rows(h, B, H, W, addvec=None if ssn else emb_out, upsample2x=True, colstats=st1)
+            else:
+                h, _, _ = conv1.rows(h, B, Ho, Wo, addvec=None if ssn else emb_out, colstats=st1)
+            if ssn:        # :264-268: out_norm(h) * (1 + scale) + shift, then out_rest (SiLU, dropout, conv)
+                h = ops.scale_shift_rows(norm2.rows(h, B, Ho * Wo, silu=False, colstats=st1), emb_out, B, Ho * Wo, silu=True)
+            else:
+                h = norm2.rows(h, B, Ho * Wo, silu=True, colstats=st1)
         if isinstance(self.skip_connection, nn.Identity):
             res = whole() if xs is None else xs
         elif self.skip_connection.kernel_size[0] == 1 and xs is None:

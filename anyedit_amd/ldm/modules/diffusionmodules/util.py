@@ -162,6 +162,21 @@ class Conv2d(nn.Conv2d, _Packed):
         return ops.conv3x3(x, w, pk["b"], B, H, W, addvec=addvec, residual=residual, stride=self.stride[0],
                            upsample2x=upsample2x, out_f32=out_f32, colstats=colstats, k_order=ko)
 
+    def rows_partials(self, x, B, H, W):
+        """The stride-1 3x3 conv stopped at the fp32 partials of its split-K plan (`ops.conv3x3_partials`; ask `ops.conv3x3_gn_splitk_ok` first): the bias is NOT
+        applied — it goes to `ops.groupnorm_splitk` with the partials (`self.packed_bias()`)."""
+        pk = self._packed()
+        ko = ops.conv_k_order(B * H * W, self.in_channels, self.out_channels, 1, False)
+        w = pk["w"]
+        if ko:
+            if "w_kmajor" not in pk:
+                pk["w_kmajor"] = ops.pack_conv3x3(self.weight, k_order=1)
+            w = pk["w_kmajor"]
+        return ops.conv3x3_partials(x, w, B, H, W, k_order=ko)[0]
+
+    def packed_bias(self):
+        return self._packed()["b"]
+
     def out_hw(self, H, W, upsample2x=False):
         """Output extent of `rows` for an H x W input."""
         if self.kernel_size[0] == 1:

@@ -5,6 +5,7 @@ Activations are channels-last bf16: [rows, C] with rows = B*H*W.
 """
 import torch
 
+import ctypes
 import os
 import threading
 
@@ -617,6 +618,61 @@ def conv3x3(x, w, bias, B, H, W, addvec=None, residual=None, stride=1, upsample2
                               _p(out), B, H, W, Cin, Cout, stride, int(upsample2x), 1 if out_f32 else 0, _p(ws), _p(colstats), int(k_order), _s()),
           "ae_conv3x3_bf16")
     return out, Ho, Wo
+
+
+# Opt-in (AE_GN_SPLITK=1): ResBlock conv1 -> GroupNorm at the 16x16 / 8x8 levels through the split-K fold below.  Built, bit-identical, one launch fewer per ResBlock (12 per UNet
+# evaluation) — and measured SLOWER in the graph: 12.345 -> 12.379 ms per evaluation (256-thread blocks) / 12.374 (1024-thread lab form), three alternating triples on one box
+# (profiles/r06_v30_gn_splitk_ab.txt): the reduce launch streams the 31-63 MB of partials with the whole chip, the slab GroupNorm behind it reads 8 MB from L2; the folding
+# GroupNorm reads the partials with 384 blocks in 160-byte row segments.  Default off.
+_GN_SPLITK = os.environ.get("AE_GN_SPLITK", "0") == "1"
+
+
+def conv3x3_gn_splitk_ok(B, H, W, Cin, Cout, groups=32):
+    """True where `conv3x3_partials` + `groupnorm_splitk` replace conv3x3 (+ its split-K reduce launch) + groupnorm: a stride-1 conv whose plan cuts K (the 16x16 /
+    8x8 UNet levels at batch 12) feeding a GroupNorm that runs the one-launch slab form (maps up to 256 positions).  Not under the training tape."""
+    if not _GN_SPLITK or (_TAPE is not None and _TAPE.active) or H * W > 256 or Cin % 8 or Cout % 8:
+        return False
+    nws = lib.ae_conv3x3_workspace_floats(B, H, W, Cin, Cout, 1, 0)
+    if nws <= 0:
+        return False
+    return bool(lib.ae_groupnorm_splitk_supported(B, H * W, Cout, groups, int(nws // (B * H * W * Cout))))
+
+
+def conv3x3_partials(x, w, B, H, W, k_order=0):
+    """The split-K plan of `conv3x3` (stride 1) stopped at its fp32 partials: returns (partials [splitk, B*H*W, Cout] fp32, splitk); the bias, the per-sample
+    vector and the rounding belong to the consumer (`groupnorm_splitk`).  Raises where the plan does not split (ask `conv3x3_gn_splitk_ok` first)."""
+    _no_tape("conv3x3_partials")
+    _chk(x, BF16, "conv3x3_partials.x", 2)
+    _chk(w, BF16, "conv3x3_partials.w", 2)
+    Cin, Cout = x.shape[1], w.shape[0]
+    if x.shape[0] != B * H * W or not x.is_contiguous() or w.shape[1] != 9 * ((Cin + 63) // 64 * 64):
+        raise ValueError(f"conv3x3_partials: x [B*H*W, Cin] contiguous and w packed [Cout, 9*CinPad] expected, got {tuple(x.shape)} / {tuple(w.shape)}")
+    nws = lib.ae_conv3x3_workspace_floats(B, H, W, Cin, Cout, 1, 0)
+    if nws <= 0:
+        raise ValueError(f"conv3x3_partials: the plan of [{B * H * W}, {Cin}] -> {Cout} does not cut K")
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+    sk = ctypes.c_int(0)
+    check(lib.ae_conv3x3_partials_bf16(_p(x), _p(w), B, H, W, Cin, Cout, _p(ws), int(k_order), ctypes.byref(sk), _s()), "ae_conv3x3_partials_bf16")
+    if sk.value < 2 or sk.value * B * H * W * Cout != nws:
+        raise RuntimeError(f"conv3x3_partials: plan mismatch (splitk {sk.value}, workspace {nws})")
+    return ws.view(sk.value, B * H * W, Cout), sk.value
+
+
+def groupnorm_splitk(partials, bias, addvec, gamma, beta, B, HW, eps, silu=False, groups=32, out=None):
+    """GroupNorm(+SiLU) of x = bf16(sum_s partials[s] + bias + addvec[b]) without x ever being written (`ae_groupnorm_splitk_nhwc_bf16`): bit-identical to
+    `conv3x3(..., bias, addvec)` followed by `groupnorm` on the small-map path.  partials: `conv3x3_partials`; bias fp32 [C] or None; addvec fp32 [B, C]
+    (rows may be strided) or None."""
+    _no_tape("groupnorm_splitk")
+    sk, M, C = partials.shape
+    if partials.dtype != torch.float32 or not partials.is_contiguous() or M != B * HW:
+        raise ValueError(f"groupnorm_splitk: partials must be contiguous fp32 [splitk, B*HW, C], got {tuple(partials.shape)} {partials.dtype}")
+    if addvec is not None and (addvec.dtype != torch.float32 or tuple(addvec.shape) != (B, C) or addvec.stride(1) != 1):
+        raise ValueError(f"groupnorm_splitk: addvec must be fp32 [B, C] with unit column stride, got {tuple(addvec.shape)} {addvec.dtype}")
+    if out is None:
+        out = torch.empty(M, C, dtype=BF16, device=partials.device)
+    check(lib.ae_groupnorm_splitk_nhwc_bf16(_p(partials), sk, _p(bias), _p(addvec), addvec.stride(0) if addvec is not None else 0, _p(gamma), _p(beta), _p(out),
+                                            B, HW, C, groups, eps, 1 if silu else 0, _s()), "ae_groupnorm_splitk_nhwc_bf16")
+    return out
 
 
 # --------------------------------------------------------------------------- norms
@@ -1658,6 +1714,11 @@ _gemm_ln_launch = _wrap_profiled(_gemm_ln_launch, _gemm_ln_label)
 gemm = _wrap_profiled(gemm, _gemm_label)
 attention_fp8 = _wrap_profiled(attention_fp8, _attn8_label)
 conv3x3 = _wrap_profiled(conv3x3, _conv_label)
+conv3x3_partials = _wrap_profiled(conv3x3_partials, lambda _r, x, w, B, H, W, k_order=0: (
+    f"gemm_kernel<{_tile_label(x.shape[0], w.shape[0], True, 9 * (-(-x.shape[1] // 64) * 64), False, x.shape[1] % 64 == 0)},conv3x3>|M={x.shape[0]} Cin={x.shape[1]} Cout={w.shape[0]} s1 partials",
+    2.0 * x.shape[0] * w.shape[0] * 9 * x.shape[1], float(2 * (x.numel() + 9 * x.shape[1] * w.shape[0]) + 2 * x.shape[0] * w.shape[0]), 1))
+groupnorm_splitk = _wrap_profiled(groupnorm_splitk, lambda _r, partials, *a, **k: (
+    f"groupnorm(splitK fold)|rows={_r.shape[0]} C={_r.shape[1]}", 0.0, 2.0 * _r.numel() * 2, 1))
 attention = _wrap_profiled(attention, _attn_label)
 groupnorm = _wrap_profiled(groupnorm, _gn_label)
 layernorm = _wrap_profiled(layernorm, _ln_label)

@@ -125,6 +125,10 @@ int ae_xattn_fused_bf16(const void* X, long ldx, const float* ln_gamma, const fl
  *   k_order: 0 = w packed (ky,kx,cin) as above; 1 = w packed (cin / 64, ky, kx, cin % 64) — the nine taps of a 64-channel chunk
  *   in consecutive K tiles, so a block re-reads its activation window from L2 (Cin % 64 == 0, no upsampling); same result.   */
 long ae_conv3x3_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride, int upsample2x);
+/* The split-K plan of ae_conv3x3_bf16 (stride 1, no upsampling) stopped at its fp32 partials: workspace (ae_conv3x3_workspace_floats elements) receives the raw
+ * products of the K ranges, [splitk][B*H*W][Cout]; *splitk_out = their number, or 0 when the plan does not cut K for this shape (nothing is launched: call
+ * ae_conv3x3_bf16).  The bias, the time-embedding vector and the rounding are the consumer's: ae_groupnorm_splitk_nhwc_bf16 (openaimodel.py:262-272).            */
+int ae_conv3x3_partials_bf16(const void* x, const void* w, int B, int H, int W, int Cin, int Cout, float* workspace, int k_order, int* splitk_out, void* stream);
 int ae_conv3x3_bf16(const void* x, const void* w, const float* bias, const float* addvec, long addvec_ld, const void* residual,
                     void* y, int B, int H, int W, int Cin, int Cout, int stride, int upsample2x, int out_f32, float* workspace,
                     float* colstats /* as for ae_gemm_bf16 (M = B*Ho*Wo, N = Cout); NULL = none */, int k_order, void* stream);
@@ -150,6 +154,13 @@ int ae_conv3x3_up2_bf16(const void* x, const void* w4, const float* bias, void* 
  * stat_out: optional fp32 [B][groups][2] (mean, rstd) kept for ae_groupnorm_bwd_nhwc_bf16.                                      */
 int ae_groupnorm_rows_per_chunk(int HW, int C);
 long ae_groupnorm_workspace_floats(int B, int HW, int C, int groups);
+/* GroupNorm(+SiLU) of x = bf16(sum_s partial[s] + bias + addvec[b]) where x is never written: ResBlock's `h = in_conv(h) + emb_out; h = out_norm(h); h = SiLU(h)`
+ * (openaimodel.py:262-272) at the 16x16 / 8x8 levels, whose convs cut K.  partial: ae_conv3x3_partials_bf16's [splitk][B*HW][C] fp32; bias [C], addvec [B, >= C]
+ * (row stride addvec_ld) fp32 or NULL.  Same arithmetic as ae_conv3x3_bf16's reduce launch followed by ae_groupnorm_nhwc_bf16 (one-launch slab form), bit for bit;
+ * one launch and one round trip of the activation less.  ae_groupnorm_splitk_supported: maps up to 256 positions, 2..8 K ranges.                                */
+int ae_groupnorm_splitk_supported(int B, int HW, int C, int groups, int splitk);
+int ae_groupnorm_splitk_nhwc_bf16(const float* partial, int splitk, const float* bias, const float* addvec, long addvec_ld, const float* gamma, const float* beta,
+                                  void* y, int B, int HW, int C, int groups, float eps, int act, void* stream);
  * colstats / colstats2: optional per-channel slab statistics of x / x2 as written by the kernels that PRODUCED them (the `colstats`
  * output of ae_gemm_bf16 / ae_ln_gemm_bf16 / ae_conv3x3_bf16: [B*HW/32][C1][2] and [B*HW/32][C-C1][2]; HW % 32 == 0).  With them the
  * statistics pass over the activation is skipped: one block per (sample, group) folds the slab sums, then the apply launch runs.    */

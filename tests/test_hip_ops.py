@@ -210,6 +210,48 @@ def test_cross_attention_half_fused_inside_the_product():
     assert "AE_XATTN_FUSED=1: fused cross-attention launches in the profiled edit: 0" not in r.stdout and "AE_XATTN_FUSED=1" in r.stdout and " OK" in r.stdout
 
 
+@pytest.mark.parametrize("B,HW_side,Cin,Cout", [(12, 16, 1280, 1280), (12, 8, 1280, 1280), (12, 16, 2560, 1280), (12, 8, 2560, 1280), (12, 16, 640, 1280), (4, 16, 1280, 1280)])
+def test_groupnorm_folds_the_splitk_partials_bit_identical(ops, B, HW_side, Cin, Cout):
+    """openaimodel.py:262-272 at the 16x16 / 8x8 levels (round 6): conv1's split-K plan stopped at its fp32 partials (ae_conv3x3_partials_bf16) and the GroupNorm + SiLU
+    folding the K ranges, the bias and the time-embedding vector itself (ae_groupnorm_splitk_nhwc_bf16) against conv3x3 (with its reduce launch) followed by groupnorm:
+    the same adds in the same order and one rounding -> bit-identical, with and without bias / vector, strided vector rows; refusals outside the envelope."""
+    H = W = HW_side
+    ops._GN_SPLITK, knob = True, ops._GN_SPLITK          # opt-in in the product (measured slower in the graph: ops.py); the operators are tested regardless
+    try:
+        _splitk_fold_case(ops, B, H, W, Cin, Cout)
+    finally:
+        ops._GN_SPLITK = knob
+
+
+def _splitk_fold_case(ops, B, H, W, Cin, Cout):
+    if not ops.conv3x3_gn_splitk_ok(B, H, W, Cin, Cout):
+        pytest.skip(f"the plan does not cut K for B={B} {H}x{W} {Cin}->{Cout}")
+    g = torch.Generator().manual_seed(B + H + Cin)
+    x = torch.randn(B * H * W, Cin, generator=g).bfloat16().to(DEV)
+    w = ops.pack_conv3x3((torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)).to(DEV))
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    emb_all = torch.randn(B, 3 * Cout, generator=g).to(DEV)
+    addvec = emb_all[:, Cout:2 * Cout]                               # strided rows, as the batched time-embedding projection hands them over
+    gamma, beta = (1.0 + 0.1 * torch.randn(Cout, generator=g)).to(DEV), (0.1 * torch.randn(Cout, generator=g)).to(DEV)
+    for bz, av in ((bias, addvec), (None, addvec), (bias, None), (None, None)):
+        for silu in (True, False):
+            h, _, _ = ops.conv3x3(x, w, bz, B, H, W, addvec=av)
+            ref = ops.groupnorm(h, gamma, beta, B, H * W, 1e-5, silu=silu)
+            part, sk = ops.conv3x3_partials(x, w, B, H, W)
+            assert part.shape == (sk, B * H * W, Cout) and 2 <= sk <= 8
+            got = ops.groupnorm_splitk(part, bz, av, gamma, beta, B, H * W, 1e-5, silu=silu)
+            assert torch.equal(got, ref), (bz is not None, av is not None, silu, float((got.float() - ref.float()).abs().max()))
+    assert torch.equal(ops.groupnorm_splitk(part, None, None, gamma, beta, B, H * W, 1e-5), got), "run-to-run bit-equal"
+    with pytest.raises(ValueError):
+        ops.groupnorm_splitk(part[:, :, :Cout - 8], None, None, gamma, beta, B, H * W, 1e-5)          # not contiguous
+    with pytest.raises(ValueError):
+        ops.groupnorm_splitk(part, None, emb_all, gamma, beta, B, H * W, 1e-5)                          # vector of the wrong width
+    assert ops.lib.ae_groupnorm_splitk_supported(B, 1024, Cout, 32, sk) == 0 and ops.lib.ae_groupnorm_splitk_supported(B, H * W, Cout, 32, 1) == 0
+    assert not ops.conv3x3_gn_splitk_ok(12, 64, 64, 320, 320) and not ops.conv3x3_gn_splitk_ok(1, 8, 8, 64, 64)   # maps beyond 256 positions; a K loop too short to cut
+    with pytest.raises(ValueError):
+        ops.conv3x3_partials(x[:64, :64].contiguous(), ops.pack_conv3x3(torch.zeros(64, 64, 3, 3, device=DEV)), 1, 8, 8)   # nine K tiles: the plan does not cut K
+
+
 @pytest.mark.parametrize("M,H,res", [(192, 1280, True), (500, 1280, True), (777, 64, False), (1000, 256, True), (49152, 1280, True), (49000, 1280, True)])
 def test_feed_forward_fused_one_launch(ops, M, H, res):
     """attention.py:49-76 behind norm3 (:271-275) as ONE launch (ae_ff_fused_bf16, round 6): LayerNorm -> GEGLU projection -> exact-erf gate -> ff2

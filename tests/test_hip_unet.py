@@ -210,6 +210,42 @@ def test_attention_block_at_map_sizes(tag, ch, hw, kw, heads, new):
     assert e <= 1.5 * c + 2e-3, (tag, e, c)
 
 
+@pytest.mark.parametrize("cin,cout,hw", [(1280, 1280, 16), (2560, 1280, 8), (1280, 1280, 8)])
+def test_resblock_small_maps_fold_splitk_into_groupnorm_bit_identical(cin, cout, hw):
+    """ResBlock at the UNet's 16x16 / 8x8 levels (batch 12): conv1 -> (+ emb) -> GroupNorm + SiLU through the split-K fold (ops.conv3x3_partials + ops.groupnorm_splitk;
+    opt-in, AE_GN_SPLITK=1: measured slower in the graph) equals the default reduce-launch path bit for bit, and launches one kernel fewer."""
+    from anyedit_amd import ops
+    from anyedit_amd.ldm.modules.diffusionmodules.openaimodel import ResBlock
+    torch.manual_seed(23)
+    with torch.device(DEV):
+        rb = ResBlock(cin, 1280, 0.0, out_channels=cout)
+    g = torch.Generator().manual_seed(24)
+    with torch.no_grad():
+        for p_ in rb.out_layers[-1].parameters():
+            p_.copy_((torch.randn(p_.shape, generator=g) * 0.02).to(DEV))
+    B = 12
+    x = torch.randn(B, cin, hw, hw, generator=g).to(DEV)
+    emb = torch.randn(B, 1280, generator=g).to(DEV)
+    knob = ops._GN_SPLITK
+    try:
+        with torch.no_grad():
+            ops._GN_SPLITK = True
+            assert ops.conv3x3_gn_splitk_ok(B, hw, hw, cin, cout)
+            with ops.OpProfiler() as prof:
+                y1 = rb(x, emb)
+            n1 = sum(v["launches"] for v in prof.summary().values())
+            assert any("splitK fold" in k for k in prof.summary())
+            ops._GN_SPLITK = False
+            with ops.OpProfiler() as prof:
+                y0 = rb(x, emb)
+            n0 = sum(v["launches"] for v in prof.summary().values())
+            assert not any("splitK fold" in k for k in prof.summary())
+    finally:
+        ops._GN_SPLITK = knob
+    assert torch.equal(y1, y0)
+    assert n1 == n0 - 1, (n1, n0)     # (conv + reduce) + slab GroupNorm = 3 launches -> partial conv + folding GroupNorm = 2
+
+
 @pytest.fixture(scope="module")
 def tiny_unet():
     from util_models import build_tiny_unet
